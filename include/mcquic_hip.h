@@ -1,0 +1,119 @@
+/*
+ * mcquic_hip.h — C-ABI of libmcquic_hip.so, the MI355X (gfx950) replacement for the PyTorch ops
+ * underneath McQuic's Compressor encode/decode hot path.
+ *
+ * The reference has no FFI for this path: it calls torch ops (nn.Conv2d / F.conv2d / torch.bmm /
+ * argmin / advanced indexing).  Each entry point below cites the reference call site(s) it replaces
+ * (paths relative to the reference tree).  The binding a reference maintainer would add (ctypes) is
+ * shown in INTEGRATION.md and is what mcquic_amd/_lib.py does.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated inside;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); work is only enqueued,
+ *     no entry point synchronises;
+ *   - return 0 on success, a negative MCQ_E* code on invalid arguments; nothing throws;
+ *   - tensors are dense fp32 NCHW; code indices are int64 [N, m, h, w]  (reference:
+ *     mcquic/modules/quantizer.py:144-150, argmin returns int64).
+ *   - all entry points are re-entrant.
+ */
+#ifndef MCQUIC_HIP_H
+#define MCQUIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCQ_OK            0
+#define MCQ_EINVAL       -1   /* NULL pointer / non-positive dimension / unsupported combination */
+#define MCQ_ELAUNCH      -2   /* hipLaunchKernel failed (hipGetLastError() != hipSuccess)        */
+#define MCQ_ETOOLARGE    -3   /* a per-image plane exceeds the 2 GiB buffer-addressing window    */
+
+/* ---- conv flags (mcq_conv_desc.flags) ------------------------------------------------------- */
+#define MCQ_CONV_SILU_IN    0x001u /* apply SiLU to the input on load   (mcquic/nn/blocks.py:70-78,179-200: act before conv) */
+#define MCQ_CONV_SQUARE_IN  0x002u /* square the input on load          (mcquic/nn/gdn.py:75: F.conv2d(x ** 2, gamma, beta))  */
+#define MCQ_CONV_SILU_OUT   0x004u /* apply SiLU to the result          (the act2 of _residulBlock, fused into conv1)        */
+#define MCQ_CONV_RESIDUAL   0x008u /* y += res_scale * res              (blocks.py:77 `out += identity`; quantizer.py:318 `z - dequant`) */
+#define MCQ_CONV_GDN        0x010u /* y = mul * (1/sqrt(acc))           (gdn.py:79  x * torch.rsqrt(std)) */
+#define MCQ_CONV_IGDN       0x020u /* y = mul * sqrt(acc)               (gdn.py:91  x * torch.sqrt(std))  */
+#define MCQ_CONV_GATE       0x040u /* y = mul * sigmoid(acc) + gate_id  (blocks.py:281-288 AttentionBlock.forward) */
+#define MCQ_CONV_SHUFFLE2   0x080u /* store through nn.PixelShuffle(2)  (mcquic/nn/convs.py:221-255 pixelShuffle3x3) */
+
+typedef struct mcq_conv_desc {
+    const float* x;        /* [N, Cin, H, W]                                                      */
+    const float* w_packed; /* from mcq_pack_conv_weight_f32                                        */
+    const float* bias;     /* [Cout] or NULL                                                       */
+    float*       y;        /* [N, Cout, Ho, Wo]; with SHUFFLE2: [N, Cout/4, 2Ho, 2Wo]              */
+    const float* res;      /* RESIDUAL: same shape as y                                            */
+    const float* mul;      /* GDN/IGDN/GATE: same shape as y                                       */
+    const float* gate_id;  /* GATE: same shape as y                                                */
+    int32_t N, Cin, H, W, Cout;
+    int32_t ksize;         /* 1 or 3 (padding = ksize/2, zeros)                                    */
+    int32_t stride;        /* 1 or 2                                                               */
+    uint32_t flags;
+    float   res_scale;     /* +1 or -1                                                             */
+    int32_t tile;          /* 0 = auto; else (MB<<4)|NB to force a wave tile (testing / tuning)    */
+} mcq_conv_desc;
+
+/* Number of floats mcq_pack_conv_weight_f32 writes for a [Cout, Cin, ks, ks] weight. */
+size_t mcq_packed_conv_weight_floats(int32_t Cout, int32_t Cin, int32_t ksize);
+
+/* Re-lay a dense OIHW weight (nn.Conv2d.weight, mcquic/nn/convs.py:77-100,257-276) into the
+ * MFMA operand stream the conv kernel reads: [Cout/128][tap][Cin/2][64 lanes][4] (zero padded). */
+int mcq_pack_conv_weight_f32(const float* w_oihw, int32_t Cout, int32_t Cin, int32_t ksize,
+                             float* w_packed, void* stream);
+
+/* Dense 2-D convolution (zeros padding ksize/2) + fused prologue/epilogue.
+ * Replaces nn.Conv2d.forward for conv3x3 / conv1x1 / pixelShuffle3x3 (mcquic/nn/convs.py:77-100,
+ * 221-276), F.conv2d in GenDivNorm.forward (mcquic/nn/gdn.py:67-79), the SiLU / residual add of
+ * _residulBlock.forward (mcquic/nn/blocks.py:70-78) and the gate of AttentionBlock.forward
+ * (blocks.py:281-288). */
+int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream);
+
+/* GDN re-parametrisation folded once at load: out = max(p, bound)^2 - pedestal
+ * (mcquic/nn/base.py:81-84 NonNegativeParametrizer.forward). */
+int mcq_nonneg_reparam_f32(const float* p, float bound, float pedestal, float* out, int64_t n,
+                           void* stream);
+
+/* ---- multi-codebook quantizer ------------------------------------------------------------- */
+
+/* Floats needed for the packed codebook of one level: the MFMA operand stream
+ * m x [k/128][d/2][64][4] (+ prefetch tail) followed by the codeword norms c2 in operand layout. */
+size_t mcq_packed_codebook_floats(int32_t m, int32_t k, int32_t d);
+
+/* Pack codebook [m, k, d] into the operand stream and append c2[g, k] = sum_j c^2
+ * (mcquic/modules/quantizer.py:163  c2 = (codebook ** 2).sum(-1)); padded codewords get +inf. */
+int mcq_vq_pack_codebook_f32(const float* codebook, int32_t m, int32_t k, int32_t d,
+                             float* cb_packed, void* stream);
+
+/* codes[n, g, y, x] = argmin_k ( (|x_v|^2 + |c_k|^2) - 2 <x_v, c_k> ), first index on ties.
+ * x: [N, m*d, h, w] (channel = g*d + j).  Replaces _multiCodebookQuantization._distance + encode
+ * (mcquic/modules/quantizer.py:144-179) without materialising [N, m, h, w, k]. */
+int mcq_vq_assign_f32(const float* x, const float* cb_packed, int64_t* codes,
+                      int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k,
+                      void* stream);
+
+/* out[n, g*d + j, y, x] = codebook[g, codes[n, g, y, x], j]
+ * (mcquic/modules/quantizer.py:249-259 _multiCodebookDeQuantization.decode).
+ * Returns MCQ_OK; indices outside [0, k) are clamped (the reference would raise IndexError). */
+int mcq_vq_gather_f32(const int64_t* codes, const float* codebook, float* out,
+                      int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k,
+                      void* stream);
+
+/* ---- small element-wise helpers on the path ------------------------------------------------ */
+
+/* out = a + b  (quantizer.py:354  xHat = q + sideHead(formerLevel)). */
+int mcq_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+/* u8 = trunc(clamp(((x + 1) / 2) * 255.999, 0, 255))   (mcquic/utils/vision.py:143-146 DeTransform). */
+int mcq_detransform_u8(const float* x, uint8_t* out, int64_t n, void* stream);
+
+/* Library / build identification: returns a static string "mcquic_hip <ver> gfx950". */
+const char* mcq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCQUIC_HIP_H */

@@ -1,0 +1,72 @@
+"""ctypes binding of libmcquic_hip.so (the C-ABI declared in include/mcquic_hip.h).
+
+There is no fallback: if the shared library is missing or a symbol is absent, importing the op layer
+raises.  The product path never routes through a CPU or PyTorch implementation of these ops.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmcquic_hip.so")
+
+MCQ_OK, MCQ_EINVAL, MCQ_ELAUNCH, MCQ_ETOOLARGE = 0, -1, -2, -3
+_ERR = {MCQ_EINVAL: "MCQ_EINVAL (invalid argument)", MCQ_ELAUNCH: "MCQ_ELAUNCH (kernel launch failed)",
+        MCQ_ETOOLARGE: "MCQ_ETOOLARGE (tensor exceeds the addressing window)"}
+
+CONV_SILU_IN, CONV_SQUARE_IN, CONV_SILU_OUT, CONV_RESIDUAL = 0x1, 0x2, 0x4, 0x8
+CONV_GDN, CONV_IGDN, CONV_GATE, CONV_SHUFFLE2 = 0x10, 0x20, 0x40, 0x80
+
+
+class ConvDesc(Structure):
+    """struct mcq_conv_desc (include/mcquic_hip.h)."""
+    _fields_ = [("x", c_void_p), ("w_packed", c_void_p), ("bias", c_void_p), ("y", c_void_p), ("res", c_void_p),
+                ("mul", c_void_p), ("gate_id", c_void_p),
+                ("N", c_int32), ("Cin", c_int32), ("H", c_int32), ("W", c_int32), ("Cout", c_int32),
+                ("ksize", c_int32), ("stride", c_int32), ("flags", c_uint32), ("res_scale", c_float),
+                ("tile", c_int32)]
+
+
+# every symbol include/mcquic_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mcq_packed_conv_weight_floats": (c_size_t, [c_int32, c_int32, c_int32]),
+    "mcq_pack_conv_weight_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "mcq_conv2d_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
+    "mcq_nonneg_reparam_f32": (c_int32, [c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
+    "mcq_packed_codebook_floats": (c_size_t, [c_int32, c_int32, c_int32]),
+    "mcq_vq_pack_codebook_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "mcq_vq_assign_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                    c_int32, c_void_p]),
+    "mcq_vq_gather_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                    c_int32, c_void_p]),
+    "mcq_add_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_detransform_u8": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_version": (c_char_p, []),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the in-tree library and type every entry point; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: run `python -m mcquic_amd.build` (or __graft_entry__.build()). "
+            "mcquic_amd has no CPU / PyTorch fallback for its HIP kernels.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != MCQ_OK:
+        raise RuntimeError(f"{what} failed: {_ERR.get(status, status)}")

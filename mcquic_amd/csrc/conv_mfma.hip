@@ -1,0 +1,372 @@
+// Dense 3x3 / 1x1 convolution for gfx950 as an implicit GEMM on exact-f32 MFMA.
+//
+// Replaces nn.Conv2d / F.conv2d under McQuic's conv3x3, conv1x1, pixelShuffle3x3 and GenDivNorm
+// (reference: mcquic/nn/convs.py:77-100,221-276, mcquic/nn/gdn.py:67-91) plus the element-wise
+// ops the reference runs around them (SiLU, `out += identity`, x*rsqrt(std), a*sigmoid(b)+x;
+// mcquic/nn/blocks.py:70-78,281-288).
+//
+// GEMM view:  D[co][p] = sum_{tap, ci} Wt[co][tap, ci] * X[ci][p + tap]
+//   rows  = output channels  (A operand = packed weights, one float4 per lane per k-step)
+//   cols  = output pixels    (B operand = activations, NCHW so 32 pixels = 32 consecutive floats)
+//   k     = (tap, ci) walked tap-major, two input channels per 32x32x2 MFMA.
+// A wave owns MB x NB accumulator tiles of 32 couts x 32 pixels and is a self-contained stream:
+// per k-step it issues one weight load (MB floats per lane) and NB activation loads (buffer
+// loads; out-of-image taps are turned into out-of-range offsets, for which the hardware returns
+// 0 = the conv's zero padding), PF steps ahead of the MFMAs that consume them.
+#include "mcq_common.h"
+#include "../../include/mcquic_hip.h"
+
+namespace {
+
+struct ConvK {
+    const float* x; const float* wp; const float* bias; float* y;
+    const float* res; const float* mul; const float* gid;
+    int N, Cin, H, W, Cout, Ho, Wo;
+    int ks, stride;
+    int S;             // input-channel pairs per tap
+    int TP;            // k-steps per 128-cout tile, padded to a multiple of 8
+    int bw_log2;       // a pixel block is (32 >> bw_log2) rows x (1 << bw_log2) cols
+    int nbx, nby, total_blocks;
+    unsigned flags; float res_scale;
+};
+
+constexpr int PRO_NONE = 0, PRO_SILU = 1, PRO_SQUARE = 2;
+
+template <int MB> struct AVec;
+template <> struct AVec<4> { typedef f32x4v T; };
+template <> struct AVec<2> { typedef f32x2v T; };
+template <> struct AVec<1> { typedef float T; };
+
+template <int MB> __device__ __forceinline__ float a_elem(const typename AVec<MB>::T& v, int i) { return v[i]; }
+template <> __device__ __forceinline__ float a_elem<1>(const float& v, int) { return v; }
+
+template <int MB, int NB, int PRO, int PF>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int gw = blockIdx.x * 4 + wave;           // wave index along the pixel-block axis
+    if (gw * NB >= p.total_blocks) return;          // wave-uniform
+    const int co_base = blockIdx.y * (32 * MB);     // first output channel of this wave
+    const int hi = lane >> 5, j = lane & 31;
+    const int BW = 1 << p.bw_log2;
+    const int ly = j >> p.bw_log2, lx = j & (BW - 1);
+    const int BH = 32 >> p.bw_log2;
+    const int HW = p.H * p.W;
+    const int pad = p.ks >> 1;
+    const int ntaps = p.ks * p.ks;
+    const unsigned plane_bytes = (unsigned)p.Cin * (unsigned)HW * 4u;
+
+    // ---- geometry of the NB pixel blocks this wave owns -------------------------------------
+    int img[NB], yo[NB], xo[NB];
+    bool valid[NB];
+    __amdgpu_buffer_rsrc_t rsrc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        int pb = gw * NB + nb;
+        const bool pbv = pb < p.total_blocks;
+        if (!pbv) pb = p.total_blocks - 1;
+        const int per_img = p.nby * p.nbx;
+        const int n = pb / per_img;
+        const int rem = pb - n * per_img;
+        const int by = rem / p.nbx;
+        const int bx = rem - by * p.nbx;
+        img[nb] = n;
+        yo[nb] = by * BH + ly;
+        xo[nb] = bx * BW + lx;
+        valid[nb] = pbv && yo[nb] < p.Ho && xo[nb] < p.Wo;
+        rsrc[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.x + (size_t)n * p.Cin * HW), plane_bytes);
+    }
+
+    auto tap_voff = [&](int tap, int nb) -> unsigned {
+        const int dy = tap / p.ks, dx = tap - dy * p.ks;          // scalar
+        const int yi = yo[nb] * p.stride + dy - pad;
+        const int xi = xo[nb] * p.stride + dx - pad;
+        const bool inb = valid[nb] && tap < ntaps && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
+        return inb ? (unsigned)(yi * p.W + xi + hi * HW) * 4u : MCQ_OOB;
+    };
+
+    // ---- operand prefetch ring ---------------------------------------------------------------
+    typedef typename AVec<MB>::T avec_t;
+    avec_t A[PF];
+    float B[PF][NB];
+    const int tile128 = co_base >> 7, q0 = (co_base & 127) >> 5;
+    const float* wl = p.wp + ((size_t)tile128 * p.TP * 64 + lane) * 4 + q0;
+    int ls = 0, lt = 0;
+    unsigned soffL = 0;
+    const unsigned step_bytes = 2u * (unsigned)HW * 4u;
+    unsigned voffL[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) voffL[nb] = tap_voff(0, nb);
+
+    auto issue = [&](int st) {
+        A[st] = *reinterpret_cast<const avec_t*>(wl);
+        wl += 256;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) B[st][nb] = mcq_buffer_load(rsrc[nb], voffL[nb] + soffL);
+        ++ls;
+        soffL += step_bytes;
+        if (ls == p.S) {                       // wave-uniform: next tap
+            ls = 0; soffL = 0; ++lt;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) voffL[nb] = tap_voff(lt, nb);
+        }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+#pragma unroll
+    for (int st = 0; st < PF; ++st) issue(st);
+
+    for (int t = 0; t < p.TP; t += PF) {
+#pragma unroll
+        for (int st = 0; st < PF; ++st) {
+            float bv[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float v = B[st][nb];
+                if (PRO == PRO_SILU) v = mcq_silu(v);
+                if (PRO == PRO_SQUARE) v = v * v;
+                bv[nb] = v;
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[st], mb), bv[nb],
+                                                                       acc[mb][nb], 0, 0, 0);
+            issue(st);   // over-reads PF steps past the tile: the packed buffer carries a zero tail
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row tile, the 16 output
+    // channels row(r) = (r & 3) + 8 (r >> 2) + 4 hi.  Side inputs are fetched 16 at a time so
+    // their latencies overlap.
+    const unsigned fl = p.flags;
+    const size_t HoWo = (size_t)p.Ho * p.Wo;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int co0 = co_base + mb * 32 + 4 * hi;      // channel of register 0
+        bool cok[16];
+        float bias16[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (r & 3) + 8 * (r >> 2);
+            cok[r] = co < p.Cout;
+            bias16[r] = 0.0f;
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (cok[r]) bias16[r] = p.bias[co0 + (r & 3) + 8 * (r >> 2)];
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const bool vld = valid[nb];
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[mb][nb][r] + bias16[r];
+
+            if (fl & MCQ_CONV_SHUFFLE2) {
+                // registers 4q..4q+3 are the 2x2 sub-pixels of output channel co/4: two float2 rows.
+                const int Co4 = p.Cout >> 2;
+                const size_t W2 = 2 * (size_t)p.Wo;
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    if (vld && cok[rq * 4]) {
+                        const int c = (co0 + 8 * rq) >> 2;
+                        float* o = p.y + (((size_t)img[nb] * Co4 + c) * (2 * (size_t)p.Ho) + 2 * (size_t)yo[nb]) * W2 +
+                                   2 * (size_t)xo[nb];
+                        *reinterpret_cast<f32x2v*>(o) = f32x2v{v[rq * 4 + 0], v[rq * 4 + 1]};
+                        *reinterpret_cast<f32x2v*>(o + W2) = f32x2v{v[rq * 4 + 2], v[rq * 4 + 3]};
+                    }
+                }
+            } else {
+                const size_t idx0 = ((size_t)img[nb] * p.Cout + co0) * HoWo + (size_t)yo[nb] * p.Wo + xo[nb];
+                bool ok[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ok[r] = vld && cok[r];
+                if (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) {
+                    float m[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[r] = ok[r] ? p.mul[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
+                    if (fl & MCQ_CONV_GDN) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = m[r] * (1.0f / sqrtf(v[r]));
+                    } else if (fl & MCQ_CONV_IGDN) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = m[r] * sqrtf(v[r]);
+                    } else {
+                        float gi[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) gi[r] = ok[r] ? p.gid[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = m[r] * mcq_sigmoid(v[r]) + gi[r];
+                    }
+                }
+                if (fl & MCQ_CONV_RESIDUAL) {
+                    float rr[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rr[r] = ok[r] ? p.res[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = v[r] + p.res_scale * rr[r];
+                }
+                if (fl & MCQ_CONV_SILU_OUT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ok[r]) p.y[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
+            }
+        }
+    }
+}
+
+// OIHW -> [Cout/128][TP][64 lanes][4]: lane l, slot q holds W[co = 128 T + 32 q + (l & 31)][ci = 2 s + (l >> 5)][tap]
+// for k-step = tap * S + s; zero beyond Cout / Cin / the real step count and in the 8-step tail.
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, int S, int TP,
+                                        int ntile, float* __restrict__ out, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    const size_t stepg = i >> 8;
+    const int tile = (int)(stepg / TP);
+    const int step = (int)(stepg - (size_t)tile * TP);
+    float v = 0.0f;
+    const int T = ks * ks * S;
+    if (tile < ntile && step < T) {
+        const int tap = step / S, s = step - tap * S;
+        const int co = tile * 128 + 32 * q + (lane & 31);
+        const int ci = 2 * s + (lane >> 5);
+        if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * (ks * ks) + tap];
+    }
+    out[i] = v;
+}
+
+__global__ void nonneg_reparam_kernel(const float* __restrict__ p, float bound, float pedestal, float* __restrict__ out,
+                                      int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float v = fmaxf(p[i], bound);
+        out[i] = v * v - pedestal;
+    }
+}
+
+inline int steps_padded(int Cin, int ks) {
+    const int S = (Cin + 1) / 2;
+    const int T = ks * ks * S;
+    return (T + 7) & ~7;
+}
+
+template <int MB, int NB, int PF>
+int launch_tile(const ConvK& k, int pro, dim3 grid, hipStream_t s) {
+    switch (pro) {
+    case PRO_NONE:   hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF>), grid, dim3(256), 0, s, k); break;
+    case PRO_SILU:   hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF>), grid, dim3(256), 0, s, k); break;
+    default:         hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SQUARE, PF>), grid, dim3(256), 0, s, k); break;
+    }
+    return mcq_check_launch();
+}
+
+}  // namespace
+
+extern "C" size_t mcq_packed_conv_weight_floats(int32_t Cout, int32_t Cin, int32_t ksize) {
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    const size_t ntile = (size_t)(Cout + 127) / 128;
+    return (ntile * (size_t)steps_padded(Cin, ksize) + 8) * 256;   // + 8 zero steps read by the prefetch tail
+}
+
+extern "C" int mcq_pack_conv_weight_f32(const float* w, int32_t Cout, int32_t Cin, int32_t ksize, float* out,
+                                        void* stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return MCQ_EINVAL;
+    const size_t total = mcq_packed_conv_weight_floats(Cout, Cin, ksize);
+    const int S = (Cin + 1) / 2, TP = steps_padded(Cin, ksize), ntile = (Cout + 127) / 128;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, ksize, S,
+                       TP, ntile, out, total);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_nonneg_reparam_f32(const float* p, float bound, float pedestal, float* out, int64_t n, void* stream) {
+    if (!p || !out || n <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(nonneg_reparam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p,
+                       bound, pedestal, out, n);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
+    if (!d || !d->x || !d->w_packed || !d->y) return MCQ_EINVAL;
+    if (d->N <= 0 || d->Cin <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return MCQ_EINVAL;
+    if ((d->ksize != 1 && d->ksize != 3) || (d->stride != 1 && d->stride != 2)) return MCQ_EINVAL;
+    const unsigned fl = d->flags;
+    if ((fl & MCQ_CONV_RESIDUAL) && !d->res) return MCQ_EINVAL;
+    if ((fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) && !d->mul) return MCQ_EINVAL;
+    if ((fl & MCQ_CONV_GATE) && !d->gate_id) return MCQ_EINVAL;
+    if ((fl & MCQ_CONV_SILU_IN) && (fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;
+    if (fl & MCQ_CONV_SHUFFLE2) {
+        if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN))) return MCQ_EINVAL;
+    }
+    if ((uint64_t)d->Cin * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
+
+    ConvK k;
+    k.x = d->x; k.wp = d->w_packed; k.bias = d->bias; k.y = d->y; k.res = d->res; k.mul = d->mul; k.gid = d->gate_id;
+    k.N = d->N; k.Cin = d->Cin; k.H = d->H; k.W = d->W; k.Cout = d->Cout;
+    k.ks = d->ksize; k.stride = d->stride;
+    const int pad = d->ksize / 2;
+    k.Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1;
+    k.Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
+    k.S = (d->Cin + 1) / 2;
+    k.TP = steps_padded(d->Cin, d->ksize);
+    k.flags = fl; k.res_scale = d->res_scale;
+
+    // pixel-block shape: the power-of-two width that wastes the fewest lanes (wider wins ties)
+    int best_log2 = 5; double best_util = -1.0;
+    for (int lg = 5; lg >= 2; --lg) {
+        const int bw = 1 << lg, bh = 32 >> lg;
+        const double cover = (double)((k.Ho + bh - 1) / bh * bh) * (double)((k.Wo + bw - 1) / bw * bw);
+        const double util = (double)k.Ho * k.Wo / cover;
+        if (util > best_util + 1e-9) { best_util = util; best_log2 = lg; }
+    }
+    k.bw_log2 = best_log2;
+    const int bw = 1 << best_log2, bh = 32 >> best_log2;
+    k.nbx = (k.Wo + bw - 1) / bw;
+    k.nby = (k.Ho + bh - 1) / bh;
+    const long long tb = (long long)k.N * k.nbx * k.nby;
+    if (tb > 0x7fffffffLL) return MCQ_ETOOLARGE;
+    k.total_blocks = (int)tb;
+
+    // wave tile: the largest MB x NB that still yields >= one wave per SIMD (1024 on MI355X)
+    const int co32 = (d->Cout + 31) / 32;
+    int MB, NB;
+    if (d->tile) { MB = d->tile >> 4; NB = d->tile & 15; }
+    else if (co32 == 1) { MB = 1; NB = 2; }
+    else {
+        static const int cand[4][2] = {{4, 2}, {2, 2}, {2, 1}, {1, 1}};
+        MB = 1; NB = 1;
+        for (int c = 0; c < 4; ++c) {
+            const int mb = cand[c][0], nb = cand[c][1];
+            if (mb > co32) continue;
+            const long long waves = ((tb + nb - 1) / nb) * ((co32 + mb - 1) / mb);
+            if (waves >= 1024 || c == 3) { MB = mb; NB = nb; break; }
+        }
+    }
+    const int pro = (fl & MCQ_CONV_SILU_IN) ? PRO_SILU : (fl & MCQ_CONV_SQUARE_IN) ? PRO_SQUARE : PRO_NONE;
+    const unsigned gx = (unsigned)(((tb + NB - 1) / NB + 3) / 4);
+    const unsigned gy = (unsigned)((co32 + MB - 1) / MB);
+    const dim3 grid(gx, gy);
+    hipStream_t s = (hipStream_t)stream;
+    if (MB == 4 && NB == 2) return launch_tile<4, 2, 4>(k, pro, grid, s);
+    if (MB == 2 && NB == 2) return launch_tile<2, 2, 8>(k, pro, grid, s);
+    if (MB == 2 && NB == 1) return launch_tile<2, 1, 8>(k, pro, grid, s);
+    if (MB == 1 && NB == 2) return launch_tile<1, 2, 8>(k, pro, grid, s);
+    if (MB == 1 && NB == 1) return launch_tile<1, 1, 8>(k, pro, grid, s);
+    return MCQ_EINVAL;
+}

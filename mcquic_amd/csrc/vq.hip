@@ -1,0 +1,330 @@
+// Multi-codebook vector quantizer kernels for gfx950.
+//
+// mcq_vq_assign_f32 replaces _multiCodebookQuantization._distance + encode
+// (reference: mcquic/modules/quantizer.py:144-179): per group g and latent vector v
+//     dist[v, k] = (|x_v|^2 + |c_k|^2) - 2 <x_v, c_k>,   code[v] = argmin_k dist[v, k] (first index on ties)
+// The reference materialises inter = bmm(x, codebook^T) as [N, m, h, w, k]; here the inner products
+// stay in MFMA accumulators (rows = 128 codewords, cols = 64 latent vectors per wave), the epilogue
+// of every 128-codeword tile folds them into a per-lane running (min, argmin), and only the int64
+// codes are written.  The epilogue keeps the reference's rounding sequence (x2 + c2) - 2*inter.
+//
+// |c_k|^2 is needed in the accumulator's row layout.  It is obtained bit-exactly with one extra
+// MFMA per 32 rows: A[i][0] = c2[i], B[0][j] = 1, everything else 0  =>  D[i][j] = c2[i].
+#include "mcq_common.h"
+#include "../../include/mcquic_hip.h"
+#include <math.h>
+
+namespace {
+
+constexpr int VQ_MB = 4, VQ_NB = 2, VQ_PF = 4;
+
+struct VqK {
+    const float* x; const float* cbp; const float* c2p; int64_t* codes;
+    int N, m, d, h, w, k;
+    int Sp;            // k-steps (channel pairs) per tile, padded to a multiple of VQ_PF
+    int ntile;         // 128-codeword tiles
+    int bw_log2, nbx, nby, total_blocks;
+};
+
+__global__ __launch_bounds__(256) void vq_assign_kernel(VqK p) {
+    constexpr int MB = VQ_MB, NB = VQ_NB, PF = VQ_PF;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int gw = blockIdx.x * 4 + wave;
+    if (gw * NB >= p.total_blocks) return;
+    const int g = blockIdx.y;
+    const int hi = lane >> 5, j = lane & 31;
+    const int BW = 1 << p.bw_log2;
+    const int ly = j >> p.bw_log2, lx = j & (BW - 1);
+    const int BH = 32 >> p.bw_log2;
+    const int HW = p.h * p.w;
+    const unsigned group_bytes = (unsigned)p.d * (unsigned)HW * 4u;
+
+    int img[NB], yo[NB], xo[NB];
+    bool valid[NB];
+    unsigned pixoff[NB];
+    __amdgpu_buffer_rsrc_t rsrc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        int pb = gw * NB + nb;
+        const bool pbv = pb < p.total_blocks;
+        if (!pbv) pb = p.total_blocks - 1;
+        const int per_img = p.nby * p.nbx;
+        const int n = pb / per_img;
+        const int rem = pb - n * per_img;
+        const int by = rem / p.nbx;
+        const int bx = rem - by * p.nbx;
+        img[nb] = n;
+        yo[nb] = by * BH + ly;
+        xo[nb] = bx * BW + lx;
+        valid[nb] = pbv && yo[nb] < p.h && xo[nb] < p.w;
+        pixoff[nb] = valid[nb] ? (unsigned)(yo[nb] * p.w + xo[nb]) * 4u : MCQ_OOB;
+        // the descriptor covers exactly this image's group-g channels, so padded k-steps read 0
+        rsrc[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.x + ((size_t)n * p.m + g) * (size_t)p.d * HW), group_bytes);
+    }
+
+    // |x_v|^2, sequential over the d channels of the group (both half-waves compute it redundantly)
+    float x2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        float s = 0.0f;
+        unsigned off = pixoff[nb];
+        for (int c = 0; c < p.d; ++c) {
+            const float v = mcq_buffer_load(rsrc[nb], off);
+            s = s + v * v;
+            off += (unsigned)HW * 4u;
+        }
+        x2[nb] = s;
+    }
+
+    f32x4v A[PF];
+    float B[PF][NB];
+    const float* wl = p.cbp + ((size_t)g * p.ntile * p.Sp * 64 + lane) * 4;
+    const f32x4v* c2l = reinterpret_cast<const f32x4v*>(p.c2p) + (size_t)g * (p.ntile + 1) * 64 + lane;
+    int ls = 0;
+    unsigned soffL = 0;
+    const unsigned step_bytes = 2u * (unsigned)HW * 4u;
+    unsigned voffL[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) voffL[nb] = valid[nb] ? pixoff[nb] + (unsigned)(hi * HW) * 4u : MCQ_OOB;
+
+    auto issue = [&](int st) {
+        A[st] = *reinterpret_cast<const f32x4v*>(wl);
+        wl += 256;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) B[st][nb] = mcq_buffer_load(rsrc[nb], voffL[nb] + soffL);
+        ++ls;
+        soffL += step_bytes;
+        if (ls == p.Sp) { ls = 0; soffL = 0; }
+    };
+
+    float best[NB];
+    int bidx[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { best[nb] = INFINITY; bidx[nb] = 0; }
+    const float bone = hi == 0 ? 1.0f : 0.0f;
+
+#pragma unroll
+    for (int st = 0; st < PF; ++st) issue(st);
+    f32x4v c2a = c2l[0];
+
+    for (int tile = 0; tile < p.ntile; ++tile) {
+        const f32x4v c2n = c2l[(size_t)(tile + 1) * 64];   // next tile's norms (one spare tile is allocated)
+        f32x16 acc[MB][NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+        for (int t = 0; t < p.Sp; t += PF) {
+#pragma unroll
+            for (int st = 0; st < PF; ++st) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st][mb], B[st][nb], acc[mb][nb], 0, 0, 0);
+                issue(st);
+            }
+        }
+
+        const int word0 = tile * 128;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+            const f32x16 c2d = __builtin_amdgcn_mfma_f32_32x32x2f32(c2a[mb], bone, z, 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // (x2 + c2) - 2 * inter ; 2 * inter is exact, so the fused form rounds identically
+                    const float dv = __builtin_fmaf(-2.0f, acc[mb][nb][r], x2[nb] + c2d[r]);
+                    const int word = word0 + mb * 32 + mcq_drow(r, hi);
+                    if (dv < best[nb]) { best[nb] = dv; bidx[nb] = word; }
+                }
+        }
+        c2a = c2n;
+    }
+
+    // the two half-waves hold interleaved codeword rows of the same latent vector
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const float ob = __shfl_xor(best[nb], 32);
+        const int oi = __shfl_xor(bidx[nb], 32);
+        if (ob < best[nb] || (ob == best[nb] && oi < bidx[nb])) { best[nb] = ob; bidx[nb] = oi; }
+        if (hi == 0 && valid[nb])
+            p.codes[(((size_t)img[nb] * p.m + g) * p.h + yo[nb]) * p.w + xo[nb]] = (int64_t)bidx[nb];
+    }
+}
+
+// codebook [m, k, d] -> cbp [m][ntile][Sp][64][4] (+ zero tail) and c2p [m][ntile + 1][64][4]
+__global__ void vq_pack_kernel(const float* __restrict__ cb, int m, int k, int d, int Sp, int ntile,
+                               float* __restrict__ cbp, size_t cb_total, size_t cb_alloc) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cb_alloc) return;
+    float v = 0.0f;
+    if (i < cb_total) {
+        const int q = (int)(i & 3);
+        const int lane = (int)((i >> 2) & 63);
+        size_t rest = i >> 8;
+        const int s = (int)(rest % Sp); rest /= Sp;
+        const int tile = (int)(rest % ntile);
+        const int g = (int)(rest / ntile);
+        const int word = tile * 128 + 32 * q + (lane & 31);
+        const int c = 2 * s + (lane >> 5);
+        if (word < k && c < d) v = cb[((size_t)g * k + word) * d + c];
+    }
+    cbp[i] = v;
+}
+
+__global__ void vq_c2_kernel(const float* __restrict__ cb, int m, int k, int d, int ntile, float* __restrict__ c2p,
+                             size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    size_t rest = i >> 8;
+    const int tile = (int)(rest % (ntile + 1));
+    const int g = (int)(rest / (ntile + 1));
+    const int word = tile * 128 + 32 * q + (lane & 31);
+    float v = 0.0f;
+    if ((lane >> 5) == 0) {
+        if (tile < ntile && word < k) {
+            const float* row = cb + ((size_t)g * k + word) * d;
+            float s = 0.0f;
+            for (int c = 0; c < d; ++c) s = s + row[c] * row[c];
+            v = s;
+        } else {
+            v = INFINITY;   // padded codewords can never win the argmin
+        }
+    }
+    c2p[i] = v;
+}
+
+__global__ void vq_gather_kernel(const int64_t* __restrict__ codes, const float* __restrict__ cb, float* __restrict__ out,
+                                 int N, int m, int d, int hw, int k) {
+    // one thread per (n, g, pixel); writes d channel planes (coalesced across threads)
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)N * m * hw;
+    if (i >= total) return;
+    const int pix = (int)(i % hw);
+    const size_t ng = i / hw;
+    const int g = (int)(ng % m);
+    const size_t n = ng / m;
+    int64_t code = codes[i];
+    code = code < 0 ? 0 : (code >= k ? k - 1 : code);
+    const float* row = cb + ((size_t)g * k + (size_t)code) * d;
+    float* o = out + ((n * m + g) * (size_t)d) * hw + pix;
+    for (int c = 0; c < d; ++c) o[(size_t)c * hw] = row[c];
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const f32x4v va = *reinterpret_cast<const f32x4v*>(a + i);
+        const f32x4v vb = *reinterpret_cast<const f32x4v*>(b + i);
+        *reinterpret_cast<f32x4v*>(out + i) = va + vb;
+    } else {
+        for (; i < n; ++i) out[i] = a[i] + b[i];
+    }
+}
+
+__global__ void detransform_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        // (x - min) / (max - min) with min = -1, max = 1, then * (255 + 1.0 - 1e-3), clamp, truncate
+        float v = (x[i] - (-1.0f)) / 2.0f;
+        v = v * 255.999f;
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+        out[i] = (uint8_t)v;
+    }
+}
+
+inline void block_shape(int Ho, int Wo, int& lg_out) {
+    int best_log2 = 5; double best_util = -1.0;
+    for (int lg = 5; lg >= 2; --lg) {
+        const int bw = 1 << lg, bh = 32 >> lg;
+        const double cover = (double)((Ho + bh - 1) / bh * bh) * (double)((Wo + bw - 1) / bw * bw);
+        const double util = (double)Ho * Wo / cover;
+        if (util > best_util + 1e-9) { best_util = util; best_log2 = lg; }
+    }
+    lg_out = best_log2;
+}
+
+inline int vq_sp(int d) { return (((d + 1) / 2) + VQ_PF - 1) / VQ_PF * VQ_PF; }
+
+}  // namespace
+
+extern "C" size_t mcq_packed_codebook_floats(int32_t m, int32_t k, int32_t d) {
+    if (m <= 0 || k <= 0 || d <= 0) return 0;
+    const size_t ntile = (size_t)(k + 127) / 128;
+    const size_t cb = ((size_t)m * ntile * vq_sp(d) + VQ_PF) * 256;   // operand stream + prefetch tail
+    const size_t c2 = (size_t)m * (ntile + 1) * 256;                  // norms (+1 spare tile per group)
+    return cb + c2;
+}
+
+extern "C" int mcq_vq_pack_codebook_f32(const float* codebook, int32_t m, int32_t k, int32_t d, float* cb_packed,
+                                        void* stream) {
+    if (!codebook || !cb_packed || m <= 0 || k <= 0 || d <= 0) return MCQ_EINVAL;
+    const int ntile = (k + 127) / 128, Sp = vq_sp(d);
+    const size_t cb_total = (size_t)m * ntile * Sp * 256;
+    const size_t cb_alloc = cb_total + (size_t)VQ_PF * 256;
+    const size_t c2_total = (size_t)m * (ntile + 1) * 256;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(vq_pack_kernel, dim3((unsigned)((cb_alloc + 255) / 256)), dim3(256), 0, s, codebook, m, k, d, Sp,
+                       ntile, cb_packed, cb_total, cb_alloc);
+    hipLaunchKernelGGL(vq_c2_kernel, dim3((unsigned)((c2_total + 255) / 256)), dim3(256), 0, s, codebook, m, k, d, ntile,
+                       cb_packed + cb_alloc, c2_total);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_vq_assign_f32(const float* x, const float* cb_packed, int64_t* codes, int32_t N, int32_t m, int32_t d,
+                                 int32_t h, int32_t w, int32_t k, void* stream) {
+    if (!x || !cb_packed || !codes || N <= 0 || m <= 0 || d <= 0 || h <= 0 || w <= 0 || k <= 0) return MCQ_EINVAL;
+    if ((uint64_t)d * h * w * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
+    VqK p;
+    p.x = x; p.codes = codes; p.N = N; p.m = m; p.d = d; p.h = h; p.w = w; p.k = k;
+    p.ntile = (k + 127) / 128;
+    p.Sp = vq_sp(d);
+    const size_t cb_alloc = ((size_t)m * p.ntile * p.Sp + VQ_PF) * 256;
+    p.cbp = cb_packed;
+    p.c2p = cb_packed + cb_alloc;
+    block_shape(h, w, p.bw_log2);
+    const int bw = 1 << p.bw_log2, bh = 32 >> p.bw_log2;
+    p.nbx = (w + bw - 1) / bw;
+    p.nby = (h + bh - 1) / bh;
+    const long long tb = (long long)N * p.nbx * p.nby;
+    if (tb > 0x7fffffffLL) return MCQ_ETOOLARGE;
+    p.total_blocks = (int)tb;
+    const unsigned gx = (unsigned)(((tb + VQ_NB - 1) / VQ_NB + 3) / 4);
+    hipLaunchKernelGGL(vq_assign_kernel, dim3(gx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, p);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_vq_gather_f32(const int64_t* codes, const float* codebook, float* out, int32_t N, int32_t m, int32_t d,
+                                 int32_t h, int32_t w, int32_t k, void* stream) {
+    if (!codes || !codebook || !out || N <= 0 || m <= 0 || d <= 0 || h <= 0 || w <= 0 || k <= 0) return MCQ_EINVAL;
+    const size_t total = (size_t)N * m * h * w;
+    hipLaunchKernelGGL(vq_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, codes,
+                       codebook, out, N, m, d, h * w, k);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n <= 0) return MCQ_EINVAL;
+    const int64_t threads = (n + 3) / 4;
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_detransform_u8(const float* x, uint8_t* out, int64_t n, void* stream) {
+    if (!x || !out || n <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(detransform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    return mcq_check_launch();
+}
+
+extern "C" const char* mcq_version(void) { return "mcquic_hip 0.1.0 gfx950"; }

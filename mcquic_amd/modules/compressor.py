@@ -1,0 +1,156 @@
+"""`Compressor` with the reference's API surface on HIP kernels (reference: mcquic/modules/compressor.py).
+
+    Compressor(channel, m, k, permutationRate=0.0)         # compressor.py:121
+    .encode(x) -> List[LongTensor [n, m, h_l, w_l]]        # :79-88
+    .decode(codes) -> Tensor [n, 3, H, W]                  # :114-117
+    .compress(x) / .decompress(binaries, headers)          # :67-77 / :90-112 (entropy coder: next row)
+    .Codebooks / .NormalizedFreq / .CDFs / .CodeUsage / .QuantizationParameter
+
+The module tree and every state_dict key are the reference's (718 entries for the qp=2 shape), so a
+reference checkpoint's `model` dict loads with `load_state_dict(strict=True)`.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..nn import AttentionBlock, ResidualBlock, ResidualBlockShuffle, ResidualBlockWithStride, conv3x3, pixelShuffle3x3
+from ..utils.specification import FileHeader, ImageSize
+from .quantizer import BaseQuantizer, UMGMQuantizer
+
+__version__ = "0.1.40"   # the reference snapshot's mcquic.__version__, written into FileHeader
+
+
+class AlignedPadding(nn.Module):
+    """Reflect-pad H, W up to multiples of `base` (reference: mcquic/data/transforms.py:81-99).
+    A no-op for 768x512.  Data movement only (torch's reflect pad on the device)."""
+
+    def __init__(self, base: int = 128):
+        super().__init__()
+        self._base = base
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        h, w = x.shape[-2], x.shape[-1]
+        wPadding = ((w // self._base + 1) * self._base - w) % self._base
+        hPadding = ((h // self._base + 1) * self._base - h) % self._base
+        if wPadding == 0 and hPadding == 0:
+            return x
+        padLeft = wPadding // 2
+        padTop = hPadding // 2
+        return F.pad(x, (padLeft, wPadding - padLeft, padTop, hPadding - padTop), "reflect")
+
+
+class BaseCompressor(nn.Module):
+    def __init__(self, encoder: nn.Module, quantizer: BaseQuantizer, decoder: nn.Module):
+        super().__init__()
+        self._encoder = encoder
+        self._decoder = decoder
+        self._quantizer = quantizer
+        self._qp = "-1"
+        self._padding = AlignedPadding()
+
+    @property
+    def QuantizationParameter(self) -> str:
+        return self._qp
+
+    @QuantizationParameter.setter
+    def QuantizationParameter(self, qp: str):
+        self._qp = qp
+
+    def forward(self, x: torch.Tensor):
+        if self.training:
+            raise NotImplementedError("the training forward (Gumbel soft-assign + straight-through backward) is "
+                                      "BASELINE config #5 and not built yet; call .eval() for encode/decode")
+        return None     # the reference's forward returns None in eval mode (compressor.py:35-43)
+
+    def reAssignCodebook(self) -> torch.Tensor:
+        return self._quantizer.reAssignCodebook()
+
+    def syncCodebook(self):
+        return self._quantizer.syncCodebook()
+
+    @property
+    def Codebooks(self):
+        return self._quantizer.Codebooks
+
+    @property
+    def CDFs(self):
+        return self._quantizer.CDFs
+
+    @property
+    def NormalizedFreq(self):
+        return self._quantizer.NormalizedFreq
+
+    @property
+    def CodeUsage(self):
+        return torch.cat(list((freq > 1e-6).flatten() for freq in self._quantizer.NormalizedFreq)).float().mean()
+
+    def _check(self, x: torch.Tensor):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError(f"expected an image batch [n, 3, h, w], got {tuple(x.shape)}")
+
+    def encode(self, x: torch.Tensor) -> List[torch.Tensor]:
+        self._check(x)
+        with torch.no_grad():
+            y = self._encoder(self._padding(x))
+            return self._quantizer.encode(y)
+
+    def decode(self, codes: List[torch.Tensor]) -> torch.Tensor:
+        with torch.no_grad():
+            return self._decoder(self._quantizer.decode(codes))
+
+    def compress(self, x: torch.Tensor) -> Tuple[List[torch.Tensor], List[List[bytes]], List[FileHeader]]:
+        self._check(x)
+        n, c, h, w = x.shape
+        with torch.no_grad():
+            y = self._encoder(self._padding(x))
+            codes, binaries, codeSizes = self._quantizer.compress(y)
+        header = [FileHeader(__version__, self._qp, codeSize, ImageSize(height=h, width=w, channel=c)) for codeSize in codeSizes]
+        return codes, binaries, header
+
+    def decompress(self, binaries: List[List[bytes]], headers: List[FileHeader]) -> torch.Tensor:
+        with torch.no_grad():
+            restored = self._decoder(self._quantizer.decompress(binaries, [header.CodeSize for header in headers]))
+        imageSize = headers[0].ImageSize
+        H, W = restored.shape[-2], restored.shape[-1]
+        h, w = imageSize.height, imageSize.width
+        cropTop, cropLeft = (H - h) // 2, (W - w) // 2
+        return restored[..., cropTop:cropTop + h, cropLeft:cropLeft + w]
+
+
+class Compressor(BaseCompressor):
+    def __init__(self, channel: int, m: int, k: List[int], permutationRate: float = 0.0):
+        encoder = nn.Sequential(
+            conv3x3(3, channel, 2),
+            ResidualBlock(channel, channel),
+            ResidualBlockWithStride(channel, channel),
+            AttentionBlock(channel),
+            ResidualBlock(channel, channel),
+            ResidualBlockWithStride(channel, channel),
+            ResidualBlock(channel, channel))
+        decoder = nn.Sequential(
+            ResidualBlock(channel, channel),
+            ResidualBlockShuffle(channel, channel),
+            AttentionBlock(channel),
+            ResidualBlock(channel, channel),
+            ResidualBlockShuffle(channel, channel),
+            ResidualBlock(channel, channel),
+            pixelShuffle3x3(channel, 3, 2))
+        quantizer = UMGMQuantizer(channel, m, k, permutationRate, {
+            "latentStageEncoder": lambda: nn.Sequential(
+                ResidualBlockWithStride(channel, channel), ResidualBlock(channel, channel), AttentionBlock(channel)),
+            "quantizationHead": lambda: nn.Sequential(
+                ResidualBlock(channel, channel), AttentionBlock(channel), conv3x3(channel, channel)),
+            "latentHead": lambda: nn.Sequential(
+                ResidualBlock(channel, channel), AttentionBlock(channel), conv3x3(channel, channel)),
+            "restoreHead": lambda: nn.Sequential(
+                AttentionBlock(channel), ResidualBlock(channel, channel), ResidualBlockShuffle(channel, channel)),
+            "dequantizationHead": lambda: nn.Sequential(
+                AttentionBlock(channel), conv3x3(channel, channel), ResidualBlock(channel, channel)),
+            "sideHead": lambda: nn.Sequential(
+                AttentionBlock(channel), conv3x3(channel, channel), ResidualBlock(channel, channel)),
+        })
+        super().__init__(encoder, quantizer, decoder)

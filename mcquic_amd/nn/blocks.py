@@ -1,0 +1,95 @@
+"""Residual / attention blocks of the Compressor path, fused onto the HIP conv kernel.
+
+Same classes, constructor arguments and state_dict keys as the reference (mcquic/nn/blocks.py):
+`ResidualBlock` (:162-200), `ResidualBlockWithStride` (:81-122), `ResidualBlockShuffle` (:124-159),
+`AttentionBlock` (:245-288).  What the reference runs as separate torch kernels (SiLU, `out += identity`,
+GDN's multiply, `a * sigmoid(b) + x`) rides in the prologue / epilogue of the conv launches:
+
+    ResidualBlock            2 launches   conv(silu_in, silu_out) ; conv(+ x)
+    ResidualBlockWithStride  4 launches   conv s2(silu_in) ; GDN 1x1 ; skip conv s2 ; conv(+ skip)
+    ResidualBlockShuffle     4 launches   conv+shuffle(silu_in) ; IGDN 1x1 ; skip conv+shuffle ; conv(+ skip)
+    AttentionBlock          13 launches   6 ResidualBlocks ; 1x1 conv with the gate a*sigmoid(b)+x as its epilogue
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .convs import Conv2d, PixelShuffle3x3, conv1x1, conv3x3, pixelShuffle3x3
+from .gdn import GenDivNorm, InvGenDivNorm
+
+__all__ = ["ResidualBlockWithStride", "ResidualBlockShuffle", "ResidualBlock", "AttentionBlock"]
+
+
+class _residulBlock(nn.Module):
+    """Container with the reference's layout: `_branch` = Sequential(act1, conv1, act2, conv2), `_skip`
+    (reference: mcquic/nn/blocks.py:62-78)."""
+
+    def __init__(self, act1: nn.Module, conv1: nn.Module, act2: nn.Module, conv2: nn.Module, skip: Optional[nn.Module]):
+        super().__init__()
+        self._branch = nn.Sequential(act1, conv1, act2, conv2)
+        self._skip = skip
+
+
+class ResidualBlock(_residulBlock):
+    """SiLU, conv3, SiLU, conv3, + x."""
+
+    def __init__(self, inChannels: int, outChannels: int, groups: int = 1, denseNorm: bool = False):
+        if inChannels != outChannels or groups != 1 or denseNorm:
+            raise NotImplementedError("Compressor only uses ResidualBlock(c, c, groups=1, denseNorm=False)")
+        super().__init__(nn.SiLU(), conv3x3(inChannels, outChannels), nn.SiLU(), conv3x3(outChannels, outChannels), None)
+
+    def forward(self, x: torch.Tensor, res2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        t = self._branch[1](x, silu_in=True, silu_out=True)      # silu(conv1(silu(x)))
+        return self._branch[3](t, res=x)                          # conv2(.) + x
+
+
+class ResidualBlockWithStride(_residulBlock):
+    """SiLU, conv3 s2, GDN, conv3, + conv3 s2 skip."""
+
+    def __init__(self, inChannels: int, outChannels: int, stride: int = 2, groups: int = 1, denseNorm: bool = False):
+        if stride != 2 or groups != 1 or denseNorm:
+            raise NotImplementedError("Compressor only uses ResidualBlockWithStride(c, c, stride=2)")
+        super().__init__(nn.SiLU(), conv3x3(inChannels, outChannels, stride=stride), GenDivNorm(outChannels),
+                         conv3x3(outChannels, outChannels), conv3x3(inChannels, outChannels, stride=stride))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        t = self._branch[1](x, silu_in=True)
+        t = self._branch[2](t)
+        identity = self._skip(x)
+        return self._branch[3](t, res=identity)
+
+
+class ResidualBlockShuffle(_residulBlock):
+    """SiLU, pixelShuffle3x3 (x2), IGDN, conv3, + pixelShuffle3x3 skip."""
+
+    def __init__(self, inChannels: int, outChannels: int, upsample: int = 2, groups: int = 1, denseNorm: bool = False):
+        if upsample != 2 or groups != 1 or denseNorm:
+            raise NotImplementedError("Compressor only uses ResidualBlockShuffle(c, c, upsample=2)")
+        super().__init__(nn.SiLU(), pixelShuffle3x3(inChannels, outChannels, upsample), InvGenDivNorm(outChannels),
+                         conv3x3(outChannels, outChannels), pixelShuffle3x3(inChannels, outChannels, upsample))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        t = self._branch[1](x, silu_in=True)
+        t = self._branch[2](t)
+        identity = self._skip(x)
+        return self._branch[3](t, res=identity)
+
+
+class AttentionBlock(nn.Module):
+    """a = RB^3(x); b = conv1x1(RB^3(x)); out = a * sigmoid(b) + x (reference: blocks.py:245-288)."""
+
+    def __init__(self, channel: int, groups: int = 1, denseNorm: bool = False):
+        super().__init__()
+        self._mainBranch = nn.Sequential(*[ResidualBlock(channel, channel, groups, denseNorm) for _ in range(3)])
+        self._sideBranch = nn.Sequential(*[ResidualBlock(channel, channel, groups, denseNorm) for _ in range(3)],
+                                         conv1x1(channel, channel))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        a = self._mainBranch(x)
+        b = x
+        for i in range(3):
+            b = self._sideBranch[i](b)
+        return self._sideBranch[3](b, gate_mul=a, gate_id=x)

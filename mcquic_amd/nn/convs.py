@@ -1,0 +1,82 @@
+"""Convolution layers of the Compressor path on HIP kernels.
+
+Mirrors the factories of the reference (mcquic/nn/convs.py): `conv3x3` (:77-100), `conv1x1` (:257-276)
+and `pixelShuffle3x3` (:221-255), with the same parameter names / state_dict keys (`weight`, `bias`;
+`0.weight`, `0.bias` for the pixel-shuffle pair).  Only the configurations `Compressor` uses exist
+(groups=1, zeros padding, r=2 up-sampling).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+
+__all__ = ["Conv2d", "conv3x3", "conv1x1", "pixelShuffle3x3", "PixelShuffle3x3"]
+
+
+class Conv2d(nn.Module):
+    """Parameter holder + launcher for one dense conv (kernel 1 or 3, stride 1 or 2, padding k//2).
+
+    Initialisation follows nn.Conv2d's default law (kaiming_uniform(a=sqrt(5)) => U(+-1/sqrt(fan_in))),
+    which is what the reference gets from `nn.Conv2d(...)`.
+    """
+
+    def __init__(self, inChannels: int, outChannels: int, kernelSize: int, stride: int = 1, bias: bool = True):
+        super().__init__()
+        self.inChannels, self.outChannels, self.kernelSize, self.stride = inChannels, outChannels, kernelSize, stride
+        bound = 1.0 / math.sqrt(inChannels * kernelSize * kernelSize)
+        self.weight = nn.Parameter(torch.empty(outChannels, inChannels, kernelSize, kernelSize).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(outChannels).uniform_(-bound, bound)) if bias else None
+        self._packed: Optional[ops.PackedConv] = None
+        self._packedKey = None
+
+    def packed(self) -> ops.PackedConv:
+        """Weights in MFMA operand order; re-packed whenever the parameters change (version / storage / device)."""
+        key = (self.weight._version, self.weight.data_ptr(), None if self.bias is None else (self.bias._version, self.bias.data_ptr()))
+        if self._packed is None or key != self._packedKey:
+            self._packed = ops.PackedConv(self.weight, self.bias)
+            self._packedKey = key
+        return self._packed
+
+    def forward(self, x: torch.Tensor, **fused) -> torch.Tensor:
+        return ops.conv2d(x, self.packed(), self.stride, **fused)
+
+    def extra_repr(self) -> str:
+        return f"{self.inChannels}, {self.outChannels}, kernel_size={self.kernelSize}, stride={self.stride}"
+
+
+def conv3x3(inChannels: int, outChannels: int, stride: int = 1, bias: bool = True, groups: int = 1) -> Conv2d:
+    """3x3 conv with padding 1 (reference: mcquic/nn/convs.py:77-100)."""
+    if groups != 1:
+        raise NotImplementedError("grouped convolutions are not on the Compressor path")
+    return Conv2d(inChannels, outChannels, 3, stride, bias)
+
+
+def conv1x1(inChannels: int, outChannels: int, stride: int = 1, bias: bool = True, groups: int = 1) -> Conv2d:
+    """1x1 conv (reference: mcquic/nn/convs.py:257-276)."""
+    if groups != 1 or stride != 1:
+        raise NotImplementedError("only dense stride-1 1x1 convolutions are on the Compressor path")
+    return Conv2d(inChannels, outChannels, 1, 1, bias)
+
+
+class PixelShuffle3x3(nn.Sequential):
+    """Sequential(Conv2d(C, C_out * r^2, 3, padding=1), PixelShuffle(r)) as ONE kernel: the shuffle is the
+    conv's store pattern (reference: mcquic/nn/convs.py:250-255).  Keys: `0.weight`, `0.bias`."""
+
+    def __init__(self, inChannels: int, outChannels: int, r: int = 2):
+        if r != 2:
+            raise NotImplementedError("only 2x up-sampling is on the Compressor path")
+        super().__init__(Conv2d(inChannels, outChannels * r * r, 3), nn.PixelShuffle(r))
+
+    def forward(self, x: torch.Tensor, **fused) -> torch.Tensor:
+        return self[0](x, shuffle2=True, **fused)
+
+
+def pixelShuffle3x3(inChannels: int, outChannels: int, r: float = 1, groups: int = 1) -> PixelShuffle3x3:
+    if groups != 1:
+        raise NotImplementedError("grouped convolutions are not on the Compressor path")
+    return PixelShuffle3x3(inChannels, outChannels, int(r))

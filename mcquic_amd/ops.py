@@ -1,0 +1,172 @@
+"""Tensor-level wrappers over the C-ABI of libmcquic_hip.so.
+
+PyTorch is used here only for device memory (torch.empty) and the current HIP stream; every op below
+is a hand-written gfx950 kernel reached through ctypes.  CPU tensors are rejected -- there is no
+fallback implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN, CONV_SILU_OUT,
+                   CONV_SQUARE_IN, ConvDesc, check)
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"mcquic_amd: `{name}` must live on a HIP device (got {t.device}); "
+                           "the HIP kernels have no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"mcquic_amd: `{name}` must be {dtype} (got {t.dtype})")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class PackedConv:
+    """A conv weight re-laid for the MFMA operand stream (+ its bias), see mcq_pack_conv_weight_f32."""
+
+    __slots__ = ("wp", "bias", "cout", "cin", "ksize")
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        weight = _dev(weight.detach(), "weight")
+        cout, cin, kh, kw = weight.shape
+        if kh != kw or kh not in (1, 3):
+            raise ValueError(f"unsupported kernel size {kh}x{kw}")
+        lib = _lib.load()
+        n = lib.mcq_packed_conv_weight_floats(cout, cin, kh)
+        self.wp = torch.empty(n, dtype=torch.float32, device=weight.device)
+        with torch.cuda.device(weight.device):
+            check(lib.mcq_pack_conv_weight_f32(_ptr(weight), cout, cin, kh, _ptr(self.wp), _stream()), "mcq_pack_conv_weight_f32")
+        self.bias = None if bias is None else _dev(bias.detach(), "bias").clone()
+        self.cout, self.cin, self.ksize = cout, cin, kh
+
+
+def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = False, square_in: bool = False,
+           silu_out: bool = False, res: Optional[torch.Tensor] = None, res_scale: float = 1.0,
+           gdn_mul: Optional[torch.Tensor] = None, igdn_mul: Optional[torch.Tensor] = None,
+           gate_mul: Optional[torch.Tensor] = None, gate_id: Optional[torch.Tensor] = None,
+           shuffle2: bool = False, tile: int = 0) -> torch.Tensor:
+    """y = epilogue(conv(prologue(x)) + bias); one kernel launch (mcq_conv2d_f32)."""
+    x = _dev(x, "x")
+    n, cin, h, wd = x.shape
+    if cin != w.cin:
+        raise ValueError(f"channel mismatch: x has {cin}, weight expects {w.cin}")
+    pad = w.ksize // 2
+    ho = (h + 2 * pad - w.ksize) // stride + 1
+    wo = (wd + 2 * pad - w.ksize) // stride + 1
+    flags = 0
+    if silu_in:
+        flags |= CONV_SILU_IN
+    if square_in:
+        flags |= CONV_SQUARE_IN
+    if silu_out:
+        flags |= CONV_SILU_OUT
+    if shuffle2:
+        flags |= CONV_SHUFFLE2
+        y = torch.empty((n, w.cout // 4, 2 * ho, 2 * wo), dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty((n, w.cout, ho, wo), dtype=torch.float32, device=x.device)
+    mul = None
+    if res is not None:
+        flags |= CONV_RESIDUAL
+        res = _dev(res, "res")
+        if res.shape != y.shape:
+            raise ValueError(f"residual shape {tuple(res.shape)} != output shape {tuple(y.shape)}")
+    for flag, t in ((CONV_GDN, gdn_mul), (CONV_IGDN, igdn_mul), (CONV_GATE, gate_mul)):
+        if t is not None:
+            flags |= flag
+            mul = _dev(t, "mul")
+            if mul.shape != y.shape:
+                raise ValueError(f"mul shape {tuple(mul.shape)} != output shape {tuple(y.shape)}")
+    if gate_id is not None:
+        gate_id = _dev(gate_id, "gate_id")
+        if gate_id.shape != y.shape:
+            raise ValueError("gate identity shape mismatch")
+    d = ConvDesc(_ptr(x), _ptr(w.wp), _ptr(w.bias), _ptr(y), _ptr(res), _ptr(mul), _ptr(gate_id),
+                 n, cin, h, wd, w.cout, w.ksize, stride, flags, float(res_scale), tile)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        check(lib.mcq_conv2d_f32(ctypes.byref(d), _stream()), "mcq_conv2d_f32")
+    return y
+
+
+def nonneg_reparam(p: torch.Tensor, bound: float, pedestal: float) -> torch.Tensor:
+    """max(p, bound)^2 - pedestal (mcquic/nn/base.py:81-84), folded once per weight version."""
+    p = _dev(p.detach(), "p")
+    out = torch.empty_like(p)
+    with torch.cuda.device(p.device):
+        check(_lib.load().mcq_nonneg_reparam_f32(_ptr(p), float(bound), float(pedestal), _ptr(out), p.numel(), _stream()),
+              "mcq_nonneg_reparam_f32")
+    return out
+
+
+class PackedCodebook:
+    """Codebook [m, k, d] in MFMA operand order + codeword norms (mcq_vq_pack_codebook_f32)."""
+
+    __slots__ = ("packed", "codebook", "m", "k", "d")
+
+    def __init__(self, codebook: torch.Tensor):
+        cb = _dev(codebook.detach(), "codebook").clone()
+        m, k, d = cb.shape
+        lib = _lib.load()
+        n = lib.mcq_packed_codebook_floats(m, k, d)
+        self.packed = torch.empty(n, dtype=torch.float32, device=cb.device)
+        with torch.cuda.device(cb.device):
+            check(lib.mcq_vq_pack_codebook_f32(_ptr(cb), m, k, d, _ptr(self.packed), _stream()), "mcq_vq_pack_codebook_f32")
+        self.codebook, self.m, self.k, self.d = cb, m, k, d
+
+
+def vq_assign(x: torch.Tensor, cb: PackedCodebook) -> torch.Tensor:
+    """int64 codes [n, m, h, w] = argmin_k distance (mcq_vq_assign_f32)."""
+    x = _dev(x, "x")
+    n, c, h, w = x.shape
+    if c != cb.m * cb.d:
+        raise ValueError(f"latent has {c} channels, codebook expects {cb.m}*{cb.d}")
+    codes = torch.empty((n, cb.m, h, w), dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().mcq_vq_assign_f32(_ptr(x), _ptr(cb.packed), _ptr(codes), n, cb.m, cb.d, h, w, cb.k, _stream()),
+              "mcq_vq_assign_f32")
+    return codes
+
+
+def vq_gather(codes: torch.Tensor, cb: PackedCodebook) -> torch.Tensor:
+    """fp32 [n, m*d, h, w] = codebook[g, codes] (mcq_vq_gather_f32)."""
+    codes = _dev(codes, "codes", torch.int64)
+    n, m, h, w = codes.shape
+    if m != cb.m:
+        raise RuntimeError(f"codes carry m={m}, codebook has m={cb.m}")
+    out = torch.empty((n, m * cb.d, h, w), dtype=torch.float32, device=codes.device)
+    with torch.cuda.device(codes.device):
+        check(_lib.load().mcq_vq_gather_f32(_ptr(codes), _ptr(cb.codebook), _ptr(out), n, m, cb.d, h, w, cb.k, _stream()),
+              "mcq_vq_gather_f32")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    a, b = _dev(a, "a"), _dev(b, "b")
+    if a.shape != b.shape:
+        raise ValueError("add: shape mismatch")
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        check(_lib.load().mcq_add_f32(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "mcq_add_f32")
+    return out
+
+
+def detransform(x: torch.Tensor) -> torch.Tensor:
+    """[-1, 1] fp32 -> uint8 (mcquic/utils/vision.py:143-146)."""
+    x = _dev(x, "x")
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().mcq_detransform_u8(_ptr(x), _ptr(out), x.numel(), _stream()), "mcq_detransform_u8")
+    return out

@@ -1,0 +1,395 @@
+"""CPU oracle: a plain-PyTorch (fp32, CPU) restatement of McQuic's Compressor encode/decode path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product (`mcquic_amd/`) imports this module; it is used by
+`tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` as the checker / the
+reported CPU baseline -- never as the thing shipped or measured as the product.
+
+Parity status: the reference tree holds no unit tests or golden vectors for this path,
+so this restatement is pinned against outputs of the reference itself, imported unmodified from
+/root/reference in the build container by `tests/golden/make_golden.py` (harness:
+`oracle/ref_harness.py`); the captured vectors live in `tests/golden/*.npz`.
+
+Every function cites the reference lines it restates (paths relative to the reference tree).  The
+restatement is functional: it walks a `state_dict` laid out exactly like the reference's
+(`_encoder.0.weight`, `_quantizer._encoders.0._quantizer._codebook`, ...), so the same weights drive
+the reference, this oracle and the HIP implementation.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+StateDict = Dict[str, torch.Tensor]
+
+EPS = 1e-6  # mcquic/consts.py:24  Consts.Eps
+
+
+# ----------------------------------------------------------------------------------------------
+# mcquic/nn/convs.py
+# ----------------------------------------------------------------------------------------------
+def conv3x3(sd: StateDict, pre: str, x: torch.Tensor, stride: int = 1) -> torch.Tensor:
+    """mcquic/nn/convs.py:77-100 -> nn.Conv2d(kernel_size=3, stride, padding=1, zeros)."""
+    return F.conv2d(x, sd[pre + "weight"], sd[pre + "bias"], stride=stride, padding=1)
+
+
+def conv1x1(sd: StateDict, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """mcquic/nn/convs.py:257-276 -> nn.Conv2d(kernel_size=1)."""
+    return F.conv2d(x, sd[pre + "weight"], sd[pre + "bias"])
+
+
+def pixel_shuffle3x3(sd: StateDict, pre: str, x: torch.Tensor, r: int = 2) -> torch.Tensor:
+    """mcquic/nn/convs.py:221-255 (r >= 1 branch): Sequential(Conv2d(C, C*r*r, 3, padding=1), PixelShuffle(r))."""
+    y = F.conv2d(x, sd[pre + "0.weight"], sd[pre + "0.bias"], padding=1)
+    return F.pixel_shuffle(y, r)
+
+
+# ----------------------------------------------------------------------------------------------
+# mcquic/nn/base.py, mcquic/nn/gdn.py
+# ----------------------------------------------------------------------------------------------
+def nonneg_reparam(p: torch.Tensor, eps_sq: torch.Tensor, bound: torch.Tensor) -> torch.Tensor:
+    """mcquic/nn/base.py:81-84: out = max(x, bound) ** 2 - eps  (`eps` buffer already holds Eps ** 2, :72)."""
+    out = torch.max(p, bound)
+    return out ** 2 - eps_sq
+
+
+def gdn(sd: StateDict, pre: str, x: torch.Tensor, inverse: bool) -> torch.Tensor:
+    """mcquic/nn/gdn.py:67-91 (groups == 1): std = conv2d(x**2, gamma[..., None, None], beta);
+    GDN: x * rsqrt(std); IGDN: x * sqrt(std)."""
+    beta = nonneg_reparam(sd[pre + "beta"], sd[pre + "beta_reparam.eps"], sd[pre + "beta_reparam.lowerBound.bound"])
+    gamma = nonneg_reparam(sd[pre + "gamma"], sd[pre + "gamma_reparam.eps"], sd[pre + "gamma_reparam.lowerBound.bound"])
+    std = F.conv2d(x ** 2, gamma[..., None, None], beta)
+    return x * torch.sqrt(std) if inverse else x * torch.rsqrt(std)
+
+
+# ----------------------------------------------------------------------------------------------
+# mcquic/nn/blocks.py
+# ----------------------------------------------------------------------------------------------
+def residual_block(sd: StateDict, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """mcquic/nn/blocks.py:162-200 + _residulBlock.forward :70-78 (inChannels == outChannels, no skip):
+    SiLU, conv3, SiLU, conv3, `out += identity`."""
+    out = conv3x3(sd, pre + "_branch.1.", F.silu(x))
+    out = conv3x3(sd, pre + "_branch.3.", F.silu(out))
+    out += x
+    return out
+
+
+def residual_block_with_stride(sd: StateDict, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """mcquic/nn/blocks.py:81-122: SiLU, conv3 s2, GDN, conv3, + conv3 s2 skip."""
+    out = conv3x3(sd, pre + "_branch.1.", F.silu(x), stride=2)
+    out = gdn(sd, pre + "_branch.2.", out, inverse=False)
+    out = conv3x3(sd, pre + "_branch.3.", out)
+    out += conv3x3(sd, pre + "_skip.", x, stride=2)
+    return out
+
+
+def residual_block_shuffle(sd: StateDict, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """mcquic/nn/blocks.py:124-159: SiLU, pixelShuffle3x3(x2), IGDN, conv3, + pixelShuffle3x3 skip."""
+    out = pixel_shuffle3x3(sd, pre + "_branch.1.", F.silu(x))
+    out = gdn(sd, pre + "_branch.2.", out, inverse=True)
+    out = conv3x3(sd, pre + "_branch.3.", out)
+    out += pixel_shuffle3x3(sd, pre + "_skip.", x)
+    return out
+
+
+def attention_block(sd: StateDict, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """mcquic/nn/blocks.py:245-288: a = RB^3(x); b = conv1x1(RB^3(x)); out = a * sigmoid(b); out += x."""
+    a = x
+    for i in range(3):
+        a = residual_block(sd, f"{pre}_mainBranch.{i}.", a)
+    b = x
+    for i in range(3):
+        b = residual_block(sd, f"{pre}_sideBranch.{i}.", b)
+    b = conv1x1(sd, pre + "_sideBranch.3.", b)
+    out = a * torch.sigmoid(b)
+    out += x
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# mcquic/modules/compressor.py: Compressor.__init__ (the graph) :120-177
+# ----------------------------------------------------------------------------------------------
+def encoder(sd: StateDict, x: torch.Tensor, pre: str = "_encoder.") -> torch.Tensor:
+    """compressor.py:122-131."""
+    y = conv3x3(sd, pre + "0.", x, stride=2)
+    y = residual_block(sd, pre + "1.", y)
+    y = residual_block_with_stride(sd, pre + "2.", y)
+    y = attention_block(sd, pre + "3.", y)
+    y = residual_block(sd, pre + "4.", y)
+    y = residual_block_with_stride(sd, pre + "5.", y)
+    y = residual_block(sd, pre + "6.", y)
+    return y
+
+
+def decoder(sd: StateDict, y: torch.Tensor, pre: str = "_decoder.") -> torch.Tensor:
+    """compressor.py:132-140."""
+    x = residual_block(sd, pre + "0.", y)
+    x = residual_block_shuffle(sd, pre + "1.", x)
+    x = attention_block(sd, pre + "2.", x)
+    x = residual_block(sd, pre + "3.", x)
+    x = residual_block_shuffle(sd, pre + "4.", x)
+    x = residual_block(sd, pre + "5.", x)
+    x = pixel_shuffle3x3(sd, pre + "6.", x)
+    return x
+
+
+def latent_stage_encoder(sd, pre, x):
+    """compressor.py:142-147: RBStride, RB, AttentionBlock."""
+    x = residual_block_with_stride(sd, pre + "0.", x)
+    x = residual_block(sd, pre + "1.", x)
+    return attention_block(sd, pre + "2.", x)
+
+
+def head_rb_attn_conv(sd, pre, x):
+    """compressor.py:148-160 quantizationHead / latentHead: RB, AttentionBlock, conv3x3."""
+    x = residual_block(sd, pre + "0.", x)
+    x = attention_block(sd, pre + "1.", x)
+    return conv3x3(sd, pre + "2.", x)
+
+
+def restore_head(sd, pre, x):
+    """compressor.py:161-165: AttentionBlock, RB, RBShuffle."""
+    x = attention_block(sd, pre + "0.", x)
+    x = residual_block(sd, pre + "1.", x)
+    return residual_block_shuffle(sd, pre + "2.", x)
+
+
+def head_attn_conv_rb(sd, pre, x):
+    """compressor.py:166-175 dequantizationHead / sideHead: AttentionBlock, conv3x3, RB."""
+    x = attention_block(sd, pre + "0.", x)
+    x = conv3x3(sd, pre + "1.", x)
+    return residual_block(sd, pre + "2.", x)
+
+
+# ----------------------------------------------------------------------------------------------
+# mcquic/modules/quantizer.py
+# ----------------------------------------------------------------------------------------------
+def vq_distance(x: torch.Tensor, codebook: torch.Tensor) -> torch.Tensor:
+    """quantizer.py:153-179 _multiCodebookQuantization._distance.
+    x [n, m*d, h, w], codebook [m, k, d] -> [n, m, h, w, k] = (x2 + c2) - 2 * inter, inter by bmm."""
+    m, k, d = codebook.shape
+    n, _, h, w = x.shape
+    x = x.reshape(n, m, d, h, w).contiguous()
+    x2 = (x ** 2).sum(2, keepdim=True)
+    c2 = (codebook ** 2).sum(-1, keepdim=True)[..., None].contiguous()
+    left = x.reshape(n * m, d, h * w).permute(0, 2, 1).contiguous()
+    right = codebook.expand(n, m, k, d).reshape(n * m, k, d).permute(0, 2, 1).contiguous()
+    inter = torch.bmm(left, right)
+    inter = inter.reshape(n, m, h, w, k).permute(0, 1, 4, 2, 3).contiguous()
+    distance = x2 + c2 - 2 * inter
+    return distance.permute(0, 1, 3, 4, 2).contiguous()
+
+
+def vq_encode(x: torch.Tensor, codebook: torch.Tensor) -> torch.Tensor:
+    """quantizer.py:144-150: distance.argmin(-1) -> int64 [n, m, h, w] (first index on ties)."""
+    return vq_distance(x, codebook).argmin(-1)
+
+
+def vq_decode(code: torch.Tensor, codebook: torch.Tensor) -> torch.Tensor:
+    """quantizer.py:249-259 _multiCodebookDeQuantization.decode: gather codebook[g, code] -> [n, m*d, h, w]."""
+    m = codebook.shape[0]
+    n, _, h, w = code.shape
+    code = code.permute(0, 2, 3, 1).contiguous()
+    ix = torch.arange(m).expand_as(code)
+    indexed = codebook[ix, code]
+    return indexed.reshape(n, h, w, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def num_levels(sd: StateDict) -> int:
+    lv = 0
+    while f"_quantizer._encoders.{lv}._quantizer._codebook" in sd:
+        lv += 1
+    return lv
+
+
+def quantizer_encode(sd: StateDict, y: torch.Tensor, collect: Optional[dict] = None) -> List[torch.Tensor]:
+    """quantizer.py:411-420 UMGMQuantizer.encode + :310-318 _quantizerEncoder.encode."""
+    codes = []
+    levels = num_levels(sd)
+    x = y
+    for lv in range(levels):
+        pre = f"_quantizer._encoders.{lv}."
+        cb = sd[pre + "_quantizer._codebook"]
+        z = latent_stage_encoder(sd, pre + "_latentStageEncoder.", x)
+        q = head_rb_attn_conv(sd, pre + "_quantizationHead.", z)
+        code = vq_encode(q, cb)
+        if collect is not None:
+            collect.setdefault("q", []).append(q)
+        codes.append(code)
+        if lv < levels - 1:
+            z2 = head_rb_attn_conv(sd, pre + "_latentHead.", z)
+            x = z2 - vq_decode(code, cb)
+    return codes
+
+
+def quantizer_decode(sd: StateDict, codes: List[torch.Tensor]) -> torch.Tensor:
+    """quantizer.py:422-428 UMGMQuantizer.decode + :351-357 _quantizerDecoder.decode (levels in reverse)."""
+    levels = len(codes)
+    former = None
+    for lv in reversed(range(levels)):
+        pre = f"_quantizer._decoders.{lv}."
+        cb = sd[pre + "_dequantizer._codebook"]
+        q = head_attn_conv_rb(sd, pre + "_dequantizationHead.", vq_decode(codes[lv], cb))
+        if lv < levels - 1:      # the smallest level has no sideHead (quantizer.py:392)
+            xhat = q + head_attn_conv_rb(sd, pre + "_sideHead.", former)
+        else:
+            xhat = q
+        former = restore_head(sd, pre + "_restoreHead.", xhat)
+    return former
+
+
+# ----------------------------------------------------------------------------------------------
+# mcquic/data/transforms.py, mcquic/modules/compressor.py API, metrics
+# ----------------------------------------------------------------------------------------------
+def aligned_padding(x: torch.Tensor, base: int = 128) -> torch.Tensor:
+    """mcquic/data/transforms.py:81-99 AlignedPadding.forward (reflect pad to multiples of `base`)."""
+    h, w = x.shape[-2], x.shape[-1]
+    w_pad = ((w // base + 1) * base - w) % base
+    h_pad = ((h // base + 1) * base - h) % base
+    left = w_pad // 2
+    top = h_pad // 2
+    return F.pad(x, (left, w_pad - left, top, h_pad - top), "reflect")
+
+
+def aligned_crop_back(restored: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """mcquic/modules/compressor.py:94-112: centre-crop `decompress` output back to the header's size."""
+    H, W = restored.shape[-2], restored.shape[-1]
+    h_crop, w_crop = H - h, W - w
+    left = w_crop // 2
+    top = h_crop // 2
+    return restored[..., top:top + h, left:left + w]
+
+
+@torch.inference_mode()
+def encode(sd: StateDict, x: torch.Tensor) -> List[torch.Tensor]:
+    """BaseCompressor.encode, compressor.py:79-88."""
+    return quantizer_encode(sd, encoder(sd, aligned_padding(x)))
+
+
+@torch.inference_mode()
+def decode(sd: StateDict, codes: List[torch.Tensor]) -> torch.Tensor:
+    """BaseCompressor.decode, compressor.py:114-117."""
+    return decoder(sd, quantizer_decode(sd, codes))
+
+
+def detransform(x: torch.Tensor) -> torch.Tensor:
+    """mcquic/utils/vision.py:135-146 DeTransform(min=-1, max=1): [-1, 1] -> uint8."""
+    x = (x - (-1.0)) / (1.0 - (-1.0))
+    return (x * (255 + 1.0 - 1e-3)).clamp(0.0, 255.0).byte()
+
+
+def psnr(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """mcquic/validate/metrics.py:264-274 PSNR.forward on uint8 images: per-image, float64."""
+    mse = ((x.double() - y.double()) ** 2).mean(dim=(1, 2, 3))
+    return 10.0 * (torch.tensor(255.0 ** 2) / (mse + 1e-4)).log10()
+
+
+# ----------------------------------------------------------------------------------------------
+# deterministic synthetic weights (no checkpoint is reachable; SURVEY.md "Five facts" #4)
+# ----------------------------------------------------------------------------------------------
+def _rng(name: str, seed: int):
+    import hashlib
+    import numpy as np
+    key = int.from_bytes(hashlib.sha256(f"{seed}:{name}".encode()).digest()[:8], "little")
+    return np.random.Generator(np.random.Philox(key))
+
+
+def _conv_params(sd, name, cout, cin, ks, seed, gain=1.0):
+    import numpy as np
+    fan_in = cin * ks * ks
+    b = gain / math.sqrt(fan_in)
+    sd[name + "weight"] = torch.from_numpy(_rng(name + "weight", seed).uniform(-b, b, (cout, cin, ks, ks)).astype(np.float32))
+    sd[name + "bias"] = torch.from_numpy(_rng(name + "bias", seed).uniform(-b, b, (cout,)).astype(np.float32))
+
+
+def _gdn_params(sd, name, c, seed):
+    """mcquic/nn/gdn.py:47-62 init (beta = 1, gamma = 0.1 * I through NonNegativeParametrizer.init), plus a small
+    seeded positive perturbation so gamma is dense and the 1x1 contraction is exercised."""
+    import numpy as np
+    eps_sq = EPS ** 2
+    beta = np.ones(c, dtype=np.float64) + _rng(name + "beta", seed).uniform(0.0, 0.5, c)
+    gamma = 0.1 * np.eye(c) + _rng(name + "gamma", seed).uniform(0.0, 0.02, (c, c))
+    sd[name + "beta"] = torch.from_numpy(np.sqrt(np.maximum(beta + eps_sq, eps_sq)).astype(np.float32))
+    sd[name + "gamma"] = torch.from_numpy(np.sqrt(np.maximum(gamma + eps_sq, eps_sq)).astype(np.float32))
+    sd[name + "beta_reparam.eps"] = torch.tensor([eps_sq], dtype=torch.float32)
+    sd[name + "beta_reparam.lowerBound.bound"] = torch.tensor([(1e-4 + eps_sq) ** 0.5], dtype=torch.float32)
+    sd[name + "gamma_reparam.eps"] = torch.tensor([eps_sq], dtype=torch.float32)
+    sd[name + "gamma_reparam.lowerBound.bound"] = torch.tensor([(0.0 + eps_sq) ** 0.5], dtype=torch.float32)
+
+
+def _rb(sd, pre, c, seed):
+    _conv_params(sd, pre + "_branch.1.", c, c, 3, seed)
+    _conv_params(sd, pre + "_branch.3.", c, c, 3, seed)
+
+
+def _rb_stride(sd, pre, c, seed):
+    _conv_params(sd, pre + "_branch.1.", c, c, 3, seed)
+    _gdn_params(sd, pre + "_branch.2.", c, seed)
+    _conv_params(sd, pre + "_branch.3.", c, c, 3, seed)
+    _conv_params(sd, pre + "_skip.", c, c, 3, seed)
+
+
+def _rb_shuffle(sd, pre, c, seed):
+    _conv_params(sd, pre + "_branch.1.0.", 4 * c, c, 3, seed)
+    _gdn_params(sd, pre + "_branch.2.", c, seed)
+    _conv_params(sd, pre + "_branch.3.", c, c, 3, seed)
+    _conv_params(sd, pre + "_skip.0.", 4 * c, c, 3, seed)
+
+
+def _attn(sd, pre, c, seed):
+    for i in range(3):
+        _rb(sd, f"{pre}_mainBranch.{i}.", c, seed)
+        _rb(sd, f"{pre}_sideBranch.{i}.", c, seed)
+    _conv_params(sd, pre + "_sideBranch.3.", c, c, 1, seed)
+
+
+def make_state_dict(channel: int, m: int, k: List[int], seed: int = 0) -> StateDict:
+    """Seeded synthetic weights with exactly the reference's `Compressor(channel, m, k).state_dict()` keys and
+    shapes (compressor.py:120-177, quantizer.py:378-407, entropyCoder.py:22).  Conv weights ~ U(+-1/sqrt(fan_in))
+    (the nn.Conv2d default law), codebooks ~ N(0, 2/(5 d)) (quantizer.py:398), temperature = 1, freqEMA uniform."""
+    import numpy as np
+    sd: StateDict = {}
+    c = channel
+    e, dcd = "_encoder.", "_decoder."
+    _conv_params(sd, e + "0.", c, 3, 3, seed)
+    _rb(sd, e + "1.", c, seed); _rb_stride(sd, e + "2.", c, seed); _attn(sd, e + "3.", c, seed)
+    _rb(sd, e + "4.", c, seed); _rb_stride(sd, e + "5.", c, seed); _rb(sd, e + "6.", c, seed)
+    _rb(sd, dcd + "0.", c, seed); _rb_shuffle(sd, dcd + "1.", c, seed); _attn(sd, dcd + "2.", c, seed)
+    _rb(sd, dcd + "3.", c, seed); _rb_shuffle(sd, dcd + "4.", c, seed); _rb(sd, dcd + "5.", c, seed)
+    _conv_params(sd, dcd + "6.0.", 3 * 4, c, 3, seed)
+    d = c // m
+    for lv, ki in enumerate(k):
+        last = lv == len(k) - 1
+        pe, pd = f"_quantizer._encoders.{lv}.", f"_quantizer._decoders.{lv}."
+        cb = _rng(pe + "codebook", seed).normal(0.0, math.sqrt(2 / (5 * c / m)), (m, ki, d)).astype(np.float32)
+        cb_t = torch.from_numpy(cb)
+        sd[pe + "_quantizer._codebook"] = cb_t
+        sd[pe + "_quantizer._temperature"] = torch.ones(m, 1, 1, 1)
+        sd[pe + "_quantizer._bound.bound"] = torch.tensor([EPS], dtype=torch.float32)
+        sd[pe + "_dequantizer._codebook"] = cb_t
+        sd[pd + "_dequantizer._codebook"] = cb_t
+        _rb_stride(sd, pe + "_latentStageEncoder.0.", c, seed); _rb(sd, pe + "_latentStageEncoder.1.", c, seed)
+        _attn(sd, pe + "_latentStageEncoder.2.", c, seed)
+        _rb(sd, pe + "_quantizationHead.0.", c, seed); _attn(sd, pe + "_quantizationHead.1.", c, seed)
+        _conv_params(sd, pe + "_quantizationHead.2.", c, c, 3, seed)
+        if not last:
+            _rb(sd, pe + "_latentHead.0.", c, seed); _attn(sd, pe + "_latentHead.1.", c, seed)
+            _conv_params(sd, pe + "_latentHead.2.", c, c, 3, seed)
+        _attn(sd, pd + "_dequantizationHead.0.", c, seed); _conv_params(sd, pd + "_dequantizationHead.1.", c, c, 3, seed)
+        _rb(sd, pd + "_dequantizationHead.2.", c, seed)
+        if not last:
+            _attn(sd, pd + "_sideHead.0.", c, seed); _conv_params(sd, pd + "_sideHead.1.", c, c, 3, seed)
+            _rb(sd, pd + "_sideHead.2.", c, seed)
+        _attn(sd, pd + "_restoreHead.0.", c, seed); _rb(sd, pd + "_restoreHead.1.", c, seed)
+        _rb_shuffle(sd, pd + "_restoreHead.2.", c, seed)
+        sd[f"_quantizer._entropyCoder._freqEMA.{lv}"] = torch.ones(m, ki) / ki
+    return sd
+
+
+def make_images(n: int, h: int, w: int, seed: int = 3407) -> torch.Tensor:
+    """Synthetic batch x = 2 U[0,1) - 1, fp32 [n, 3, h, w] (seed 3407 = mcquic/train/utils.py:332)."""
+    import numpy as np
+    u = _rng(f"images:{n}x{h}x{w}", seed).random((n, 3, h, w), dtype=np.float32)
+    return torch.from_numpy(u * 2.0 - 1.0)

@@ -1,0 +1,68 @@
+"""End-to-end parity of mcquic_amd.Compressor (HIP) against the CPU oracle on seeded synthetic weights."""
+import pytest
+import torch
+
+from oracle import mcquic_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(dev, channel, m, k, n, h, w, seed, pix_tol):
+    from mcquic_amd import Compressor
+    sd = R.make_state_dict(channel, m, k, seed=seed)
+    model = Compressor(channel, m, k).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    x = R.make_images(n, h, w)
+    collect = {}
+    want_codes = R.quantizer_encode(sd, R.encoder(sd, R.aligned_padding(x)), collect)
+    got_codes = model.encode(x.to(dev))
+    mism = 0
+    for lv, (g, wc) in enumerate(zip(got_codes, want_codes)):
+        assert g.dtype == torch.int64 and g.shape == wc.shape
+        bad = g.cpu() != wc
+        if bad.any():
+            # near-tie audit on the oracle's own distances at this level
+            cb = sd[f"_quantizer._encoders.{lv}._quantizer._codebook"]
+            dist = R.vq_distance(collect["q"][lv], cb).double()
+            dg = torch.gather(dist, -1, g.cpu().unsqueeze(-1)).squeeze(-1)
+            dw = torch.gather(dist, -1, wc.unsqueeze(-1)).squeeze(-1)
+            gap = (dg - dw).abs()[bad].max().item()
+            assert gap < 1e-4, f"level {lv}: {int(bad.sum())} code mismatches, worst oracle gap {gap:.3e}"
+            mism += int(bad.sum())
+    # decode parity is checked from the ORACLE's codes so that an audited near-tie does not leak into pixels
+    want = R.decode(sd, want_codes)
+    got = model.decode([c.to(dev) for c in want_codes]).cpu()
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item()
+    assert err <= pix_tol, f"decode max abs err {err:.3e}"
+    u_got, u_want = R.detransform(got), R.detransform(want)
+    psnr = R.psnr(u_got, u_want)
+    assert float(psnr.min()) > 60.0       # identical up to a few rounding-boundary pixels
+    return mism, err
+
+
+def test_small_model_padded_input(dev):
+    _compare(dev, 8, 2, [32, 16, 8], n=2, h=200, w=136, seed=1, pix_tol=1e-4)
+
+
+def test_small_model_aligned_input(dev):
+    _compare(dev, 8, 2, [32, 16, 8], n=3, h=128, w=256, seed=2, pix_tol=1e-4)
+
+
+def test_qp2_model_one_image(dev):
+    """Compressor(128, 2, [8192, 2048, 512]) on one 256x384 image (the CPU oracle takes a few seconds)."""
+    _compare(dev, 128, 2, [8192, 2048, 512], n=1, h=256, w=384, seed=0, pix_tol=1e-4)
+
+
+def test_encode_is_batch_invariant(dev):
+    from mcquic_amd import Compressor
+    sd = R.make_state_dict(128, 2, [8192, 2048, 512], seed=0)
+    model = Compressor(128, 2, [8192, 2048, 512]).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    x = R.make_images(4, 128, 128).to(dev)
+    all_codes = model.encode(x)
+    one = model.encode(x[2:3])
+    for a, b in zip(all_codes, one):
+        assert torch.equal(a[2:3], b)

@@ -1,0 +1,212 @@
+"""GPU parity of every HIP entry point against the CPU oracle (oracle/mcquic_ref.py), through the C-ABI.
+
+Tolerances: the kernels accumulate in exact fp32 (v_mfma_f32_32x32x2_f32) but in a different order than
+oneDNN / MKL, so conv outputs agree to a few 1e-6 relative to the magnitude of the sum; indices and
+gathers are exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mcquic_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _close(got, want, tol, what):
+    got = got.cpu()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    assert err <= tol * max(ref, 1.0), f"{what}: max abs err {err:.3e} (ref max {ref:.3e})"
+
+
+CONV_CASES = [
+    # n, cin, cout, h, w, ks, stride
+    (2, 128, 128, 24, 32, 3, 1),
+    (1, 128, 128, 13, 37, 3, 1),     # ragged: not a multiple of any block shape
+    (2, 128, 128, 24, 16, 3, 2),
+    (1, 128, 128, 7, 5, 3, 2),
+    (3, 128, 128, 12, 8, 3, 1),      # smallest qp=2 level
+    (2, 3, 128, 32, 48, 3, 2),       # stem
+    (2, 128, 128, 16, 24, 1, 1),
+    (1, 8, 8, 10, 6, 3, 1),          # tiny channel count (the small fixture model)
+    (1, 8, 8, 9, 7, 1, 1),
+    (1, 128, 12, 16, 32, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [0, 0x42, 0x22, 0x21, 0x12, 0x11])
+def test_conv_plain(dev, case, tile):
+    from mcquic_amd import ops
+    n, cin, cout, h, w, ks, stride = case
+    if tile and (tile >> 4) * 32 > ((cout + 31) // 32) * 32:
+        pytest.skip("tile taller than Cout")
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, ks, ks), 2, 1.0 / np.sqrt(cin * ks * ks))
+    b = _rand((cout,), 3, 0.1)
+    want = F.conv2d(x, wt, b, stride=stride, padding=ks // 2)
+    pk = ops.PackedConv(wt.to(dev), b.to(dev))
+    got = ops.conv2d(x.to(dev), pk, stride, tile=tile)
+    assert got.shape == want.shape
+    _close(got, want, 2e-6, f"conv{case} tile={tile:#x}")
+
+
+def test_conv_identity_weight_asymmetric(dev):
+    """A = I with an asymmetric B catches row/col swaps of the MFMA fragment maps."""
+    from mcquic_amd import ops
+    c = 128
+    wt = torch.zeros(c, c, 1, 1)
+    wt[torch.arange(c), torch.arange(c), 0, 0] = 1.0
+    x = torch.arange(2 * c * 6 * 10, dtype=torch.float32).reshape(2, c, 6, 10) / 1000.0
+    pk = ops.PackedConv(wt.to(dev), None)
+    got = ops.conv2d(x.to(dev), pk)
+    assert torch.equal(got.cpu(), x)
+
+
+def test_conv_fused_epilogues(dev):
+    from mcquic_amd import ops
+    n, c, h, w = 2, 128, 20, 28
+    x = _rand((n, c, h, w), 11)
+    wt = _rand((c, c, 3, 3), 12, 1.0 / np.sqrt(c * 9))
+    b = _rand((c,), 13, 0.1)
+    res = _rand((n, c, h, w), 14)
+    a = _rand((n, c, h, w), 15)
+    pk = ops.PackedConv(wt.to(dev), b.to(dev))
+    xd = x.to(dev)
+    base = F.conv2d(F.silu(x), wt, b, padding=1)
+    _close(ops.conv2d(xd, pk, silu_in=True), base, 2e-6, "silu_in")
+    _close(ops.conv2d(xd, pk, silu_in=True, silu_out=True), F.silu(base), 2e-6, "silu_in+silu_out")
+    plain = F.conv2d(x, wt, b, padding=1)
+    _close(ops.conv2d(xd, pk, res=res.to(dev)), plain + res, 2e-6, "residual")
+    _close(ops.conv2d(xd, pk, res=res.to(dev), res_scale=-1.0), plain - res, 2e-6, "residual(-1)")
+    _close(ops.conv2d(xd, pk, gate_mul=a.to(dev), gate_id=res.to(dev)), a * torch.sigmoid(plain) + res, 2e-6, "gate")
+
+
+def test_conv_pixel_shuffle(dev):
+    from mcquic_amd import ops
+    n, c, h, w = 2, 128, 12, 20
+    x = _rand((n, c, h, w), 21)
+    wt = _rand((4 * c, c, 3, 3), 22, 1.0 / np.sqrt(c * 9))
+    b = _rand((4 * c,), 23, 0.1)
+    want = F.pixel_shuffle(F.conv2d(F.silu(x), wt, b, padding=1), 2)
+    got = ops.conv2d(x.to(dev), ops.PackedConv(wt.to(dev), b.to(dev)), silu_in=True, shuffle2=True)
+    assert got.shape == want.shape
+    _close(got, want, 2e-6, "pixel shuffle 512")
+    wt = _rand((12, c, 3, 3), 24, 1.0 / np.sqrt(c * 9))
+    b = _rand((12,), 25, 0.1)
+    want = F.pixel_shuffle(F.conv2d(x, wt, b, padding=1), 2)
+    got = ops.conv2d(x.to(dev), ops.PackedConv(wt.to(dev), b.to(dev)), shuffle2=True)
+    _close(got, want, 2e-6, "pixel shuffle head 12")
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("c", [8, 128])
+def test_gdn(dev, inverse, c):
+    from mcquic_amd.nn import GenDivNorm, InvGenDivNorm
+    sd = {}
+    R._gdn_params(sd, "g.", c, seed=3)
+    x = _rand((2, c, 14, 18), 31, 2.0)
+    want = R.gdn(sd, "g.", x, inverse)
+    mod = (InvGenDivNorm if inverse else GenDivNorm)(c)
+    mod.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    got = mod.to(dev)(x.to(dev))
+    _close(got, want, 3e-6, f"gdn inverse={inverse} c={c}")
+
+
+@pytest.mark.parametrize("c", [8, 128])
+def test_blocks(dev, c):
+    from mcquic_amd import nn as N
+    x = _rand((2, c, 16, 24), 41)
+    cases = [
+        (N.ResidualBlock(c, c), R._rb, R.residual_block),
+        (N.ResidualBlockWithStride(c, c), R._rb_stride, R.residual_block_with_stride),
+        (N.ResidualBlockShuffle(c, c), R._rb_shuffle, R.residual_block_shuffle),
+        (N.AttentionBlock(c), R._attn, R.attention_block),
+    ]
+    for mod, mk, fn in cases:
+        sd = {}
+        mk(sd, "b.", c, 7)
+        mod.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+        want = fn(sd, "b.", x)
+        got = mod.to(dev)(x.to(dev))
+        assert got.shape == want.shape
+        _close(got, want, 5e-6, type(mod).__name__)
+
+
+def _vq_case(m, k, d, n, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    cb = torch.randn((m, k, d), generator=g) * np.sqrt(2 / (5 * d))
+    x = torch.randn((n, m * d, h, w), generator=g) * 0.1
+    return x, cb
+
+
+def _audit_codes(got, x, cb, eps, what):
+    """Bit-exact indices, except where the oracle's own top-2 distance gap is below eps (near-tie audit)."""
+    dist = R.vq_distance(x, cb)                     # [n, m, h, w, k] fp32, the reference's arithmetic
+    want = dist.argmin(-1)
+    got = got.cpu()
+    bad = got != want
+    if bad.any():
+        dd = dist.double()
+        dg = torch.gather(dd, -1, got.unsqueeze(-1)).squeeze(-1)
+        dw = torch.gather(dd, -1, want.unsqueeze(-1)).squeeze(-1)
+        gap = (dg - dw).abs()[bad]
+        assert gap.max().item() < eps, f"{what}: {int(bad.sum())} mismatches, worst oracle gap {gap.max().item():.3e}"
+    return int(bad.sum())
+
+
+@pytest.mark.parametrize("shape", [(2, 8192, 64, 2, 12, 16), (2, 2048, 64, 2, 6, 8), (2, 512, 64, 3, 3, 5),
+                                   (4, 4096, 256, 1, 8, 8), (2, 32, 4, 2, 8, 8), (2, 200, 64, 1, 5, 7)])
+def test_vq_assign(dev, shape):
+    from mcquic_amd import ops
+    m, k, d, n, h, w = shape
+    x, cb = _vq_case(m, k, d, n, h, w, 51)
+    pk = ops.PackedCodebook(cb.to(dev))
+    got = ops.vq_assign(x.to(dev), pk)
+    assert got.dtype == torch.int64 and tuple(got.shape) == (n, m, h, w)
+    assert int(got.min()) >= 0 and int(got.max()) < k
+    _audit_codes(got, x, cb, 2e-6, f"vq{shape}")
+
+
+def test_vq_exact_ties_pick_first_index(dev):
+    """Duplicate codewords give bit-identical distances: argmin must return the first index (torch.argmin)."""
+    from mcquic_amd import ops
+    m, k, d = 2, 256, 64
+    x, cb = _vq_case(m, k, d, 1, 8, 8, 61)
+    cb[:, 128:, :] = cb[:, :128, :]          # every codeword appears twice, 128 apart (different MFMA tiles)
+    cb[:, 1::2, :] = cb[:, 0::2, :]          # and adjacent duplicates (same tile, neighbouring rows / half-waves)
+    got = ops.vq_assign(x.to(dev), ops.PackedCodebook(cb.to(dev))).cpu()
+    want = R.vq_encode(x, cb)
+    assert torch.equal(got, want)
+    assert int((got % 2).max()) == 0 and int(got.max()) < 128
+
+
+def test_vq_gather(dev):
+    from mcquic_amd import ops
+    m, k, d, n, h, w = 2, 512, 64, 3, 5, 7
+    _, cb = _vq_case(m, k, d, n, h, w, 71)
+    codes = torch.randint(0, k, (n, m, h, w), generator=torch.Generator().manual_seed(72))
+    got = ops.vq_gather(codes.to(dev), ops.PackedCodebook(cb.to(dev)))
+    assert torch.equal(got.cpu(), R.vq_decode(codes, cb))
+
+
+def test_add_and_detransform(dev):
+    from mcquic_amd import ops
+    a, b = _rand((3, 5, 7, 11), 81), _rand((3, 5, 7, 11), 82)
+    assert torch.equal(ops.add(a.to(dev), b.to(dev)).cpu(), a + b)
+    x = _rand((2, 3, 33, 17), 83, 1.2)
+    assert torch.equal(ops.detransform(x.to(dev)).cpu(), R.detransform(x))
+
+
+def test_cpu_tensor_is_rejected():
+    from mcquic_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.add(torch.zeros(4), torch.zeros(4))

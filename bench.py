@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Throughput of the Compressor encode+decode hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = `encode` (images -> codes) followed by `decode` (codes -> pixels) of one synthetic batch of
+32 images of 768x512 per GPU through the qp=2 model `Compressor(128, 2, [8192, 2048, 512])`, tensor path only
+(the protocol of the reference's `Validator.speed`, mcquic/validate/validator.py:60-97, minus the dead entropy
+coder).  Inputs are resident in HBM before the timed region.  Image batches shard across ranks with no
+data-path collective ("weak" scaling: 32 images per GPU); RCCL is used only for the barrier / max-time reduce.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel `conv_mfma_kernel` (fp32 MFMA bound):
+algorithmic FLOPs of the conv launches in the timed steps / their summed durations, both measured live with
+HIP events on the launch stream.  `cpu_baseline` times the CPU oracle (oracle/mcquic_ref.py, a plain PyTorch
+restatement of the reference proven bit-equal to it) on this host's cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+BATCH_PER_GPU = 32
+H, W = 768, 512
+MODEL = dict(channel=128, m=2, k=[8192, 2048, 512])
+
+
+class ConvProfiler:
+    """Brackets every conv launch with HIP events on the current stream (no host sync inside the region)."""
+
+    def __init__(self):
+        self.records = []           # (start, end, flops, bytes, tile)
+
+    def install(self):
+        from mcquic_amd import ops
+        self._orig = ops.conv2d
+        prof = self
+
+        def wrapped(x, w, stride=1, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = prof._orig(x, w, stride, **kw)
+            e.record()
+            n, cin, h, wd = x.shape
+            pad = w.ksize // 2
+            ho = (h + 2 * pad - w.ksize) // stride + 1
+            wo = (wd + 2 * pad - w.ksize) // stride + 1
+            flops = 2.0 * n * ho * wo * w.cout * cin * w.ksize * w.ksize
+            nbytes = 4.0 * (x.numel() + y.numel())
+            prof.records.append((s, e, flops, nbytes))
+            return y
+
+        ops.conv2d = wrapped
+        return self
+
+    def remove(self):
+        from mcquic_amd import ops
+        ops.conv2d = self._orig
+
+    def summary(self):
+        ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
+        fl = sum(r[2] for r in self.records)
+        by = sum(r[3] for r in self.records)
+        return dict(launches=len(self.records), ms=ms, flops=fl, bytes=by)
+
+
+def cpu_baseline(state_dict_cpu, x_cpu, iters=2):
+    """The CPU oracle on this host: batch len(x_cpu) of 768x512, 1 warm-up + `iters` timed encode+decode passes."""
+    from oracle import mcquic_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    codes = R.encode(state_dict_cpu, x_cpu)          # warm-up (also the parity sample)
+    pixels = R.decode(state_dict_cpu, codes)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        c = R.encode(state_dict_cpu, x_cpu)
+        R.decode(state_dict_cpu, c)
+    dt = time.perf_counter() - t0
+    base = {"value": round(len(x_cpu) * iters / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/mcquic_ref.py (PyTorch-CPU restatement, bit-equal to the reference in the build container): "
+                      f"batch {len(x_cpu)}x3x{H}x{W}, 1 warm-up + {iters} timed encode+decode passes, {dt:.1f} s"}
+    return base, codes, pixels
+
+
+def parity_report(gpu_codes, gpu_pixels, cpu_codes, cpu_pixels):
+    from oracle import mcquic_ref as R
+    mism = sum(int((a.cpu() != b).sum()) for a, b in zip(gpu_codes, cpu_codes))
+    total = sum(b.numel() for b in cpu_codes)
+    err = float((gpu_pixels.cpu() - cpu_pixels).abs().max())
+    psnr = float(R.psnr(R.detransform(gpu_pixels.cpu()), R.detransform(cpu_pixels)).min())
+    return {"code_mismatches": mism, "codes": total, "decode_max_abs_err": err,
+            "psnr_gpu_vs_cpu_u8_min_db": round(psnr, 2), "note": "decode compared from the CPU oracle's codes"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    from mcquic_amd import Compressor
+    torch.manual_seed(3407)                                   # same random-init weights on every rank
+    model = Compressor(**MODEL).eval().to(dev)
+    g = torch.Generator(device="cpu").manual_seed(3407 + rank)
+    x = (torch.rand((args.batch, 3, H, W), generator=g) * 2 - 1).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        codes = model.encode(x)
+        return codes, model.decode(codes)
+
+    for _ in range(args.warmup):
+        step()
+    prof = ConvProfiler().install()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof.remove()
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # secondary: each direction on its own (Mpps as in the reference's README), untimed region
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record(); codes = model.encode(x); e[1].record(); pix = model.decode(codes); e[2].record()
+    torch.cuda.synchronize()
+    enc_ms, dec_ms = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+
+    if rank == 0:
+        conv = prof.summary()
+        images = world * args.batch * args.steps
+        value = images / dt
+        achieved_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        out = {
+            "metric": "images/sec encode+decode, 768x512 Kodak-shape batch, qp=2",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (uniform [-1,1) images, random-init weights)",
+            "config": {"workload": f"qp=2 reference model Compressor(128, 2, [8192, 2048, 512]), batch={args.batch} "
+                                   f"768x512 random images per GPU, encode+decode tensor path (BASELINE configs[1])",
+                       "images_per_gpu": args.batch, "parallelism": f"dp{world} (independent image shards, no data-path collective)"},
+            "encode_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3),
+            "encode_mpps": round(args.batch * H * W / 1e3 / enc_ms, 3), "decode_mpps": round(args.batch * H * W / 1e3 / dec_ms, 3),
+            "roofline": {
+                "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM, all tile variants)",
+                "achieved": round(achieved_tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved_tf / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": conv["launches"] // max(args.steps, 1),
+                "avg_launch_ms": round(conv["ms"] / max(conv["launches"], 1), 4),
+                "conv_ms_per_step": round(conv["ms"] / max(args.steps, 1), 3),
+                "algorithmic_gflop_per_step": round(conv["flops"] / max(args.steps, 1) / 1e9, 2),
+                "hbm_algorithmic_gbs": round(conv["bytes"] / (conv["ms"] * 1e-3) / 1e9, 1) if conv["ms"] > 0 else None,
+                "whole_step_frac": round(536.63e9 * args.batch / (dt / args.steps) / (FP32_MATRIX_PEAK_TFLOPS * 1e12), 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            nb = min(args.cpu_batch, args.batch)
+            sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            base, cpu_codes, cpu_pix = cpu_baseline(sd_cpu, x[:nb].cpu())
+            gpu_pix = model.decode([c.to(dev) for c in cpu_codes])
+            out["cpu_baseline"] = base
+            out["parity"] = parity_report([c[:nb] for c in codes], gpu_pix, cpu_codes, cpu_pix)
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

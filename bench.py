@@ -75,10 +75,23 @@ class ConvProfiler:
         return dict(launches=len(self.records), ms=ms, flops=fl, bytes=by)
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask and cgroup CPU quota, not the host's core count
+    (oversubscribing a quota-limited container with one thread per host core is pathologically slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(state_dict_cpu, x_cpu, iters=2):
     """The CPU oracle on this host: batch len(x_cpu) of 768x512, 1 warm-up + `iters` timed encode+decode passes."""
     from oracle import mcquic_ref as R
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     codes = R.encode(state_dict_cpu, x_cpu)          # warm-up (also the parity sample)
     pixels = R.decode(state_dict_cpu, codes)

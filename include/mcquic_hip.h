@@ -40,12 +40,14 @@ extern "C" {
 #define MCQ_CONV_IGDN       0x020u /* y = mul * sqrt(acc)               (gdn.py:91  x * torch.sqrt(std))  */
 #define MCQ_CONV_GATE       0x040u /* y = mul * sigmoid(acc) + gate_id  (blocks.py:281-288 AttentionBlock.forward) */
 #define MCQ_CONV_SHUFFLE2   0x080u /* store through nn.PixelShuffle(2)  (mcquic/nn/convs.py:221-255 pixelShuffle3x3) */
+#define MCQ_CONV_DUAL_SILU  0x100u /* also store silu(y) to y_silu: the next block's act1(x), computed once per element */
 
 typedef struct mcq_conv_desc {
     const float* x;        /* [N, Cin, H, W]                                                      */
     const float* w_packed; /* from mcq_pack_conv_weight_f32                                        */
     const float* bias;     /* [Cout] or NULL                                                       */
     float*       y;        /* [N, Cout, Ho, Wo]; with SHUFFLE2: [N, Cout/4, 2Ho, 2Wo]              */
+    float*       y_silu;   /* DUAL_SILU: same shape as y, receives silu(y)                         */
     const float* res;      /* RESIDUAL: same shape as y                                            */
     const float* mul;      /* GDN/IGDN/GATE: same shape as y                                       */
     const float* gate_id;  /* GATE: same shape as y                                                */
@@ -98,14 +100,14 @@ int mcq_vq_assign_f32(const float* x, const float* cb_packed, int64_t* codes,
 /* out[n, g*d + j, y, x] = codebook[g, codes[n, g, y, x], j]
  * (mcquic/modules/quantizer.py:249-259 _multiCodebookDeQuantization.decode).
  * Returns MCQ_OK; indices outside [0, k) are clamped (the reference would raise IndexError). */
-int mcq_vq_gather_f32(const int64_t* codes, const float* codebook, float* out,
+int mcq_vq_gather_f32(const int64_t* codes, const float* codebook, float* out, float* out_silu /* or NULL */,
                       int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k,
                       void* stream);
 
 /* ---- small element-wise helpers on the path ------------------------------------------------ */
 
 /* out = a + b  (quantizer.py:354  xHat = q + sideHead(formerLevel)). */
-int mcq_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+int mcq_add_f32(const float* a, const float* b, float* out, float* out_silu /* or NULL */, int64_t n, void* stream);
 
 /* u8 = trunc(clamp(((x + 1) / 2) * 255.999, 0, 255))   (mcquic/utils/vision.py:143-146 DeTransform). */
 int mcq_detransform_u8(const float* x, uint8_t* out, int64_t n, void* stream);

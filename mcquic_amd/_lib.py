@@ -17,12 +17,12 @@ _ERR = {MCQ_EINVAL: "MCQ_EINVAL (invalid argument)", MCQ_ELAUNCH: "MCQ_ELAUNCH (
         MCQ_ETOOLARGE: "MCQ_ETOOLARGE (tensor exceeds the addressing window)"}
 
 CONV_SILU_IN, CONV_SQUARE_IN, CONV_SILU_OUT, CONV_RESIDUAL = 0x1, 0x2, 0x4, 0x8
-CONV_GDN, CONV_IGDN, CONV_GATE, CONV_SHUFFLE2 = 0x10, 0x20, 0x40, 0x80
+CONV_GDN, CONV_IGDN, CONV_GATE, CONV_SHUFFLE2, CONV_DUAL_SILU = 0x10, 0x20, 0x40, 0x80, 0x100
 
 
 class ConvDesc(Structure):
     """struct mcq_conv_desc (include/mcquic_hip.h)."""
-    _fields_ = [("x", c_void_p), ("w_packed", c_void_p), ("bias", c_void_p), ("y", c_void_p), ("res", c_void_p),
+    _fields_ = [("x", c_void_p), ("w_packed", c_void_p), ("bias", c_void_p), ("y", c_void_p), ("y_silu", c_void_p), ("res", c_void_p),
                 ("mul", c_void_p), ("gate_id", c_void_p),
                 ("N", c_int32), ("Cin", c_int32), ("H", c_int32), ("W", c_int32), ("Cout", c_int32),
                 ("ksize", c_int32), ("stride", c_int32), ("flags", c_uint32), ("res_scale", c_float),
@@ -39,9 +39,9 @@ SYMBOLS = {
     "mcq_vq_pack_codebook_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "mcq_vq_assign_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
-    "mcq_vq_gather_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+    "mcq_vq_gather_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
-    "mcq_add_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_add_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_detransform_u8": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_version": (c_char_p, []),
 }

@@ -19,12 +19,12 @@
 namespace {
 
 struct ConvK {
-    const float* x; const float* wp; const float* bias; float* y;
+    const float* x; const float* wp; const float* bias; float* y; float* y2;
     const float* res; const float* mul; const float* gid;
     int N, Cin, H, W, Cout, Ho, Wo;
     int ks, stride;
     int S;             // input-channel pairs per tap
-    int TP;            // k-steps per 128-cout tile, padded to a multiple of 8
+    int TP;            // k-steps per 128-cout tile, padded to a multiple of 16 (the deepest prefetch ring)
     int bw_log2;       // a pixel block is (32 >> bw_log2) rows x (1 << bw_log2) cols
     int nbx, nby, total_blocks;
     unsigned flags; float res_scale;
@@ -224,13 +224,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (ok[r]) p.y[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
+                if (fl & MCQ_CONV_DUAL_SILU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (ok[r]) p.y2[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
+                }
             }
         }
     }
 }
 
 // OIHW -> [Cout/128][TP][64 lanes][4]: lane l, slot q holds W[co = 128 T + 32 q + (l & 31)][ci = 2 s + (l >> 5)][tap]
-// for k-step = tap * S + s; zero beyond Cout / Cin / the real step count and in the 8-step tail.
+// for k-step = tap * S + s; zero beyond Cout / Cin / the real step count and in the 16-step tail.
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, int S, int TP,
                                         int ntile, float* __restrict__ out, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,7 +270,7 @@ __global__ void nonneg_reparam_kernel(const float* __restrict__ p, float bound, 
 inline int steps_padded(int Cin, int ks) {
     const int S = (Cin + 1) / 2;
     const int T = ks * ks * S;
-    return (T + 7) & ~7;
+    return (T + 15) & ~15;
 }
 
 template <int MB, int NB, int PF>
@@ -281,7 +288,7 @@ int launch_tile(const ConvK& k, int pro, dim3 grid, hipStream_t s) {
 extern "C" size_t mcq_packed_conv_weight_floats(int32_t Cout, int32_t Cin, int32_t ksize) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
     const size_t ntile = (size_t)(Cout + 127) / 128;
-    return (ntile * (size_t)steps_padded(Cin, ksize) + 8) * 256;   // + 8 zero steps read by the prefetch tail
+    return (ntile * (size_t)steps_padded(Cin, ksize) + 16) * 256;   // + 16 zero steps read by the prefetch tail
 }
 
 extern "C" int mcq_pack_conv_weight_f32(const float* w, int32_t Cout, int32_t Cin, int32_t ksize, float* out,
@@ -310,6 +317,7 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     if ((fl & MCQ_CONV_RESIDUAL) && !d->res) return MCQ_EINVAL;
     if ((fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) && !d->mul) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_GATE) && !d->gate_id) return MCQ_EINVAL;
+    if ((fl & MCQ_CONV_DUAL_SILU) && (!d->y_silu || (fl & MCQ_CONV_SILU_OUT))) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_SILU_IN) && (fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;
     if (fl & MCQ_CONV_SHUFFLE2) {
         if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN))) return MCQ_EINVAL;
@@ -317,7 +325,7 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     if ((uint64_t)d->Cin * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
 
     ConvK k;
-    k.x = d->x; k.wp = d->w_packed; k.bias = d->bias; k.y = d->y; k.res = d->res; k.mul = d->mul; k.gid = d->gate_id;
+    k.x = d->x; k.wp = d->w_packed; k.bias = d->bias; k.y = d->y; k.y2 = d->y_silu; k.res = d->res; k.mul = d->mul; k.gid = d->gate_id;
     k.N = d->N; k.Cin = d->Cin; k.H = d->H; k.W = d->W; k.Cout = d->Cout;
     k.ks = d->ksize; k.stride = d->stride;
     const int pad = d->ksize / 2;
@@ -365,8 +373,8 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (MB == 4 && NB == 2) return launch_tile<4, 2, 4>(k, pro, grid, s);
     if (MB == 2 && NB == 2) return launch_tile<2, 2, 8>(k, pro, grid, s);
-    if (MB == 2 && NB == 1) return launch_tile<2, 1, 8>(k, pro, grid, s);
+    if (MB == 2 && NB == 1) return launch_tile<2, 1, 16>(k, pro, grid, s);
     if (MB == 1 && NB == 2) return launch_tile<1, 2, 8>(k, pro, grid, s);
-    if (MB == 1 && NB == 1) return launch_tile<1, 1, 8>(k, pro, grid, s);
+    if (MB == 1 && NB == 1) return launch_tile<1, 1, 16>(k, pro, grid, s);
     return MCQ_EINVAL;
 }

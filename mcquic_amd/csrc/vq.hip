@@ -206,7 +206,7 @@ __global__ void vq_c2_kernel(const float* __restrict__ cb, int m, int k, int d, 
 }
 
 __global__ void vq_gather_kernel(const int64_t* __restrict__ codes, const float* __restrict__ cb, float* __restrict__ out,
-                                 int N, int m, int d, int hw, int k) {
+                                 float* __restrict__ out2, int N, int m, int d, int hw, int k) {
     // one thread per (n, g, pixel); writes d channel planes (coalesced across threads)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)N * m * hw;
@@ -220,16 +220,27 @@ __global__ void vq_gather_kernel(const int64_t* __restrict__ codes, const float*
     const float* row = cb + ((size_t)g * k + (size_t)code) * d;
     float* o = out + ((n * m + g) * (size_t)d) * hw + pix;
     for (int c = 0; c < d; ++c) o[(size_t)c * hw] = row[c];
+    if (out2) {
+        float* o2 = out2 + ((n * m + g) * (size_t)d) * hw + pix;
+        for (int c = 0; c < d; ++c) o2[(size_t)c * hw] = mcq_silu(row[c]);
+    }
 }
 
-__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n) {
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                           float* __restrict__ out2, int64_t n) {
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
         const f32x4v va = *reinterpret_cast<const f32x4v*>(a + i);
         const f32x4v vb = *reinterpret_cast<const f32x4v*>(b + i);
-        *reinterpret_cast<f32x4v*>(out + i) = va + vb;
+        const f32x4v vs = va + vb;
+        *reinterpret_cast<f32x4v*>(out + i) = vs;
+        if (out2) *reinterpret_cast<f32x4v*>(out2 + i) = f32x4v{mcq_silu(vs[0]), mcq_silu(vs[1]), mcq_silu(vs[2]), mcq_silu(vs[3])};
     } else {
-        for (; i < n; ++i) out[i] = a[i] + b[i];
+        for (; i < n; ++i) {
+            const float v = a[i] + b[i];
+            out[i] = v;
+            if (out2) out2[i] = mcq_silu(v);
+        }
     }
 }
 
@@ -305,19 +316,19 @@ extern "C" int mcq_vq_assign_f32(const float* x, const float* cb_packed, int64_t
     return mcq_check_launch();
 }
 
-extern "C" int mcq_vq_gather_f32(const int64_t* codes, const float* codebook, float* out, int32_t N, int32_t m, int32_t d,
-                                 int32_t h, int32_t w, int32_t k, void* stream) {
+extern "C" int mcq_vq_gather_f32(const int64_t* codes, const float* codebook, float* out, float* out_silu, int32_t N,
+                                 int32_t m, int32_t d, int32_t h, int32_t w, int32_t k, void* stream) {
     if (!codes || !codebook || !out || N <= 0 || m <= 0 || d <= 0 || h <= 0 || w <= 0 || k <= 0) return MCQ_EINVAL;
     const size_t total = (size_t)N * m * h * w;
     hipLaunchKernelGGL(vq_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, codes,
-                       codebook, out, N, m, d, h * w, k);
+                       codebook, out, out_silu, N, m, d, h * w, k);
     return mcq_check_launch();
 }
 
-extern "C" int mcq_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+extern "C" int mcq_add_f32(const float* a, const float* b, float* out, float* out_silu, int64_t n, void* stream) {
     if (!a || !b || !out || n <= 0) return MCQ_EINVAL;
     const int64_t threads = (n + 3) / 4;
-    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, out_silu, n);
     return mcq_check_launch();
 }
 

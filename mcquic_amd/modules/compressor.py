@@ -92,11 +92,17 @@ class BaseCompressor(nn.Module):
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError(f"expected an image batch [n, 3, h, w], got {tuple(x.shape)}")
 
+    def _encode_latent(self, x: torch.Tensor) -> torch.Tensor:
+        """`self._encoder(self._padding(x))`; the stem conv also emits silu(.) for the first ResidualBlock."""
+        y = self._encoder[0](self._padding(x), dual_silu=True)
+        for i in range(1, len(self._encoder)):
+            y = self._encoder[i](y)
+        return y
+
     def encode(self, x: torch.Tensor) -> List[torch.Tensor]:
         self._check(x)
         with torch.no_grad():
-            y = self._encoder(self._padding(x))
-            return self._quantizer.encode(y)
+            return self._quantizer.encode(self._encode_latent(x))
 
     def decode(self, codes: List[torch.Tensor]) -> torch.Tensor:
         with torch.no_grad():
@@ -106,8 +112,7 @@ class BaseCompressor(nn.Module):
         self._check(x)
         n, c, h, w = x.shape
         with torch.no_grad():
-            y = self._encoder(self._padding(x))
-            codes, binaries, codeSizes = self._quantizer.compress(y)
+            codes, binaries, codeSizes = self._quantizer.compress(self._encode_latent(x))
         header = [FileHeader(__version__, self._qp, codeSize, ImageSize(height=h, width=w, channel=c)) for codeSize in codeSizes]
         return codes, binaries, header
 

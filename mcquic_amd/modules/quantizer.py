@@ -68,9 +68,9 @@ class _multiCodebookDeQuantization(nn.Module):
         self._codebook = codebook
         self._cache = [cache]
 
-    def decode(self, code: torch.Tensor) -> torch.Tensor:
+    def decode(self, code: torch.Tensor, dual_silu: bool = False) -> torch.Tensor:
         """int64 [n, m, h, w] -> [n, m*d, h, w] (:249-259)."""
-        return ops.vq_gather(code, self._cache[0].get(self._codebook))
+        return ops.vq_gather(code, self._cache[0].get(self._codebook), dual_silu=dual_silu)
 
 
 class _quantizerEncoder(nn.Module):
@@ -99,7 +99,7 @@ class _quantizerEncoder(nn.Module):
         t = z
         for i in range(len(head) - 1):
             t = head[i](t)
-        return head[len(head) - 1](t, res=deq, res_scale=-1.0), code
+        return head[len(head) - 1](t, res=deq, res_scale=-1.0, dual_silu=True), code
 
 
 class _quantizerDecoder(nn.Module):
@@ -113,9 +113,9 @@ class _quantizerDecoder(nn.Module):
         self._restoreHead = restoreHead
 
     def decode(self, code: torch.Tensor, formerLevel: Optional[torch.Tensor]):
-        q = self._dequantizationHead(self._dequantizer.decode(code))
+        q = self._dequantizationHead(self._dequantizer.decode(code, dual_silu=True))
         if self._sideHead is not None:
-            xHat = ops.add(q, self._sideHead(formerLevel))          # q + sideHead(formerLevel) (:354)
+            xHat = ops.add(q, self._sideHead(formerLevel), dual_silu=True)     # q + sideHead(formerLevel) (:354)
         else:
             xHat = q
         return self._restoreHead(xHat)

@@ -5,6 +5,9 @@ Same classes, constructor arguments and state_dict keys as the reference (mcquic
 `AttentionBlock` (:245-288).  What the reference runs as separate torch kernels (SiLU, `out += identity`,
 GDN's multiply, `a * sigmoid(b) + x`) rides in the prologue / epilogue of the conv launches:
 
+Every block's closing launch also stores silu(out) beside out (`dual_silu`): the next block's act1 is then
+computed once per element in an epilogue instead of once per tap inside the consumer's k-loop.
+
     ResidualBlock            2 launches   conv(silu_in, silu_out) ; conv(+ x)
     ResidualBlockWithStride  4 launches   conv s2(silu_in) ; GDN 1x1 ; skip conv s2 ; conv(+ skip)
     ResidualBlockShuffle     4 launches   conv+shuffle(silu_in) ; IGDN 1x1 ; skip conv+shuffle ; conv(+ skip)
@@ -43,7 +46,7 @@ class ResidualBlock(_residulBlock):
 
     def forward(self, x: torch.Tensor, res2: Optional[torch.Tensor] = None) -> torch.Tensor:
         t = self._branch[1](x, silu_in=True, silu_out=True)      # silu(conv1(silu(x)))
-        return self._branch[3](t, res=x)                          # conv2(.) + x
+        return self._branch[3](t, res=x, dual_silu=True)          # conv2(.) + x
 
 
 class ResidualBlockWithStride(_residulBlock):
@@ -59,7 +62,7 @@ class ResidualBlockWithStride(_residulBlock):
         t = self._branch[1](x, silu_in=True)
         t = self._branch[2](t)
         identity = self._skip(x)
-        return self._branch[3](t, res=identity)
+        return self._branch[3](t, res=identity, dual_silu=True)
 
 
 class ResidualBlockShuffle(_residulBlock):
@@ -75,7 +78,7 @@ class ResidualBlockShuffle(_residulBlock):
         t = self._branch[1](x, silu_in=True)
         t = self._branch[2](t)
         identity = self._skip(x)
-        return self._branch[3](t, res=identity)
+        return self._branch[3](t, res=identity, dual_silu=True)
 
 
 class AttentionBlock(nn.Module):
@@ -92,4 +95,4 @@ class AttentionBlock(nn.Module):
         b = x
         for i in range(3):
             b = self._sideBranch[i](b)
-        return self._sideBranch[3](b, gate_mul=a, gate_id=x)
+        return self._sideBranch[3](b, gate_mul=a, gate_id=x, dual_silu=True)

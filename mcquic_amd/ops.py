@@ -12,8 +12,18 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN, CONV_SILU_OUT,
-                   CONV_SQUARE_IN, ConvDesc, check)
+from ._lib import (CONV_DUAL_SILU, CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN,
+                   CONV_SILU_OUT, CONV_SQUARE_IN, ConvDesc, check)
+
+# A producer asked for `dual_silu` hangs silu(y) on its result under this attribute; a consumer asked for
+# `silu_in` uses the twin instead of re-evaluating SiLU inside its k-loop (9 taps x 2 half-waves times per
+# element).  The twin is only valid while y is not modified in place -- nothing in this package does that.
+_TWIN = "_mcq_silu_twin"
+
+
+def silu_twin(t: torch.Tensor) -> Optional[torch.Tensor]:
+    return getattr(t, _TWIN, None)
+
 
 
 def _stream() -> ctypes.c_void_p:
@@ -56,8 +66,12 @@ def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = F
            silu_out: bool = False, res: Optional[torch.Tensor] = None, res_scale: float = 1.0,
            gdn_mul: Optional[torch.Tensor] = None, igdn_mul: Optional[torch.Tensor] = None,
            gate_mul: Optional[torch.Tensor] = None, gate_id: Optional[torch.Tensor] = None,
-           shuffle2: bool = False, tile: int = 0) -> torch.Tensor:
+           shuffle2: bool = False, dual_silu: bool = False, tile: int = 0) -> torch.Tensor:
     """y = epilogue(conv(prologue(x)) + bias); one kernel launch (mcq_conv2d_f32)."""
+    if silu_in:
+        twin = silu_twin(x)
+        if twin is not None:
+            x, silu_in = twin, False
     x = _dev(x, "x")
     n, cin, h, wd = x.shape
     if cin != w.cin:
@@ -77,6 +91,10 @@ def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = F
         y = torch.empty((n, w.cout // 4, 2 * ho, 2 * wo), dtype=torch.float32, device=x.device)
     else:
         y = torch.empty((n, w.cout, ho, wo), dtype=torch.float32, device=x.device)
+    y2 = None
+    if dual_silu:
+        flags |= CONV_DUAL_SILU
+        y2 = torch.empty_like(y)
     mul = None
     if res is not None:
         flags |= CONV_RESIDUAL
@@ -93,11 +111,13 @@ def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = F
         gate_id = _dev(gate_id, "gate_id")
         if gate_id.shape != y.shape:
             raise ValueError("gate identity shape mismatch")
-    d = ConvDesc(_ptr(x), _ptr(w.wp), _ptr(w.bias), _ptr(y), _ptr(res), _ptr(mul), _ptr(gate_id),
+    d = ConvDesc(_ptr(x), _ptr(w.wp), _ptr(w.bias), _ptr(y), _ptr(y2), _ptr(res), _ptr(mul), _ptr(gate_id),
                  n, cin, h, wd, w.cout, w.ksize, stride, flags, float(res_scale), tile)
     lib = _lib.load()
     with torch.cuda.device(x.device):
         check(lib.mcq_conv2d_f32(ctypes.byref(d), _stream()), "mcq_conv2d_f32")
+    if y2 is not None:
+        setattr(y, _TWIN, y2)
     return y
 
 
@@ -140,26 +160,32 @@ def vq_assign(x: torch.Tensor, cb: PackedCodebook) -> torch.Tensor:
     return codes
 
 
-def vq_gather(codes: torch.Tensor, cb: PackedCodebook) -> torch.Tensor:
+def vq_gather(codes: torch.Tensor, cb: PackedCodebook, dual_silu: bool = False) -> torch.Tensor:
     """fp32 [n, m*d, h, w] = codebook[g, codes] (mcq_vq_gather_f32)."""
     codes = _dev(codes, "codes", torch.int64)
     n, m, h, w = codes.shape
     if m != cb.m:
         raise RuntimeError(f"codes carry m={m}, codebook has m={cb.m}")
     out = torch.empty((n, m * cb.d, h, w), dtype=torch.float32, device=codes.device)
+    out2 = torch.empty_like(out) if dual_silu else None
     with torch.cuda.device(codes.device):
-        check(_lib.load().mcq_vq_gather_f32(_ptr(codes), _ptr(cb.codebook), _ptr(out), n, m, cb.d, h, w, cb.k, _stream()),
-              "mcq_vq_gather_f32")
+        check(_lib.load().mcq_vq_gather_f32(_ptr(codes), _ptr(cb.codebook), _ptr(out), _ptr(out2), n, m, cb.d, h, w, cb.k,
+                                            _stream()), "mcq_vq_gather_f32")
+    if out2 is not None:
+        setattr(out, _TWIN, out2)
     return out
 
 
-def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def add(a: torch.Tensor, b: torch.Tensor, dual_silu: bool = False) -> torch.Tensor:
     a, b = _dev(a, "a"), _dev(b, "b")
     if a.shape != b.shape:
         raise ValueError("add: shape mismatch")
     out = torch.empty_like(a)
+    out2 = torch.empty_like(a) if dual_silu else None
     with torch.cuda.device(a.device):
-        check(_lib.load().mcq_add_f32(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "mcq_add_f32")
+        check(_lib.load().mcq_add_f32(_ptr(a), _ptr(b), _ptr(out), _ptr(out2), a.numel(), _stream()), "mcq_add_f32")
+    if out2 is not None:
+        setattr(out, _TWIN, out2)
     return out
 
 

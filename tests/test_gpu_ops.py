@@ -210,3 +210,30 @@ def test_cpu_tensor_is_rejected():
     from mcquic_amd import ops
     with pytest.raises(RuntimeError):
         ops.add(torch.zeros(4), torch.zeros(4))
+
+
+def test_dual_silu_twin(dev):
+    """A producer's `dual_silu` twin is silu(y) and a consumer's `silu_in` picks it up (same result as the
+    in-kernel SiLU prologue, which stays available for inputs without a twin)."""
+    from mcquic_amd import ops
+    n, c, h, w = 2, 128, 10, 14
+    x = _rand((n, c, h, w), 91)
+    wt = _rand((c, c, 3, 3), 92, 1.0 / np.sqrt(c * 9))
+    b = _rand((c,), 93, 0.1)
+    pk = ops.PackedConv(wt.to(dev), b.to(dev))
+    y = ops.conv2d(x.to(dev), pk, dual_silu=True)
+    twin = ops.silu_twin(y)
+    assert twin is not None
+    want_y = F.conv2d(x, wt, b, padding=1)
+    _close(y, want_y, 2e-6, "dual y")
+    _close(twin, F.silu(want_y), 2e-6, "dual silu(y)")
+    z_twin = ops.conv2d(y, pk, silu_in=True)                    # consumes the twin
+    z_fused = ops.conv2d(y.clone(), pk, silu_in=True)           # clone drops the twin: in-kernel SiLU
+    want_z = F.conv2d(F.silu(want_y), wt, b, padding=1)
+    _close(z_twin, want_z, 3e-6, "silu_in via twin")
+    _close(z_fused, want_z, 3e-6, "silu_in in-kernel")
+    g = ops.vq_gather(torch.zeros((1, 2, 3, 3), dtype=torch.int64, device=dev),
+                      ops.PackedCodebook(_rand((2, 16, 4), 94).to(dev)), dual_silu=True)
+    assert torch.equal(ops.silu_twin(g).cpu(), F.silu(g.cpu())) or (ops.silu_twin(g).cpu() - F.silu(g.cpu())).abs().max() < 1e-6
+    s = ops.add(x.to(dev), x.to(dev), dual_silu=True)
+    assert (ops.silu_twin(s).cpu() - F.silu(x + x)).abs().max() < 1e-6

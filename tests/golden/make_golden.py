@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the REAL reference (xiaosu-zhu/McQuic, imported unmodified from /root/reference
+through oracle/ref_harness.py).  Runs only in the build container; the outputs (small .npz files of inputs /
+expected outputs -- data, no reference source) are committed under tests/golden/.
+
+    python tests/golden/make_golden.py
+
+Inputs and weights come from the repo's own seeded generators (oracle.mcquic_ref.make_state_dict / make_images /
+plain torch.Generator), so fixtures store seeds + expected outputs and stay small.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import mcquic_ref as R          # noqa: E402  (generators only; expected values come from the reference)
+from oracle import ref_harness              # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
+
+
+def main():
+    C = ref_harness.load()
+    import mcquic.nn as RN                      # the reference's layers
+    import mcquic.modules.quantizer as RQ
+    from mcquic.data.transforms import AlignedPadding
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    # ---- F1: per-block I/O at C = 8 (odd sizes) -------------------------------------------------------
+    blocks = {}
+    c = 8
+    x = rand((2, c, 13, 18), 101)
+    blocks["x"] = x.numpy()
+    for name, ctor, mk in [("ResidualBlock", lambda: RN.ResidualBlock(c, c), R._rb),
+                           ("ResidualBlockWithStride", lambda: RN.ResidualBlockWithStride(c, c), R._rb_stride),
+                           ("ResidualBlockShuffle", lambda: RN.ResidualBlockShuffle(c, c), R._rb_shuffle),
+                           ("AttentionBlock", lambda: RN.blocks.AttentionBlock(c), R._attn)]:
+        sd = {}
+        mk(sd, "", c, 11)
+        mod = ctor().eval()
+        mod.load_state_dict(sd, strict=True)
+        with torch.inference_mode():
+            blocks[name] = mod(x.clone()).numpy()
+    for name, cls in [("GenDivNorm", RN.GenDivNorm), ("InvGenDivNorm", RN.InvGenDivNorm)]:
+        sd = {}
+        R._gdn_params(sd, "", c, 12)
+        mod = cls(c).eval()
+        mod.load_state_dict(sd, strict=True)
+        with torch.inference_mode():
+            blocks[name] = mod(x.clone() * 2).numpy()
+    np.savez_compressed(os.path.join(OUT, "f1_blocks_c8.npz"), **blocks)
+
+    # ---- F2 / F3: VQ distance + argmin, gather (the reference's _multiCodebookQuantization) -------------
+    vq = {}
+    for tag, (m, k, d, n, h, w) in {"qp2_l2": (2, 512, 64, 2, 6, 8), "qp2_l1": (2, 2048, 64, 1, 6, 8),
+                                    "small": (2, 32, 4, 2, 8, 8)}.items():
+        g = torch.Generator().manual_seed(7)
+        cb = torch.randn((m, k, d), generator=g) * np.sqrt(2 / (5 * d))
+        xx = torch.randn((n, m * d, h, w), generator=g) * 0.1
+        q = RQ._multiCodebookQuantization(torch.nn.Parameter(cb), 0.0)
+        dq = RQ._multiCodebookDeQuantization(torch.nn.Parameter(cb))
+        with torch.inference_mode():
+            dist = q._distance(xx)
+            code = q.encode(xx)
+            deq = dq.decode(code)
+        top2 = torch.topk(dist, 2, dim=-1, largest=False).values
+        vq[tag + "_shape"] = np.array([m, k, d, n, h, w])
+        vq[tag + "_code"] = code.numpy().astype(np.int16)
+        vq[tag + "_gap"] = (top2[..., 1] - top2[..., 0]).numpy()
+        vq[tag + "_mindist"] = top2[..., 0].numpy()
+        vq[tag + "_deq_sha"] = np.frombuffer(bytes.fromhex(sha(deq)), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "f2_vq.npz"), **vq)
+
+    # ---- F4: the full small model Compressor(8, 2, [32, 16, 8]) ----------------------------------------
+    small = {}
+    sd = R.make_state_dict(8, 2, [32, 16, 8], seed=1)
+    model = ref_harness.reference_compressor(8, 2, [32, 16, 8], sd)
+    for tag, (n, h, w) in {"pad": (2, 200, 136), "aligned": (1, 128, 256)}.items():
+        xi = R.make_images(n, h, w)
+        with torch.inference_mode():
+            codes = model.encode(xi)
+            rec = model.decode(codes)
+        small[tag + "_shape"] = np.array([n, h, w])
+        for lv, cd in enumerate(codes):
+            small[f"{tag}_code{lv}"] = cd.numpy().astype(np.int16)
+        small[tag + "_rec_strided"] = rec[..., ::4, ::4].numpy()
+        small[tag + "_rec_crop"] = rec[..., 32:96, 32:96].numpy()
+        small[tag + "_rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
+        small[tag + "_padded_sha"] = np.frombuffer(bytes.fromhex(sha(AlignedPadding()(xi))), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "f4_small_model.npz"), **small)
+
+    # ---- F5: the qp=2 model Compressor(128, 2, [8192, 2048, 512]) on one 256x384 image -----------------
+    qp2 = {}
+    sd = R.make_state_dict(128, 2, [8192, 2048, 512], seed=0)
+    model = ref_harness.reference_compressor(128, 2, [8192, 2048, 512], sd)
+    xi = R.make_images(1, 256, 384)
+    with torch.inference_mode():
+        codes = model.encode(xi)
+        rec = model.decode(codes)
+    qp2["shape"] = np.array([1, 256, 384])
+    qp2["n_state_dict_entries"] = np.array([len(model.state_dict())])
+    for lv, cd in enumerate(codes):
+        qp2[f"code{lv}"] = cd.numpy().astype(np.int16)
+    qp2["rec_crop"] = rec[:, :, 96:160, 160:224].numpy()
+    qp2["rec_mean_abs"] = np.array([rec.abs().mean().item()])
+    qp2["rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "f5_qp2_model.npz"), **qp2)
+    print("golden vectors written to", OUT)
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+"""CPU, world_size 2 over gloo: the N>1 path = contiguous image shards + statistics collectives only."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mcquic_amd import parallel
+    n = 5                                                     # ragged: 3 + 2
+    lo, hi = parallel.shard_range(n, rank, world)
+    g = torch.Generator().manual_seed(0)
+    stats_all = torch.rand((n, 3), generator=g)
+    codes_all = [torch.randint(0, k, (n, 2, s, s), generator=g) for k, s in ((32, 4), (16, 2), (8, 1))]
+    stats = parallel.gather_image_stats(stats_all[lo:hi])
+    hist = parallel.code_histograms([c[lo:hi] for c in codes_all], [32, 16, 8])
+    ok = torch.equal(stats, stats_all)
+    for h, c, k in zip(hist, codes_all, (32, 16, 8)):
+        want = torch.stack([torch.bincount(c[:, m].reshape(-1), minlength=k) for m in range(2)])
+        ok = ok and torch.equal(h, want)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_batch():
+    from mcquic_amd import parallel
+    for n in (0, 1, 7, 32, 256):
+        for world in (1, 2, 8):
+            spans = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_stats_collectives_world2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world))

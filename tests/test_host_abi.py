@@ -1,0 +1,82 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mcquic_hip.h declares; host-side logic."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mcquic_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mcquic_amd import _lib
+    lib = _lib.load()
+    declared = _declared()
+    assert declared, "no declarations parsed"
+    assert sorted(_lib.SYMBOLS) == declared
+    for name in declared:
+        assert getattr(lib, name) is not None
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (mcq_[a-z0-9_]+)", out))
+    assert set(declared) <= exported
+    assert lib.mcq_version().decode().startswith("mcquic_hip")
+
+
+def test_size_queries_run_without_a_gpu():
+    from mcquic_amd import _lib
+    lib = _lib.load()
+    # 128 -> 128 3x3: 576 k-steps (+16 tail) x 64 lanes x 4 floats
+    assert lib.mcq_packed_conv_weight_floats(128, 128, 3) == (576 + 16) * 256
+    assert lib.mcq_packed_conv_weight_floats(512, 128, 3) == (4 * 576 + 16) * 256
+    assert lib.mcq_packed_conv_weight_floats(128, 3, 3) == (32 + 16) * 256      # 9 taps x 2 channel pairs -> 18 -> 32
+    assert lib.mcq_packed_conv_weight_floats(128, 128, 5) == 0                   # unsupported kernel size
+    assert lib.mcq_packed_codebook_floats(2, 8192, 64) == (2 * 64 * 32 + 4) * 256 + 2 * 65 * 256
+
+
+def test_invalid_arguments_return_einval():
+    from mcquic_amd import _lib
+    lib = _lib.load()
+    assert lib.mcq_conv2d_f32(None, None) == _lib.MCQ_EINVAL
+    d = _lib.ConvDesc()
+    assert lib.mcq_conv2d_f32(d, None) == _lib.MCQ_EINVAL
+    assert lib.mcq_add_f32(None, None, None, None, 4, None) == _lib.MCQ_EINVAL
+    assert lib.mcq_vq_assign_f32(None, None, None, 1, 2, 64, 4, 4, 512, None) == _lib.MCQ_EINVAL
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    from mcquic_amd import Compressor
+    model = Compressor(8, 2, [32, 16, 8]).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.encode(torch.zeros(1, 3, 128, 128))
+
+
+def test_api_surface_and_errors():
+    from mcquic_amd import Compressor
+    from mcquic_amd.modules.compressor import AlignedPadding
+    model = Compressor(8, 2, [32, 16, 8])
+    assert model.QuantizationParameter == "-1"
+    model.QuantizationParameter = "2"
+    assert model.QuantizationParameter == "2"
+    assert [tuple(c.shape) for c in model.Codebooks] == [(2, 32, 4), (2, 16, 4), (2, 8, 4)]
+    assert [tuple(f.shape) for f in model.NormalizedFreq] == [(2, 32), (2, 16), (2, 8)]
+    assert float(model.CodeUsage) == 1.0
+    assert model.eval()(torch.zeros(1, 3, 8, 8)) is None           # eval-mode forward returns None like the reference
+    with pytest.raises(RuntimeError):
+        model.encode(torch.zeros(3, 8, 8))
+    with pytest.raises(RuntimeError):
+        model._quantizer._entropyCoder._checkShape([])
+    with pytest.raises(RuntimeError):
+        model._quantizer._entropyCoder._checkShape([torch.zeros(1, 2, 4, 4), torch.zeros(1, 3, 2, 2)])
+    pad = AlignedPadding()
+    assert tuple(pad(torch.zeros(1, 3, 200, 136)).shape) == (1, 3, 256, 256)
+    x = torch.arange(2 * 3 * 130 * 250, dtype=torch.float32).reshape(2, 3, 130, 250)
+    from oracle import mcquic_ref as R
+    assert torch.equal(pad(x), R.aligned_padding(x))
+    assert pad(torch.zeros(1, 3, 768, 512)).shape[-2:] == (768, 512)

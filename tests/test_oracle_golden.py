@@ -1,0 +1,94 @@
+"""CPU: the oracle (oracle/mcquic_ref.py) against golden vectors captured from the real reference
+(tests/golden/make_golden.py).  Floats are compared at 1e-6 (a different host may pick different oneDNN kernels);
+indices are exact except where the reference's own recorded top-2 gap is below 1e-5."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mcquic_ref as R
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _sha(t):
+    return np.frombuffer(hashlib.sha256(t.contiguous().numpy().tobytes()).digest(), dtype=np.uint8)
+
+
+def test_blocks_match_reference():
+    z = np.load(os.path.join(G, "f1_blocks_c8.npz"))
+    c = 8
+    x = torch.from_numpy(z["x"])
+    assert torch.equal(x, _rand((2, c, 13, 18), 101))
+    for name, mk, fn in [("ResidualBlock", R._rb, R.residual_block),
+                         ("ResidualBlockWithStride", R._rb_stride, R.residual_block_with_stride),
+                         ("ResidualBlockShuffle", R._rb_shuffle, R.residual_block_shuffle),
+                         ("AttentionBlock", R._attn, R.attention_block)]:
+        sd = {}
+        mk(sd, "", c, 11)
+        got = fn(sd, "", x.clone())
+        np.testing.assert_allclose(got.numpy(), z[name], rtol=0, atol=1e-6, err_msg=name)
+    for name, inv in [("GenDivNorm", False), ("InvGenDivNorm", True)]:
+        sd = {}
+        R._gdn_params(sd, "", c, 12)
+        np.testing.assert_allclose(R.gdn(sd, "", x.clone() * 2, inv).numpy(), z[name], rtol=0, atol=1e-6, err_msg=name)
+
+
+def test_vq_matches_reference():
+    z = np.load(os.path.join(G, "f2_vq.npz"))
+    for tag in ("qp2_l2", "qp2_l1", "small"):
+        m, k, d, n, h, w = [int(v) for v in z[tag + "_shape"]]
+        g = torch.Generator().manual_seed(7)
+        cb = torch.randn((m, k, d), generator=g) * np.sqrt(2 / (5 * d))
+        x = torch.randn((n, m * d, h, w), generator=g) * 0.1
+        code = R.vq_encode(x, cb)
+        want = torch.from_numpy(z[tag + "_code"].astype(np.int64))
+        bad = (code != want).numpy()
+        assert (z[tag + "_gap"][bad] < 1e-5).all(), f"{tag}: mismatch away from a near-tie"
+        deq = R.vq_decode(want, cb)
+        assert (_sha(deq) == z[tag + "_deq_sha"]).all()
+
+
+@pytest.mark.parametrize("tag", ["pad", "aligned"])
+def test_small_model_matches_reference(tag):
+    z = np.load(os.path.join(G, "f4_small_model.npz"))
+    n, h, w = [int(v) for v in z[tag + "_shape"]]
+    sd = R.make_state_dict(8, 2, [32, 16, 8], seed=1)
+    x = R.make_images(n, h, w)
+    assert (_sha(R.aligned_padding(x)) == z[tag + "_padded_sha"]).all()
+    codes = R.encode(sd, x)
+    for lv, c in enumerate(codes):
+        assert torch.equal(c, torch.from_numpy(z[f"{tag}_code{lv}"].astype(np.int64))), f"level {lv}"
+    rec = R.decode(sd, codes)
+    np.testing.assert_allclose(rec[..., ::4, ::4].numpy(), z[tag + "_rec_strided"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rec[..., 32:96, 32:96].numpy(), z[tag + "_rec_crop"], rtol=0, atol=1e-6)
+
+
+def test_qp2_model_matches_reference():
+    z = np.load(os.path.join(G, "f5_qp2_model.npz"))
+    sd = R.make_state_dict(128, 2, [8192, 2048, 512], seed=0)
+    assert len(sd) == int(z["n_state_dict_entries"][0]) == 718
+    x = R.make_images(1, 256, 384)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    codes = R.encode(sd, x)
+    for lv, c in enumerate(codes):
+        assert torch.equal(c, torch.from_numpy(z[f"code{lv}"].astype(np.int64))), f"level {lv}"
+    rec = R.decode(sd, codes)
+    np.testing.assert_allclose(rec[:, :, 96:160, 160:224].numpy(), z["rec_crop"], rtol=0, atol=1e-6)
+    assert abs(rec.abs().mean().item() - float(z["rec_mean_abs"][0])) < 1e-6
+
+
+def test_detransform_and_psnr_formulas():
+    x = torch.tensor([[-1.0, -0.9999, 0.0, 0.5, 0.99999, 1.0, 1.2, -3.0]]).reshape(1, 1, 2, 4)
+    u = R.detransform(x)
+    assert u.dtype == torch.uint8
+    assert u.flatten().tolist() == [0, 0, 127, 191, 255, 255, 255, 0]
+    a = torch.zeros(1, 3, 4, 4, dtype=torch.uint8)
+    assert abs(float(R.psnr(a, a)) - 10 * np.log10(255.0 ** 2 / 1e-4)) < 1e-9

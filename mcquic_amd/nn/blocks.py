@@ -15,7 +15,8 @@ computed once per element in an epilogue instead of once per tap inside the cons
 """
 from __future__ import annotations
 
-from typing import Optional
+import os
+from typing import Dict, Optional
 
 import torch
 from torch import nn
@@ -24,6 +25,52 @@ from .convs import Conv2d, PixelShuffle3x3, conv1x1, conv3x3, pixelShuffle3x3
 from .gdn import GenDivNorm, InvGenDivNorm
 
 __all__ = ["ResidualBlockWithStride", "ResidualBlockShuffle", "ResidualBlock", "AttentionBlock"]
+
+# Independent branches (AttentionBlock's main / side stacks, a strided block's skip conv) are enqueued on a second
+# HIP stream: the tail of one branch's kernel (a launch is only ~6 rounds of waves at 192x128) is filled by the other
+# branch's workgroups, and the launch-latency-bound small levels run two kernels at once.  MCQUIC_AMD_BRANCH_STREAMS=0
+# turns it off (single stream, same results).
+_BRANCH_STREAMS = os.environ.get("MCQUIC_AMD_BRANCH_STREAMS", "1") != "0"
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(device: torch.device) -> "torch.cuda.Stream":
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(idx)
+    if st is None:
+        st = _side_streams[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
+class _fork:
+    """`with _fork(x) as f:` runs the body on the side stream after everything enqueued so far; `f.join(t)` makes the
+    main stream wait for it and hands tensor `t` (allocated on the side stream) over to the main stream."""
+
+    def __init__(self, x: torch.Tensor):
+        self.on = _BRANCH_STREAMS and x.is_cuda
+        if self.on:
+            self.main = torch.cuda.current_stream(x.device)
+            self.side = _side_stream(x.device)
+            self.on = self.main != self.side
+        self.ctx = None
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, t: torch.Tensor) -> torch.Tensor:
+        if self.on:
+            self.main.wait_stream(self.side)
+            t.record_stream(self.main)
+        return t
 
 
 class _residulBlock(nn.Module):
@@ -59,10 +106,11 @@ class ResidualBlockWithStride(_residulBlock):
                          conv3x3(outChannels, outChannels), conv3x3(inChannels, outChannels, stride=stride))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        with _fork(x) as f:
+            identity = self._skip(x)
         t = self._branch[1](x, silu_in=True)
         t = self._branch[2](t)
-        identity = self._skip(x)
-        return self._branch[3](t, res=identity, dual_silu=True)
+        return self._branch[3](t, res=f.join(identity), dual_silu=True)
 
 
 class ResidualBlockShuffle(_residulBlock):
@@ -75,10 +123,11 @@ class ResidualBlockShuffle(_residulBlock):
                          conv3x3(outChannels, outChannels), pixelShuffle3x3(inChannels, outChannels, upsample))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        with _fork(x) as f:
+            identity = self._skip(x)
         t = self._branch[1](x, silu_in=True)
         t = self._branch[2](t)
-        identity = self._skip(x)
-        return self._branch[3](t, res=identity, dual_silu=True)
+        return self._branch[3](t, res=f.join(identity), dual_silu=True)
 
 
 class AttentionBlock(nn.Module):
@@ -91,8 +140,9 @@ class AttentionBlock(nn.Module):
                                          conv1x1(channel, channel))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        with _fork(x) as f:
+            b = x
+            for i in range(3):
+                b = self._sideBranch[i](b)
         a = self._mainBranch(x)
-        b = x
-        for i in range(3):
-            b = self._sideBranch[i](b)
-        return self._sideBranch[3](b, gate_mul=a, gate_id=x, dual_silu=True)
+        return self._sideBranch[3](f.join(b), gate_mul=a, gate_id=x, dual_silu=True)

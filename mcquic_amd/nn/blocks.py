@@ -31,14 +31,15 @@ __all__ = ["ResidualBlockWithStride", "ResidualBlockShuffle", "ResidualBlock", "
 # branch's workgroups, and the launch-latency-bound small levels run two kernels at once.  MCQUIC_AMD_BRANCH_STREAMS=0
 # turns it off (single stream, same results).
 _BRANCH_STREAMS = os.environ.get("MCQUIC_AMD_BRANCH_STREAMS", "1") != "0"
-_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+_side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
 
 
-def _side_stream(device: torch.device) -> "torch.cuda.Stream":
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    st = _side_streams.get(idx)
+def _side_stream(main: "torch.cuda.Stream") -> "torch.cuda.Stream":
+    """The side stream paired with `main` (one per main stream, so pipelined sub-batches do not share one)."""
+    key = (main.device.index, main.cuda_stream)
+    st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[idx] = torch.cuda.Stream(device=idx)
+        st = _side_streams[key] = torch.cuda.Stream(device=main.device)
     return st
 
 
@@ -50,8 +51,7 @@ class _fork:
         self.on = _BRANCH_STREAMS and x.is_cuda
         if self.on:
             self.main = torch.cuda.current_stream(x.device)
-            self.side = _side_stream(x.device)
-            self.on = self.main != self.side
+            self.side = _side_stream(self.main)
         self.ctx = None
 
     def __enter__(self):

@@ -66,3 +66,26 @@ def test_encode_is_batch_invariant(dev):
     one = model.encode(x[2:3])
     for a, b in zip(all_codes, one):
         assert torch.equal(a[2:3], b)
+
+
+def test_pipelined_sub_batches_match_oracle(dev):
+    """n >= 8 takes the two-stream sub-batch pipeline (odd n: halves of 4 and 5); results must not change."""
+    _compare(dev, 8, 2, [32, 16, 8], n=9, h=128, w=128, seed=4, pix_tol=1e-4)
+
+
+def test_pipeline_repeatable_under_load(dev):
+    """Stream hand-offs: repeated pipelined encode/decode calls (allocator reuse across streams) stay identical."""
+    from mcquic_amd import Compressor
+    sd = R.make_state_dict(8, 2, [32, 16, 8], seed=5)
+    model = Compressor(8, 2, [32, 16, 8]).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    x = R.make_images(16, 256, 256).to(dev)
+    codes0 = model.encode(x)
+    rec0 = model.decode(codes0)
+    for _ in range(5):
+        codes = model.encode(x)
+        rec = model.decode(codes)
+        for a, b in zip(codes, codes0):
+            assert torch.equal(a, b)
+        assert torch.equal(rec, rec0)

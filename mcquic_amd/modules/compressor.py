@@ -11,8 +11,7 @@ reference checkpoint's `model` dict loads with `load_state_dict(strict=True)`.
 """
 from __future__ import annotations
 
-import os
-from typing import Dict, List, Tuple
+from typing import List, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -23,23 +22,6 @@ from ..utils.specification import FileHeader, ImageSize
 from .quantizer import BaseQuantizer, UMGMQuantizer
 
 __version__ = "0.1.40"   # the reference snapshot's mcquic.__version__, written into FileHeader
-
-
-# Sub-batch pipelining: a batch of >= 2*_PIPE_MIN images is cut in two halves that run on two HIP streams, the
-# second one started when the first leaves the full-resolution encoder / the deep decoder levels.  The small
-# (48x32 ... 12x8) levels cannot fill 256 CUs on their own; this way they share the chip with the other half's
-# large layers.  Images are independent, so results are identical.  MCQUIC_AMD_PIPELINE=0 turns it off.
-_PIPELINE = os.environ.get("MCQUIC_AMD_PIPELINE", "1") != "0"
-_PIPE_MIN = 4
-_pipe_streams: Dict[tuple, tuple] = {}
-
-
-def _pipeline_streams(main: "torch.cuda.Stream"):
-    key = (main.device.index, main.cuda_stream)
-    st = _pipe_streams.get(key)
-    if st is None:
-        st = _pipe_streams[key] = (torch.cuda.Stream(device=main.device), torch.cuda.Stream(device=main.device))
-    return st
 
 
 class AlignedPadding(nn.Module):
@@ -117,52 +99,14 @@ class BaseCompressor(nn.Module):
             y = self._encoder[i](y)
         return y
 
-    def _two_halves(self, n: int, device, first_stage, second_stage, parts):
-        """Run `second_stage(first_stage(part))` for two batch halves on two streams, the second half released
-        when the first finishes `first_stage`.  Returns the two results (already handed to the current stream)."""
-        main = torch.cuda.current_stream(device)
-        sA, sB = _pipeline_streams(main)
-        sA.wait_stream(main)
-        sB.wait_stream(main)
-        with torch.cuda.stream(sA):
-            mid = first_stage(parts[0])
-            handoff = torch.cuda.Event()
-            handoff.record(sA)
-            outA = second_stage(mid)
-        with torch.cuda.stream(sB):
-            sB.wait_event(handoff)
-            outB = second_stage(first_stage(parts[1]))
-        main.wait_stream(sA)
-        main.wait_stream(sB)
-        return outA, outB
-
-    @staticmethod
-    def _handover(t: torch.Tensor, stream) -> torch.Tensor:
-        t.record_stream(stream)
-        return t
-
     def encode(self, x: torch.Tensor) -> List[torch.Tensor]:
         self._check(x)
         with torch.no_grad():
-            n = x.shape[0]
-            if not (_PIPELINE and x.is_cuda and n >= 2 * _PIPE_MIN):
-                return self._quantizer.encode(self._encode_latent(x))
-            x = self._padding(x)
-            h = n // 2
-            a, b = self._two_halves(n, x.device, self._encode_latent, self._quantizer.encode, (x[:h], x[h:]))
-            main = torch.cuda.current_stream(x.device)
-            return [torch.cat([self._handover(ca, main), self._handover(cb, main)], 0) for ca, cb in zip(a, b)]
+            return self._quantizer.encode(self._encode_latent(x))
 
     def decode(self, codes: List[torch.Tensor]) -> torch.Tensor:
         with torch.no_grad():
-            n = codes[0].shape[0]
-            if not (_PIPELINE and codes[0].is_cuda and n >= 2 * _PIPE_MIN):
-                return self._decoder(self._quantizer.decode(codes))
-            h = n // 2
-            a, b = self._two_halves(n, codes[0].device, self._quantizer.decode, self._decoder,
-                                    ([c[:h] for c in codes], [c[h:] for c in codes]))
-            main = torch.cuda.current_stream(codes[0].device)
-            return torch.cat([self._handover(a, main), self._handover(b, main)], 0)
+            return self._decoder(self._quantizer.decode(codes))
 
     def compress(self, x: torch.Tensor) -> Tuple[List[torch.Tensor], List[List[bytes]], List[FileHeader]]:
         self._check(x)

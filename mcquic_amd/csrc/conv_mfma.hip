@@ -27,6 +27,9 @@ struct ConvK {
     int TP;            // k-steps per 128-cout tile, padded to a multiple of 16 (the deepest prefetch ring)
     int bw_log2;       // a pixel block is (32 >> bw_log2) rows x (1 << bw_log2) cols
     int nbx, nby, total_blocks;
+    int ks_log2;       // split-K: 1 << ks_log2 waves of a workgroup share one output tile, each a slice of the k-steps
+    int slice_steps;   // k-steps per slice (multiple of PF)
+    int tiles_log2;    // (1 << tiles_log2) output tiles per workgroup
     unsigned flags; float res_scale;
 };
 
@@ -40,12 +43,18 @@ template <> struct AVec<1> { typedef float T; };
 template <int MB> __device__ __forceinline__ float a_elem(const typename AVec<MB>::T& v, int i) { return v[i]; }
 template <> __device__ __forceinline__ float a_elem<1>(const float& v, int) { return v; }
 
+extern __shared__ __attribute__((aligned(16))) float mcq_lds[];
+
 template <int MB, int NB, int PRO, int PF>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
+__global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int gw = blockIdx.x * 4 + wave;           // wave index along the pixel-block axis
-    if (gw * NB >= p.total_blocks) return;          // wave-uniform
+    const int KS = 1 << p.ks_log2;
+    const int tile_in_wg = wave >> p.ks_log2;       // which output tile of this workgroup
+    const int kslice = wave & (KS - 1);             // which slice of the k-steps
+    const int gw = (blockIdx.x << p.tiles_log2) + tile_in_wg;   // tile index along the pixel-block axis
+    const bool active = gw * NB < p.total_blocks;   // wave-uniform
+    if (KS == 1 && !active) return;                 // (split-K waves stay for the barriers)
     const int co_base = blockIdx.y * (32 * MB);     // first output channel of this wave
     const int hi = lane >> 5, j = lane & 31;
     const int BW = 1 << p.bw_log2;
@@ -90,13 +99,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
     avec_t A[PF];
     float B[PF][NB];
     const int tile128 = co_base >> 7, q0 = (co_base & 127) >> 5;
-    const float* wl = p.wp + ((size_t)tile128 * p.TP * 64 + lane) * 4 + q0;
-    int ls = 0, lt = 0;
-    unsigned soffL = 0;
+    const int t0 = kslice * p.slice_steps;          // first k-step of this wave's slice
+    const float* wl = p.wp + (((size_t)tile128 * p.TP + t0) * 64 + lane) * 4 + q0;
+    int lt = t0 / p.S;
+    int ls = t0 - lt * p.S;
     const unsigned step_bytes = 2u * (unsigned)HW * 4u;
+    unsigned soffL = (unsigned)ls * step_bytes;
     unsigned voffL[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) voffL[nb] = tap_voff(0, nb);
+    for (int nb = 0; nb < NB; ++nb) voffL[nb] = tap_voff(lt, nb);
 
     auto issue = [&](int st) {
         A[st] = *reinterpret_cast<const avec_t*>(wl);
@@ -120,10 +131,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
+    const int nsteps = active ? p.slice_steps : 0;
+    if (active) {
 #pragma unroll
-    for (int st = 0; st < PF; ++st) issue(st);
+        for (int st = 0; st < PF; ++st) issue(st);
+    }
 
-    for (int t = 0; t < p.TP; t += PF) {
+    for (int t = 0; t < nsteps; t += PF) {
 #pragma unroll
         for (int st = 0; st < PF; ++st) {
             float bv[NB];
@@ -150,15 +164,79 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
     // their latencies overlap.
     const unsigned fl = p.flags;
     const size_t HoWo = (size_t)p.Ho * p.Wo;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
+
+    auto finish = [&](int mb, int nb, float (&v)[16], const float (&bias16)[16], const bool (&cok)[16]) {
         const int co0 = co_base + mb * 32 + 4 * hi;      // channel of register 0
-        bool cok[16];
-        float bias16[16];
+        const bool vld = valid[nb];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = v[r] + bias16[r];
+
+        if (fl & MCQ_CONV_SHUFFLE2) {
+            // registers 4q..4q+3 are the 2x2 sub-pixels of output channel co/4: two float2 rows.
+            const int Co4 = p.Cout >> 2;
+            const size_t W2 = 2 * (size_t)p.Wo;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                if (vld && cok[rq * 4]) {
+                    const int c = (co0 + 8 * rq) >> 2;
+                    float* o = p.y + (((size_t)img[nb] * Co4 + c) * (2 * (size_t)p.Ho) + 2 * (size_t)yo[nb]) * W2 +
+                               2 * (size_t)xo[nb];
+                    *reinterpret_cast<f32x2v*>(o) = f32x2v{v[rq * 4 + 0], v[rq * 4 + 1]};
+                    *reinterpret_cast<f32x2v*>(o + W2) = f32x2v{v[rq * 4 + 2], v[rq * 4 + 3]};
+                }
+            }
+            return;
+        }
+        const size_t idx0 = ((size_t)img[nb] * p.Cout + co0) * HoWo + (size_t)yo[nb] * p.Wo + xo[nb];
+        bool ok[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ok[r] = vld && cok[r];
+        if (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) {
+            float m[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[r] = ok[r] ? p.mul[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
+            if (fl & MCQ_CONV_GDN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = m[r] * (1.0f / sqrtf(v[r]));
+            } else if (fl & MCQ_CONV_IGDN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = m[r] * sqrtf(v[r]);
+            } else {
+                float gi[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gi[r] = ok[r] ? p.gid[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = m[r] * mcq_sigmoid(v[r]) + gi[r];
+            }
+        }
+        if (fl & MCQ_CONV_RESIDUAL) {
+            float rr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rr[r] = ok[r] ? p.res[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] + p.res_scale * rr[r];
+        }
+        if (fl & MCQ_CONV_SILU_OUT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok[r]) p.y[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
+        if (fl & MCQ_CONV_DUAL_SILU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (ok[r]) p.y2[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
+        }
+    };
+
+    auto load_bias = [&](int mb, float (&bias16)[16], bool (&cok)[16]) {
+        const int co0 = co_base + mb * 32 + 4 * hi;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = co0 + (r & 3) + 8 * (r >> 2);
-            cok[r] = co < p.Cout;
+            cok[r] = co0 + (r & 3) + 8 * (r >> 2) < p.Cout;
             bias16[r] = 0.0f;
         }
         if (p.bias) {
@@ -166,73 +244,56 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
             for (int r = 0; r < 16; ++r)
                 if (cok[r]) bias16[r] = p.bias[co0 + (r & 3) + 8 * (r >> 2)];
         }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const bool vld = valid[nb];
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[mb][nb][r] + bias16[r];
+    };
 
-            if (fl & MCQ_CONV_SHUFFLE2) {
-                // registers 4q..4q+3 are the 2x2 sub-pixels of output channel co/4: two float2 rows.
-                const int Co4 = p.Cout >> 2;
-                const size_t W2 = 2 * (size_t)p.Wo;
+    if (KS == 1) {
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    if (vld && cok[rq * 4]) {
-                        const int c = (co0 + 8 * rq) >> 2;
-                        float* o = p.y + (((size_t)img[nb] * Co4 + c) * (2 * (size_t)p.Ho) + 2 * (size_t)yo[nb]) * W2 +
-                                   2 * (size_t)xo[nb];
-                        *reinterpret_cast<f32x2v*>(o) = f32x2v{v[rq * 4 + 0], v[rq * 4 + 1]};
-                        *reinterpret_cast<f32x2v*>(o + W2) = f32x2v{v[rq * 4 + 2], v[rq * 4 + 3]};
-                    }
-                }
-            } else {
-                const size_t idx0 = ((size_t)img[nb] * p.Cout + co0) * HoWo + (size_t)yo[nb] * p.Wo + xo[nb];
-                bool ok[16];
+        for (int mb = 0; mb < MB; ++mb) {
+            float bias16[16];
+            bool cok[16];
+            load_bias(mb, bias16, cok);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ok[r] = vld && cok[r];
-                if (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) {
-                    float m[16];
+            for (int nb = 0; nb < NB; ++nb) {
+                float v[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m[r] = ok[r] ? p.mul[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
-                    if (fl & MCQ_CONV_GDN) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = m[r] * (1.0f / sqrtf(v[r]));
-                    } else if (fl & MCQ_CONV_IGDN) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = m[r] * sqrtf(v[r]);
-                    } else {
-                        float gi[16];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) gi[r] = ok[r] ? p.gid[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = m[r] * mcq_sigmoid(v[r]) + gi[r];
-                    }
-                }
-                if (fl & MCQ_CONV_RESIDUAL) {
-                    float rr[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rr[r] = ok[r] ? p.res[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = v[r] + p.res_scale * rr[r];
-                }
-                if (fl & MCQ_CONV_SILU_OUT) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (ok[r]) p.y[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
-                if (fl & MCQ_CONV_DUAL_SILU) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (ok[r]) p.y2[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
-                }
+                for (int r = 0; r < 16; ++r) v[r] = acc[mb][nb][r];
+                finish(mb, nb, v, bias16, cok);
             }
         }
+        return;
+    }
+
+    // split-K: the KS partial tiles of a 32-row band meet in LDS ([slice][nb][r][lane], conflict-free), wave
+    // (mb % KS) adds them in slice order (deterministic) and runs the band's epilogue.
+    float* slot0 = mcq_lds + (size_t)(tile_in_wg << p.ks_log2) * (NB * 1024);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        if (active) {
+            float* mine = slot0 + (size_t)kslice * (NB * 1024) + lane;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(nb * 16 + r) * 64] = acc[mb][nb][r];
+        }
+        __syncthreads();
+        if (active && kslice == (mb & (KS - 1))) {
+            float bias16[16];
+            bool cok[16];
+            load_bias(mb, bias16, cok);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = slot0[(nb * 16 + r) * 64 + lane];
+                for (int w = 1; w < KS; ++w) {
+                    const float* other = slot0 + (size_t)w * (NB * 1024) + lane;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = v[r] + other[(nb * 16 + r) * 64];
+                }
+                finish(mb, nb, v, bias16, cok);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -274,11 +335,22 @@ inline int steps_padded(int Cin, int ks) {
 }
 
 template <int MB, int NB, int PF>
-int launch_tile(const ConvK& k, int pro, dim3 grid, hipStream_t s) {
+int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2, hipStream_t s) {
+    // split-K slices must be whole prefetch rounds and at least 16 steps long
+    while (ksplit_log2 > 0 && ((k.TP >> ksplit_log2) % PF != 0 || (k.TP >> ksplit_log2) < 16 ||
+                               ((k.TP >> ksplit_log2) << ksplit_log2) != k.TP))
+        --ksplit_log2;
+    k.ks_log2 = ksplit_log2;
+    k.slice_steps = k.TP >> ksplit_log2;
+    k.tiles_log2 = ksplit_log2 >= 2 ? 0 : 2 - ksplit_log2;           // 4 waves per workgroup, 8 for 8-way split
+    const int waves = 1 << (k.ks_log2 + k.tiles_log2);
+    const size_t lds = ksplit_log2 ? (size_t)waves * NB * 1024 * sizeof(float) : 0;
+    const dim3 grid((unsigned)((tiles + (1 << k.tiles_log2) - 1) >> k.tiles_log2), (unsigned)co_tiles);
+    const dim3 block(64 * waves);
     switch (pro) {
-    case PRO_NONE:   hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF>), grid, dim3(256), 0, s, k); break;
-    case PRO_SILU:   hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF>), grid, dim3(256), 0, s, k); break;
-    default:         hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SQUARE, PF>), grid, dim3(256), 0, s, k); break;
+    case PRO_NONE:   hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF>), grid, block, lds, s, k); break;
+    case PRO_SILU:   hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF>), grid, block, lds, s, k); break;
+    default:         hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SQUARE, PF>), grid, block, lds, s, k); break;
     }
     return mcq_check_launch();
 }
@@ -351,30 +423,35 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     if (tb > 0x7fffffffLL) return MCQ_ETOOLARGE;
     k.total_blocks = (int)tb;
 
-    // wave tile: the largest MB x NB that still yields >= one wave per SIMD (1024 on MI355X)
+    // Wave tile and split-K.  Weight traffic per wave is the whole filter bank whatever the tile, so the tile stays
+    // as large as the layer allows (128 co x 64 px); when that leaves fewer than ~2 waves per SIMD (2048 on MI355X)
+    // the k-steps of a tile are split over 2/4/8 waves of one workgroup and reduced through LDS.
     const int co32 = (d->Cout + 31) / 32;
-    int MB, NB;
-    if (d->tile) { MB = d->tile >> 4; NB = d->tile & 15; }
+    int MB, NB, ksl = 0;
+    const int forced = d->tile & 0xff;
+    if (forced) { MB = forced >> 4; NB = forced & 15; ksl = (d->tile >> 8) & 3; }
     else if (co32 == 1) { MB = 1; NB = 2; }
     else {
-        static const int cand[4][2] = {{4, 2}, {2, 2}, {2, 1}, {1, 1}};
+        static const int cand[3][2] = {{4, 2}, {2, 2}, {1, 1}};
         MB = 1; NB = 1;
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 3; ++c) {
             const int mb = cand[c][0], nb = cand[c][1];
             if (mb > co32) continue;
-            const long long waves = ((tb + nb - 1) / nb) * ((co32 + mb - 1) / mb);
-            if (waves >= 1024 || c == 3) { MB = mb; NB = nb; break; }
+            const long long tiles = ((tb + nb - 1) / nb) * ((co32 + mb - 1) / mb);
+            MB = mb; NB = nb;
+            if (tiles * 8 >= 1024) break;          // even an 8-way split would leave SIMDs idle: try a smaller tile
         }
+        const long long tiles = ((tb + NB - 1) / NB) * ((co32 + MB - 1) / MB);
+        while (ksl < 3 && (tiles << ksl) < 2048) ++ksl;
     }
     const int pro = (fl & MCQ_CONV_SILU_IN) ? PRO_SILU : (fl & MCQ_CONV_SQUARE_IN) ? PRO_SQUARE : PRO_NONE;
-    const unsigned gx = (unsigned)(((tb + NB - 1) / NB + 3) / 4);
-    const unsigned gy = (unsigned)((co32 + MB - 1) / MB);
-    const dim3 grid(gx, gy);
+    const long long ptiles = (tb + NB - 1) / NB;
+    const int co_tiles = (co32 + MB - 1) / MB;
     hipStream_t s = (hipStream_t)stream;
-    if (MB == 4 && NB == 2) return launch_tile<4, 2, 4>(k, pro, grid, s);
-    if (MB == 2 && NB == 2) return launch_tile<2, 2, 8>(k, pro, grid, s);
-    if (MB == 2 && NB == 1) return launch_tile<2, 1, 16>(k, pro, grid, s);
-    if (MB == 1 && NB == 2) return launch_tile<1, 2, 8>(k, pro, grid, s);
-    if (MB == 1 && NB == 1) return launch_tile<1, 1, 16>(k, pro, grid, s);
+    if (MB == 4 && NB == 2) return launch_tile<4, 2, 4>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 2 && NB == 2) return launch_tile<2, 2, 8>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 2 && NB == 1) return launch_tile<2, 1, 16>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 1 && NB == 2) return launch_tile<1, 2, 8>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 1 && NB == 1) return launch_tile<1, 1, 16>(k, pro, ptiles, co_tiles, ksl, s);
     return MCQ_EINVAL;
 }

@@ -43,11 +43,12 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 0x42, 0x22, 0x21, 0x12, 0x11])
+@pytest.mark.parametrize("tile", [0, 0x42, 0x22, 0x21, 0x12, 0x11, 0x142, 0x242, 0x342, 0x222, 0x311, 0x321])
 def test_conv_plain(dev, case, tile):
+    """tile = (log2 split-K << 8) | (MB << 4) | NB; 0 = the library's own choice."""
     from mcquic_amd import ops
     n, cin, cout, h, w, ks, stride = case
-    if tile and (tile >> 4) * 32 > ((cout + 31) // 32) * 32:
+    if tile and ((tile >> 4) & 15) * 32 > ((cout + 31) // 32) * 32:
         pytest.skip("tile taller than Cout")
     x = _rand((n, cin, h, w), 1)
     wt = _rand((cout, cin, ks, ks), 2, 1.0 / np.sqrt(cin * ks * ks))
@@ -88,6 +89,11 @@ def test_conv_fused_epilogues(dev):
     _close(ops.conv2d(xd, pk, res=res.to(dev)), plain + res, 2e-6, "residual")
     _close(ops.conv2d(xd, pk, res=res.to(dev), res_scale=-1.0), plain - res, 2e-6, "residual(-1)")
     _close(ops.conv2d(xd, pk, gate_mul=a.to(dev), gate_id=res.to(dev)), a * torch.sigmoid(plain) + res, 2e-6, "gate")
+    # the same epilogues behind the split-K (LDS-reduced) path
+    for tile in (0x242, 0x322):
+        _close(ops.conv2d(xd, pk, silu_in=True, silu_out=True, tile=tile), F.silu(base), 2e-6, f"split-K silu {tile:#x}")
+        _close(ops.conv2d(xd, pk, res=res.to(dev), res_scale=-1.0, dual_silu=True, tile=tile), plain - res, 2e-6, f"split-K res {tile:#x}")
+        _close(ops.conv2d(xd, pk, gate_mul=a.to(dev), gate_id=res.to(dev), tile=tile), a * torch.sigmoid(plain) + res, 2e-6, f"split-K gate {tile:#x}")
 
 
 def test_conv_pixel_shuffle(dev):
@@ -100,6 +106,8 @@ def test_conv_pixel_shuffle(dev):
     got = ops.conv2d(x.to(dev), ops.PackedConv(wt.to(dev), b.to(dev)), silu_in=True, shuffle2=True)
     assert got.shape == want.shape
     _close(got, want, 2e-6, "pixel shuffle 512")
+    got = ops.conv2d(x.to(dev), ops.PackedConv(wt.to(dev), b.to(dev)), silu_in=True, shuffle2=True, tile=0x242)
+    _close(got, want, 2e-6, "pixel shuffle 512, split-K")
     wt = _rand((12, c, 3, 3), 24, 1.0 / np.sqrt(c * 9))
     b = _rand((12,), 25, 0.1)
     want = F.pixel_shuffle(F.conv2d(x, wt, b, padding=1), 2)

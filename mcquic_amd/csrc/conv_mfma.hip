@@ -159,141 +159,116 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
-    // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row tile, the 16 output
-    // channels row(r) = (r & 3) + 8 (r >> 2) + 4 hi.  Side inputs are fetched 16 at a time so
-    // their latencies overlap.
+    // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row band mb, the 16 output channels
+    // row(r) = (r & 3) + 8 (r >> 2) + 4 hi.  The accumulators of a band are parked in LDS ([wave][nb][r][lane],
+    // conflict-free) and finished by a COMPACT runtime loop, 8 values at a time: a fully unrolled register
+    // epilogue is ~300 KB of straight-line code that each wave runs once -- instruction-fetch bound, and the
+    // whole cost of the small layers.  With split-K the KS partial bands of a tile meet in the same LDS slots and
+    // wave (mb % KS) adds them in slice order (deterministic).
     const unsigned fl = p.flags;
     const size_t HoWo = (size_t)p.Ho * p.Wo;
+    float* const myslot = mcq_lds + (size_t)wave * (NB * 1024) + lane;
+    const float* const tileslot = mcq_lds + (size_t)(tile_in_wg << p.ks_log2) * (NB * 1024) + lane;
 
-    auto finish = [&](int mb, int nb, float (&v)[16], const float (&bias16)[16], const bool (&cok)[16]) {
-        const int co0 = co_base + mb * 32 + 4 * hi;      // channel of register 0
-        const bool vld = valid[nb];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = v[r] + bias16[r];
-
-        if (fl & MCQ_CONV_SHUFFLE2) {
-            // registers 4q..4q+3 are the 2x2 sub-pixels of output channel co/4: two float2 rows.
-            const int Co4 = p.Cout >> 2;
-            const size_t W2 = 2 * (size_t)p.Wo;
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                if (vld && cok[rq * 4]) {
-                    const int c = (co0 + 8 * rq) >> 2;
-                    float* o = p.y + (((size_t)img[nb] * Co4 + c) * (2 * (size_t)p.Ho) + 2 * (size_t)yo[nb]) * W2 +
-                               2 * (size_t)xo[nb];
-                    *reinterpret_cast<f32x2v*>(o) = f32x2v{v[rq * 4 + 0], v[rq * 4 + 1]};
-                    *reinterpret_cast<f32x2v*>(o + W2) = f32x2v{v[rq * 4 + 2], v[rq * 4 + 3]};
-                }
-            }
-            return;
-        }
-        const size_t idx0 = ((size_t)img[nb] * p.Cout + co0) * HoWo + (size_t)yo[nb] * p.Wo + xo[nb];
-        bool ok[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ok[r] = vld && cok[r];
-        if (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) {
-            float m[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m[r] = ok[r] ? p.mul[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
-            if (fl & MCQ_CONV_GDN) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = m[r] * (1.0f / sqrtf(v[r]));
-            } else if (fl & MCQ_CONV_IGDN) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = m[r] * sqrtf(v[r]);
-            } else {
-                float gi[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gi[r] = ok[r] ? p.gid[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = m[r] * mcq_sigmoid(v[r]) + gi[r];
-            }
-        }
-        if (fl & MCQ_CONV_RESIDUAL) {
-            float rr[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rr[r] = ok[r] ? p.res[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] + p.res_scale * rr[r];
-        }
-        if (fl & MCQ_CONV_SILU_OUT) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (ok[r]) p.y[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
-        if (fl & MCQ_CONV_DUAL_SILU) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (ok[r]) p.y2[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
-        }
-    };
-
-    auto load_bias = [&](int mb, float (&bias16)[16], bool (&cok)[16]) {
-        const int co0 = co_base + mb * 32 + 4 * hi;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            cok[r] = co0 + (r & 3) + 8 * (r >> 2) < p.Cout;
-            bias16[r] = 0.0f;
-        }
-        if (p.bias) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (cok[r]) bias16[r] = p.bias[co0 + (r & 3) + 8 * (r >> 2)];
-        }
-    };
-
-    if (KS == 1) {
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            float bias16[16];
-            bool cok[16];
-            load_bias(mb, bias16, cok);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = acc[mb][nb][r];
-                finish(mb, nb, v, bias16, cok);
-            }
-        }
-        return;
-    }
-
-    // split-K: the KS partial tiles of a 32-row band meet in LDS ([slice][nb][r][lane], conflict-free), wave
-    // (mb % KS) adds them in slice order (deterministic) and runs the band's epilogue.
-    float* slot0 = mcq_lds + (size_t)(tile_in_wg << p.ks_log2) * (NB * 1024);
-#pragma unroll
+#pragma unroll 1
     for (int mb = 0; mb < MB; ++mb) {
         if (active) {
-            float* mine = slot0 + (size_t)kslice * (NB * 1024) + lane;
+            // static register index per band: one switch arm per mb
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+            for (int m2 = 0; m2 < MB; ++m2)
+                if (m2 == mb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mine[(nb * 16 + r) * 64] = acc[mb][nb][r];
-        }
-        __syncthreads();
-        if (active && kslice == (mb & (KS - 1))) {
-            float bias16[16];
-            bool cok[16];
-            load_bias(mb, bias16, cok);
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = slot0[(nb * 16 + r) * 64 + lane];
-                for (int w = 1; w < KS; ++w) {
-                    const float* other = slot0 + (size_t)w * (NB * 1024) + lane;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = v[r] + other[(nb * 16 + r) * 64];
+                        for (int r = 0; r < 16; ++r) myslot[(nb * 16 + r) * 64] = acc[m2][nb][r];
                 }
-                finish(mb, nb, v, bias16, cok);
+        }
+        if (KS > 1) __syncthreads();
+        if (active && kslice == (mb & (KS - 1))) {
+            const int co0 = co_base + mb * 32 + 4 * hi;      // channel of register 0
+#pragma unroll 1
+            for (int c = 0; c < NB * 2; ++c) {               // 8 registers (= 2 groups of 4 consecutive channels)
+                const int nb = c >> 1, rb = (c & 1) * 8;
+                const bool vld = nb == 0 ? valid[0] : valid[NB - 1];
+                const int im = nb == 0 ? img[0] : img[NB - 1];
+                const int py = nb == 0 ? yo[0] : yo[NB - 1];
+                const int px = nb == 0 ? xo[0] : xo[NB - 1];
+                const int cobase = co0 + 2 * rb;             // rows (r & 3) + 8 (r >> 2): r = rb + i
+                float v[8];
+                bool ok[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = tileslot[(nb * 16 + rb + i) * 64];
+                for (int w = 1; w < KS; ++w) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = v[i] + tileslot[(size_t)w * (NB * 1024) + (nb * 16 + rb + i) * 64];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ok[i] = vld && (cobase + (i & 3) + 8 * (i >> 2)) < p.Cout;
+                if (p.bias) {
+                    float bb[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bb[i] = ok[i] ? p.bias[cobase + (i & 3) + 8 * (i >> 2)] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = v[i] + bb[i];
+                }
+                if (fl & MCQ_CONV_SHUFFLE2) {
+                    // registers 4q..4q+3 are the 2x2 sub-pixels of output channel co/4: two float2 rows.
+                    const int Co4 = p.Cout >> 2;
+                    const size_t W2 = 2 * (size_t)p.Wo;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (ok[q * 4]) {
+                            const int ch = (cobase + 8 * q) >> 2;
+                            float* o = p.y + (((size_t)im * Co4 + ch) * (2 * (size_t)p.Ho) + 2 * (size_t)py) * W2 + 2 * (size_t)px;
+                            *reinterpret_cast<f32x2v*>(o) = f32x2v{v[q * 4 + 0], v[q * 4 + 1]};
+                            *reinterpret_cast<f32x2v*>(o + W2) = f32x2v{v[q * 4 + 2], v[q * 4 + 3]};
+                        }
+                    }
+                    continue;
+                }
+                const size_t idx0 = ((size_t)im * p.Cout + cobase) * HoWo + (size_t)py * p.Wo + px;
+                if (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) {
+                    float m[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) m[i] = ok[i] ? p.mul[idx0 + (size_t)((i & 3) + 8 * (i >> 2)) * HoWo] : 0.0f;
+                    if (fl & MCQ_CONV_GDN) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = m[i] * (1.0f / sqrtf(v[i]));
+                    } else if (fl & MCQ_CONV_IGDN) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = m[i] * sqrtf(v[i]);
+                    } else {
+                        float gi[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) gi[i] = ok[i] ? p.gid[idx0 + (size_t)((i & 3) + 8 * (i >> 2)) * HoWo] : 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = m[i] * mcq_sigmoid(v[i]) + gi[i];
+                    }
+                }
+                if (fl & MCQ_CONV_RESIDUAL) {
+                    float rr[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) rr[i] = ok[i] ? p.res[idx0 + (size_t)((i & 3) + 8 * (i >> 2)) * HoWo] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = v[i] + p.res_scale * rr[i];
+                }
+                if (fl & MCQ_CONV_SILU_OUT) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = mcq_silu(v[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (ok[i]) p.y[idx0 + (size_t)((i & 3) + 8 * (i >> 2)) * HoWo] = v[i];
+                if (fl & MCQ_CONV_DUAL_SILU) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = mcq_silu(v[i]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (ok[i]) p.y2[idx0 + (size_t)((i & 3) + 8 * (i >> 2)) * HoWo] = v[i];
+                }
             }
         }
-        __syncthreads();
+        if (KS > 1) __syncthreads();
     }
 }
 
@@ -344,7 +319,7 @@ int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2
     k.slice_steps = k.TP >> ksplit_log2;
     k.tiles_log2 = ksplit_log2 >= 2 ? 0 : 2 - ksplit_log2;           // 4 waves per workgroup, 8 for 8-way split
     const int waves = 1 << (k.ks_log2 + k.tiles_log2);
-    const size_t lds = ksplit_log2 ? (size_t)waves * NB * 1024 * sizeof(float) : 0;
+    const size_t lds = (size_t)waves * NB * 1024 * sizeof(float);      // one parked band per wave
     const dim3 grid((unsigned)((tiles + (1 << k.tiles_log2) - 1) >> k.tiles_log2), (unsigned)co_tiles);
     const dim3 block(64 * waves);
     switch (pro) {

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
     // ---- epilogue ---------------------------------------------------------------------------
     // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row band mb, the 16 output channels
     // row(r) = (r & 3) + 8 (r >> 2) + 4 hi.  The accumulators of a band are parked in LDS ([wave][nb][r][lane],
-    // conflict-free) and finished by a COMPACT runtime loop, 8 values at a time: a fully unrolled register
+    // conflict-free) and finished by a COMPACT runtime loop, one 32x32 tile at a time: a fully unrolled register
     // epilogue is ~300 KB of straight-line code that each wave runs once -- instruction-fetch bound, and the
     // whole cost of the small layers.  With split-K the KS partial bands of a tile meet in the same LDS slots and
     // wave (mb % KS) adds them in slice order (deterministic).
@@ -187,38 +187,47 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
         if (active && kslice == (mb & (KS - 1))) {
             const int co0 = co_base + mb * 32 + 4 * hi;      // channel of register 0
 #pragma unroll 1
-            for (int c = 0; c < NB * 2; ++c) {               // 8 registers (= 2 groups of 4 consecutive channels)
-                const int nb = c >> 1, rb = (c & 1) * 8;
+            for (int nb = 0; nb < NB; ++nb) {                // one 32 x 32 tile = 16 registers per lane
                 const bool vld = nb == 0 ? valid[0] : valid[NB - 1];
                 const int im = nb == 0 ? img[0] : img[NB - 1];
                 const int py = nb == 0 ? yo[0] : yo[NB - 1];
                 const int px = nb == 0 ? xo[0] : xo[NB - 1];
-                const int cobase = co0 + 2 * rb;             // rows (r & 3) + 8 (r >> 2): r = rb + i
-                float v[8];
-                bool ok[8];
+                const size_t idx0 = ((size_t)im * p.Cout + co0) * HoWo + (size_t)py * p.Wo + px;
+                bool ok[16];
+                float v[16], bb[16], m[16], gi[16], rr[16];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = tileslot[(nb * 16 + rb + i) * 64];
+                for (int r = 0; r < 16; ++r) ok[r] = vld && (co0 + (r & 3) + 8 * (r >> 2)) < p.Cout;
+                // every side input is requested before anything is consumed, so the latencies overlap
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bb[r] = (p.bias && ok[r]) ? p.bias[co0 + (r & 3) + 8 * (r >> 2)] : 0.0f;
+                if (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[r] = ok[r] ? p.mul[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
+                }
+                if (fl & MCQ_CONV_GATE) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gi[r] = ok[r] ? p.gid[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
+                }
+                if (fl & MCQ_CONV_RESIDUAL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rr[r] = ok[r] ? p.res[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = tileslot[(nb * 16 + r) * 64];
                 for (int w = 1; w < KS; ++w) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = v[i] + tileslot[(size_t)w * (NB * 1024) + (nb * 16 + rb + i) * 64];
+                    for (int r = 0; r < 16; ++r) v[r] = v[r] + tileslot[(size_t)w * (NB * 1024) + (nb * 16 + r) * 64];
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) ok[i] = vld && (cobase + (i & 3) + 8 * (i >> 2)) < p.Cout;
-                if (p.bias) {
-                    float bb[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) bb[i] = ok[i] ? p.bias[cobase + (i & 3) + 8 * (i >> 2)] : 0.0f;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = v[i] + bb[i];
-                }
+                for (int r = 0; r < 16; ++r) v[r] = v[r] + bb[r];
                 if (fl & MCQ_CONV_SHUFFLE2) {
                     // registers 4q..4q+3 are the 2x2 sub-pixels of output channel co/4: two float2 rows.
                     const int Co4 = p.Cout >> 2;
                     const size_t W2 = 2 * (size_t)p.Wo;
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int q = 0; q < 4; ++q) {
                         if (ok[q * 4]) {
-                            const int ch = (cobase + 8 * q) >> 2;
+                            const int ch = (co0 + 8 * q) >> 2;
                             float* o = p.y + (((size_t)im * Co4 + ch) * (2 * (size_t)p.Ho) + 2 * (size_t)py) * W2 + 2 * (size_t)px;
                             *reinterpret_cast<f32x2v*>(o) = f32x2v{v[q * 4 + 0], v[q * 4 + 1]};
                             *reinterpret_cast<f32x2v*>(o + W2) = f32x2v{v[q * 4 + 2], v[q * 4 + 3]};
@@ -226,45 +235,33 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
                     }
                     continue;
                 }
-                const size_t idx0 = ((size_t)im * p.Cout + cobase) * HoWo + (size_t)py * p.Wo + px;
-                if (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) {
-                    float m[8];
+                if (fl & MCQ_CONV_GDN) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) m[i] = ok[i] ? p.mul[idx0 + (size_t)((i & 3) + 8 * (i >> 2)) * HoWo] : 0.0f;
-                    if (fl & MCQ_CONV_GDN) {
+                    for (int r = 0; r < 16; ++r) v[r] = m[r] * (1.0f / sqrtf(v[r]));
+                } else if (fl & MCQ_CONV_IGDN) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] = m[i] * (1.0f / sqrtf(v[i]));
-                    } else if (fl & MCQ_CONV_IGDN) {
+                    for (int r = 0; r < 16; ++r) v[r] = m[r] * sqrtf(v[r]);
+                } else if (fl & MCQ_CONV_GATE) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] = m[i] * sqrtf(v[i]);
-                    } else {
-                        float gi[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) gi[i] = ok[i] ? p.gid[idx0 + (size_t)((i & 3) + 8 * (i >> 2)) * HoWo] : 0.0f;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] = m[i] * mcq_sigmoid(v[i]) + gi[i];
-                    }
+                    for (int r = 0; r < 16; ++r) v[r] = m[r] * mcq_sigmoid(v[r]) + gi[r];
                 }
                 if (fl & MCQ_CONV_RESIDUAL) {
-                    float rr[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) rr[i] = ok[i] ? p.res[idx0 + (size_t)((i & 3) + 8 * (i >> 2)) * HoWo] : 0.0f;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = v[i] + p.res_scale * rr[i];
+                    for (int r = 0; r < 16; ++r) v[r] = v[r] + p.res_scale * rr[r];
                 }
                 if (fl & MCQ_CONV_SILU_OUT) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = mcq_silu(v[i]);
+                    for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (ok[i]) p.y[idx0 + (size_t)((i & 3) + 8 * (i >> 2)) * HoWo] = v[i];
+                for (int r = 0; r < 16; ++r)
+                    if (ok[r]) p.y[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
                 if (fl & MCQ_CONV_DUAL_SILU) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = mcq_silu(v[i]);
+                    for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (ok[i]) p.y2[idx0 + (size_t)((i & 3) + 8 * (i >> 2)) * HoWo] = v[i];
+                    for (int r = 0; r < 16; ++r)
+                        if (ok[r]) p.y2[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
                 }
             }
         }
@@ -423,7 +420,7 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     const long long ptiles = (tb + NB - 1) / NB;
     const int co_tiles = (co32 + MB - 1) / MB;
     hipStream_t s = (hipStream_t)stream;
-    if (MB == 4 && NB == 2) return launch_tile<4, 2, 4>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 4 && NB == 2) return launch_tile<4, 2, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 2) return launch_tile<2, 2, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 1) return launch_tile<2, 1, 16>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 1 && NB == 2) return launch_tile<1, 2, 8>(k, pro, ptiles, co_tiles, ksl, s);

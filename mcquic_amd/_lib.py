@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmcquic_hip.so")
+LIB_PATH = os.environ.get("MCQUIC_AMD_LIB") or os.path.join(HERE, "libmcquic_hip.so")   # override: kernel A/B experiments
 
 MCQ_OK, MCQ_EINVAL, MCQ_ELAUNCH, MCQ_ETOOLARGE = 0, -1, -2, -3
 _ERR = {MCQ_EINVAL: "MCQ_EINVAL (invalid argument)", MCQ_ELAUNCH: "MCQ_ELAUNCH (kernel launch failed)",

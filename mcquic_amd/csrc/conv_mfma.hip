@@ -159,113 +159,147 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
-    // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row band mb, the 16 output channels
-    // row(r) = (r & 3) + 8 (r >> 2) + 4 hi.  The accumulators of a band are parked in LDS ([wave][nb][r][lane],
-    // conflict-free) and finished by a COMPACT runtime loop, one 32x32 tile at a time: a fully unrolled register
-    // epilogue is ~300 KB of straight-line code that each wave runs once -- instruction-fetch bound, and the
-    // whole cost of the small layers.  With split-K the KS partial bands of a tile meet in the same LDS slots and
-    // wave (mb % KS) adds them in slice order (deterministic).
+    // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row tile, the 16 output
+    // channels row(r) = (r & 3) + 8 (r >> 2) + 4 hi.  Side inputs are fetched 16 at a time so
+    // their latencies overlap.
     const unsigned fl = p.flags;
     const size_t HoWo = (size_t)p.Ho * p.Wo;
-    float* const myslot = mcq_lds + (size_t)wave * (NB * 1024) + lane;
-    const float* const tileslot = mcq_lds + (size_t)(tile_in_wg << p.ks_log2) * (NB * 1024) + lane;
 
-#pragma unroll 1
-    for (int mb = 0; mb < MB; ++mb) {
-        if (active) {
-            // static register index per band: one switch arm per mb
+    auto finish = [&](int mb, int nb, float (&v)[16], const float (&bias16)[16], const bool (&cok)[16]) {
+        const int co0 = co_base + mb * 32 + 4 * hi;      // channel of register 0
+        const bool vld = valid[nb];
 #pragma unroll
-            for (int m2 = 0; m2 < MB; ++m2)
-                if (m2 == mb) {
+        for (int r = 0; r < 16; ++r) v[r] = v[r] + bias16[r];
+
+        if (fl & MCQ_CONV_SHUFFLE2) {
+            // registers 4q..4q+3 are the 2x2 sub-pixels of output channel co/4: two float2 rows.
+            const int Co4 = p.Cout >> 2;
+            const size_t W2 = 2 * (size_t)p.Wo;
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) myslot[(nb * 16 + r) * 64] = acc[m2][nb][r];
-                }
-        }
-        if (KS > 1) __syncthreads();
-        if (active && kslice == (mb & (KS - 1))) {
-            const int co0 = co_base + mb * 32 + 4 * hi;      // channel of register 0
-#pragma unroll 1
-            for (int nb = 0; nb < NB; ++nb) {                // one 32 x 32 tile = 16 registers per lane
-                const bool vld = nb == 0 ? valid[0] : valid[NB - 1];
-                const int im = nb == 0 ? img[0] : img[NB - 1];
-                const int py = nb == 0 ? yo[0] : yo[NB - 1];
-                const int px = nb == 0 ? xo[0] : xo[NB - 1];
-                const size_t idx0 = ((size_t)im * p.Cout + co0) * HoWo + (size_t)py * p.Wo + px;
-                bool ok[16];
-                float v[16], bb[16], m[16], gi[16], rr[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ok[r] = vld && (co0 + (r & 3) + 8 * (r >> 2)) < p.Cout;
-                // every side input is requested before anything is consumed, so the latencies overlap
-#pragma unroll
-                for (int r = 0; r < 16; ++r) bb[r] = (p.bias && ok[r]) ? p.bias[co0 + (r & 3) + 8 * (r >> 2)] : 0.0f;
-                if (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) m[r] = ok[r] ? p.mul[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
-                }
-                if (fl & MCQ_CONV_GATE) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) gi[r] = ok[r] ? p.gid[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
-                }
-                if (fl & MCQ_CONV_RESIDUAL) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rr[r] = ok[r] ? p.res[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = tileslot[(nb * 16 + r) * 64];
-                for (int w = 1; w < KS; ++w) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = v[r] + tileslot[(size_t)w * (NB * 1024) + (nb * 16 + r) * 64];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = v[r] + bb[r];
-                if (fl & MCQ_CONV_SHUFFLE2) {
-                    // registers 4q..4q+3 are the 2x2 sub-pixels of output channel co/4: two float2 rows.
-                    const int Co4 = p.Cout >> 2;
-                    const size_t W2 = 2 * (size_t)p.Wo;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (ok[q * 4]) {
-                            const int ch = (co0 + 8 * q) >> 2;
-                            float* o = p.y + (((size_t)im * Co4 + ch) * (2 * (size_t)p.Ho) + 2 * (size_t)py) * W2 + 2 * (size_t)px;
-                            *reinterpret_cast<f32x2v*>(o) = f32x2v{v[q * 4 + 0], v[q * 4 + 1]};
-                            *reinterpret_cast<f32x2v*>(o + W2) = f32x2v{v[q * 4 + 2], v[q * 4 + 3]};
-                        }
-                    }
-                    continue;
-                }
-                if (fl & MCQ_CONV_GDN) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = m[r] * (1.0f / sqrtf(v[r]));
-                } else if (fl & MCQ_CONV_IGDN) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = m[r] * sqrtf(v[r]);
-                } else if (fl & MCQ_CONV_GATE) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = m[r] * mcq_sigmoid(v[r]) + gi[r];
-                }
-                if (fl & MCQ_CONV_RESIDUAL) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = v[r] + p.res_scale * rr[r];
-                }
-                if (fl & MCQ_CONV_SILU_OUT) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (ok[r]) p.y[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
-                if (fl & MCQ_CONV_DUAL_SILU) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (ok[r]) p.y2[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
+            for (int rq = 0; rq < 4; ++rq) {
+                if (vld && cok[rq * 4]) {
+                    const int c = (co0 + 8 * rq) >> 2;
+                    float* o = p.y + (((size_t)img[nb] * Co4 + c) * (2 * (size_t)p.Ho) + 2 * (size_t)yo[nb]) * W2 +
+                               2 * (size_t)xo[nb];
+                    *reinterpret_cast<f32x2v*>(o) = f32x2v{v[rq * 4 + 0], v[rq * 4 + 1]};
+                    *reinterpret_cast<f32x2v*>(o + W2) = f32x2v{v[rq * 4 + 2], v[rq * 4 + 3]};
                 }
             }
+            return;
         }
-        if (KS > 1) __syncthreads();
+        const size_t idx0 = ((size_t)img[nb] * p.Cout + co0) * HoWo + (size_t)yo[nb] * p.Wo + xo[nb];
+        bool ok[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ok[r] = vld && cok[r];
+        if (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) {
+            float m[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[r] = ok[r] ? p.mul[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
+            if (fl & MCQ_CONV_GDN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = m[r] * (1.0f / sqrtf(v[r]));
+            } else if (fl & MCQ_CONV_IGDN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = m[r] * sqrtf(v[r]);
+            } else {
+                float gi[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gi[r] = ok[r] ? p.gid[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = m[r] * mcq_sigmoid(v[r]) + gi[r];
+            }
+        }
+        if (fl & MCQ_CONV_RESIDUAL) {
+            float rr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rr[r] = ok[r] ? p.res[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] + p.res_scale * rr[r];
+        }
+        if (fl & MCQ_CONV_SILU_OUT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok[r]) p.y[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
+        if (fl & MCQ_CONV_DUAL_SILU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (ok[r]) p.y2[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
+        }
+    };
+
+    auto load_bias = [&](int mb, float (&bias16)[16], bool (&cok)[16]) {
+        const int co0 = co_base + mb * 32 + 4 * hi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            cok[r] = co0 + (r & 3) + 8 * (r >> 2) < p.Cout;
+            bias16[r] = 0.0f;
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (cok[r]) bias16[r] = p.bias[co0 + (r & 3) + 8 * (r >> 2)];
+        }
+    };
+
+    if (KS == 1) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            float bias16[16];
+            bool cok[16];
+            load_bias(mb, bias16, cok);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[mb][nb][r];
+                finish(mb, nb, v, bias16, cok);
+            }
+        }
+        return;
+    }
+
+    // split-K: the KS partial tiles of a 32-row band meet in LDS ([slice][nb][r][lane], conflict-free) and wave
+    // (mb % KS) adds them in slice order (deterministic).  The owner only SUMS between the two barriers and keeps
+    // the band in registers; the global-memory epilogues of all bands then run concurrently on their owner waves
+    // after the last barrier (finishing inside the barrier pair serialised the bands: ~11 us each).
+    float* slot0 = mcq_lds + (size_t)(tile_in_wg << p.ks_log2) * (NB * 1024);
+    float own[NB][16];                         // band `kslice` (the launcher guarantees KS >= MB when it splits)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        if (active) {
+            float* mine = slot0 + (size_t)kslice * (NB * 1024) + lane;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(nb * 16 + r) * 64] = acc[mb][nb][r];
+        }
+        __syncthreads();
+        if (active && kslice == mb) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) own[nb][r] = slot0[(nb * 16 + r) * 64 + lane];
+            for (int w = 1; w < KS; ++w) {
+                const float* other = slot0 + (size_t)w * (NB * 1024) + lane;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) own[nb][r] = own[nb][r] + other[(nb * 16 + r) * 64];
+            }
+        }
+        __syncthreads();
+    }
+    if (active && kslice < MB) {
+        float bias16[16];
+        bool cok[16];
+        load_bias(kslice, bias16, cok);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) finish(kslice, nb, own[nb], bias16, cok);
     }
 }
 
@@ -308,15 +342,17 @@ inline int steps_padded(int Cin, int ks) {
 
 template <int MB, int NB, int PF>
 int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2, hipStream_t s) {
-    // split-K slices must be whole prefetch rounds and at least 16 steps long
-    while (ksplit_log2 > 0 && ((k.TP >> ksplit_log2) % PF != 0 || (k.TP >> ksplit_log2) < 16 ||
+    // split-K slices must be whole prefetch rounds and at least 64 steps long (1x1 convs are never split)
+    if (ksplit_log2 > 0 && (1 << ksplit_log2) < MB) ksplit_log2 = MB == 4 ? 2 : 1;   // one band per owner wave
+    while (ksplit_log2 > 0 && ((k.TP >> ksplit_log2) % PF != 0 || (k.TP >> ksplit_log2) < 64 ||
                                ((k.TP >> ksplit_log2) << ksplit_log2) != k.TP))
         --ksplit_log2;
+    if ((1 << ksplit_log2) < MB) ksplit_log2 = 0;
     k.ks_log2 = ksplit_log2;
     k.slice_steps = k.TP >> ksplit_log2;
     k.tiles_log2 = ksplit_log2 >= 2 ? 0 : 2 - ksplit_log2;           // 4 waves per workgroup, 8 for 8-way split
     const int waves = 1 << (k.ks_log2 + k.tiles_log2);
-    const size_t lds = (size_t)waves * NB * 1024 * sizeof(float);      // one parked band per wave
+    const size_t lds = ksplit_log2 ? (size_t)waves * NB * 1024 * sizeof(float) : 0;
     const dim3 grid((unsigned)((tiles + (1 << k.tiles_log2) - 1) >> k.tiles_log2), (unsigned)co_tiles);
     const dim3 block(64 * waves);
     switch (pro) {
@@ -420,7 +456,7 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     const long long ptiles = (tb + NB - 1) / NB;
     const int co_tiles = (co32 + MB - 1) / MB;
     hipStream_t s = (hipStream_t)stream;
-    if (MB == 4 && NB == 2) return launch_tile<4, 2, 8>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 4 && NB == 2) return launch_tile<4, 2, 4>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 2) return launch_tile<2, 2, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 1) return launch_tile<2, 1, 16>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 1 && NB == 2) return launch_tile<1, 2, 8>(k, pro, ptiles, co_tiles, ksl, s);

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Per-shape conv timings on the GPU for forced wave tiles / split-K factors (kernel tuning aid).
+
+    python tools/microbench_conv.py                 # default shape list
+    MCQUIC_AMD_LIB=path/to/variant.so python tools/microbench_conv.py
+
+Each measurement cycles through `--nweights` distinct weight tensors so that a launch never finds its own
+filter bank hot in L2 (as in the real network, where consecutive convs use different weights).
+"""
+import argparse
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mcquic_amd import ops  # noqa: E402
+
+SHAPES = [  # n, cin, cout, h, w, ks, stride
+    (32, 128, 128, 384, 256, 3, 1),
+    (32, 128, 128, 192, 128, 3, 1),
+    (32, 128, 128, 96, 64, 3, 1),
+    (32, 128, 128, 48, 32, 3, 1),
+    (32, 128, 128, 24, 16, 3, 1),
+    (32, 128, 128, 12, 8, 3, 1),
+    (32, 128, 128, 48, 32, 1, 1),
+]
+TILES = [0, 0x42, 0x142, 0x242, 0x342, 0x22, 0x122, 0x222, 0x322, 0x11, 0x211, 0x311]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--nweights", type=int, default=12)
+    ap.add_argument("--flags", default="res")
+    ap.add_argument("--small", action="store_true", help="only the three small levels")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    print("lib:", os.environ.get("MCQUIC_AMD_LIB", "default"))
+    for (n, cin, cout, h, w, ks, stride) in (SHAPES[3:6] if args.small else SHAPES):
+        x = torch.randn(n, cin, h, w, device=dev)
+        res = torch.randn(n, cout, h // stride, w // stride, device=dev)
+        packs = [ops.PackedConv(torch.randn(cout, cin, ks, ks, device=dev) * 0.03, torch.randn(cout, device=dev)) for _ in range(args.nweights)]
+        flops = 2.0 * n * (h // stride) * (w // stride) * cout * cin * ks * ks
+        row = []
+        for tile in TILES:
+            if h * w > 100 * 64 and tile not in (0, 0x42, 0x22):
+                continue
+            kw = dict(tile=tile)
+            if args.flags == "res":
+                kw.update(res=res, dual_silu=True)
+            for i in range(3):
+                ops.conv2d(x, packs[i % len(packs)], stride, **kw)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for i in range(args.iters):
+                ops.conv2d(x, packs[i % len(packs)], stride, **kw)
+            e.record()
+            torch.cuda.synchronize()
+            us = s.elapsed_time(e) * 1e3 / args.iters
+            row.append(f"{tile:#05x}:{us:8.1f}us {flops / us / 1e6:6.1f}TF")
+        print(f"{n}x{cin}->{cout} {h}x{w} k{ks}s{stride}: " + " | ".join(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -12,8 +12,8 @@ coder).  Inputs are resident in HBM before the timed region.  Image batches shar
 data-path collective ("weak" scaling: 32 images per GPU); RCCL is used only for the barrier / max-time reduce.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel `conv_mfma_kernel` (fp32 MFMA bound):
-algorithmic FLOPs of the conv launches in the timed steps / their summed durations, both measured live with
-HIP events on the launch stream.  `cpu_baseline` times the CPU oracle (oracle/mcquic_ref.py, a plain PyTorch
+algorithmic FLOPs of the conv launches in the timed steps / the time during which a conv kernel was in flight
+(union of the per-launch [start, end] intervals, HIP events on the launch streams), both measured live.  `cpu_baseline` times the CPU oracle (oracle/mcquic_ref.py, a plain PyTorch
 restatement of the reference proven bit-equal to it) on this host's cores on a bounded sample.
 """
 from __future__ import annotations
@@ -37,15 +37,22 @@ MODEL = dict(channel=128, m=2, k=[8192, 2048, 512])
 
 
 class ConvProfiler:
-    """Brackets every conv launch with HIP events on the current stream (no host sync inside the region)."""
+    """Brackets every conv launch with HIP events on the stream it is launched on (no host sync in the region).
+
+    Branch streams let two conv kernels overlap, so per-launch durations are not additive: the busy time reported
+    is the UNION of the [start, end] intervals (time during which at least one conv kernel was in flight), from
+    event timestamps relative to one base event."""
 
     def __init__(self):
-        self.records = []           # (start, end, flops, bytes, tile)
+        self.records = []           # (start, end, flops, bytes)
+        self.base = None
 
     def install(self):
         from mcquic_amd import ops
         self._orig = ops.conv2d
         prof = self
+        self.base = torch.cuda.Event(enable_timing=True)
+        self.base.record()
 
         def wrapped(x, w, stride=1, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -69,10 +76,31 @@ class ConvProfiler:
         ops.conv2d = self._orig
 
     def summary(self):
-        ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
+        iv = sorted((self.base.elapsed_time(s), self.base.elapsed_time(e)) for s, e, _, _ in self.records)
+        busy, cur_s, cur_e = 0.0, None, None
+        for a, b in iv:
+            if cur_e is None or a > cur_e:
+                if cur_e is not None:
+                    busy += cur_e - cur_s
+                cur_s, cur_e = a, b
+            else:
+                cur_e = max(cur_e, b)
+        if cur_e is not None:
+            busy += cur_e - cur_s
         fl = sum(r[2] for r in self.records)
         by = sum(r[3] for r in self.records)
-        return dict(launches=len(self.records), ms=ms, flops=fl, bytes=by)
+        return dict(launches=len(self.records), ms=busy, flops=fl, bytes=by,
+                    sum_ms=sum(s.elapsed_time(e) for s, e, _, _ in self.records))
+
+
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (separate
+    FETCH_SIZE / WRITE_SIZE passes of this same command; profiles/rNN_pmc.json).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    try:
+        return json.load(open(path))
+    except (OSError, ValueError):
+        return None
 
 
 def usable_cores() -> int:
@@ -194,10 +222,10 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM, all tile variants)",
                 "achieved": round(achieved_tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved_tf / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved_tf / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                 "launches_per_step": conv["launches"] // max(args.steps, 1),
-                "avg_launch_ms": round(conv["ms"] / max(conv["launches"], 1), 4),
-                "conv_ms_per_step": round(conv["ms"] / max(args.steps, 1), 3),
+                "avg_launch_ms": round(conv["sum_ms"] / max(conv["launches"], 1), 4),
+                "conv_busy_ms_per_step": round(conv["ms"] / max(args.steps, 1), 3),
                 "algorithmic_gflop_per_step": round(conv["flops"] / max(args.steps, 1) / 1e9, 2),
                 "hbm_algorithmic_gbs": round(conv["bytes"] / (conv["ms"] * 1e-3) / 1e9, 1) if conv["ms"] > 0 else None,
                 "whole_step_frac": round(536.63e9 * args.batch / (dt / args.steps) / (FP32_MATRIX_PEAK_TFLOPS * 1e12), 4),

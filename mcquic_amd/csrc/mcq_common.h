@@ -25,8 +25,22 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 // SiLU / sigmoid spelled like ATen's CPU kernels (x / (1 + exp(-x)), 1 / (1 + exp(-x))) with
 // correctly rounded division; expf is the ocml implementation (~1 ulp).
+#ifndef MCQ_FAST_ACT
+#define MCQ_FAST_ACT 0
+#endif
+#if MCQ_FAST_ACT
+// hardware transcendentals: exp(-x) = exp2(-x * log2(e)) (v_exp_f32, ~1 ulp) and v_rcp_f32 (1 ulp) instead of the
+// ocml expf + IEEE division (~40 VALU instructions per value).
+__device__ __forceinline__ float mcq_silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+__device__ __forceinline__ float mcq_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+#else
 __device__ __forceinline__ float mcq_silu(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float mcq_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+#endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mcq_make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);

@@ -34,10 +34,11 @@ def main():
     ap.add_argument("--nweights", type=int, default=12)
     ap.add_argument("--flags", default="res")
     ap.add_argument("--small", action="store_true", help="only the three small levels")
+    ap.add_argument("--big", action="store_true", help="only the two largest levels")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     print("lib:", os.environ.get("MCQUIC_AMD_LIB", "default"))
-    for (n, cin, cout, h, w, ks, stride) in (SHAPES[3:6] if args.small else SHAPES):
+    for (n, cin, cout, h, w, ks, stride) in (SHAPES[3:6] if args.small else SHAPES[:2] if args.big else SHAPES):
         x = torch.randn(n, cin, h, w, device=dev)
         res = torch.randn(n, cout, h // stride, w // stride, device=dev)
         packs = [ops.PackedConv(torch.randn(cout, cin, ks, ks, device=dev) * 0.03, torch.randn(cout, device=dev)) for _ in range(args.nweights)]
@@ -49,6 +50,10 @@ def main():
             kw = dict(tile=tile)
             if args.flags == "res":
                 kw.update(res=res, dual_silu=True)
+            elif args.flags == "resonly":
+                kw.update(res=res)
+            elif args.flags == "silu_out":
+                kw.update(silu_out=True)
             for i in range(3):
                 ops.conv2d(x, packs[i % len(packs)], stride, **kw)
             torch.cuda.synchronize()

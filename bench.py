@@ -116,17 +116,20 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline(state_dict_cpu, x_cpu, iters=2):
-    """The CPU oracle on this host: batch len(x_cpu) of 768x512, 1 warm-up + `iters` timed encode+decode passes."""
+def cpu_baseline(state_dict_cpu, x_cpu, min_seconds=12.0, max_iters=12):
+    """The CPU oracle on this host: batch len(x_cpu) of 768x512, 1 warm-up pass, then timed encode+decode passes
+    until `min_seconds` of CPU work have been measured (bounded sample: about 10-30 s in all)."""
     from oracle import mcquic_ref as R
     cores = usable_cores()
     torch.set_num_threads(cores)
     codes = R.encode(state_dict_cpu, x_cpu)          # warm-up (also the parity sample)
     pixels = R.decode(state_dict_cpu, codes)
     t0 = time.perf_counter()
-    for _ in range(iters):
+    iters = 0
+    while iters < 2 or (time.perf_counter() - t0 < min_seconds and iters < max_iters):
         c = R.encode(state_dict_cpu, x_cpu)
         R.decode(state_dict_cpu, c)
+        iters += 1
     dt = time.perf_counter() - t0
     base = {"value": round(len(x_cpu) * iters / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"oracle/mcquic_ref.py (PyTorch-CPU restatement, bit-equal to the reference in the build container): "

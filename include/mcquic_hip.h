@@ -112,6 +112,27 @@ int mcq_add_f32(const float* a, const float* b, float* out, float* out_silu /* o
 /* u8 = trunc(clamp(((x + 1) / 2) * 255.999, 0, 255))   (mcquic/utils/vision.py:143-146 DeTransform). */
 int mcq_detransform_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 
+/* ---- entropy coder beside the tensor path (host code, no GPU work) ------------------------------ */
+
+/* cdf[0..k] (uint32, cdf[0] = 0, cdf[k] = 1 << precision, strictly increasing) from pmf[0..k-1].
+ * Same arithmetic as pmfToQuantizedCDF (third_party/CompressAI/cpp_exts/ops.cpp:42-111). */
+int mcq_pmf_to_quantized_cdf(const float* pmf, int32_t k, int32_t precision, uint32_t* cdf);
+
+/* One rANS stream over symbols[0..n): symbol i is coded with CDF number indexes[i]; CDF c occupies
+ * cdfs[cdf_starts[c] ...], cdf_sizes[c] follows the reference's convention (sentinel slot = cdf_sizes[c] - 2,
+ * the reference passes k + 2), offsets[c] is subtracted from the symbol.  Returns the number of bytes written to
+ * `out`, or a negative MCQ_E* (MCQ_ETOOLARGE if `capacity` is too small: 4 * n + 8 always suffices without
+ * bypass symbols).  Bit-identical to RansEncoder.encodeWithIndexes
+ * (cpp_exts/buffered_rans_encoder.cpp:104-196 over ryg_rans/rans64.h). */
+int64_t mcq_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexes, int64_t n,
+                                     const uint32_t* cdfs, const int32_t* cdf_starts, const int32_t* cdf_sizes,
+                                     const int32_t* offsets, int32_t n_cdfs, uint8_t* out, int64_t capacity);
+
+/* Inverse of the above (cpp_exts/rans_decoder.cpp:104-167); MCQ_EINVAL on a truncated / malformed stream. */
+int mcq_rans_decode_with_indexes(const uint8_t* in, int64_t nbytes, const int32_t* indexes, int64_t n,
+                                 const uint32_t* cdfs, const int32_t* cdf_starts, const int32_t* cdf_sizes,
+                                 const int32_t* offsets, int32_t n_cdfs, int32_t* out_symbols);
+
 /* Library / build identification: returns a static string "mcquic_hip <ver> gfx950". */
 const char* mcq_version(void);
 

@@ -43,6 +43,11 @@ SYMBOLS = {
                                     c_int32, c_void_p]),
     "mcq_add_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_detransform_u8": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_pmf_to_quantized_cdf": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
+    "mcq_rans_encode_with_indexes": (c_int64, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                               c_void_p, c_int64]),
+    "mcq_rans_decode_with_indexes": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_int32, c_void_p]),
     "mcq_version": (c_char_p, []),
 }
 

@@ -3,7 +3,7 @@
     Compressor(channel, m, k, permutationRate=0.0)         # compressor.py:121
     .encode(x) -> List[LongTensor [n, m, h_l, w_l]]        # :79-88
     .decode(codes) -> Tensor [n, 3, H, W]                  # :114-117
-    .compress(x) / .decompress(binaries, headers)          # :67-77 / :90-112 (entropy coder: next row)
+    .compress(x) / .decompress(binaries, headers)          # :67-77 / :90-112 (rANS streams, csrc/rans.cpp)
     .Codebooks / .NormalizedFreq / .CDFs / .CodeUsage / .QuantizationParameter
 
 The module tree and every state_dict key are the reference's (718 entries for the qp=2 shape), so a

@@ -1,17 +1,78 @@
-"""Entropy-coder state that sits beside the tensor path (reference: mcquic/modules/entropyCoder.py:15-154).
+"""Entropy coder beside the tensor path (reference: mcquic/modules/entropyCoder.py:15-154).
 
-Only what the Compressor API needs at this stage is present: the per-level code-frequency EMA
-(`_freqEMA.{l}` in the state_dict) and the `NormalizedFreq` view.  `compress` / `decompress` (rANS byte
-streams) raise NotImplementedError exactly as the reference snapshot does (entropyCoder.py:107,140:
-both bodies start with `raise NotImplementedError`); the rANS coder is the first "next" row of
-SURVEY.md §8(f).
+State: the per-level code-frequency EMA (`_freqEMA.{l}` in the state_dict).  From it: normalised frequencies,
+16-bit quantized CDFs (`mcq_pmf_to_quantized_cdf`), and per image x level rANS streams over the flattened
+`code[m, h, w]` with the group index selecting the CDF (`mcq_rans_encode_with_indexes` / `_decode_`): the host-side
+C++ coder in csrc/rans.cpp, bit-compatible with the reference's `mcquic.rans` extension.
+
+The reference snapshot's `compress` / `decompress` start with `raise NotImplementedError` (entropyCoder.py:107,140)
+and the dead body is self-inconsistent (`CodeSize.m` is built from an int at :126 and iterated as a list at :146).
+What is implemented here is the evident intent of that body -- symbols = code.flatten(), indexes = group id,
+cdfs = pmfToQuantizedCDF(freq_g, 16), cdfSizes = k + 2, offsets = 0 -- with `CodeSize.m` as the typed list
+(`mcquic/utils/specification.py:89`).  The byte streams are pinned at the rANS level (bit-equal to the compiled
+reference extension, tests/test_entropy_coder.py), not at the `Compressor.compress` level, which the reference
+cannot execute.
 """
 from __future__ import annotations
 
-from typing import List
+import ctypes
+from typing import List, Tuple
 
+import numpy as np
 import torch
 from torch import nn
+
+from .. import _lib
+from ..utils.specification import CodeSize
+
+
+def _vp(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def pmfToQuantizedCDF(pmf, precision: int = 16) -> List[int]:
+    """Same contract as `mcquic.rans.pmfToQuantizedCDF` (list of floats -> list of k + 1 ints)."""
+    p = np.ascontiguousarray(np.asarray(pmf, dtype=np.float32))
+    cdf = np.empty(p.shape[0] + 1, dtype=np.uint32)
+    rc = _lib.load().mcq_pmf_to_quantized_cdf(_vp(p), p.shape[0], precision, _vp(cdf))
+    if rc != 0:
+        raise ValueError("Invalid `pmf`: negative / non-finite element, all zero, or more symbols than 2**precision")
+    return cdf.tolist()
+
+
+class _Tables:
+    """CDFs of one level flattened for the C ABI: m CDFs of k + 1 entries each."""
+
+    def __init__(self, cdfs: List[List[int]], k: int):
+        m = len(cdfs)
+        self.cdfs = np.ascontiguousarray(np.asarray(cdfs, dtype=np.uint32).reshape(-1))
+        self.starts = np.ascontiguousarray(np.arange(m, dtype=np.int32) * (k + 1))
+        self.sizes = np.full(m, k + 2, dtype=np.int32)           # the reference's convention (entropyCoder.py:121)
+        self.offsets = np.zeros(m, dtype=np.int32)
+        self.m = m
+
+
+def ransEncodeWithIndexes(symbols: np.ndarray, indexes: np.ndarray, t: _Tables) -> bytes:
+    symbols = np.ascontiguousarray(symbols, dtype=np.int32)
+    indexes = np.ascontiguousarray(indexes, dtype=np.int32)
+    cap = 4 * symbols.size + 64
+    out = np.empty(cap, dtype=np.uint8)
+    n = _lib.load().mcq_rans_encode_with_indexes(_vp(symbols), _vp(indexes), symbols.size, _vp(t.cdfs), _vp(t.starts),
+                                                 _vp(t.sizes), _vp(t.offsets), t.m, _vp(out), cap)
+    if n < 0:
+        raise RuntimeError(f"rANS encode failed ({n})")
+    return out[:n].tobytes()
+
+
+def ransDecodeWithIndexes(binary: bytes, indexes: np.ndarray, t: _Tables) -> np.ndarray:
+    indexes = np.ascontiguousarray(indexes, dtype=np.int32)
+    buf = np.frombuffer(binary, dtype=np.uint8)
+    out = np.empty(indexes.size, dtype=np.int32)
+    rc = _lib.load().mcq_rans_decode_with_indexes(_vp(buf), buf.size, _vp(indexes), indexes.size, _vp(t.cdfs), _vp(t.starts),
+                                                  _vp(t.sizes), _vp(t.offsets), t.m, _vp(out))
+    if rc != 0:
+        raise RuntimeError("Got a truncated or malformed rANS stream.")
+    return out
 
 
 class EntropyCoder(nn.Module):
@@ -20,15 +81,43 @@ class EntropyCoder(nn.Module):
         # initial value is uniform (entropyCoder.py:22)
         self._freqEMA = nn.ParameterList(nn.Parameter(torch.ones(m, ki) / ki, requires_grad=False) for ki in k)
         self._m, self._k, self._ema = m, k, ema
+        self._cdfs = None
+        self._normalizedFreq = None
+        self._tables = None
+        self._key = None
+
+    # ---- frequency / CDF tables (entropyCoder.py:46-79) ------------------------------------------------------
+    def resetFreqAndCDF(self):
+        self._normalizedFreq = None
+        self._cdfs = None
+        self._tables = None
+
+    def _stale(self) -> bool:
+        key = tuple((f._version, f.data_ptr()) for f in self._freqEMA)
+        if key != self._key:
+            self._key = key
+            return True
+        return self._cdfs is None
+
+    def updateFreqAndCDF(self):
+        freq = [(f / f.sum(-1, keepdim=True)).detach().clone() for f in self._freqEMA]
+        cdfs = [[pmfToQuantizedCDF(frAtM.tolist(), 16) for frAtM in fr.cpu()] for fr in freq]
+        self._normalizedFreq = freq
+        self._cdfs = cdfs
+        self._tables = [_Tables(c, ki) for c, ki in zip(cdfs, self._k)]
+
+    @property
+    def CDFs(self) -> List[List[List[int]]]:
+        if self._stale():
+            self.updateFreqAndCDF()
+        return self._cdfs
 
     @property
     def NormalizedFreq(self) -> List[torch.Tensor]:
-        """List of [m, k_l] probabilities (entropyCoder.py:50-55,73-79)."""
-        return [(f / f.sum(-1, keepdim=True)).detach().clone() for f in self._freqEMA]
-
-    @property
-    def CDFs(self):
-        raise NotImplementedError("rANS CDF tables: next row (SURVEY.md §8(f) #1); dead in the reference snapshot too")
+        """List of [m, k_l] probabilities."""
+        if self._stale():
+            self.updateFreqAndCDF()
+        return self._normalizedFreq
 
     def _checkShape(self, codes: List[torch.Tensor]):
         """Same checks and RuntimeErrors as entropyCoder.py:79-93."""
@@ -47,10 +136,37 @@ class EntropyCoder(nn.Module):
                 raise RuntimeError(info + "Now `n` is inconsisitent.")
         return n, m
 
-    def compress(self, codes):
-        raise NotImplementedError("EntropyCoder.compress: rANS byte streams are a 'next' row (SURVEY.md §8(f) #1); "
-                                  "the reference snapshot raises here as well (entropyCoder.py:107)")
+    # ---- byte streams (entropyCoder.py:95-154) ----------------------------------------------------------------
+    @torch.inference_mode()
+    def compress(self, codes: List[torch.Tensor]) -> Tuple[List[List[bytes]], List[CodeSize]]:
+        """codes: level-length list of [n, m, h, w] -> (binaries[n][level], CodeSize per image)."""
+        n, m = self._checkShape(codes)
+        self.CDFs  # refresh the tables if the EMA changed
+        compressed: List[List[bytes]] = [[] for _ in range(n)]
+        heights, widths = [], []
+        for code, table in zip(codes, self._tables):
+            _, _, h, w = code.shape
+            heights.append(h)
+            widths.append(w)
+            host = code.detach().to("cpu", torch.int32).numpy()            # one D2H copy per level
+            idx = np.repeat(np.arange(m, dtype=np.int32), h * w)            # group id per symbol, [m, h, w] order
+            for i in range(n):
+                compressed[i].append(ransEncodeWithIndexes(host[i].reshape(-1), idx, table))
+        return compressed, [CodeSize([m] * len(codes), heights, widths, list(self._k)) for _ in range(n)]
 
-    def decompress(self, binaries, codeSizes):
-        raise NotImplementedError("EntropyCoder.decompress: rANS byte streams are a 'next' row (SURVEY.md §8(f) #1); "
-                                  "the reference snapshot raises here as well (entropyCoder.py:140)")
+    @torch.inference_mode()
+    def decompress(self, binaries: List[List[bytes]], codeSizes: List[CodeSize]) -> List[torch.Tensor]:
+        """binaries[n][level] -> level-length list of int64 [n, m, h, w] on the coder's device."""
+        if len(binaries) < 1 or len(binaries) != len(codeSizes):
+            raise RuntimeError("`binaries` and `codeSizes` must be non-empty and of equal length.")
+        self.CDFs
+        levels = len(binaries[0])
+        out = [[] for _ in range(levels)]
+        for binary, codeSize in zip(binaries, codeSizes):
+            if len(binary) != levels or len(codeSize.heights) != levels:
+                raise RuntimeError("Every image must carry one stream per level.")
+            for lv, (b, table, mi, h, w) in enumerate(zip(binary, self._tables, codeSize.m, codeSize.heights, codeSize.widths)):
+                idx = np.repeat(np.arange(mi, dtype=np.int32), h * w)
+                out[lv].append(torch.from_numpy(ransDecodeWithIndexes(b, idx, table).reshape(mi, h, w).astype(np.int64)))
+        device = self._freqEMA[0].device
+        return [torch.stack(c, 0).to(device) for c in out]

@@ -119,6 +119,41 @@ def main():
     qp2["rec_mean_abs"] = np.array([rec.abs().mean().item()])
     qp2["rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, "f5_qp2_model.npz"), **qp2)
+    # ---- F8: rANS byte streams + quantized CDFs from the reference's native coder (oracle/_ref, built from the
+    #          reference's own sources by oracle/Makefile) ---------------------------------------------------------
+    import glob
+    import importlib.util
+    so = glob.glob(os.path.join(ROOT, "oracle", "_ref", "rans*.so"))
+    if so:
+        spec = importlib.util.spec_from_file_location("rans", so[0])
+        RA = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(RA)
+        rng = np.random.default_rng(0)
+        f8 = {}
+        for tag, k, m, h, w in (("k8", 8, 2, 5, 7), ("k512", 512, 2, 12, 8), ("k8192", 8192, 2, 48, 32)):
+            pmfs = []
+            for g in range(m):
+                pm = rng.random(k).astype(np.float32) ** (4 if g == 0 else 1)
+                pmfs.append((pm / pm.sum()).astype(np.float32))
+            cdfs = [RA.pmfToQuantizedCDF(pm.tolist(), 16) for pm in pmfs]
+            sym = rng.integers(0, k, m * h * w).astype(np.int32)
+            idx = np.repeat(np.arange(m, dtype=np.int32), h * w)
+            by = RA.RansEncoder().encodeWithIndexes(sym.tolist(), idx.tolist(), cdfs, [k + 2] * m, [0] * m)
+            f8[tag + "_pmf"] = np.stack(pmfs)
+            f8[tag + "_cdf"] = np.asarray(cdfs, dtype=np.uint32)
+            f8[tag + "_sym"] = sym
+            f8[tag + "_shape"] = np.array([m, h, w, k])
+            f8[tag + "_bytes"] = np.frombuffer(by, dtype=np.uint8)
+        # bypass path: CompressAI's own convention cdfSizes = len(cdf) (sentinel = last slot), symbols beyond it / negative
+        k = 16
+        pm = (np.ones(k) / k).astype(np.float32)
+        cdf = RA.pmfToQuantizedCDF(pm.tolist(), 16)
+        sym = np.array([0, 3, 14, 15, 16, 40, 1000, -1, -7, 5], dtype=np.int32)
+        by = RA.RansEncoder().encodeWithIndexes(sym.tolist(), [0] * len(sym), [cdf], [k + 1], [0])
+        f8["bypass_cdf"] = np.asarray(cdf, dtype=np.uint32)
+        f8["bypass_sym"] = sym
+        f8["bypass_bytes"] = np.frombuffer(by, dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, "f8_rans.npz"), **f8)
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -104,6 +104,28 @@ int mcq_vq_gather_f32(const int64_t* codes, const float* codebook, float* out, f
                       int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k,
                       void* stream);
 
+/* ---- training-mode quantizer forward (BASELINE config #5, forward half) ------------------------------ */
+
+/* logits[n, g, y, x, k] = ((-1 * dist) / sqrt(k)) * max(temperature[g], bound), dist as in mcq_vq_assign_f32.
+ * Replaces _logit (mcquic/modules/quantizer.py:181-183) and the temperature scaling of _sample (:204). */
+int mcq_vq_logits_f32(const float* x, const float* cb_packed, const float* temperature /* [m] */, float bound,
+                      float* logits, int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k, void* stream);
+
+/* Per latent vector, with the two uniform draws of the reference given as inputs u_drop, u_gumbel [N, m, h, w, k]:
+ *   logits[c] += -1e9 where u_drop[c] ** drop_exponent[0] < freq_ema[g, c]      (_randomDrop, quantizer.py:194-200)
+ *   codes        = argmax_c logits[c]                                            (forward, :232-239)
+ *   sample_index = argmax_c softmax(logits + gumbel(u_gumbel))[c], sample_hot = (1 - s) + s with s the soft
+ *   probability there: the value of y_hard - y_soft.detach() + y_soft, which is zero everywhere else
+ *                                                                                (gumbelSoftmax, mcquic/nn/base.py:118-133) */
+int mcq_vq_gumbel_sample_f32(float* logits, const float* u_drop, const float* u_gumbel, const float* freq_ema /* [m, k] */,
+                             const float* drop_exponent /* device scalar */, int64_t* codes, int64_t* sample_index,
+                             float* sample_hot, int32_t N, int32_t m, int32_t h, int32_t w, int32_t k, void* stream);
+
+/* out[n, g*d + j, y, x] = sample_hot * codebook[g, sample_index, j]: bmm(sample, codebook) for the one-hot-valued
+ * straight-through sample (_multiCodebookDeQuantization.forward, quantizer.py:262-274). */
+int mcq_vq_dequant_soft_f32(const int64_t* sample_index, const float* sample_hot, const float* codebook, float* out,
+                            int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k, void* stream);
+
 /* ---- small element-wise helpers on the path ------------------------------------------------ */
 
 /* out = a + b  (quantizer.py:354  xHat = q + sideHead(formerLevel)). */

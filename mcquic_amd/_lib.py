@@ -41,6 +41,12 @@ SYMBOLS = {
                                     c_int32, c_void_p]),
     "mcq_vq_gather_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
+    "mcq_vq_logits_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                    c_int32, c_void_p]),
+    "mcq_vq_gumbel_sample_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "mcq_vq_dequant_soft_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                          c_int32, c_void_p]),
     "mcq_add_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_detransform_u8": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_pmf_to_quantized_cdf": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),

@@ -11,20 +11,11 @@
 // |c_k|^2 is needed in the accumulator's row layout.  It is obtained bit-exactly with one extra
 // MFMA per 32 rows: A[i][0] = c2[i], B[0][j] = 1, everything else 0  =>  D[i][j] = c2[i].
 #include "mcq_common.h"
+#include "vq_common.h"
 #include "../../include/mcquic_hip.h"
 #include <math.h>
 
 namespace {
-
-constexpr int VQ_MB = 4, VQ_NB = 2, VQ_PF = 4;
-
-struct VqK {
-    const float* x; const float* cbp; const float* c2p; int64_t* codes;
-    int N, m, d, h, w, k;
-    int Sp;            // k-steps (channel pairs) per tile, padded to a multiple of VQ_PF
-    int ntile;         // 128-codeword tiles
-    int bw_log2, nbx, nby, total_blocks;
-};
 
 __global__ __launch_bounds__(256) void vq_assign_kernel(VqK p) {
     constexpr int MB = VQ_MB, NB = VQ_NB, PF = VQ_PF;
@@ -254,19 +245,6 @@ __global__ void detransform_kernel(const float* __restrict__ x, uint8_t* __restr
         out[i] = (uint8_t)v;
     }
 }
-
-inline void block_shape(int Ho, int Wo, int& lg_out) {
-    int best_log2 = 5; double best_util = -1.0;
-    for (int lg = 5; lg >= 2; --lg) {
-        const int bw = 1 << lg, bh = 32 >> lg;
-        const double cover = (double)((Ho + bh - 1) / bh * bh) * (double)((Wo + bw - 1) / bw * bw);
-        const double util = (double)Ho * Wo / cover;
-        if (util > best_util + 1e-9) { best_util = util; best_log2 = lg; }
-    }
-    lg_out = best_log2;
-}
-
-inline int vq_sp(int d) { return (((d + 1) / 2) + VQ_PF - 1) / VQ_PF * VQ_PF; }
 
 }  // namespace
 

@@ -60,11 +60,19 @@ class BaseCompressor(nn.Module):
     def QuantizationParameter(self, qp: str):
         self._qp = qp
 
-    def forward(self, x: torch.Tensor):
-        if self.training:
-            raise NotImplementedError("the training forward (Gumbel soft-assign + straight-through backward) is "
-                                      "BASELINE config #5 and not built yet; call .eval() for encode/decode")
-        return None     # the reference's forward returns None in eval mode (compressor.py:35-43)
+    def forward(self, x: torch.Tensor, uniforms=None):
+        """Training-mode forward (compressor.py:35-43): (xHat, yHat, codes, logits); None in eval mode like the
+        reference.  FORWARD VALUES ONLY for now: the kernels run outside autograd (the straight-through backward of
+        BASELINE config #5 is not built yet), so the outputs carry no graph.  `uniforms`: optional per-level
+        (u_drop, u_gumbel) draws replacing the two `torch.rand_like(logit)` calls of the reference."""
+        if not self.training:
+            return None
+        self._check(x)
+        with torch.no_grad():
+            y = self._encode_latent(x, pad=False)          # the training forward does not pad (compressor.py:39)
+            yHat, codes, logits = self._quantizer(y, uniforms)
+            xHat = self._decoder(yHat)
+        return xHat, yHat, codes, logits
 
     def reAssignCodebook(self) -> torch.Tensor:
         return self._quantizer.reAssignCodebook()
@@ -92,9 +100,9 @@ class BaseCompressor(nn.Module):
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError(f"expected an image batch [n, 3, h, w], got {tuple(x.shape)}")
 
-    def _encode_latent(self, x: torch.Tensor) -> torch.Tensor:
+    def _encode_latent(self, x: torch.Tensor, pad: bool = True) -> torch.Tensor:
         """`self._encoder(self._padding(x))`; the stem conv also emits silu(.) for the first ResidualBlock."""
-        y = self._encoder[0](self._padding(x), dual_silu=True)
+        y = self._encoder[0](self._padding(x) if pad else x, dual_silu=True)
         for i in range(1, len(self._encoder)):
             y = self._encoder[i](y)
         return y

@@ -86,6 +86,20 @@ class EntropyCoder(nn.Module):
         self._tables = None
         self._key = None
 
+    @torch.no_grad()
+    def forward(self, codes: List[torch.Tensor]):
+        """Frequency EMA update of a training step (entropyCoder.py:28-44).  The reference sums one-hot codes
+        [n, m, h, w, k] over (n, h, w) and all-reduces each level; here the counts are histograms of the int64 codes
+        and the three levels share ONE all-reduce (parallel.code_histograms)."""
+        from ..parallel import code_histograms
+        counts = code_histograms(codes, self._k)
+        for lv, totalCount in enumerate(counts):
+            totalCount = totalCount.to(self._freqEMA[lv].dtype)
+            normalized = totalCount / totalCount.sum(-1, keepdim=True)
+            ema = (1 - self._ema) * normalized + self._ema * self._freqEMA[lv]
+            self._freqEMA[lv].copy_(ema)
+        self.resetFreqAndCDF()
+
     # ---- frequency / CDF tables (entropyCoder.py:46-79) ------------------------------------------------------
     def resetFreqAndCDF(self):
         self._normalizedFreq = None

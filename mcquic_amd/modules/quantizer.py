@@ -58,6 +58,25 @@ class _multiCodebookQuantization(nn.Module):
         """[n, m*d, h, w] -> int64 [n, m, h, w] = argmin_k ((x2 + c2) - 2 x.c), first index on ties (:144-179)."""
         return ops.vq_assign(x, self._cache[0].get(self._codebook))
 
+    def forward(self, x: torch.Tensor, freqEMA: torch.Tensor, uniforms=None):
+        """Training-mode forward (:181-239), forward values only (no autograd graph yet).
+
+        logit = (-dist / sqrt(k)) * max(temperature, eps); random drop against the level's frequency EMA;
+        gumbelSoftmax(hard=True); code = argmax(logit).  The straight-through sample y_hard - y_soft + y_soft is
+        zero except at its arg-max, so it is carried as (index, hot value) instead of a dense [n, m, h, w, k]
+        tensor.  `uniforms` = (u_drop, u_gumbel), the reference's two `torch.rand_like(logit)` draws; drawn here
+        with torch.rand when None.  Returns ((index, hot), code, logit)."""
+        cb = self._cache[0].get(self._codebook)
+        logit = ops.vq_logits(x, cb, self._temperature, float(EPS))
+        if uniforms is None:
+            uniforms = (torch.rand(logit.shape, device=logit.device), torch.rand(logit.shape, device=logit.device))
+        bits = math.log2(self._k)
+        # exponent of _randomDrop (:196-198), kept on the device: no host sync in the step
+        usage = (freqEMA > EPS).float().mean().clamp(0., 1.)
+        exponent = -(bits - 1) * (usage ** 2) + bits
+        code, index, hot = ops.vq_gumbel_sample(logit, uniforms[0], uniforms[1], freqEMA, exponent)
+        return (index, hot), code, logit
+
 
 class _multiCodebookDeQuantization(nn.Module):
     """reference: quantizer.py:242-274."""
@@ -67,6 +86,11 @@ class _multiCodebookDeQuantization(nn.Module):
         self._m, self._k, self._d = codebook.shape
         self._codebook = codebook
         self._cache = [cache]
+
+    def forward(self, sample) -> torch.Tensor:
+        """bmm(sample, codebook) (:262-274) for the (index, hot value) form of the straight-through sample."""
+        index, hot = sample
+        return ops.vq_dequant_soft(index, hot, self._cache[0].get(self._codebook))
 
     def decode(self, code: torch.Tensor, dual_silu: bool = False) -> torch.Tensor:
         """int64 [n, m, h, w] -> [n, m*d, h, w] (:249-259)."""
@@ -102,6 +126,23 @@ class _quantizerEncoder(nn.Module):
         return head[len(head) - 1](t, res=deq, res_scale=-1.0, dual_silu=True), code
 
 
+    def _forward(self, x: torch.Tensor, freqEMA: torch.Tensor, uniforms=None):
+        """Training-mode level (:295-305): returns (sample, residual for the next level, code, logit)."""
+        z = self._latentStageEncoder(x)
+        q, code, logit = self._quantizer(self._quantizationHead(z), freqEMA, uniforms)
+        if self._latentHead is None:
+            return q, None, code, logit
+        deq = self._dequantizer(q)
+        head = self._latentHead
+        t = z
+        for i in range(len(head) - 1):
+            t = head[i](t)
+        return q, head[len(head) - 1](t, res=deq, res_scale=-1.0, dual_silu=True), code, logit
+
+    def forward(self, x: torch.Tensor, freqEMA: torch.Tensor, uniforms=None):
+        return self._forward(x, freqEMA, uniforms)
+
+
 class _quantizerDecoder(nn.Module):
     """reference: quantizer.py:330-365."""
 
@@ -119,6 +160,14 @@ class _quantizerDecoder(nn.Module):
         else:
             xHat = q
         return self._restoreHead(xHat)
+
+
+    def forward(self, q, formerLevel: Optional[torch.Tensor]):
+        """Training-mode level (:359-365): like decode, from the straight-through sample."""
+        x = self._dequantizationHead(self._dequantizer(q))
+        if self._sideHead is not None:
+            x = ops.add(x, self._sideHead(formerLevel), dual_silu=True)
+        return self._restoreHead(x)
 
 
 class BaseQuantizer(nn.Module):
@@ -189,6 +238,23 @@ class UMGMQuantizer(BaseQuantizer):
         for decoder, code in zip(self._decoders[::-1], codes[::-1]):
             formerLevel = decoder.decode(code, formerLevel)
         return formerLevel
+
+    def forward(self, x: torch.Tensor, uniforms=None):
+        """Training-mode forward (:443-467), forward values only: per level soft-assign with the level's frequency EMA
+        (the reference snapshot passes `permutationRate` where this tensor belongs, :399 -- repaired here), decoders in
+        reverse, then the code-frequency EMA update with its all-reduce (entropyCoder.py:28-44).
+        `uniforms`: optional list of (u_drop, u_gumbel) per level.  Returns (yHat, codes, logits)."""
+        quantizeds, codes, logits = [], [], []
+        for lv, encoder in enumerate(self._encoders):
+            quantized, x, code, logit = encoder(x, self._entropyCoder._freqEMA[lv], None if uniforms is None else uniforms[lv])
+            quantizeds.append(quantized)
+            codes.append(code)
+            logits.append(logit)
+        formerLevel = None
+        for decoder, quantized in zip(self._decoders[::-1], quantizeds[::-1]):
+            formerLevel = decoder(quantized, formerLevel)
+        self._entropyCoder(codes)
+        return formerLevel, codes, logits
 
     def reAssignCodebook(self):
         raise NotImplementedError("training-side codebook maintenance is a 'next' row (SURVEY.md §8(f) #4)")

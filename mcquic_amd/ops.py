@@ -176,6 +176,51 @@ def vq_gather(codes: torch.Tensor, cb: PackedCodebook, dual_silu: bool = False) 
     return out
 
 
+def vq_logits(x: torch.Tensor, cb: PackedCodebook, temperature: torch.Tensor, bound: float) -> torch.Tensor:
+    """Training logits [n, m, h, w, k] = (-dist / sqrt(k)) * max(temperature, bound) (mcq_vq_logits_f32)."""
+    x = _dev(x, "x")
+    n, c, h, w = x.shape
+    if c != cb.m * cb.d:
+        raise ValueError(f"latent has {c} channels, codebook expects {cb.m}*{cb.d}")
+    t = _dev(temperature.detach().reshape(-1), "temperature")
+    logits = torch.empty((n, cb.m, h, w, cb.k), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().mcq_vq_logits_f32(_ptr(x), _ptr(cb.packed), _ptr(t), float(bound), _ptr(logits), n, cb.m, cb.d, h, w,
+                                            cb.k, _stream()), "mcq_vq_logits_f32")
+    return logits
+
+
+def vq_gumbel_sample(logits: torch.Tensor, u_drop: torch.Tensor, u_gumbel: torch.Tensor, freq_ema: torch.Tensor,
+                     drop_exponent: torch.Tensor):
+    """In place on `logits`: random drop; returns (codes, sample_index, sample_hot), each [n, m, h, w]."""
+    logits = _dev(logits, "logits")
+    n, m, h, w, k = logits.shape
+    u_drop, u_gumbel = _dev(u_drop, "u_drop"), _dev(u_gumbel, "u_gumbel")
+    if u_drop.shape != logits.shape or u_gumbel.shape != logits.shape:
+        raise ValueError("uniform draws must have the logits' shape")
+    freq = _dev(freq_ema.detach(), "freq_ema")
+    expo = _dev(drop_exponent.detach().reshape(1), "drop_exponent")
+    codes = torch.empty((n, m, h, w), dtype=torch.int64, device=logits.device)
+    index = torch.empty_like(codes)
+    hot = torch.empty((n, m, h, w), dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        check(_lib.load().mcq_vq_gumbel_sample_f32(_ptr(logits), _ptr(u_drop), _ptr(u_gumbel), _ptr(freq), _ptr(expo), _ptr(codes),
+                                                   _ptr(index), _ptr(hot), n, m, h, w, k, _stream()), "mcq_vq_gumbel_sample_f32")
+    return codes, index, hot
+
+
+def vq_dequant_soft(index: torch.Tensor, hot: torch.Tensor, cb: PackedCodebook) -> torch.Tensor:
+    """sample @ codebook for the one-hot-valued straight-through sample -> [n, m*d, h, w]."""
+    index = _dev(index, "sample_index", torch.int64)
+    hot = _dev(hot, "sample_hot")
+    n, m, h, w = index.shape
+    out = torch.empty((n, m * cb.d, h, w), dtype=torch.float32, device=index.device)
+    with torch.cuda.device(index.device):
+        check(_lib.load().mcq_vq_dequant_soft_f32(_ptr(index), _ptr(hot), _ptr(cb.codebook), _ptr(out), n, m, cb.d, h, w, cb.k,
+                                                  _stream()), "mcq_vq_dequant_soft_f32")
+    return out
+
+
 def add(a: torch.Tensor, b: torch.Tensor, dual_silu: bool = False) -> torch.Tensor:
     a, b = _dev(a, "a"), _dev(b, "b")
     if a.shape != b.shape:

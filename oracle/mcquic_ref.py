@@ -393,3 +393,94 @@ def make_images(n: int, h: int, w: int, seed: int = 3407) -> torch.Tensor:
     import numpy as np
     u = _rng(f"images:{n}x{h}x{w}", seed).random((n, 3, h, w), dtype=np.float32)
     return torch.from_numpy(u * 2.0 - 1.0)
+
+
+# ----------------------------------------------------------------------------------------------
+# training-mode forward (BASELINE config #5), mcquic/modules/quantizer.py:181-239,262-274,295-305,359-365,443-467
+# ----------------------------------------------------------------------------------------------
+# The reference snapshot cannot run this path as shipped: UMGMQuantizer hands the float `permutationRate` to
+# _multiCodebookQuantization where the per-level `freqEMA` tensor is expected (quantizer.py:399 vs :100,109), so
+# `_randomDrop` fails on `(0.0 > eps).float()` (:196).  This restatement uses the evident intent -- the level's
+# `_entropyCoder._freqEMA[l]`, exactly what ResidualBackwardQuantizer does at :608 -- and is pinned against the
+# reference with that one attribute repaired (tests/golden/make_golden.py, F6).  Random numbers are inputs: the two
+# `torch.rand_like(logit)` draws per level (:198 then nn/base.py:120) are passed in as `uniforms[l] = (u_drop, u_gumbel)`.
+
+def vq_logit(x: torch.Tensor, codebook: torch.Tensor, temperature: torch.Tensor, bound: torch.Tensor) -> torch.Tensor:
+    """quantizer.py:181-183 + :204: logit = (-1 * distance / sqrt(k)) * max(temperature, bound)."""
+    k = codebook.shape[1]
+    logit = -1 * vq_distance(x, codebook)
+    logit = logit / math.sqrt(k)
+    return logit * torch.max(temperature, bound)
+
+
+def random_drop(logit: torch.Tensor, freq_ema: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    """quantizer.py:194-200 `_randomDrop` with the uniform draw `u` given."""
+    k = logit.shape[-1]
+    bits = math.log2(k)
+    code_usage = (freq_ema > EPS).float().mean().clamp(0., 1.)
+    mask = (u ** (-(bits - 1) * (code_usage ** 2) + bits)) < freq_ema[:, None, None, ...]
+    logit = logit.clone()
+    logit[mask] += -1e9
+    return logit
+
+
+def gumbel_softmax_hard(logits: torch.Tensor, u: torch.Tensor, temperature: float = 1.0):
+    """mcquic/nn/base.py:118-133 with the uniform draw `u` given.  Returns (ret, y_soft, index)."""
+    eps = torch.finfo(logits.dtype).eps
+    uniforms = u.clamp(eps, 1 - eps)
+    gumbels = -((-(uniforms.log())).log())
+    y_soft = ((logits + gumbels) / temperature).softmax(-1)
+    index = y_soft.max(-1, keepdim=True)[1]
+    y_hard = torch.zeros_like(logits).scatter_(-1, index, 1.0)
+    return y_hard - y_soft.detach() + y_soft, y_soft, index
+
+
+def dequant_soft(sample: torch.Tensor, codebook: torch.Tensor) -> torch.Tensor:
+    """quantizer.py:262-274 _multiCodebookDeQuantization.forward: bmm(sample [nm, hw, k], codebook [nm, k, d])."""
+    m, k, d = codebook.shape
+    n, _, h, w, _ = sample.shape
+    left = sample.reshape(n * m, h * w, k).contiguous()
+    right = codebook.expand(n, m, k, d).reshape(n * m, k, d).contiguous()
+    result = torch.bmm(left, right)
+    return result.reshape(n, m, h, w, d).permute(0, 1, 4, 2, 3).reshape(n, -1, h, w).contiguous()
+
+
+def forward_train(sd: StateDict, x: torch.Tensor, uniforms):
+    """BaseCompressor.forward in training mode (compressor.py:35-43) with UMGMQuantizer.forward (:443-467).
+    Returns (xHat, yHat, codes, logits, oneHotCounts) -- oneHotCounts[l] = oneHot.sum((0, 2, 3)) feeds the
+    frequency EMA (entropyCoder.py:28-44)."""
+    y = encoder(sd, x)
+    levels = num_levels(sd)
+    samples, codes, logits, counts = [], [], [], []
+    cur = y
+    for lv in range(levels):
+        pre = f"_quantizer._encoders.{lv}."
+        cb = sd[pre + "_quantizer._codebook"]
+        z = latent_stage_encoder(sd, pre + "_latentStageEncoder.", cur)
+        q = head_rb_attn_conv(sd, pre + "_quantizationHead.", z)
+        logit = vq_logit(q, cb, sd[pre + "_quantizer._temperature"], sd[pre + "_quantizer._bound.bound"])
+        logit = random_drop(logit, sd[f"_quantizer._entropyCoder._freqEMA.{lv}"], uniforms[lv][0])
+        sample, _, _ = gumbel_softmax_hard(logit, uniforms[lv][1], 1.0)
+        code = logit.argmax(-1, keepdim=True)
+        one_hot = torch.zeros_like(logit).scatter_(-1, code, 1)
+        samples.append(sample)
+        codes.append(code[..., 0].contiguous())
+        logits.append(logit)
+        counts.append(one_hot.sum((0, 2, 3)))
+        if lv < levels - 1:
+            z2 = head_rb_attn_conv(sd, pre + "_latentHead.", z)
+            cur = z2 - dequant_soft(sample, cb)
+    former = None
+    for lv in reversed(range(levels)):
+        pre = f"_quantizer._decoders.{lv}."
+        cb = sd[pre + "_dequantizer._codebook"]
+        q = head_attn_conv_rb(sd, pre + "_dequantizationHead.", dequant_soft(samples[lv], cb))
+        xhat = q + head_attn_conv_rb(sd, pre + "_sideHead.", former) if lv < levels - 1 else q
+        former = restore_head(sd, pre + "_restoreHead.", xhat)
+    return decoder(sd, former), former, codes, logits, counts
+
+
+def freq_ema_update(freq_ema: torch.Tensor, total_count: torch.Tensor, ema: float = 0.9) -> torch.Tensor:
+    """entropyCoder.py:38-43 after the all_reduce: normalise the counts, blend with the running EMA."""
+    normalized = total_count / total_count.sum(-1, keepdim=True)
+    return (1 - ema) * normalized + ema * freq_ema

@@ -119,6 +119,40 @@ def main():
     qp2["rec_mean_abs"] = np.array([rec.abs().mean().item()])
     qp2["rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, "f5_qp2_model.npz"), **qp2)
+    # ---- F6: training-mode forward of the small model (reference with its one broken attribute repaired:
+    #          _multiCodebookQuantization._freqEMA = the level's entropy-coder EMA, see oracle/mcquic_ref.py) -----
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    ch, m, ks = 8, 2, [32, 16, 8]
+    sd = R.make_state_dict(ch, m, ks, seed=2)
+    g = torch.Generator().manual_seed(3)
+    for lv, k in enumerate(ks):
+        f = torch.rand((m, k), generator=g) ** 3 + 1e-3
+        sd[f"_quantizer._entropyCoder._freqEMA.{lv}"] = f / f.sum(-1, keepdim=True)
+    model = ref_harness.reference_compressor(ch, m, ks, sd)
+    for lv, enc in enumerate(model._quantizer._encoders):
+        enc._quantizer._freqEMA = model._quantizer._entropyCoder._freqEMA[lv]
+    model.train()
+    xi = R.make_images(2, 128, 128, seed=4)
+    shapes = [(2, m, 8, 8, 32), (2, m, 4, 4, 16), (2, m, 2, 2, 8)]
+    us = [(torch.rand(sh, generator=g), torch.rand(sh, generator=g)) for sh in shapes]
+    it = iter([u for pair in us for u in pair])
+    orig = torch.rand_like
+    torch.rand_like = lambda t, **kw: next(it).clone()
+    try:
+        xHat, yHat, codes, logits = model(xi.clone())
+    finally:
+        torch.rand_like = orig
+    f6 = {"xHat_strided": xHat.detach()[..., ::2, ::2].numpy(), "yHat": yHat.detach().numpy()}
+    for lv in range(3):
+        f6[f"code{lv}"] = codes[lv].numpy().astype(np.int16)
+        f6[f"logit{lv}"] = logits[lv].detach().numpy()
+        f6[f"ema{lv}"] = model._quantizer._entropyCoder._freqEMA[lv].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "f6_train_forward.npz"), **f6)
+
     # ---- F8: rANS byte streams + quantized CDFs from the reference's native coder (oracle/_ref, built from the
     #          reference's own sources by oracle/Makefile) ---------------------------------------------------------
     import glob

@@ -92,3 +92,30 @@ def test_detransform_and_psnr_formulas():
     assert u.flatten().tolist() == [0, 0, 127, 191, 255, 255, 255, 0]
     a = torch.zeros(1, 3, 4, 4, dtype=torch.uint8)
     assert abs(float(R.psnr(a, a)) - 10 * np.log10(255.0 ** 2 / 1e-4)) < 1e-9
+
+
+def _train_case():
+    ch, m, ks = 8, 2, [32, 16, 8]
+    sd = R.make_state_dict(ch, m, ks, seed=2)
+    g = torch.Generator().manual_seed(3)
+    for lv, k in enumerate(ks):
+        f = torch.rand((m, k), generator=g) ** 3 + 1e-3
+        sd[f"_quantizer._entropyCoder._freqEMA.{lv}"] = f / f.sum(-1, keepdim=True)
+    x = R.make_images(2, 128, 128, seed=4)
+    shapes = [(2, m, 8, 8, 32), (2, m, 4, 4, 16), (2, m, 2, 2, 8)]
+    us = [(torch.rand(sh, generator=g), torch.rand(sh, generator=g)) for sh in shapes]
+    return sd, x, us
+
+
+def test_training_forward_matches_repaired_reference():
+    z = np.load(os.path.join(G, "f6_train_forward.npz"))
+    sd, x, us = _train_case()
+    with torch.no_grad():
+        xHat, yHat, codes, logits, counts = R.forward_train(sd, x, us)
+    np.testing.assert_allclose(xHat[..., ::2, ::2].numpy(), z["xHat_strided"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(yHat.numpy(), z["yHat"], rtol=0, atol=1e-6)
+    for lv in range(3):
+        assert torch.equal(codes[lv], torch.from_numpy(z[f"code{lv}"].astype(np.int64)))
+        np.testing.assert_allclose(logits[lv].numpy(), z[f"logit{lv}"], rtol=1e-6, atol=1e-6)
+        ema = R.freq_ema_update(sd[f"_quantizer._entropyCoder._freqEMA.{lv}"], counts[lv])
+        np.testing.assert_allclose(ema.numpy(), z[f"ema{lv}"], rtol=0, atol=1e-7)

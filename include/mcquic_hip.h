@@ -40,6 +40,7 @@ extern "C" {
 #define MCQ_CONV_IGDN       0x020u /* y = mul * sqrt(acc)               (gdn.py:91  x * torch.sqrt(std))  */
 #define MCQ_CONV_GATE       0x040u /* y = mul * sigmoid(acc) + gate_id  (blocks.py:281-288 AttentionBlock.forward) */
 #define MCQ_CONV_SHUFFLE2   0x080u /* store through nn.PixelShuffle(2)  (mcquic/nn/convs.py:221-255 pixelShuffle3x3) */
+#define MCQ_CONV_MUL        0x200u /* y = mul * acc                     (GDN backward: 2 x * (gamma^T ds))                    */
 #define MCQ_CONV_DUAL_SILU  0x100u /* also store silu(y) to y_silu: the next block's act1(x), computed once per element */
 
 typedef struct mcq_conv_desc {
@@ -125,6 +126,43 @@ int mcq_vq_gumbel_sample_f32(float* logits, const float* u_drop, const float* u_
  * straight-through sample (_multiCodebookDeQuantization.forward, quantizer.py:262-274). */
 int mcq_vq_dequant_soft_f32(const int64_t* sample_index, const float* sample_hot, const float* codebook, float* out,
                             int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k, void* stream);
+
+/* ---- backward pass of the training step (BASELINE config #5) ----------------------------------------- */
+/* Input gradients of the convolutions reuse mcq_conv2d_f32 with transformed weights (see mcquic_amd/autograd.py);
+ * the reference obtains all of these from torch.autograd over nn.Conv2d / SiLU / GDN / sigmoid
+ * (mcquic/nn/convs.py, nn/gdn.py:67-91, nn/blocks.py:70-78,281-288). */
+
+/* out[n][p][c] = x[n][c][p] (squared if `square`): channel-major copies feeding the weight-gradient GEMM. */
+int mcq_nchw_to_nhwc_f32(const float* x, float* out, int32_t N, int32_t C, int32_t HW, int32_t square, void* stream);
+
+/* dW[co][ci][ky][kx] = sum_{n,yo,xo} dY[n][co][yo][xo] * X[n][ci][yo*stride + ky - k/2][xo*stride + kx - k/2]
+ * from NHWC copies of X [N,H,W,Cin] and dY [N,Ho,Wo,Cout]; `workspace` holds the per-range partial sums. */
+size_t mcq_conv2d_wgrad_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize,
+                                         int32_t stride);
+int mcq_conv2d_wgrad_f32(const float* x_nhwc, const float* dy_nhwc, float* dw, float* workspace, int32_t N, int32_t Cin,
+                         int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, void* stream);
+
+/* out[c] = sum_{n,p} x[n][c][p]   (bias / beta gradients). */
+int mcq_channel_sum_f32(const float* x, float* out, int32_t N, int32_t C, int32_t HW, void* stream);
+
+/* Stand-alone forms of ops that the inference path fuses into conv prologues / epilogues; the training graph keeps
+ * them separate so that each has its own backward:  y = silu(x);  out = a * sigmoid(b) + x;  out = alpha a + beta b. */
+int mcq_silu_f32(const float* x, float* y, int64_t n, void* stream);
+int mcq_gate_f32(const float* a, const float* b, const float* x, float* out, int64_t n, void* stream);
+int mcq_axpby_f32(const float* a, const float* b, float alpha, float beta, float* out, int64_t n, void* stream);
+
+/* dx = dy * d/dx silu(x). */
+int mcq_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+
+/* AttentionBlock gate out = a * sigmoid(b) + x: da = dout * s, db = dout * a * s (1 - s). */
+int mcq_gate_bwd_f32(const float* a, const float* b, const float* dout, float* da, float* db, int64_t n, void* stream);
+
+/* GDN / IGDN y = x * f(s): dx_direct = dy * f(s), ds = dy * x * f'(s) (f = s^-1/2, or s^1/2 when `inverse`). */
+int mcq_gdn_bwd_prep_f32(const float* x, const float* s, const float* dy, int32_t inverse, float* dx_direct, float* ds,
+                         int64_t n, void* stream);
+
+/* out[n][c*4 + i*2 + j][y][x] = in[n][c][2y + i][2x + j]: the adjoint of nn.PixelShuffle(2). */
+int mcq_pixel_unshuffle2_f32(const float* in, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 
 /* ---- small element-wise helpers on the path ------------------------------------------------ */
 

@@ -17,7 +17,7 @@ _ERR = {MCQ_EINVAL: "MCQ_EINVAL (invalid argument)", MCQ_ELAUNCH: "MCQ_ELAUNCH (
         MCQ_ETOOLARGE: "MCQ_ETOOLARGE (tensor exceeds the addressing window)"}
 
 CONV_SILU_IN, CONV_SQUARE_IN, CONV_SILU_OUT, CONV_RESIDUAL = 0x1, 0x2, 0x4, 0x8
-CONV_GDN, CONV_IGDN, CONV_GATE, CONV_SHUFFLE2, CONV_DUAL_SILU = 0x10, 0x20, 0x40, 0x80, 0x100
+CONV_GDN, CONV_IGDN, CONV_GATE, CONV_SHUFFLE2, CONV_DUAL_SILU, CONV_MUL = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 
 
 class ConvDesc(Structure):
@@ -47,6 +47,18 @@ SYMBOLS = {
                                            c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_vq_dequant_soft_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_int32, c_void_p]),
+    "mcq_nchw_to_nhwc_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "mcq_conv2d_wgrad_workspace_floats": (c_size_t, [c_int32] * 7),
+    "mcq_conv2d_wgrad_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                       c_int32, c_int32, c_void_p]),
+    "mcq_channel_sum_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "mcq_silu_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_gate_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_axpby_f32": (c_int32, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
+    "mcq_silu_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_gate_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_gdn_bwd_prep_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_pixel_unshuffle2_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_add_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_detransform_u8": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_pmf_to_quantized_cdf": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),

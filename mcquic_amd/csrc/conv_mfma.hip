@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
         bool ok[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) ok[r] = vld && cok[r];
-        if (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) {
+        if (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL)) {
             float m[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) m[r] = ok[r] ? p.mul[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
@@ -201,6 +201,9 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
             } else if (fl & MCQ_CONV_IGDN) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = m[r] * sqrtf(v[r]);
+            } else if (fl & MCQ_CONV_MUL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = m[r] * v[r];
             } else {
                 float gi[16];
 #pragma unroll
@@ -395,7 +398,7 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     if ((d->ksize != 1 && d->ksize != 3) || (d->stride != 1 && d->stride != 2)) return MCQ_EINVAL;
     const unsigned fl = d->flags;
     if ((fl & MCQ_CONV_RESIDUAL) && !d->res) return MCQ_EINVAL;
-    if ((fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE)) && !d->mul) return MCQ_EINVAL;
+    if ((fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL)) && !d->mul) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_GATE) && !d->gate_id) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_DUAL_SILU) && (!d->y_silu || (fl & MCQ_CONV_SILU_OUT))) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_SILU_IN) && (fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;

@@ -1,0 +1,349 @@
+// Backward-pass kernels of the Compressor training step (BASELINE config #5) for gfx950.
+//
+// The reference gets these from torch.autograd over nn.Conv2d / F.conv2d / SiLU / GDN / sigmoid gates
+// (mcquic/nn/convs.py, nn/gdn.py, nn/blocks.py); here:
+//   * input gradients of every convolution reuse the forward MFMA kernel (conv_mfma.hip) with transformed weights
+//     (flip + transpose; stride-2 and pixel-shuffle convs through the sub-pixel identity), so only the WEIGHT
+//     gradient needs its own contraction;
+//   * mcq_conv2d_wgrad_f32: dW[co][ci][tap] = sum over output pixels of dY[co][p] * X[ci][p + tap] -- a GEMM whose
+//     reduction axis is the pixel axis.  Both operands are read channel-major (NHWC copies made by
+//     mcq_nchw_to_nhwc_f32), which makes the MFMA operand loads runs of 32 consecutive floats exactly like the
+//     forward kernel's; the pixel range is split over waves and the partial sums are reduced in a second,
+//     deterministic pass (no atomics);
+//   * small element-wise backward kernels (SiLU, gate, GDN) and reductions (bias / beta gradients).
+#include "mcq_common.h"
+#include "../../include/mcquic_hip.h"
+
+namespace {
+
+// ---- NCHW -> NHWC (optionally squaring), 32 x 32 tiles through LDS --------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int HW, int square) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows per pass
+    const float* xi = x + (size_t)n * C * HW;
+    float* oi = out + (size_t)n * C * HW;
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int c = c0 + ty + r, p = p0 + tx;
+        float v = (c < C && p < HW) ? xi[(size_t)c * HW + p] : 0.0f;
+        if (square) v = v * v;
+        tile[ty + r][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int p = p0 + ty + r, c = c0 + tx;
+        if (c < C && p < HW) oi[(size_t)p * C + c] = tile[tx][ty + r];
+    }
+}
+
+// ---- weight gradient -------------------------------------------------------------------------------------------
+struct WgradK {
+    const float* xt; const float* dyt; float* part;
+    int N, Cin, H, W, Cout, Ho, Wo, ks, stride;
+    int splits;          // number of pixel ranges
+    int chunk;           // output pixels per range (even)
+    int ci_tiles;        // ceil(Cin / 64)
+    long long P;         // N * Ho * Wo
+};
+
+constexpr int WG_MB = 4, WG_NB = 2, WG_PF = 4;
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
+    constexpr int MB = WG_MB, NB = WG_NB, PF = WG_PF;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int split = blockIdx.x * 4 + wave;
+    if (split >= p.splits) return;
+    const int tap = blockIdx.y / p.ci_tiles;
+    const int ci_base = (blockIdx.y - tap * p.ci_tiles) * (32 * NB);
+    const int co_base = blockIdx.z * (32 * MB);
+    const int hi = lane >> 5, j = lane & 31;
+    const int pad = p.ks >> 1;
+    const int dy = tap / p.ks, dx = tap - dy * p.ks;
+    const long long p_begin = (long long)split * p.chunk;
+    long long p_end = p_begin + p.chunk;
+    if (p_end > p.P) p_end = p.P;
+
+    const __amdgpu_buffer_rsrc_t rx = mcq_make_rsrc(mcq_uniform_ptr(p.xt), (uint32_t)((size_t)p.N * p.H * p.W * p.Cin * 4));
+    const __amdgpu_buffer_rsrc_t rd = mcq_make_rsrc(mcq_uniform_ptr(p.dyt), (uint32_t)((size_t)p.P * p.Cout * 4));
+
+    // this lane's pixel: p_begin + hi, advancing by 2 per k-step
+    long long pp = p_begin + hi;
+    const int HoWo = p.Ho * p.Wo;
+    int n = (int)(pp / HoWo);
+    int rem = (int)(pp - (long long)n * HoWo);
+    int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+
+    bool cok[MB], iok[NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) cok[mb] = co_base + 32 * mb + j < p.Cout;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) iok[nb] = ci_base + 32 * nb + j < p.Cin;
+
+    float A[PF][MB], B[PF][NB];
+    auto issue = [&](int st) {
+        const bool live = pp < p_end;
+        const unsigned doff = (unsigned)(((size_t)pp * p.Cout + co_base + j) * 4);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            A[st][mb] = mcq_buffer_load(rd, (live && cok[mb]) ? doff + (unsigned)(128 * mb) : MCQ_OOB);
+        const int yi = yo * p.stride + dy - pad, xi = xo * p.stride + dx - pad;
+        const bool inb = live && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
+        const unsigned xoff = (unsigned)(((((size_t)n * p.H + yi) * p.W + xi) * p.Cin + ci_base + j) * 4);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            B[st][nb] = mcq_buffer_load(rx, (inb && iok[nb]) ? xoff + (unsigned)(128 * nb) : MCQ_OOB);
+        pp += 2;
+        xo += 2;
+        if (xo >= p.Wo) { xo -= p.Wo; ++yo; if (xo >= p.Wo) { xo -= p.Wo; ++yo; } }
+        if (yo >= p.Ho) { yo -= p.Ho; ++n; if (yo >= p.Ho) { yo -= p.Ho; ++n; } }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+#pragma unroll
+    for (int st = 0; st < PF; ++st) issue(st);
+    const int steps = (p.chunk / 2 + PF - 1) / PF * PF;        // whole prefetch rounds; the tail loads are masked to 0
+    for (int t = 0; t < steps; t += PF) {
+#pragma unroll
+        for (int st = 0; st < PF; ++st) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st][mb], B[st][nb], acc[mb][nb], 0, 0, 0);
+            issue(st);
+        }
+    }
+
+    // partial sums: part[split][tap][co][ci] (ci contiguous: 32 lanes = 128 B)
+    const int taps = p.ks * p.ks;
+    float* out = p.part + ((size_t)split * taps + tap) * (size_t)p.Cout * p.Cin;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int ci = ci_base + 32 * nb + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + 32 * mb + mcq_drow(r, hi);
+                if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Cin + ci] = acc[mb][nb][r];
+            }
+        }
+}
+
+// dW[co][ci][tap] = sum_split part[split][tap][co][ci]   (fixed order: deterministic)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int taps, int Cout, int Cin) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // index into [tap][co][ci]
+    const size_t per = (size_t)taps * Cout * Cin;
+    if (i >= per) return;
+    float s = 0.0f;
+    for (int sp = 0; sp < splits; ++sp) s += part[(size_t)sp * per + i];
+    const int ci = (int)(i % Cin);
+    const size_t r = i / Cin;
+    const int co = (int)(r % Cout);
+    const int tap = (int)(r / Cout);
+    dw[((size_t)co * Cin + ci) * taps + tap] = s;
+}
+
+// out[c] = sum over n, pixels of x[n][c][p]; one workgroup per channel, fixed-order tree
+__global__ void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int C, int HW) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float s = 0.0f;
+    for (int n = 0; n < N; ++n) {
+        const float* row = x + ((size_t)n * C + c) * HW;
+        for (int p = threadIdx.x; p < HW; p += 256) s += row[p];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = red[0];
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void silu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = mcq_silu(x[i]);
+}
+
+__global__ void gate_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ x,
+                                float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] * mcq_sigmoid(b[i]) + x[i];
+}
+
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float alpha, float beta,
+                             float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = alpha * a[i] + beta * b[i];
+}
+
+// dx = dy * silu'(x),  silu'(x) = s (1 + x (1 - s)),  s = sigmoid(x)
+__global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float s = sigmoidf_(x[i]);
+        dx[i] = dy[i] * (s * (1.0f + x[i] * (1.0f - s)));
+    }
+}
+
+// out = a * sigmoid(b) + x:  da = dout * s,  db = dout * a * s * (1 - s)
+__global__ void gate_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ dout,
+                                float* __restrict__ da, float* __restrict__ db, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float s = sigmoidf_(b[i]);
+        const float g = dout[i];
+        da[i] = g * s;
+        db[i] = g * a[i] * s * (1.0f - s);
+    }
+}
+
+// y = x * f(s): GDN f = s^-1/2, IGDN f = s^1/2.  dxd = dy * f(s);  ds = dy * x * f'(s)
+__global__ void gdn_bwd_prep_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ dy,
+                                    int inverse, float* __restrict__ dxd, float* __restrict__ ds, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float sv = s[i], g = dy[i], xv = x[i];
+        const float rs = 1.0f / sqrtf(sv);
+        if (inverse) {                       // f = sqrt(s), f' = 1 / (2 sqrt(s))
+            dxd[i] = g * sqrtf(sv);
+            ds[i] = g * xv * (0.5f * rs);
+        } else {                             // f = s^-1/2, f' = -1/2 s^-3/2
+            dxd[i] = g * rs;
+            ds[i] = g * xv * (-0.5f * rs * rs * rs);
+        }
+    }
+}
+
+// out[n][c*4 + i*2 + j][y][x] = in[n][c][2y + i][2x + j]   (inverse of nn.PixelShuffle(2))
+__global__ void pixel_unshuffle2_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int H, int W) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // over the INPUT [N, C, 2H, 2W]
+    const size_t total = (size_t)N * C * 4 * H * W;
+    if (i >= total) return;
+    const int W2 = 2 * W, H2 = 2 * H;
+    const int xx = (int)(i % W2);
+    const size_t r1 = i / W2;
+    const int yy = (int)(r1 % H2);
+    const size_t nc = r1 / H2;
+    const int c = (int)(nc % C);
+    const size_t n = nc / C;
+    const int sub = (yy & 1) * 2 + (xx & 1);
+    out[(((n * C + c) * 4 + sub) * H + (yy >> 1)) * W + (xx >> 1)] = in[i];
+}
+
+}  // namespace
+
+extern "C" int mcq_nchw_to_nhwc_f32(const float* x, float* out, int32_t N, int32_t C, int32_t HW, int32_t square, void* stream) {
+    if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return MCQ_EINVAL;
+    const dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, C, HW, square);
+    return mcq_check_launch();
+}
+
+extern "C" size_t mcq_conv2d_wgrad_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize,
+                                                    int32_t stride) {
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
+    const int pad = ksize / 2;
+    const long long Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const long long P = (long long)N * Ho * Wo;
+    const int taps = ksize * ksize, ci_tiles = (Cin + 63) / 64, co_tiles = (Cout + 127) / 128;
+    long long splits = 4096 / ((long long)taps * ci_tiles * co_tiles);
+    if (splits < 1) splits = 1;
+    const long long max_splits = (P + 63) / 64;                 // at least 64 pixels per range
+    if (splits > max_splits) splits = max_splits;
+    return (size_t)splits * taps * Cout * Cin;
+}
+
+extern "C" int mcq_conv2d_wgrad_f32(const float* x_nhwc, const float* dy_nhwc, float* dw, float* workspace, int32_t N, int32_t Cin,
+                                    int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, void* stream) {
+    if (!x_nhwc || !dy_nhwc || !dw || !workspace) return MCQ_EINVAL;
+    const size_t wsf = mcq_conv2d_wgrad_workspace_floats(N, Cin, H, W, Cout, ksize, stride);
+    if (wsf == 0) return MCQ_EINVAL;
+    WgradK p;
+    p.xt = x_nhwc; p.dyt = dy_nhwc; p.part = workspace;
+    p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.ks = ksize; p.stride = stride;
+    const int pad = ksize / 2;
+    p.Ho = (H + 2 * pad - ksize) / stride + 1;
+    p.Wo = (W + 2 * pad - ksize) / stride + 1;
+    p.P = (long long)N * p.Ho * p.Wo;
+    if ((uint64_t)N * H * W * Cin * 4ull >= 0x80000000ull || (uint64_t)p.P * Cout * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
+    const int taps = ksize * ksize;
+    p.ci_tiles = (Cin + 63) / 64;
+    const int co_tiles = (Cout + 127) / 128;
+    p.splits = (int)(wsf / ((size_t)taps * Cout * Cin));
+    long long chunk = (p.P + p.splits - 1) / p.splits;
+    chunk = (chunk + 1) & ~1LL;                                 // even: a k-step covers two pixels
+    p.chunk = (int)chunk;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((p.splits + 3) / 4), (unsigned)(taps * p.ci_tiles), (unsigned)co_tiles);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
+    const size_t per = (size_t)taps * Cout * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, workspace, dw, p.splits, taps, Cout, Cin);   // dW in OIHW order
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_channel_sum_f32(const float* x, float* out, int32_t N, int32_t C, int32_t HW, void* stream) {
+    if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, x, out, N, C, HW);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_silu_f32(const float* x, float* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(silu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_gate_f32(const float* a, const float* b, const float* x, float* out, int64_t n, void* stream) {
+    if (!a || !b || !x || !out || n <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, x, out, n);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_axpby_f32(const float* a, const float* b, float alpha, float beta, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, beta, out, n);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+    if (!x || !dy || !dx || n <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_gate_bwd_f32(const float* a, const float* b, const float* dout, float* da, float* db, int64_t n, void* stream) {
+    if (!a || !b || !dout || !da || !db || n <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, dout, da, db, n);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_gdn_bwd_prep_f32(const float* x, const float* s, const float* dy, int32_t inverse, float* dx_direct, float* ds,
+                                    int64_t n, void* stream) {
+    if (!x || !s || !dy || !dx_direct || !ds || n <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(gdn_bwd_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, s, dy, inverse,
+                       dx_direct, ds, n);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_pixel_unshuffle2_f32(const float* in, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return MCQ_EINVAL;
+    const size_t total = (size_t)N * C * 4 * H * W;
+    hipLaunchKernelGGL(pixel_unshuffle2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, N, C, H, W);
+    return mcq_check_launch();
+}

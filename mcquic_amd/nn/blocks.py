@@ -21,6 +21,7 @@ from typing import Dict, Optional
 import torch
 from torch import nn
 
+from .. import autograd as AG
 from .convs import Conv2d, PixelShuffle3x3, conv1x1, conv3x3, pixelShuffle3x3
 from .gdn import GenDivNorm, InvGenDivNorm
 
@@ -92,6 +93,9 @@ class ResidualBlock(_residulBlock):
         super().__init__(nn.SiLU(), conv3x3(inChannels, outChannels), nn.SiLU(), conv3x3(outChannels, outChannels), None)
 
     def forward(self, x: torch.Tensor, res2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():             # training graph: separate ops, HIP backward
+            t = self._branch[1](AG.silu(x))
+            return self._branch[3](AG.silu(t), res=x)
         t = self._branch[1](x, silu_in=True, silu_out=True)      # silu(conv1(silu(x)))
         return self._branch[3](t, res=x, dual_silu=True)          # conv2(.) + x
 
@@ -106,6 +110,9 @@ class ResidualBlockWithStride(_residulBlock):
                          conv3x3(outChannels, outChannels), conv3x3(inChannels, outChannels, stride=stride))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():
+            t = self._branch[2](self._branch[1](AG.silu(x)))
+            return self._branch[3](t, res=self._skip(x))
         with _fork(x) as f:
             identity = self._skip(x)
         t = self._branch[1](x, silu_in=True)
@@ -123,6 +130,9 @@ class ResidualBlockShuffle(_residulBlock):
                          conv3x3(outChannels, outChannels), pixelShuffle3x3(inChannels, outChannels, upsample))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():
+            t = self._branch[2](self._branch[1](AG.silu(x)))
+            return self._branch[3](t, res=self._skip(x))
         with _fork(x) as f:
             identity = self._skip(x)
         t = self._branch[1](x, silu_in=True)
@@ -140,6 +150,8 @@ class AttentionBlock(nn.Module):
                                          conv1x1(channel, channel))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():
+            return AG.gate(self._mainBranch(x), self._sideBranch(x), x)
         with _fork(x) as f:
             b = x
             for i in range(3):

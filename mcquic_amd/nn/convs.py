@@ -43,6 +43,13 @@ class Conv2d(nn.Module):
         return self._packed
 
     def forward(self, x: torch.Tensor, **fused) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():
+            # training graph: plain conv (+ residual / pixel-shuffle store) with HIP backward kernels
+            from .. import autograd as AG
+            extra = set(fused) - {"res", "shuffle2", "dual_silu"}
+            if extra:
+                raise NotImplementedError(f"fused conv options {sorted(extra)} are inference-only")
+            return AG.conv(x, self, res=fused.get("res"), shuffle2=bool(fused.get("shuffle2", False)))
         return ops.conv2d(x, self.packed(), self.stride, **fused)
 
     def extra_repr(self) -> str:

@@ -70,6 +70,9 @@ class GenDivNorm(nn.Module):
         return self._packed
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():
+            from .. import autograd as AG
+            return AG.gdn(x, self, self._inverse)
         if self._inverse:
             return ops.conv2d(x, self.packed(), square_in=True, igdn_mul=x)
         return ops.conv2d(x, self.packed(), square_in=True, gdn_mul=x)

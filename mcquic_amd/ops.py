@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (CONV_DUAL_SILU, CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN,
+from ._lib import (CONV_DUAL_SILU, CONV_MUL, CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN,
                    CONV_SILU_OUT, CONV_SQUARE_IN, ConvDesc, check)
 
 # A producer asked for `dual_silu` hangs silu(y) on its result under this attribute; a consumer asked for
@@ -66,7 +66,7 @@ def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = F
            silu_out: bool = False, res: Optional[torch.Tensor] = None, res_scale: float = 1.0,
            gdn_mul: Optional[torch.Tensor] = None, igdn_mul: Optional[torch.Tensor] = None,
            gate_mul: Optional[torch.Tensor] = None, gate_id: Optional[torch.Tensor] = None,
-           shuffle2: bool = False, dual_silu: bool = False, tile: int = 0) -> torch.Tensor:
+           mul: Optional[torch.Tensor] = None, shuffle2: bool = False, dual_silu: bool = False, tile: int = 0) -> torch.Tensor:
     """y = epilogue(conv(prologue(x)) + bias); one kernel launch (mcq_conv2d_f32)."""
     if silu_in:
         twin = silu_twin(x)
@@ -95,13 +95,14 @@ def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = F
     if dual_silu:
         flags |= CONV_DUAL_SILU
         y2 = torch.empty_like(y)
+    mul_in = mul
     mul = None
     if res is not None:
         flags |= CONV_RESIDUAL
         res = _dev(res, "res")
         if res.shape != y.shape:
             raise ValueError(f"residual shape {tuple(res.shape)} != output shape {tuple(y.shape)}")
-    for flag, t in ((CONV_GDN, gdn_mul), (CONV_IGDN, igdn_mul), (CONV_GATE, gate_mul)):
+    for flag, t in ((CONV_GDN, gdn_mul), (CONV_IGDN, igdn_mul), (CONV_GATE, gate_mul), (CONV_MUL, mul_in)):
         if t is not None:
             flags |= flag
             mul = _dev(t, "mul")
@@ -240,4 +241,96 @@ def detransform(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         check(_lib.load().mcq_detransform_u8(_ptr(x), _ptr(out), x.numel(), _stream()), "mcq_detransform_u8")
+    return out
+
+
+# ---- backward-pass kernels (training step) ---------------------------------------------------------------------
+def nchw_to_nhwc(x: torch.Tensor, square: bool = False) -> torch.Tensor:
+    x = _dev(x, "x")
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().mcq_nchw_to_nhwc_f32(_ptr(x), _ptr(out), n, c, h * w, int(square), _stream()), "mcq_nchw_to_nhwc_f32")
+    return out
+
+
+def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, square_x: bool = False) -> torch.Tensor:
+    """dW [Cout, Cin, k, k] of y = conv(x, W) from NCHW x and dy (channel-major copies are made here)."""
+    x, dy = _dev(x, "x"), _dev(dy, "dy")
+    n, cin, h, w = x.shape
+    cout = dy.shape[1]
+    lib = _lib.load()
+    xt, dyt = nchw_to_nhwc(x, square_x), nchw_to_nhwc(dy)
+    ws = torch.empty(lib.mcq_conv2d_wgrad_workspace_floats(n, cin, h, w, cout, ksize, stride), dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.mcq_conv2d_wgrad_f32(_ptr(xt), _ptr(dyt), _ptr(dw), _ptr(ws), n, cin, h, w, cout, ksize, stride, _stream()),
+              "mcq_conv2d_wgrad_f32")
+    return dw
+
+
+def channel_sum(x: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, "x")
+    n, c, h, w = x.shape
+    out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().mcq_channel_sum_f32(_ptr(x), _ptr(out), n, c, h * w, _stream()), "mcq_channel_sum_f32")
+    return out
+
+
+def silu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    x, dy = _dev(x, "x"), _dev(dy, "dy")
+    dx = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(_lib.load().mcq_silu_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _stream()), "mcq_silu_bwd_f32")
+    return dx
+
+
+def gate_bwd(a: torch.Tensor, b: torch.Tensor, dout: torch.Tensor):
+    a, b, dout = _dev(a, "a"), _dev(b, "b"), _dev(dout, "dout")
+    da, db = torch.empty_like(a), torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        check(_lib.load().mcq_gate_bwd_f32(_ptr(a), _ptr(b), _ptr(dout), _ptr(da), _ptr(db), a.numel(), _stream()), "mcq_gate_bwd_f32")
+    return da, db
+
+
+def gdn_bwd_prep(x: torch.Tensor, s: torch.Tensor, dy: torch.Tensor, inverse: bool):
+    x, s, dy = _dev(x, "x"), _dev(s, "s"), _dev(dy, "dy")
+    dxd, ds = torch.empty_like(x), torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(_lib.load().mcq_gdn_bwd_prep_f32(_ptr(x), _ptr(s), _ptr(dy), int(inverse), _ptr(dxd), _ptr(ds), x.numel(), _stream()),
+              "mcq_gdn_bwd_prep_f32")
+    return dxd, ds
+
+
+def pixel_unshuffle2(x: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, "x")
+    n, c, h2, w2 = x.shape
+    out = torch.empty((n, c * 4, h2 // 2, w2 // 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().mcq_pixel_unshuffle2_f32(_ptr(x), _ptr(out), n, c, h2 // 2, w2 // 2, _stream()), "mcq_pixel_unshuffle2_f32")
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, "x")
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(_lib.load().mcq_silu_f32(_ptr(x), _ptr(y), x.numel(), _stream()), "mcq_silu_f32")
+    return y
+
+
+def gate(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    a, b, x = _dev(a, "a"), _dev(b, "b"), _dev(x, "x")
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        check(_lib.load().mcq_gate_f32(_ptr(a), _ptr(b), _ptr(x), _ptr(out), a.numel(), _stream()), "mcq_gate_f32")
+    return out
+
+
+def axpby(a: torch.Tensor, b: torch.Tensor, alpha: float, beta: float) -> torch.Tensor:
+    a, b = _dev(a, "a"), _dev(b, "b")
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        check(_lib.load().mcq_axpby_f32(_ptr(a), _ptr(b), float(alpha), float(beta), _ptr(out), a.numel(), _stream()), "mcq_axpby_f32")
     return out

@@ -127,6 +127,22 @@ int mcq_vq_gumbel_sample_f32(float* logits, const float* u_drop, const float* u_
 int mcq_vq_dequant_soft_f32(const int64_t* sample_index, const float* sample_hot, const float* codebook, float* out,
                             int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k, void* stream);
 
+/* out[n, g, y, x, k] = <x_v, c_k>: the logits kernel's GEMM without the distance / temperature transform
+ * (backward: dSample = dDeq . C^T, the adjoint of quantizer.py:262-274). */
+int mcq_vq_inner_f32(const float* x, const float* cb_packed, float* out, int32_t N, int32_t m, int32_t d, int32_t h, int32_t w,
+                     int32_t k, void* stream);
+
+/* Backward of gumbelSoftmax(hard=True) + _logit per latent vector: ds_inout holds dSample on entry and d dist on
+ * exit; rowsum[v] = sum_k d dist, dtrow[v] = the vector's contribution to d max(temperature, bound). */
+int mcq_vq_softmax_bwd_f32(const float* logits, const float* u_gumbel, float* ds_inout, const float* temperature, float bound,
+                           float* rowsum, float* dtrow, int32_t N, int32_t m, int32_t h, int32_t w, int32_t k, void* stream);
+
+/* Latent and codebook gradients of dist = |x|^2 + |c|^2 - 2 <x, c> given d dist, plus the codebook gradient of
+ * sample @ codebook (rows sample_index scaled by sample_hot).  Deterministic (no atomics). */
+int mcq_vq_soft_bwd_f32(const float* ddist, const float* rowsum, const float* x, const float* x_nhwc, const float* ddeq_nhwc,
+                        const int64_t* sample_index, const float* sample_hot, const float* codebook, float* dx,
+                        float* dcodebook, int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k, void* stream);
+
 /* ---- backward pass of the training step (BASELINE config #5) ----------------------------------------- */
 /* Input gradients of the convolutions reuse mcq_conv2d_f32 with transformed weights (see mcquic_amd/autograd.py);
  * the reference obtains all of these from torch.autograd over nn.Conv2d / SiLU / GDN / sigmoid

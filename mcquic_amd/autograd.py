@@ -191,3 +191,36 @@ def gdn(x, module, inverse: bool):
     beta = LowerBoundFn.apply(module.beta, module.beta_reparam.lowerBound.bound) ** 2 - module.beta_reparam.eps
     gamma = LowerBoundFn.apply(module.gamma, module.gamma_reparam.lowerBound.bound) ** 2 - module.gamma_reparam.eps
     return GdnFn.apply(x, beta, gamma, inverse)
+
+
+class SoftQuantizeFn(torch.autograd.Function):
+    """One level of the training quantizer (reference: _multiCodebookQuantization.forward + the two
+    _multiCodebookDeQuantization.forward calls on its sample, quantizer.py:181-239,262-274):
+        logit = (-dist / sqrt(k)) * max(T, eps) ; random drop ; sample = gumbelSoftmax(logit, hard=True)
+        deq   = sample @ codebook                       (differentiable output; used by the residual AND the decoder)
+        code  = argmax(logit), logits                   (non-differentiable outputs)
+    Backward: straight-through -- the gradient reaches `sample` through y_soft only -- then through the logits to the
+    latent, the codebook (distance terms + the sample @ codebook product) and the temperature."""
+
+    @staticmethod
+    def forward(ctx, x, codebook, temperature, freq_ema, u_drop, u_gumbel, drop_exponent, packed, bound):
+        logits = ops.vq_logits(x, packed, temperature, bound)
+        code, index, hot = ops.vq_gumbel_sample(logits, u_drop, u_gumbel, freq_ema, drop_exponent)
+        deq = ops.vq_dequant_soft(index, hot, packed)
+        ctx.save_for_backward(x, logits, u_gumbel, index, hot, temperature)
+        ctx.packed, ctx.bound = packed, bound
+        ctx.mark_non_differentiable(code, logits)
+        return deq, code, logits
+
+    @staticmethod
+    def backward(ctx, ddeq, _dcode, _dlogits):
+        x, logits, u_gumbel, index, hot, temperature = ctx.saved_tensors
+        packed = ctx.packed
+        ddeq = ddeq.contiguous()
+        ds = ops.vq_inner(ddeq, packed)                                        # dSample = dDeq . C^T
+        rowsum, dtrow = ops.vq_softmax_bwd(logits, u_gumbel, ds, temperature, ctx.bound)   # ds now holds d dist
+        dx, dcb = ops.vq_soft_bwd(ds, rowsum, x, ddeq, index, hot, packed)
+        dtb = ops.channel_sum(dtrow)                                           # [m]: d max(T, bound)
+        t = temperature.detach().reshape(-1)
+        dt = (((t >= ctx.bound) | (dtb < 0)).to(dtb.dtype) * dtb).reshape(temperature.shape)   # LowerBound's rule
+        return dx, dcb, dt, None, None, None, None, None, None

@@ -24,6 +24,7 @@ struct VqLogitK {
     float bound;
     float scale;                // sqrt(k)
     float* logits;              // [N, m, h, w, k]
+    int raw;                    // 1: store the inner products <x_v, c_k> themselves (backward: dSample = dDeq . C^T)
 };
 
 __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
         if (ls == p.Sp) { ls = 0; soffL = 0; }
     };
 
-    const float tmax = fmaxf(q.temperature[g], q.bound);
+    const float tmax = q.raw ? 1.0f : fmaxf(q.temperature[g], q.bound);
 #pragma unroll
     for (int st = 0; st < PF; ++st) issue(st);
 
@@ -142,8 +143,12 @@ __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
                     for (int wb = 0; wb < NW; ++wb) {
                         const int word = tile * 128 + wb * 32 + j;
                         if (word < p.k) {
-                            const float dist = __builtin_fmaf(-2.0f, acc[nb][wb][r], x2d[nb][r] + c2t[wb]);
-                            row[word] = ((-1.0f * dist) / q.scale) * tmax;
+                            if (q.raw) {
+                                row[word] = acc[nb][wb][r];
+                            } else {
+                                const float dist = __builtin_fmaf(-2.0f, acc[nb][wb][r], x2d[nb][r] + c2t[wb]);
+                                row[word] = ((-1.0f * dist) / q.scale) * tmax;
+                            }
                         }
                     }
                 }
@@ -224,6 +229,108 @@ __global__ void vq_dequant_soft_kernel(const int64_t* __restrict__ index, const 
     for (int c = 0; c < d; ++c) o[(size_t)c * hw] = v * row[c];
 }
 
+// ---- backward of the soft assignment ----------------------------------------------------------------------------
+// One wave per latent vector.  y = softmax(logit + gumbel) is recomputed from the saved (post-drop) logits and the
+// gumbel draw; dS[k] = <dDeq_v, c_k> comes in and is overwritten by d dist[k]:
+//   dz = y (dS - <y, dS>)            (straight-through: the gradient reaches the sample through y_soft only)
+//   d dist = dz * (-Tb / sqrt(k)),   d Tb += sum_k dz[k] * logit[k] / Tb,   rowsum = sum_k d dist[k]
+__global__ __launch_bounds__(256) void vq_softmax_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ u_gumbel,
+                                                             float* __restrict__ ds, const float* __restrict__ temperature,
+                                                             float bound, float scale, float* __restrict__ rowsum,
+                                                             float* __restrict__ dtrow, int rows, int m, int hw, int k) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int g = (row / hw) % m;
+    const float tb = fmaxf(temperature[g], bound);
+    const float* lr = logits + (size_t)row * k;
+    const float* ug = u_gumbel + (size_t)row * k;
+    float* dr = ds + (size_t)row * k;
+    const float eps = 1.1920928955078125e-07f;
+    float mx = -INFINITY;
+    for (int c = lane; c < k; c += 64) {
+        const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
+        mx = fmaxf(mx, lr[c] + (-logf(-logf(u))));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.0f, dot = 0.0f;
+    for (int c = lane; c < k; c += 64) {
+        const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
+        const float e = expf((lr[c] + (-logf(-logf(u)))) - mx);
+        sum += e;
+        dot += e * dr[c];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { sum += __shfl_xor(sum, off); dot += __shfl_xor(dot, off); }
+    const float inv = 1.0f / sum;
+    dot *= inv;                                   // <y, dS>
+    float rs = 0.0f, dt = 0.0f;
+    const float dscale = -tb / scale;
+    for (int c = lane; c < k; c += 64) {
+        const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
+        const float y = expf((lr[c] + (-logf(-logf(u)))) - mx) * inv;
+        const float dz = y * (dr[c] - dot);
+        if (dz != 0.0f) dt += dz * (lr[c] / tb);  // dropped entries (logit = -1e9) have y = 0 exactly
+        const float dd = dz * dscale;
+        dr[c] = dd;
+        rs += dd;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { rs += __shfl_xor(rs, off); dt += __shfl_xor(dt, off); }
+    if (lane == 0) { rowsum[row] = rs; dtrow[row] = dt; }
+}
+
+// dx_v[j] = 2 x_v[j] rowsum_v - 2 sum_k ddist[v][k] c_k[j]; one wave per latent vector, lanes over j
+__global__ __launch_bounds__(256) void vq_dx_kernel(const float* __restrict__ ddist, const float* __restrict__ rowsum,
+                                                    const float* __restrict__ x, const float* __restrict__ cb, float* __restrict__ dx,
+                                                    int rows, int m, int d, int hw, int k) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int pix = row % hw;
+    const int ng = row / hw;                      // n * m + g
+    const int g = ng % m;
+    const float* dr = ddist + (size_t)row * k;
+    const float* cg = cb + (size_t)g * k * d;
+    const float rs = rowsum[row];
+    for (int j = lane; j < d; j += 64) {
+        float acc = 0.0f;
+        for (int c = 0; c < k; ++c) acc = __builtin_fmaf(dr[c], cg[(size_t)c * d + j], acc);
+        const size_t xi = ((size_t)ng * d + j) * hw + pix;
+        dx[xi] = 2.0f * x[xi] * rs - 2.0f * acc;
+    }
+}
+
+// dC[g][c][j] = 2 C[g][c][j] colsum_c - 2 sum_v ddist[v][c] x_v[j] + sum_{v: index_v = c} hot_v dDeq_v[j];
+// one wave per codeword, lanes over j, vectors visited in order (deterministic, no atomics).  xt / dqt are the
+// channel-major (NHWC) copies of the latent and of the incoming gradient.
+__global__ __launch_bounds__(256) void vq_dc_kernel(const float* __restrict__ ddist, const float* __restrict__ xt,
+                                                    const float* __restrict__ dqt, const int64_t* __restrict__ index,
+                                                    const float* __restrict__ hot, const float* __restrict__ cb,
+                                                    float* __restrict__ dcb, int N, int m, int d, int hw, int k) {
+    const int lane = threadIdx.x & 63;
+    const int word = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = blockIdx.y;
+    if (word >= k) return;
+    const int C = m * d;
+    for (int j = lane; j < d; j += 64) {
+        float acc = 0.0f, cs = 0.0f, sc = 0.0f;
+        for (int n = 0; n < N; ++n) {
+            for (int p = 0; p < hw; ++p) {
+                const size_t row = ((size_t)n * m + g) * hw + p;
+                const float dd = ddist[row * k + word];
+                const size_t t = ((size_t)n * hw + p) * C + (size_t)g * d + j;
+                acc = __builtin_fmaf(dd, xt[t], acc);
+                cs += dd;
+                if (index[row] == word) sc = __builtin_fmaf(hot[row], dqt[t], sc);
+            }
+        }
+        const size_t ci = ((size_t)g * k + word) * d + j;
+        dcb[ci] = 2.0f * cb[ci] * cs - 2.0f * acc + sc;
+    }
+}
+
 }  // namespace
 
 extern "C" int mcq_vq_logits_f32(const float* x, const float* cb_packed, const float* temperature, float bound, float* logits,
@@ -233,9 +340,22 @@ extern "C" int mcq_vq_logits_f32(const float* x, const float* cb_packed, const f
     VqLogitK q;
     if (!vq_setup(q.v, x, cb_packed, N, m, d, h, w, k)) return MCQ_ETOOLARGE;
     q.v.codes = nullptr;
-    q.temperature = temperature; q.bound = bound; q.logits = logits;
+    q.temperature = temperature; q.bound = bound; q.logits = logits; q.raw = 0;
     // sqrt(k) as the reference computes it: math.sqrt (double) then used as a Python float in a float32 division
     q.scale = (float)sqrt((double)k);
+    const unsigned gx = (unsigned)(((q.v.total_blocks + VQ_NB - 1) / VQ_NB + 3) / 4);
+    hipLaunchKernelGGL(vq_logits_kernel, dim3(gx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, q);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_vq_inner_f32(const float* x, const float* cb_packed, float* out, int32_t N, int32_t m, int32_t d, int32_t h,
+                                int32_t w, int32_t k, void* stream) {
+    if (!x || !cb_packed || !out || N <= 0 || m <= 0 || d <= 0 || h <= 0 || w <= 0 || k <= 0) return MCQ_EINVAL;
+    if ((uint64_t)d * h * w * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
+    VqLogitK q;
+    if (!vq_setup(q.v, x, cb_packed, N, m, d, h, w, k)) return MCQ_ETOOLARGE;
+    q.v.codes = nullptr;
+    q.temperature = nullptr; q.bound = 0.0f; q.scale = 1.0f; q.logits = out; q.raw = 1;
     const unsigned gx = (unsigned)(((q.v.total_blocks + VQ_NB - 1) / VQ_NB + 3) / 4);
     hipLaunchKernelGGL(vq_logits_kernel, dim3(gx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, q);
     return mcq_check_launch();
@@ -259,5 +379,34 @@ extern "C" int mcq_vq_dequant_soft_f32(const int64_t* sample_index, const float*
     const size_t total = (size_t)N * m * h * w;
     hipLaunchKernelGGL(vq_dequant_soft_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        sample_index, sample_hot, codebook, out, N, m, d, h * w, k);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_vq_softmax_bwd_f32(const float* logits, const float* u_gumbel, float* ds_inout, const float* temperature,
+                                      float bound, float* rowsum, float* dtrow, int32_t N, int32_t m, int32_t h, int32_t w,
+                                      int32_t k, void* stream) {
+    if (!logits || !u_gumbel || !ds_inout || !temperature || !rowsum || !dtrow || N <= 0 || m <= 0 || h <= 0 || w <= 0 || k <= 0)
+        return MCQ_EINVAL;
+    const long long rows = (long long)N * m * h * w;
+    if (rows > 0x7fffffffLL) return MCQ_ETOOLARGE;
+    hipLaunchKernelGGL(vq_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, u_gumbel,
+                       ds_inout, temperature, bound, (float)sqrt((double)k), rowsum, dtrow, (int)rows, m, h * w, k);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_vq_soft_bwd_f32(const float* ddist, const float* rowsum, const float* x, const float* x_nhwc,
+                                   const float* ddeq_nhwc, const int64_t* sample_index, const float* sample_hot,
+                                   const float* codebook, float* dx, float* dcodebook, int32_t N, int32_t m, int32_t d, int32_t h,
+                                   int32_t w, int32_t k, void* stream) {
+    if (!ddist || !rowsum || !x || !x_nhwc || !ddeq_nhwc || !sample_index || !sample_hot || !codebook || !dx || !dcodebook)
+        return MCQ_EINVAL;
+    if (N <= 0 || m <= 0 || d <= 0 || h <= 0 || w <= 0 || k <= 0) return MCQ_EINVAL;
+    const long long rows = (long long)N * m * h * w;
+    if (rows > 0x7fffffffLL) return MCQ_ETOOLARGE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(vq_dx_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ddist, rowsum, x, codebook, dx, (int)rows, m, d,
+                       h * w, k);
+    hipLaunchKernelGGL(vq_dc_kernel, dim3((unsigned)((k + 3) / 4), (unsigned)m), dim3(256), 0, s, ddist, x_nhwc, ddeq_nhwc, sample_index,
+                       sample_hot, codebook, dcodebook, N, m, d, h * w, k);
     return mcq_check_launch();
 }

@@ -62,16 +62,19 @@ class BaseCompressor(nn.Module):
 
     def forward(self, x: torch.Tensor, uniforms=None):
         """Training-mode forward (compressor.py:35-43): (xHat, yHat, codes, logits); None in eval mode like the
-        reference.  FORWARD VALUES ONLY for now: the kernels run outside autograd (the straight-through backward of
-        BASELINE config #5 is not built yet), so the outputs carry no graph.  `uniforms`: optional per-level
-        (u_drop, u_gumbel) draws replacing the two `torch.rand_like(logit)` calls of the reference."""
+        reference.  With grad enabled the step runs through mcquic_amd.autograd (HIP kernels in both directions:
+        xHat.backward(...) fills every parameter's .grad); under torch.no_grad() the fused inference kernels are used.
+        `uniforms`: optional per-level (u_drop, u_gumbel) draws replacing the two `torch.rand_like(logit)` calls."""
         if not self.training:
             return None
         self._check(x)
-        with torch.no_grad():
-            y = self._encode_latent(x, pad=False)          # the training forward does not pad (compressor.py:39)
+        if torch.is_grad_enabled():
+            y = self._encoder(x)                          # no padding in the training forward (compressor.py:39)
             yHat, codes, logits = self._quantizer(y, uniforms)
-            xHat = self._decoder(yHat)
+            return self._decoder(yHat), yHat, codes, logits
+        y = self._encode_latent(x, pad=False)
+        yHat, codes, logits = self._quantizer(y, uniforms)
+        xHat = self._decoder(yHat)
         return xHat, yHat, codes, logits
 
     def reAssignCodebook(self) -> torch.Tensor:

@@ -67,13 +67,21 @@ class _multiCodebookQuantization(nn.Module):
         tensor.  `uniforms` = (u_drop, u_gumbel), the reference's two `torch.rand_like(logit)` draws; drawn here
         with torch.rand when None.  Returns ((index, hot), code, logit)."""
         cb = self._cache[0].get(self._codebook)
-        logit = ops.vq_logits(x, cb, self._temperature, float(EPS))
+        n, _, h, w = x.shape
+        shape = (n, self._m, h, w, self._k)
         if uniforms is None:
-            uniforms = (torch.rand(logit.shape, device=logit.device), torch.rand(logit.shape, device=logit.device))
+            uniforms = (torch.rand(shape, device=x.device), torch.rand(shape, device=x.device))
         bits = math.log2(self._k)
         # exponent of _randomDrop (:196-198), kept on the device: no host sync in the step
-        usage = (freqEMA > EPS).float().mean().clamp(0., 1.)
-        exponent = -(bits - 1) * (usage ** 2) + bits
+        with torch.no_grad():
+            usage = (freqEMA > EPS).float().mean().clamp(0., 1.)
+            exponent = -(bits - 1) * (usage ** 2) + bits
+        if torch.is_grad_enabled():
+            from ..autograd import SoftQuantizeFn
+            deq, code, logit = SoftQuantizeFn.apply(x, self._codebook, self._temperature, freqEMA.detach(), uniforms[0], uniforms[1],
+                                                    exponent, cb, float(EPS))
+            return deq, code, logit           # the sample is represented by its (differentiable) dequantisation
+        logit = ops.vq_logits(x, cb, self._temperature, float(EPS))
         code, index, hot = ops.vq_gumbel_sample(logit, uniforms[0], uniforms[1], freqEMA, exponent)
         return (index, hot), code, logit
 
@@ -89,6 +97,8 @@ class _multiCodebookDeQuantization(nn.Module):
 
     def forward(self, sample) -> torch.Tensor:
         """bmm(sample, codebook) (:262-274) for the (index, hot value) form of the straight-through sample."""
+        if torch.is_tensor(sample):           # training graph: SoftQuantizeFn already produced sample @ codebook
+            return sample
         index, hot = sample
         return ops.vq_dequant_soft(index, hot, self._cache[0].get(self._codebook))
 
@@ -134,6 +144,9 @@ class _quantizerEncoder(nn.Module):
             return q, None, code, logit
         deq = self._dequantizer(q)
         head = self._latentHead
+        if torch.is_grad_enabled():
+            from .. import autograd as AG
+            return q, AG.sub(head(z), deq), code, logit
         t = z
         for i in range(len(head) - 1):
             t = head[i](t)
@@ -166,7 +179,11 @@ class _quantizerDecoder(nn.Module):
         """Training-mode level (:359-365): like decode, from the straight-through sample."""
         x = self._dequantizationHead(self._dequantizer(q))
         if self._sideHead is not None:
-            x = ops.add(x, self._sideHead(formerLevel), dual_silu=True)
+            if torch.is_grad_enabled():
+                from .. import autograd as AG
+                x = AG.add(x, self._sideHead(formerLevel))
+            else:
+                x = ops.add(x, self._sideHead(formerLevel), dual_silu=True)
         return self._restoreHead(x)
 
 

@@ -334,3 +334,40 @@ def axpby(a: torch.Tensor, b: torch.Tensor, alpha: float, beta: float) -> torch.
     with torch.cuda.device(a.device):
         check(_lib.load().mcq_axpby_f32(_ptr(a), _ptr(b), float(alpha), float(beta), _ptr(out), a.numel(), _stream()), "mcq_axpby_f32")
     return out
+
+
+def vq_inner(x: torch.Tensor, cb: PackedCodebook) -> torch.Tensor:
+    """[n, m, h, w, k] inner products <x_v, c_k> (mcq_vq_inner_f32)."""
+    x = _dev(x, "x")
+    n, c, h, w = x.shape
+    out = torch.empty((n, cb.m, h, w, cb.k), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().mcq_vq_inner_f32(_ptr(x), _ptr(cb.packed), _ptr(out), n, cb.m, cb.d, h, w, cb.k, _stream()), "mcq_vq_inner_f32")
+    return out
+
+
+def vq_softmax_bwd(logits: torch.Tensor, u_gumbel: torch.Tensor, ds: torch.Tensor, temperature: torch.Tensor, bound: float):
+    """In place on `ds` (dSample -> d dist); returns (rowsum, dtrow), each [n, m, h, w]."""
+    logits, u_gumbel, ds = _dev(logits, "logits"), _dev(u_gumbel, "u_gumbel"), _dev(ds, "ds")
+    n, m, h, w, k = logits.shape
+    t = _dev(temperature.detach().reshape(-1), "temperature")
+    rowsum = torch.empty((n, m, h, w), dtype=torch.float32, device=logits.device)
+    dtrow = torch.empty_like(rowsum)
+    with torch.cuda.device(logits.device):
+        check(_lib.load().mcq_vq_softmax_bwd_f32(_ptr(logits), _ptr(u_gumbel), _ptr(ds), _ptr(t), float(bound), _ptr(rowsum), _ptr(dtrow),
+                                                 n, m, h, w, k, _stream()), "mcq_vq_softmax_bwd_f32")
+    return rowsum, dtrow
+
+
+def vq_soft_bwd(ddist: torch.Tensor, rowsum: torch.Tensor, x: torch.Tensor, ddeq: torch.Tensor, index: torch.Tensor,
+                hot: torch.Tensor, cb: PackedCodebook):
+    """(dx [n, m*d, h, w], dcodebook [m, k, d]) of the soft assignment + soft dequantisation."""
+    x, ddeq = _dev(x, "x"), _dev(ddeq, "ddeq")
+    n, m, h, w, k = ddist.shape
+    xt, dqt = nchw_to_nhwc(x), nchw_to_nhwc(ddeq)
+    dx = torch.empty_like(x)
+    dcb = torch.empty_like(cb.codebook)
+    with torch.cuda.device(x.device):
+        check(_lib.load().mcq_vq_soft_bwd_f32(_ptr(ddist), _ptr(rowsum), _ptr(x), _ptr(xt), _ptr(dqt), _ptr(index), _ptr(hot),
+                                              _ptr(cb.codebook), _ptr(dx), _ptr(dcb), n, m, cb.d, h, w, k, _stream()), "mcq_vq_soft_bwd_f32")
+    return dx, dcb

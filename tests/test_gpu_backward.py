@@ -93,3 +93,58 @@ def test_blocks_backward(dev, c):
             want = params[name].grad
             assert want is not None, name
             _close(p.grad, want, 2e-5, f"{type(mod).__name__} d{name}")
+
+
+def _train_setup(ch, m, ks, n, hw, seed):
+    sd = R.make_state_dict(ch, m, ks, seed=seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    for lv, k in enumerate(ks):
+        f = torch.rand((m, k), generator=g) ** 3 + 1e-3
+        sd[f"_quantizer._entropyCoder._freqEMA.{lv}"] = f / f.sum(-1, keepdim=True)
+        sd[f"_quantizer._encoders.{lv}._quantizer._temperature"] = torch.rand((m, 1, 1, 1), generator=g) + 0.5
+    x = R.make_images(n, hw, hw, seed=seed + 1)
+    us = []
+    for lv, k in enumerate(ks):
+        s = hw // 16 // (2 ** lv)
+        us.append((torch.rand((n, m, s, s, k), generator=g), torch.rand((n, m, s, s, k), generator=g)))
+    return sd, x, us
+
+
+@pytest.mark.parametrize("cfg", [(8, 2, [32, 16, 8], 2, 128), (128, 2, [512, 64, 16], 1, 128)])
+def test_full_training_step_gradients(dev, cfg):
+    """forward + backward of Compressor in training mode: every parameter gradient against CPU autograd through the
+    oracle's forward_train (same weights, same uniform draws, loss = <xHat, G>)."""
+    from mcquic_amd import Compressor
+    ch, m, ks, n, hw = cfg
+    sd, x, us = _train_setup(ch, m, ks, n, hw, 21)
+    leaf = {k: (v.clone().requires_grad_() if v.is_floating_point() and "reparam" not in k and "_bound" not in k and "_freqEMA" not in k else v)
+            for k, v in sd.items()}
+    # the codebook is one tensor under three names
+    for lv in range(len(ks)):
+        cb = leaf[f"_quantizer._encoders.{lv}._quantizer._codebook"]
+        leaf[f"_quantizer._encoders.{lv}._dequantizer._codebook"] = cb
+        leaf[f"_quantizer._decoders.{lv}._dequantizer._codebook"] = cb
+    xHat, yHat, codes, logits, _ = R.forward_train(leaf, x, us)
+    G = torch.rand(xHat.shape, generator=torch.Generator().manual_seed(5)) - 0.5
+    (xHat * G).sum().backward()
+
+    model = Compressor(ch, m, ks)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    out = model(x.to(dev), uniforms=[(a.to(dev), b.to(dev)) for a, b in us])
+    for lv in range(len(ks)):
+        assert torch.equal(out[2][lv].cpu(), codes[lv]), f"codes level {lv}"
+    _close(out[0], xHat.detach(), 1e-4, "xHat")
+    (out[0] * G.to(dev)).sum().backward()
+    worst = ("", 0.0)
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        want = leaf[name].grad
+        assert want is not None, f"oracle has no grad for {name}"
+        assert p.grad is not None, f"no grad for {name}"
+        got = p.grad.detach().cpu()
+        rel = (got - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+        if rel > worst[1]:
+            worst = (name, rel)
+    assert worst[1] < 2e-3, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"

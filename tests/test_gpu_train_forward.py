@@ -91,9 +91,17 @@ def test_training_forward_against_reference_vectors(dev):
         np.testing.assert_allclose(logits[lv].cpu().numpy(), z[f"logit{lv}"], rtol=1e-5, atol=2e-5)
         np.testing.assert_allclose(model._quantizer._entropyCoder._freqEMA[lv].detach().cpu().numpy(), z[f"ema{lv}"],
                                    rtol=0, atol=1e-6)
-    np.testing.assert_allclose(yHat.cpu().numpy(), z["yHat"], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(xHat.cpu()[..., ::2, ::2].numpy(), z["xHat_strided"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(yHat.detach().cpu().numpy(), z["yHat"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(xHat.detach().cpu()[..., ::2, ::2].numpy(), z["xHat_strided"], rtol=0, atol=1e-4)
     assert model.eval()(x.to(dev)) is None
+    # the same forward without autograd (fused inference kernels + the (index, hot) sample form)
+    model.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        x2, y2, c2, l2 = model.train()(x.to(dev), uniforms=[(a.to(dev), b.to(dev)) for a, b in us])
+    assert not x2.requires_grad
+    for lv in range(3):
+        assert torch.equal(c2[lv], codes[lv])
+    assert (x2 - xHat.detach()).abs().max().item() < 1e-4
 
 
 def test_training_forward_draws_its_own_uniforms(dev):
@@ -108,3 +116,4 @@ def test_training_forward_draws_its_own_uniforms(dev):
     assert [tuple(c.shape) for c in codes] == [(2, m, 8, 8), (2, m, 4, 4), (2, m, 2, 2)]
     assert [tuple(l.shape) for l in logits] == [(2, m, 8, 8, 32), (2, m, 4, 4, 16), (2, m, 2, 2, 8)]
     assert all(torch.isfinite(t).all() for t in (xHat, yHat))
+    assert xHat.requires_grad

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Training-step timing (BASELINE config #5): forward + Gumbel straight-through backward of Compressor(128, 2,
+[8192, 2048, 512]) on 256x256 crops, 8 images per GPU, gradients all-reduced by torch DDP over RCCL when launched
+with torch.distributed.run.  Not the headline metric (bench.py is); prints one JSON line on rank 0.
+
+    python tools/bench_train.py [--steps K --warmup W --batch 8]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--crop", type=int, default=256)
+    args = ap.parse_args()
+    rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from mcquic_amd import Compressor
+    torch.manual_seed(3407)
+    model = Compressor(128, 2, [8192, 2048, 512]).to(dev).train()
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
+    x = (torch.rand((args.batch, 3, args.crop, args.crop), generator=torch.Generator().manual_seed(rank)) * 2 - 1).to(dev)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        xHat, yHat, codes, logits = net(x)
+        loss = torch.nn.functional.mse_loss(xHat, x)       # loss glue is the trainer's business (out of scope): plain MSE
+        loss.backward()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+        print(json.dumps({"metric": "training step (forward + backward), 256x256 crops, qp=2 model", "n_gpus": world,
+                          "images_per_gpu": args.batch, "ms_per_step": round(dt / args.steps * 1e3, 2),
+                          "images_per_s": round(world * args.batch * args.steps / dt, 2), "loss": float(loss), "grad_norm": gn,
+                          "dtype": "f32", "optimizer_step": "not included (trainer glue)"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,14 +24,14 @@ def test_blocks_against_reference_vectors(dev):
         mk(sd, "", c, 11)
         mod = ctor()
         mod.load_state_dict(sd, strict=True)
-        got = mod.to(dev)(x).cpu().numpy()
+        got = mod.to(dev).eval()(x).cpu().numpy()
         np.testing.assert_allclose(got, z[name], rtol=0, atol=5e-6, err_msg=name)
     for name, cls in [("GenDivNorm", N.GenDivNorm), ("InvGenDivNorm", N.InvGenDivNorm)]:
         sd = {}
         R._gdn_params(sd, "", c, 12)
         mod = cls(c)
         mod.load_state_dict(sd, strict=True)
-        np.testing.assert_allclose(mod.to(dev)(x * 2).cpu().numpy(), z[name], rtol=0, atol=5e-6, err_msg=name)
+        np.testing.assert_allclose(mod.to(dev).eval()(x * 2).cpu().numpy(), z[name], rtol=0, atol=5e-6, err_msg=name)
 
 
 def test_vq_against_reference_vectors(dev):

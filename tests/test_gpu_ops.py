@@ -125,7 +125,7 @@ def test_gdn(dev, inverse, c):
     want = R.gdn(sd, "g.", x, inverse)
     mod = (InvGenDivNorm if inverse else GenDivNorm)(c)
     mod.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
-    got = mod.to(dev)(x.to(dev))
+    got = mod.to(dev).eval()(x.to(dev))
     _close(got, want, 3e-6, f"gdn inverse={inverse} c={c}")
 
 
@@ -144,7 +144,7 @@ def test_blocks(dev, c):
         mk(sd, "b.", c, 7)
         mod.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
         want = fn(sd, "b.", x)
-        got = mod.to(dev)(x.to(dev))
+        got = mod.to(dev).eval()(x.to(dev))
         assert got.shape == want.shape
         _close(got, want, 5e-6, type(mod).__name__)
 

@@ -54,6 +54,37 @@ class _multiCodebookQuantization(nn.Module):
         self._bound = LowerBound(EPS)
         self._cache = [cache]          # list: keep the cache out of nn.Module's attribute registration
 
+    @torch.no_grad()
+    def reAssignCodebook(self, freq: torch.Tensor) -> torch.Tensor:
+        """Replace never-assigned codewords by copies of the most used ones (reference: quantizer.py:111-136).
+        Parameter-sized host logic (torch ops on [k, d]); returns the per-codeword "changed" mask, flattened."""
+        codebook = self._codebook.detach().clone()
+        freq = freq.to(self._codebook.device).detach().clone()
+        for m, (codebookGroup, freqGroup) in enumerate(zip(self._codebook, freq)):
+            neverAssignedLoc = freqGroup < EPS
+            totalNeverAssigned = int(neverAssignedLoc.sum())
+            if totalNeverAssigned > self._k // 2:          # more than half never assigned: drop a random part of them
+                mask = torch.zeros((totalNeverAssigned,), device=self._codebook.device)
+                maskIdx = torch.randperm(len(mask), device=mask.device)[self._k // 2:]
+                mask[maskIdx] = -1.
+                freqGroup[neverAssignedLoc] = mask
+                neverAssignedLoc = (freqGroup < EPS) * (freqGroup > (-EPS))
+                totalNeverAssigned = int(neverAssignedLoc.sum())
+            argIdx = torch.argsort(freqGroup, descending=True)
+            mostAssigned = codebookGroup[argIdx]
+            codebook.data[m, neverAssignedLoc] = mostAssigned[:totalNeverAssigned]
+        diff = ((codebook - self._codebook) ** 2).sum(-1) > 1e-4
+        self._codebook.data.copy_(codebook)
+        return diff.flatten()
+
+    @torch.no_grad()
+    def syncCodebook(self):
+        """Broadcast rank 0's codebook (reference: quantizer.py:138-142)."""
+        import torch.distributed as dist
+        codebook = self._codebook.detach().clone()
+        dist.broadcast(codebook, 0)
+        self._codebook.data.copy_(codebook)
+
     def encode(self, x: torch.Tensor) -> torch.Tensor:
         """[n, m*d, h, w] -> int64 [n, m, h, w] = argmin_k ((x2 + c2) - 2 x.c), first index on ties (:144-179)."""
         return ops.vq_assign(x, self._cache[0].get(self._codebook))
@@ -121,6 +152,12 @@ class _quantizerEncoder(nn.Module):
     @property
     def Codebook(self):
         return self._quantizer._codebook
+
+    def syncCodebook(self):
+        self._quantizer.syncCodebook()
+
+    def reAssignCodebook(self, freq: torch.Tensor) -> torch.Tensor:
+        return self._quantizer.reAssignCodebook(freq)
 
     def encode(self, x: torch.Tensor):
         z = self._latentStageEncoder(x)
@@ -273,8 +310,15 @@ class UMGMQuantizer(BaseQuantizer):
         self._entropyCoder(codes)
         return formerLevel, codes, logits
 
-    def reAssignCodebook(self):
-        raise NotImplementedError("training-side codebook maintenance is a 'next' row (SURVEY.md §8(f) #4)")
+    def reAssignCodebook(self) -> torch.Tensor:
+        """reference: quantizer.py:430-436."""
+        freqs = self.NormalizedFreq
+        reassigned = [encoder.reAssignCodebook(freq) for encoder, freq in zip(self._encoders, freqs)]
+        return torch.cat(reassigned).float().mean()
 
     def syncCodebook(self):
-        raise NotImplementedError("training-side codebook maintenance is a 'next' row (SURVEY.md §8(f) #4)")
+        """reference: quantizer.py:438-441."""
+        import torch.distributed as dist
+        dist.barrier()
+        for encoder in self._encoders:
+            encoder.syncCodebook()

@@ -57,3 +57,48 @@ def test_stats_collectives_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(world))
+
+
+def _ema_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mcquic_amd.modules.entropyCoder import EntropyCoder
+    from oracle import mcquic_ref as R
+    m, ks = 2, [32, 16, 8]
+    coder = EntropyCoder(m, ks)
+    g = torch.Generator().manual_seed(1)
+    codes_all = [torch.randint(0, k, (6, m, s, s), generator=g) for k, s in zip(ks, (4, 2, 1))]
+    before = [f.detach().clone() for f in coder._freqEMA]
+    lo, hi = (0, 3) if rank == 0 else (3, 6)                      # each rank sees its shard of the batch
+    coder([c[lo:hi] for c in codes_all])
+    ok = True
+    for lv, (c, k) in enumerate(zip(codes_all, ks)):
+        counts = torch.stack([torch.bincount(c[:, g_].reshape(-1), minlength=k) for g_ in range(m)]).float()
+        want = R.freq_ema_update(before[lv], counts)              # the reference's update on the WHOLE batch
+        ok = ok and torch.allclose(coder._freqEMA[lv], want, atol=1e-7)
+    # codebook sync: rank 1 ends up with rank 0's codebook
+    from mcquic_amd import Compressor
+    torch.manual_seed(rank)
+    model = Compressor(8, 2, [32, 16, 8])
+    model.syncCodebook()
+    ref = [cb.detach().clone() for cb in model.Codebooks]
+    for cb in ref:
+        dist.broadcast(cb, 0)
+    ok = ok and all(torch.equal(a, b) for a, b in zip(model.Codebooks, ref))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_freq_ema_allreduce_and_codebook_sync_world2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_ema_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world))

@@ -164,7 +164,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1
+    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run: take the RCCL path even at N=1
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -17,7 +17,7 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void vq_assign_kernel(VqK p) {
+__global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
     constexpr int MB = VQ_MB, NB = VQ_NB, PF = VQ_PF;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -21,7 +21,7 @@ from ..nn import AttentionBlock, ResidualBlock, ResidualBlockShuffle, ResidualBl
 from ..utils.specification import FileHeader, ImageSize
 from .quantizer import BaseQuantizer, UMGMQuantizer
 
-__version__ = "0.1.40"   # the reference snapshot's mcquic.__version__, written into FileHeader
+from ..utils.specification import VERSION as __version__   # the reference snapshot's mcquic.__version__ (FileHeader)
 
 
 class AlignedPadding(nn.Module):

@@ -1,3 +1,3 @@
-from .specification import CodeSize, FileHeader, ImageSize
+from .specification import CodeSize, File, FileHeader, ImageSize, versionCheck
 
-__all__ = ["CodeSize", "FileHeader", "ImageSize"]
+__all__ = ["CodeSize", "File", "FileHeader", "ImageSize", "versionCheck"]

@@ -80,3 +80,25 @@ def test_api_surface_and_errors():
     from oracle import mcquic_ref as R
     assert torch.equal(pad(x), R.aligned_padding(x))
     assert pad(torch.zeros(1, 3, 768, 512)).shape[-2:] == (768, 512)
+
+
+def test_mcq_container_round_trip_and_version_rules():
+    from mcquic_amd.utils import CodeSize, File, FileHeader, ImageSize, versionCheck
+    header = FileHeader("0.1.40", "2", CodeSize([2, 2, 2], [48, 24, 12], [32, 16, 8], [8192, 2048, 512]), ImageSize(768, 512, 3))
+    f = File(header, [b"\x01\x02\x03", b"abc", b"\xff" * 10])
+    blob = f.serialize()
+    import msgpack
+    doc = msgpack.unpackb(blob, raw=False)
+    assert list(doc) == ["fileHeader", "contents"] and list(doc["fileHeader"]) == ["qp", "version", "codeSize", "imageSize"]
+    g = File.deserialize(blob)
+    assert g.FileHeader.QuantizationParameter == "2" and g.FileHeader.CodeSize.k == [8192, 2048, 512]
+    assert g.Content == f.Content and g.FileHeader.ImageSize.Pixels == 768 * 512
+    assert abs(g.BPP - 16 * 8 / (768 * 512)) < 1e-12 and g.size() == 16
+    with pytest.raises(ValueError, match="too new"):
+        versionCheck("0.2.0")
+    with pytest.raises(ValueError, match="too new"):
+        FileHeader("1.0.0", "2", header.codeSize, header.imageSize)
+    with pytest.warns(UserWarning, match="Minor version mismatch"):
+        assert versionCheck("0.0.9")
+    with pytest.raises(ValueError):
+        File.deserialize(msgpack.packb({"nope": 1}))

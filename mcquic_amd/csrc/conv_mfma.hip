@@ -8,13 +8,22 @@
 // GEMM view:  D[co][p] = sum_{tap, ci} Wt[co][tap, ci] * X[ci][p + tap]
 //   rows  = output channels  (A operand = packed weights, one float4 per lane per k-step)
 //   cols  = output pixels    (B operand = activations, NCHW so 32 pixels = 32 consecutive floats)
-//   k     = (tap, ci) walked tap-major, two input channels per 32x32x2 MFMA.
+//   k     = (ci pair, tap) walked channel-major / tap-inner (two input channels per 32x32x2 MFMA): the nine taps
+//           of a channel pair re-read the same rows back to back, so they hit L1 instead of being nine separate
+//           sweeps over the whole activation (tap-major measured 2.4-4.8x the algorithmic bytes at the L2 fabric).
 // A wave owns MB x NB accumulator tiles of 32 couts x 32 pixels and is a self-contained stream:
 // per k-step it issues one weight load (MB floats per lane) and NB activation loads (buffer
 // loads; out-of-image taps are turned into out-of-range offsets, for which the hardware returns
 // 0 = the conv's zero padding), PF steps ahead of the MFMAs that consume them.
 #include "mcq_common.h"
 #include "../../include/mcquic_hip.h"
+
+#ifndef MCQ_SCHED_FENCE
+#define MCQ_SCHED_FENCE 1
+#endif
+#ifndef MCQ_PF42
+#define MCQ_PF42 9     // ring depth of the 128 x 64 tile: 9 = one whole channel pair ahead (3 measured 8 % slower)
+#endif
 
 namespace {
 
@@ -23,12 +32,12 @@ struct ConvK {
     const float* res; const float* mul; const float* gid;
     int N, Cin, H, W, Cout, Ho, Wo;
     int ks, stride;
-    int S;             // input-channel pairs per tap
-    int TP;            // k-steps per 128-cout tile, padded to a multiple of 16 (the deepest prefetch ring)
+    int S;             // input-channel pairs (padded to a multiple of 16 for 1x1 convs)
+    int TP;            // k-steps per 128-cout tile = S * taps
     int bw_log2;       // a pixel block is (32 >> bw_log2) rows x (1 << bw_log2) cols
     int nbx, nby, total_blocks;
     int ks_log2;       // split-K: 1 << ks_log2 waves of a workgroup share one output tile, each a slice of the k-steps
-    int slice_steps;   // k-steps per slice (multiple of PF)
+    int slice_pairs;   // channel pairs per split-K slice
     int tiles_log2;    // (1 << tiles_log2) output tiles per workgroup
     unsigned flags; float res_scale;
 };
@@ -45,8 +54,9 @@ template <> __device__ __forceinline__ float a_elem<1>(const float& v, int) { re
 
 extern __shared__ __attribute__((aligned(16))) float mcq_lds[];
 
-template <int MB, int NB, int PRO, int PF>
+template <int MB, int NB, int PRO, int PF, int TAPS>
 __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
+    static_assert(TAPS == 1 || (TAPS == 9 && 9 % PF == 0), "3x3: the ring depth must divide the nine taps");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int KS = 1 << p.ks_log2;
@@ -61,14 +71,14 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
     const int ly = j >> p.bw_log2, lx = j & (BW - 1);
     const int BH = 32 >> p.bw_log2;
     const int HW = p.H * p.W;
-    const int pad = p.ks >> 1;
-    const int ntaps = p.ks * p.ks;
+    const int pad = TAPS == 9 ? 1 : 0;
     const unsigned plane_bytes = (unsigned)p.Cin * (unsigned)HW * 4u;
 
     // ---- geometry of the NB pixel blocks this wave owns -------------------------------------
     int img[NB], yo[NB], xo[NB];
     bool valid[NB];
     __amdgpu_buffer_rsrc_t rsrc[NB];
+    unsigned voff[NB][TAPS];                        // per-tap byte offset of this lane's pixel, or the OOB marker
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         int pb = gw * NB + nb;
@@ -84,44 +94,29 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
         xo[nb] = bx * BW + lx;
         valid[nb] = pbv && yo[nb] < p.Ho && xo[nb] < p.Wo;
         rsrc[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.x + (size_t)n * p.Cin * HW), plane_bytes);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
+            const int yi = yo[nb] * p.stride + dy - pad;
+            const int xi = xo[nb] * p.stride + dx - pad;
+            const bool inb = valid[nb] && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
+            voff[nb][tap] = inb ? (unsigned)(yi * p.W + xi + hi * HW) * 4u : MCQ_OOB;
+        }
     }
 
-    auto tap_voff = [&](int tap, int nb) -> unsigned {
-        const int dy = tap / p.ks, dx = tap - dy * p.ks;          // scalar
-        const int yi = yo[nb] * p.stride + dy - pad;
-        const int xi = xo[nb] * p.stride + dx - pad;
-        const bool inb = valid[nb] && tap < ntaps && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
-        return inb ? (unsigned)(yi * p.W + xi + hi * HW) * 4u : MCQ_OOB;
-    };
-
     // ---- operand prefetch ring ---------------------------------------------------------------
+    // A k-step is (channel pair s, tap).  The loop body covers U consecutive steps with every ring slot, tap
+    // and look-ahead distance a compile-time constant: the nine taps of one pair for 3x3 (U = 9), PF pairs for
+    // 1x1 (U = PF).  Loads run PF steps ahead of the MFMAs that consume them.
+    constexpr int U = TAPS == 9 ? 9 : PF;
     typedef typename AVec<MB>::T avec_t;
     avec_t A[PF];
     float B[PF][NB];
     const int tile128 = co_base >> 7, q0 = (co_base & 127) >> 5;
-    const int t0 = kslice * p.slice_steps;          // first k-step of this wave's slice
-    const float* wl = p.wp + (((size_t)tile128 * p.TP + t0) * 64 + lane) * 4 + q0;
-    int lt = t0 / p.S;
-    int ls = t0 - lt * p.S;
-    const unsigned step_bytes = 2u * (unsigned)HW * 4u;
-    unsigned soffL = (unsigned)ls * step_bytes;
-    unsigned voffL[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) voffL[nb] = tap_voff(lt, nb);
-
-    auto issue = [&](int st) {
-        A[st] = *reinterpret_cast<const avec_t*>(wl);
-        wl += 256;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) B[st][nb] = mcq_buffer_load(rsrc[nb], voffL[nb] + soffL);
-        ++ls;
-        soffL += step_bytes;
-        if (ls == p.S) {                       // wave-uniform: next tap
-            ls = 0; soffL = 0; ++lt;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) voffL[nb] = tap_voff(lt, nb);
-        }
-    };
+    const int s0 = kslice * p.slice_pairs;          // first channel pair of this wave's slice
+    const float* wl = p.wp + (((size_t)tile128 * p.TP + (size_t)s0 * TAPS) * 64 + lane) * 4 + q0;
+    const unsigned step_bytes = 2u * (unsigned)HW * 4u;     // one channel pair further
+    unsigned soff = (unsigned)s0 * step_bytes;
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -131,15 +126,23 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
-    const int nsteps = active ? p.slice_steps : 0;
+    const int npairs = active ? p.slice_pairs : 0;
     if (active) {
 #pragma unroll
-        for (int st = 0; st < PF; ++st) issue(st);
+        for (int st = 0; st < PF; ++st) {           // steps 0 .. PF-1 of the slice
+            A[st] = *reinterpret_cast<const avec_t*>(wl);
+            wl += 256;
+            const int tap = TAPS == 9 ? st : 0;
+            const unsigned so = TAPS == 9 ? soff : soff + (unsigned)st * step_bytes;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) B[st][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tap] + so);
+        }
     }
 
-    for (int t = 0; t < nsteps; t += PF) {
+    for (int sp = 0; sp < npairs; sp += (TAPS == 9 ? 1 : PF)) {
 #pragma unroll
-        for (int st = 0; st < PF; ++st) {
+        for (int u = 0; u < U; ++u) {
+            const int st = u % PF;
             float bv[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -154,8 +157,22 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
                 for (int nb = 0; nb < NB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[st], mb), bv[nb],
                                                                        acc[mb][nb], 0, 0, 0);
-            issue(st);   // over-reads PF steps past the tile: the packed buffer carries a zero tail
+            // refill the slot with the step PF ahead (over-reads PF steps past the slice: the packed weights carry
+            // a zero tail, and activation offsets past the last channel are out of range = 0)
+            A[st] = *reinterpret_cast<const avec_t*>(wl);
+            wl += 256;
+            const int tl = TAPS == 9 ? (u + PF) % 9 : 0;                        // tap of the step being loaded
+            const int ds = TAPS == 9 ? (u + PF) / 9 : u + PF;                   // its channel-pair distance
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                B[st][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tl] + soff + (unsigned)ds * step_bytes);
+#if MCQ_SCHED_FENCE
+            // keep the software pipeline as written: without this fence the scheduler sinks the loads of all U
+            // steps to the end of the (branch-free) body and waits for them one step later
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+        soff += (TAPS == 9 ? 1u : (unsigned)PF) * step_bytes;
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
 }
 
 // OIHW -> [Cout/128][TP][64 lanes][4]: lane l, slot q holds W[co = 128 T + 32 q + (l & 31)][ci = 2 s + (l >> 5)][tap]
-// for k-step = tap * S + s; zero beyond Cout / Cin / the real step count and in the 16-step tail.
+// for k-step = s * taps + tap (channel-major, tap-inner); zero beyond Cout / Cin and in the 16-step tail.
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, int S, int TP,
                                         int ntile, float* __restrict__ out, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,9 +335,9 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
     const int tile = (int)(stepg / TP);
     const int step = (int)(stepg - (size_t)tile * TP);
     float v = 0.0f;
-    const int T = ks * ks * S;
-    if (tile < ntile && step < T) {
-        const int tap = step / S, s = step - tap * S;
+    const int taps = ks * ks;
+    if (tile < ntile && step < TP) {
+        const int s = step / taps, tap = step - s * taps;
         const int co = tile * 128 + 32 * q + (lane & 31);
         const int ci = 2 * s + (lane >> 5);
         if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * (ks * ks) + tap];
@@ -337,31 +354,35 @@ __global__ void nonneg_reparam_kernel(const float* __restrict__ p, float bound, 
     }
 }
 
-inline int steps_padded(int Cin, int ks) {
+inline int pairs_padded(int Cin, int ks) {        // 1x1 loops advance a whole prefetch ring (<= 16 pairs) at a time
     const int S = (Cin + 1) / 2;
-    const int T = ks * ks * S;
-    return (T + 15) & ~15;
+    return ks == 1 ? (S + 15) & ~15 : S;
 }
+inline int steps_padded(int Cin, int ks) { return pairs_padded(Cin, ks) * ks * ks; }
 
-template <int MB, int NB, int PF>
+template <int MB, int NB, int PF3, int PF1>
 int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2, hipStream_t s) {
-    // split-K slices must be whole prefetch rounds and at least 64 steps long (1x1 convs are never split)
-    if (ksplit_log2 > 0 && (1 << ksplit_log2) < MB) ksplit_log2 = MB == 4 ? 2 : 1;   // one band per owner wave
-    while (ksplit_log2 > 0 && ((k.TP >> ksplit_log2) % PF != 0 || (k.TP >> ksplit_log2) < 64 ||
-                               ((k.TP >> ksplit_log2) << ksplit_log2) != k.TP))
-        --ksplit_log2;
+    // split-K: one 32-row band per owner wave (KS >= MB), whole channel pairs per slice, slices of >= 8 pairs of a
+    // 3x3 conv (1x1 convs, 64 steps in all, are never split)
+    if (ksplit_log2 > 0 && (1 << ksplit_log2) < MB) ksplit_log2 = MB == 4 ? 2 : 1;
+    if (k.ks == 1) ksplit_log2 = 0;
+    while (ksplit_log2 > 0 && (k.S % (1 << ksplit_log2) != 0 || (k.S >> ksplit_log2) < 8)) --ksplit_log2;
     if ((1 << ksplit_log2) < MB) ksplit_log2 = 0;
     k.ks_log2 = ksplit_log2;
-    k.slice_steps = k.TP >> ksplit_log2;
+    k.slice_pairs = k.S >> ksplit_log2;
     k.tiles_log2 = ksplit_log2 >= 2 ? 0 : 2 - ksplit_log2;           // 4 waves per workgroup, 8 for 8-way split
     const int waves = 1 << (k.ks_log2 + k.tiles_log2);
     const size_t lds = ksplit_log2 ? (size_t)waves * NB * 1024 * sizeof(float) : 0;
     const dim3 grid((unsigned)((tiles + (1 << k.tiles_log2) - 1) >> k.tiles_log2), (unsigned)co_tiles);
     const dim3 block(64 * waves);
-    switch (pro) {
-    case PRO_NONE:   hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF>), grid, block, lds, s, k); break;
-    case PRO_SILU:   hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF>), grid, block, lds, s, k); break;
-    default:         hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SQUARE, PF>), grid, block, lds, s, k); break;
+    if (k.ks == 3) {
+        if (pro == PRO_SILU) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF3, 9>), grid, block, lds, s, k);
+        else if (pro == PRO_NONE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF3, 9>), grid, block, lds, s, k);
+        else return MCQ_EINVAL;
+    } else {
+        if (pro == PRO_SQUARE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SQUARE, PF1, 1>), grid, block, lds, s, k);
+        else if (pro == PRO_NONE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF1, 1>), grid, block, lds, s, k);
+        else return MCQ_EINVAL;
     }
     return mcq_check_launch();
 }
@@ -378,7 +399,7 @@ extern "C" int mcq_pack_conv_weight_f32(const float* w, int32_t Cout, int32_t Ci
                                         void* stream) {
     if (!w || !out || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return MCQ_EINVAL;
     const size_t total = mcq_packed_conv_weight_floats(Cout, Cin, ksize);
-    const int S = (Cin + 1) / 2, TP = steps_padded(Cin, ksize), ntile = (Cout + 127) / 128;
+    const int S = pairs_padded(Cin, ksize), TP = steps_padded(Cin, ksize), ntile = (Cout + 127) / 128;
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, ksize, S,
                        TP, ntile, out, total);
@@ -414,7 +435,7 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     const int pad = d->ksize / 2;
     k.Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1;
     k.Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
-    k.S = (d->Cin + 1) / 2;
+    k.S = pairs_padded(d->Cin, d->ksize);
     k.TP = steps_padded(d->Cin, d->ksize);
     k.flags = fl; k.res_scale = d->res_scale;
 
@@ -459,10 +480,10 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     const long long ptiles = (tb + NB - 1) / NB;
     const int co_tiles = (co32 + MB - 1) / MB;
     hipStream_t s = (hipStream_t)stream;
-    if (MB == 4 && NB == 2) return launch_tile<4, 2, 4>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 2 && NB == 2) return launch_tile<2, 2, 8>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 2 && NB == 1) return launch_tile<2, 1, 16>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 1 && NB == 2) return launch_tile<1, 2, 8>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 1 && NB == 1) return launch_tile<1, 1, 16>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42, 4>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 2 && NB == 2) return launch_tile<2, 2, 9, 8>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 2 && NB == 1) return launch_tile<2, 1, 9, 16>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 1 && NB == 2) return launch_tile<1, 2, 9, 8>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 1 && NB == 1) return launch_tile<1, 1, 9, 16>(k, pro, ptiles, co_tiles, ksl, s);
     return MCQ_EINVAL;
 }

@@ -35,7 +35,8 @@ def test_size_queries_run_without_a_gpu():
     # 128 -> 128 3x3: 576 k-steps (+16 tail) x 64 lanes x 4 floats
     assert lib.mcq_packed_conv_weight_floats(128, 128, 3) == (576 + 16) * 256
     assert lib.mcq_packed_conv_weight_floats(512, 128, 3) == (4 * 576 + 16) * 256
-    assert lib.mcq_packed_conv_weight_floats(128, 3, 3) == (32 + 16) * 256      # 9 taps x 2 channel pairs -> 18 -> 32
+    assert lib.mcq_packed_conv_weight_floats(128, 3, 3) == (18 + 16) * 256      # 2 channel pairs x 9 taps
+    assert lib.mcq_packed_conv_weight_floats(128, 8, 1) == (16 + 16) * 256      # 1x1: 4 pairs padded to one 16-deep ring
     assert lib.mcq_packed_conv_weight_floats(128, 128, 5) == 0                   # unsupported kernel size
     assert lib.mcq_packed_codebook_floats(2, 8192, 64) == (2 * 64 * 32 + 4) * 256 + 2 * 65 * 256
 

@@ -225,7 +225,10 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM, all tile variants)",
                 "achieved": round(achieved_tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved_tf / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
+                "frac": round(achieved_tf / FP32_MATRIX_PEAK_TFLOPS, 4),
+                "traffic": (lambda t: None if t is None else round(t["fetch_bytes_per_launch_x2_corrected"] + t["write_size_bytes_per_launch"]))(pmc_traffic()),
+                "traffic_unit": "HBM-side bytes per launch of conv_mfma_kernel<4,2,0,9,9> (PMC FETCH_SIZE x2-corrected + WRITE_SIZE, profiles/r01_pmc.json)",
+                "algorithmic_bytes_per_launch": round(conv["bytes"] / max(conv["launches"], 1)),
                 "launches_per_step": conv["launches"] // max(args.steps, 1),
                 "avg_launch_ms": round(conv["sum_ms"] / max(conv["launches"], 1), 4),
                 "conv_busy_ms_per_step": round(conv["ms"] / max(args.steps, 1), 3),

@@ -158,8 +158,8 @@ size_t mcq_conv2d_wgrad_workspace_floats(int32_t N, int32_t Cin, int32_t H, int3
 int mcq_conv2d_wgrad_f32(const float* x_nhwc, const float* dy_nhwc, float* dw, float* workspace, int32_t N, int32_t Cin,
                          int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, void* stream);
 
-/* out[c] = sum_{n,p} x[n][c][p]   (bias / beta gradients). */
-int mcq_channel_sum_f32(const float* x, float* out, int32_t N, int32_t C, int32_t HW, void* stream);
+/* out[c] = sum_{n,p} x[n][c][p]   (bias / beta gradients); optional workspace of min(N, 16) * C floats. */
+int mcq_channel_sum_f32(const float* x, float* out, float* workspace, int32_t N, int32_t C, int32_t HW, void* stream);
 
 /* Stand-alone forms of ops that the inference path fuses into conv prologues / epilogues; the training graph keeps
  * them separate so that each has its own backward:  y = silu(x);  out = a * sigmoid(b) + x;  out = alpha a + beta b. */

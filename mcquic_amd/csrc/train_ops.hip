@@ -155,12 +155,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
     dw[((size_t)co * Cin + ci) * taps + tap] = s;
 }
 
-// out[c] = sum over n, pixels of x[n][c][p]; one workgroup per channel, fixed-order tree
-__global__ void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int C, int HW) {
+// out[c] = sum over n, pixels of x[n][c][p].  Stage 1: one workgroup per (channel, image-chunk) -> part[chunk][c];
+// stage 2 (chunks == 1 skips it): fixed-order sum over the chunks.  Deterministic.
+__global__ void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int C, int HW, int nchunk) {
     __shared__ float red[256];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, chunk = blockIdx.y;
+    const int per = (N + nchunk - 1) / nchunk;
+    const int n0 = chunk * per, n1 = n0 + per < N ? n0 + per : N;
     float s = 0.0f;
-    for (int n = 0; n < N; ++n) {
+    for (int n = n0; n < n1; ++n) {
         const float* row = x + ((size_t)n * C + c) * HW;
         for (int p = threadIdx.x; p < HW; p += 256) s += row[p];
     }
@@ -170,7 +173,15 @@ __global__ void channel_sum_kernel(const float* __restrict__ x, float* __restric
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[c] = red[0];
+    if (threadIdx.x == 0) out[(size_t)chunk * C + c] = red[0];
+}
+
+__global__ void channel_sum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int nchunk) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.0f;
+    for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * C + c];
+    out[c] = s;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -262,7 +273,7 @@ extern "C" size_t mcq_conv2d_wgrad_workspace_floats(int32_t N, int32_t Cin, int3
     const long long Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const long long P = (long long)N * Ho * Wo;
     const int taps = ksize * ksize, ci_tiles = (Cin + 63) / 64, co_tiles = (Cout + 127) / 128;
-    long long splits = 4096 / ((long long)taps * ci_tiles * co_tiles);
+    long long splits = 4096 / ((long long)taps * ci_tiles * co_tiles);      // ~4 waves per SIMD in all
     if (splits < 1) splits = 1;
     const long long max_splits = (P + 63) / 64;                 // at least 64 pixels per range
     if (splits > max_splits) splits = max_splits;
@@ -297,9 +308,17 @@ extern "C" int mcq_conv2d_wgrad_f32(const float* x_nhwc, const float* dy_nhwc, f
     return mcq_check_launch();
 }
 
-extern "C" int mcq_channel_sum_f32(const float* x, float* out, int32_t N, int32_t C, int32_t HW, void* stream) {
+extern "C" int mcq_channel_sum_f32(const float* x, float* out, float* workspace, int32_t N, int32_t C, int32_t HW, void* stream) {
     if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return MCQ_EINVAL;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, x, out, N, C, HW);
+    // `workspace` (>= min(N, 16) * C floats) lets the images be summed by several workgroups per channel
+    const int nchunk = workspace ? (N < 16 ? N : 16) : 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (nchunk == 1) {
+        hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C, 1), dim3(256), 0, s, x, out, N, C, HW, 1);
+    } else {
+        hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C, (unsigned)nchunk), dim3(256), 0, s, x, workspace, N, C, HW, nchunk);
+        hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, workspace, out, C, nchunk);
+    }
     return mcq_check_launch();
 }
 

@@ -273,8 +273,9 @@ def channel_sum(x: torch.Tensor) -> torch.Tensor:
     x = _dev(x, "x")
     n, c, h, w = x.shape
     out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    ws = torch.empty((min(n, 16) * c,), dtype=torch.float32, device=x.device) if n > 1 else None
     with torch.cuda.device(x.device):
-        check(_lib.load().mcq_channel_sum_f32(_ptr(x), _ptr(out), n, c, h * w, _stream()), "mcq_channel_sum_f32")
+        check(_lib.load().mcq_channel_sum_f32(_ptr(x), _ptr(out), _ptr(ws), n, c, h * w, _stream()), "mcq_channel_sum_f32")
     return out
 
 

@@ -103,3 +103,14 @@ def test_mcq_container_round_trip_and_version_rules():
         assert versionCheck("0.0.9")
     with pytest.raises(ValueError):
         File.deserialize(msgpack.packb({"nope": 1}))
+
+
+def test_oversized_planes_are_rejected_before_any_launch():
+    """A per-image plane set of 2 GiB or more cannot be addressed through one buffer descriptor: MCQ_ETOOLARGE."""
+    from mcquic_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    d.x = d.w_packed = d.y = 1                      # never dereferenced: the size check comes first
+    d.N, d.Cin, d.H, d.W, d.Cout, d.ksize, d.stride = 1, 128, 4096, 1024, 128, 3, 1
+    assert lib.mcq_conv2d_f32(d, None) == _lib.MCQ_ETOOLARGE
+    assert lib.mcq_vq_assign_f32(1, 1, 1, 1, 2, 64, 4096, 2048, 512, None) == _lib.MCQ_ETOOLARGE

@@ -456,31 +456,37 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     k.total_blocks = (int)tb;
 
     // Wave tile and split-K.  Weight traffic per wave is the whole filter bank whatever the tile, so the tile stays
-    // as large as the layer allows (128 co x 64 px); when that leaves fewer than ~2 waves per SIMD (2048 on MI355X)
-    // the k-steps of a tile are split over 2/4/8 waves of one workgroup and reduced through LDS.
+    // as large as the layer allows (128 co x 64 px); when that leaves too few waves for the 1024 SIMDs the k-steps of
+    // a tile are split over 2/4/8 waves of one workgroup and reduced through LDS.
     const int co32 = (d->Cout + 31) / 32;
     int MB, NB, ksl = 0;
     const int forced = d->tile & 0xff;
     if (forced) { MB = forced >> 4; NB = forced & 15; ksl = (d->tile >> 8) & 3; }
     else if (co32 == 1) { MB = 1; NB = 2; }
     else {
-        static const int cand[3][2] = {{4, 2}, {2, 2}, {1, 1}};
-        MB = 1; NB = 1;
-        for (int c = 0; c < 3; ++c) {
+        // the largest tile that reaches ~1.5 waves per SIMD (1536) with at most a 4-way k split; failing that,
+        // 128 co x 32 px with a 4-way split (measured best on the 24x16 and 12x8 levels)
+        static const int cand[4][2] = {{4, 2}, {4, 1}, {2, 2}, {1, 1}};
+        MB = 0; NB = 0;
+        for (int c = 0; c < 4 && !MB; ++c) {
             const int mb = cand[c][0], nb = cand[c][1];
             if (mb > co32) continue;
             const long long tiles = ((tb + nb - 1) / nb) * ((co32 + mb - 1) / mb);
-            MB = mb; NB = nb;
-            if (tiles * 8 >= 1024) break;          // even an 8-way split would leave SIMDs idle: try a smaller tile
+            for (int kk = 0; kk <= 2; ++kk)
+                if ((tiles << kk) >= 1536) { MB = mb; NB = nb; ksl = kk; break; }
         }
-        const long long tiles = ((tb + NB - 1) / NB) * ((co32 + MB - 1) / MB);
-        while (ksl < 3 && (tiles << ksl) < 2048) ++ksl;
+        if (!MB) {
+            if (co32 >= 4) { MB = 4; NB = 1; ksl = 2; }
+            else { MB = 1; NB = 1; ksl = 2; }
+        }
+        if (d->ksize == 1 && MB == 4 && NB == 2 && tb < 4096) { MB = 2; NB = 2; }   // short k loop: smaller tile, no split
     }
     const int pro = (fl & MCQ_CONV_SILU_IN) ? PRO_SILU : (fl & MCQ_CONV_SQUARE_IN) ? PRO_SQUARE : PRO_NONE;
     const long long ptiles = (tb + NB - 1) / NB;
     const int co_tiles = (co32 + MB - 1) / MB;
     hipStream_t s = (hipStream_t)stream;
     if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42, 4>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 2) return launch_tile<2, 2, 9, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 1) return launch_tile<2, 1, 9, 16>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 1 && NB == 2) return launch_tile<1, 2, 9, 8>(k, pro, ptiles, co_tiles, ksl, s);

@@ -25,7 +25,7 @@ SHAPES = [  # n, cin, cout, h, w, ks, stride
     (32, 128, 128, 12, 8, 3, 1),
     (32, 128, 128, 48, 32, 1, 1),
 ]
-TILES = [0, 0x42, 0x142, 0x242, 0x342, 0x22, 0x122, 0x222, 0x322, 0x11, 0x211, 0x311]
+TILES = [0, 0x42, 0x242, 0x342, 0x41, 0x241, 0x341, 0x22, 0x122, 0x222, 0x322, 0x11, 0x311]
 
 
 def main():
@@ -45,7 +45,7 @@ def main():
         flops = 2.0 * n * (h // stride) * (w // stride) * cout * cin * ks * ks
         row = []
         for tile in TILES:
-            if h * w > 100 * 64 and tile not in (0, 0x42, 0x22):
+            if h * w > 100 * 64 and tile not in (0, 0x42, 0x41, 0x22):
                 continue
             kw = dict(tile=tile)
             if args.flags == "res":

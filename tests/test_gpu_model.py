@@ -114,3 +114,32 @@ def test_compress_decompress_round_trip(dev):
     assert torch.equal(restored, R.aligned_crop_back(full, 200, 136))
     bits = sum(len(s) for b in binaries for s in b) * 8
     assert 0 < bits / (3 * 200 * 136) < 1.0                      # bpp of the uniform-prior streams is sane
+
+
+def test_cli_compress_then_restore(dev, tmp_path):
+    """`python -m mcquic_amd img.png out.mcq` then `python -m mcquic_amd out.mcq out.png` (the reference's
+    `mcquic -qp 2 sample.png ./ ; mcquic sample.mcq ./` smoke, .github/workflows/test-all.yml:37-45), with a
+    ragged image size so that padding and the crop-back are exercised.  Restoring twice gives identical pixels."""
+    import numpy as np
+    from PIL import Image
+    from mcquic_amd.demo import main
+    from mcquic_amd.utils import File
+    rng = np.random.default_rng(0)
+    img = (rng.random((150, 200, 3)) * 255).astype(np.uint8)
+    src = tmp_path / "sample.png"
+    Image.fromarray(img).save(src)
+    assert main(["-q", str(src), str(tmp_path)]) == 0
+    mcq = tmp_path / "sample.mcq"
+    doc = File.deserialize(mcq.read_bytes())
+    assert doc.FileHeader.ImageSize.height == 150 and doc.FileHeader.ImageSize.width == 200
+    assert doc.FileHeader.CodeSize.heights == [16, 8, 4] and len(doc.Content) == 3
+    out1, out2 = tmp_path / "a.png", tmp_path / "b.png"
+    assert main(["-q", str(mcq), str(out1)]) == 0 and main(["-q", str(mcq), str(out2)]) == 0
+    a, b = np.asarray(Image.open(out1)), np.asarray(Image.open(out2))
+    assert a.shape == (150, 200, 3) and np.array_equal(a, b)
+
+
+def test_sample_png_geometry_against_oracle(dev):
+    """BASELINE configs[0]: one 2048x1152 image (the geometry of the reference's assets/sample.png: no padding,
+    latents 128x72 / 64x36 / 32x18) through the qp=2 model; codes and pixels against the CPU oracle."""
+    _compare(dev, 128, 2, [8192, 2048, 512], n=1, h=1152, w=2048, seed=0, pix_tol=1e-4)

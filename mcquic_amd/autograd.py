@@ -42,7 +42,7 @@ class _DgradCache:
         self.key, self.packed = None, None
 
     def get(self, weight: torch.Tensor, stride: int) -> ops.PackedConv:
-        key = (weight._version, weight.data_ptr(), stride)
+        key = (ops.tensor_version(weight), weight.data_ptr(), stride)
         if key != self.key:
             self.packed = ops.PackedConv(_dgrad_weight(weight.detach(), stride), None)
             self.key = key

@@ -81,7 +81,7 @@ def main(argv=None) -> int:
         if a.input.suffix.lower() in (".png", ".jpg", ".jpeg"):
             from PIL import Image
             model = loadModel(a.qp, a.local, device)
-            image = torch.from_numpy(np.asarray(Image.open(a.input).convert("RGB"))).permute(2, 0, 1).to(device)
+            image = torch.from_numpy(np.array(Image.open(a.input).convert("RGB"))).permute(2, 0, 1).to(device)
             target = compressImage(image, model, a.crop)
             raw = a.input.stat().st_size
             say(f"{target.FileHeader.ImageSize} -> {target.size(True)}, {target.BPP:.4f} bpp "

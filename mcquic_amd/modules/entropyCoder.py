@@ -23,6 +23,7 @@ import torch
 from torch import nn
 
 from .. import _lib
+from ..ops import tensor_version
 from ..utils.specification import CodeSize
 
 
@@ -107,7 +108,7 @@ class EntropyCoder(nn.Module):
         self._tables = None
 
     def _stale(self) -> bool:
-        key = tuple((f._version, f.data_ptr()) for f in self._freqEMA)
+        key = tuple((tensor_version(f), f.data_ptr()) for f in self._freqEMA)
         if key != self._key:
             self._key = key
             return True

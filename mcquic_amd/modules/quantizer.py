@@ -29,7 +29,7 @@ class _CodebookCache:
         self._key = None
 
     def get(self, codebook: torch.Tensor) -> ops.PackedCodebook:
-        key = (codebook._version, codebook.data_ptr())
+        key = (ops.tensor_version(codebook), codebook.data_ptr())
         if self._packed is None or key != self._key:
             self._packed = ops.PackedCodebook(codebook)
             self._key = key

@@ -36,7 +36,7 @@ class Conv2d(nn.Module):
 
     def packed(self) -> ops.PackedConv:
         """Weights in MFMA operand order; re-packed whenever the parameters change (version / storage / device)."""
-        key = (self.weight._version, self.weight.data_ptr(), None if self.bias is None else (self.bias._version, self.bias.data_ptr()))
+        key = (ops.tensor_version(self.weight), self.weight.data_ptr(), None if self.bias is None else (ops.tensor_version(self.bias), self.bias.data_ptr()))
         if self._packed is None or key != self._packedKey:
             self._packed = ops.PackedConv(self.weight, self.bias)
             self._packedKey = key

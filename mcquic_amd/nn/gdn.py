@@ -60,8 +60,8 @@ class GenDivNorm(nn.Module):
     def packed(self) -> ops.PackedConv:
         bb, gb = self.beta_reparam.lowerBound.bound, self.gamma_reparam.lowerBound.bound
         # keyed on versions / storages only: reading a buffer's value here would force a device sync per call
-        key = (self.beta._version, self.beta.data_ptr(), self.gamma._version, self.gamma.data_ptr(),
-               bb._version, bb.data_ptr(), gb._version, gb.data_ptr())
+        key = (ops.tensor_version(self.beta), self.beta.data_ptr(), ops.tensor_version(self.gamma), self.gamma.data_ptr(),
+               ops.tensor_version(bb), bb.data_ptr(), ops.tensor_version(gb), gb.data_ptr())
         if self._packed is None or key != self._packedKey:
             beta = ops.nonneg_reparam(self.beta, float(self.beta_reparam.lowerBound.bound), float(self.beta_reparam.eps))
             gamma = ops.nonneg_reparam(self.gamma, float(self.gamma_reparam.lowerBound.bound), float(self.gamma_reparam.eps))

@@ -26,6 +26,16 @@ def silu_twin(t: torch.Tensor) -> Optional[torch.Tensor]:
 
 
 
+def tensor_version(t: torch.Tensor) -> int:
+    """`t._version` for cache keys; tensors created under torch.inference_mode() (the reference CLI builds its model
+    there, mcquic/cli.py:60) do not track one -- they cannot be updated by an optimizer either, so the storage
+    pointer alone identifies their contents."""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
 def _stream() -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

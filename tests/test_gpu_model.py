@@ -143,3 +143,25 @@ def test_sample_png_geometry_against_oracle(dev):
     """BASELINE configs[0]: one 2048x1152 image (the geometry of the reference's assets/sample.png: no padding,
     latents 128x72 / 64x36 / 32x18) through the qp=2 model; codes and pixels against the CPU oracle."""
     _compare(dev, 128, 2, [8192, 2048, 512], n=1, h=1152, w=2048, seed=0, pix_tol=1e-4)
+
+
+def test_inference_mode_like_the_reference_harness(dev):
+    """The reference wraps its callers in torch.inference_mode() (cli.py:60, validator.py:40,60): same results."""
+    from mcquic_amd import Compressor
+    sd = R.make_state_dict(8, 2, [32, 16, 8], seed=7)
+    model = Compressor(8, 2, [32, 16, 8]).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    x = R.make_images(2, 128, 128).to(dev)
+    codes = model.encode(x)
+    rec = model.decode(codes)
+    with torch.inference_mode():
+        codes_i = model.encode(x)
+        rec_i = model.decode(codes_i)
+        model2 = Compressor(8, 2, [32, 16, 8]).eval()          # parameters born as inference tensors
+        model2.load_state_dict(sd, strict=True)
+        model2 = model2.to(dev)
+        codes_2 = model2.encode(x)
+    for a, b, c in zip(codes, codes_i, codes_2):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert torch.equal(rec, rec_i)

@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--graphs", action="store_true", help="replay encode/decode as captured hipGraphs (small-batch latency)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,6 +174,8 @@ def main():
     from mcquic_amd import Compressor
     torch.manual_seed(3407)                                   # same random-init weights on every rank
     model = Compressor(**MODEL).eval().to(dev)
+    if args.graphs:
+        model.enableGraphs(True)
     g = torch.Generator(device="cpu").manual_seed(3407 + rank)
     x = (torch.rand((args.batch, 3, H, W), generator=g) * 2 - 1).to(dev)
 

@@ -165,3 +165,25 @@ def test_inference_mode_like_the_reference_harness(dev):
     for a, b, c in zip(codes, codes_i, codes_2):
         assert torch.equal(a, b) and torch.equal(a, c)
     assert torch.equal(rec, rec_i)
+
+
+def test_graph_replay_matches_eager(dev):
+    """enableGraphs(): encode / decode replayed from captured hipGraphs give the eager results, also for new data."""
+    from mcquic_amd import Compressor
+    sd = R.make_state_dict(8, 2, [32, 16, 8], seed=8)
+    model = Compressor(8, 2, [32, 16, 8]).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    xs = [R.make_images(2, 128, 256, seed=s).to(dev) for s in (1, 2, 3)]
+    eager = [(model.encode(x), None) for x in xs]
+    eager = [(c, model.decode(c)) for c, _ in eager]
+    model.enableGraphs(True)
+    for x, (codes, rec) in zip(xs, eager):
+        got_codes = model.encode(x)
+        got = model.decode(got_codes)
+        for a, b in zip(codes, got_codes):
+            assert torch.equal(a, b)
+        assert torch.equal(rec, got)
+    assert len(model._graphs) == 2
+    model.enableGraphs(False)
+    assert torch.equal(model.decode(eager[0][0]), eager[0][1])

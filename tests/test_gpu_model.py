@@ -187,3 +187,18 @@ def test_graph_replay_matches_eager(dev):
     assert len(model._graphs) == 2
     model.enableGraphs(False)
     assert torch.equal(model.decode(eager[0][0]), eager[0][1])
+
+
+def test_validate_helpers(dev):
+    from mcquic_amd import Compressor, validate
+    sd = R.make_state_dict(8, 2, [32, 16, 8], seed=9)
+    model = Compressor(8, 2, [32, 16, 8]).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    x = R.make_images(3, 128, 128).to(dev)
+    rows = validate.validate(model, x)
+    assert tuple(rows.shape) == (3, 2) and torch.isfinite(rows).all() and float(rows[:, 1].min()) > 0
+    want = R.psnr(R.detransform(x.cpu()), R.detransform(model.decode(model.encode(x)).cpu()))
+    assert torch.allclose(rows[:, 0].cpu(), want, atol=1e-9)
+    enc, dec = validate.speed(model, iters=2, batch=2, height=128, width=128)
+    assert enc > 0 and dec > 0

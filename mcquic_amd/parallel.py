@@ -49,7 +49,10 @@ def code_histograms(codes: Sequence[torch.Tensor], ks: Sequence[int], group=None
     for code, k in zip(codes, ks):
         n, m = code.shape[0], code.shape[1]
         idx = code.permute(1, 0, 2, 3).reshape(m, -1) + (torch.arange(m, device=code.device) * k)[:, None]
-        flat.append(torch.bincount(idx.reshape(-1), minlength=m * k))
+        # scatter_add instead of torch.bincount: bincount reads its maximum back to the host (a sync, and illegal
+        # inside a captured hipGraph)
+        idx = idx.reshape(-1)
+        flat.append(torch.zeros(m * k, dtype=torch.int64, device=code.device).scatter_add_(0, idx, torch.ones_like(idx)))
     buf = torch.cat(flat)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(buf, group=group)

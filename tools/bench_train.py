@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--crop", type=int, default=256)
+    ap.add_argument("--graph", action="store_true", help="capture forward+backward in one hipGraph and replay it (single GPU)")
     args = ap.parse_args()
     rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     torch.cuda.set_device(local)
@@ -45,6 +46,21 @@ def main():
         return loss
 
     for _ in range(args.warmup):
+        step()
+    if args.graph and world == 1:
+        # whole-step capture: ~5000 kernel launches per step become one graph launch
+        torch.cuda.synchronize()
+        for p in model.parameters():
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            xHat, yHat, codes, logits = net(x)
+            static_loss = torch.nn.functional.mse_loss(xHat, x)
+            static_loss.backward()
+
+        def step():                                        # noqa: F811
+            graph.replay()
+            return static_loss
         step()
     torch.cuda.synchronize()
     if world > 1:

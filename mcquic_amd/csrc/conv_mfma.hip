@@ -21,8 +21,15 @@
 #ifndef MCQ_SCHED_FENCE
 #define MCQ_SCHED_FENCE 1
 #endif
-#ifndef MCQ_PF42
-#define MCQ_PF42 9     // ring depth of the 128 x 64 tile: 9 = one whole channel pair ahead (3 measured 8 % slower)
+// 3x3 ring depths in k-steps (weights / activations).  Activations 18 steps = two channel pairs ahead.
+#ifndef MCQ_PF42A
+#define MCQ_PF42A 9
+#endif
+#ifndef MCQ_PF42B
+#define MCQ_PF42B 18
+#endif
+#ifndef MCQ_PFB
+#define MCQ_PFB 18
 #endif
 
 namespace {
@@ -54,9 +61,10 @@ template <> __device__ __forceinline__ float a_elem<1>(const float& v, int) { re
 
 extern __shared__ __attribute__((aligned(16))) float mcq_lds[];
 
-template <int MB, int NB, int PRO, int PF, int TAPS>
-__global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
-    static_assert(TAPS == 1 || (TAPS == 9 && 9 % PF == 0), "3x3: the ring depth must divide the nine taps");
+template <int MB, int NB, int PRO, int PFA, int PFB, int TAPS, int OCC>
+__global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
+    static_assert(TAPS == 1 ? PFA == PFB : ((9 % PFA == 0 || PFA % 9 == 0) && PFB % 9 == 0 && PFB % PFA == 0),
+                  "ring depths must tile the unrolled body");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int KS = 1 << p.ks_log2;
@@ -104,14 +112,16 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
         }
     }
 
-    // ---- operand prefetch ring ---------------------------------------------------------------
-    // A k-step is (channel pair s, tap).  The loop body covers U consecutive steps with every ring slot, tap
-    // and look-ahead distance a compile-time constant: the nine taps of one pair for 3x3 (U = 9), PF pairs for
-    // 1x1 (U = PF).  Loads run PF steps ahead of the MFMAs that consume them.
-    constexpr int U = TAPS == 9 ? 9 : PF;
+    // ---- operand prefetch rings -------------------------------------------------------------
+    // A k-step is (channel pair s, tap).  Weights (L2 resident, shared by every wave of the launch) run PFA steps
+    // ahead of the MFMAs that consume them; activations, whose first touch of a row comes from HBM / MALL
+    // (~2.5 us under load, i.e. more than the nine steps of one channel pair), run PFB steps ahead.  The loop body
+    // covers U consecutive steps so that every ring slot, tap and look-ahead distance is a compile-time constant.
+    constexpr int U = TAPS == 9 ? PFB : PFA;        // 3x3: one or two channel pairs; 1x1: PFA pairs
+    constexpr int PAIRS_PER_ITER = TAPS == 9 ? U / 9 : U;
     typedef typename AVec<MB>::T avec_t;
-    avec_t A[PF];
-    float B[PF][NB];
+    avec_t A[PFA];
+    float B[PFB][NB];
     const int tile128 = co_base >> 7, q0 = (co_base & 127) >> 5;
     const int s0 = kslice * p.slice_pairs;          // first channel pair of this wave's slice
     const float* wl = p.wp + (((size_t)tile128 * p.TP + (size_t)s0 * TAPS) * 64 + lane) * 4 + q0;
@@ -129,24 +139,28 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
     const int npairs = active ? p.slice_pairs : 0;
     if (active) {
 #pragma unroll
-        for (int st = 0; st < PF; ++st) {           // steps 0 .. PF-1 of the slice
+        for (int st = 0; st < PFA; ++st) {          // weights of steps 0 .. PFA-1 of the slice
             A[st] = *reinterpret_cast<const avec_t*>(wl);
             wl += 256;
-            const int tap = TAPS == 9 ? st : 0;
-            const unsigned so = TAPS == 9 ? soff : soff + (unsigned)st * step_bytes;
+        }
+#pragma unroll
+        for (int st = 0; st < PFB; ++st) {          // activations of steps 0 .. PFB-1
+            const int tap = TAPS == 9 ? st % 9 : 0;
+            const unsigned so = soff + (unsigned)(TAPS == 9 ? st / 9 : st) * step_bytes;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) B[st][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tap] + so);
         }
     }
 
-    for (int sp = 0; sp < npairs; sp += (TAPS == 9 ? 1 : PF)) {
+    for (int sp = 0; sp < npairs; sp += PAIRS_PER_ITER) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int st = u % PF;
+            if (TAPS == 9 && u == 9 && sp + 1 >= npairs) break;     // odd slice: the second pair of the body is past it
+            const int sa = u % PFA, sb = u % PFB;
             float bv[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                float v = B[st][nb];
+                float v = B[sb][nb];
                 if (PRO == PRO_SILU) v = mcq_silu(v);
                 if (PRO == PRO_SQUARE) v = v * v;
                 bv[nb] = v;
@@ -155,24 +169,24 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_kernel(ConvK p) {
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[st], mb), bv[nb],
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[sa], mb), bv[nb],
                                                                        acc[mb][nb], 0, 0, 0);
-            // refill the slot with the step PF ahead (over-reads PF steps past the slice: the packed weights carry
+            // refill the slots with the steps PFA / PFB ahead (over-reads past the slice: the packed weights carry
             // a zero tail, and activation offsets past the last channel are out of range = 0)
-            A[st] = *reinterpret_cast<const avec_t*>(wl);
+            A[sa] = *reinterpret_cast<const avec_t*>(wl);
             wl += 256;
-            const int tl = TAPS == 9 ? (u + PF) % 9 : 0;                        // tap of the step being loaded
-            const int ds = TAPS == 9 ? (u + PF) / 9 : u + PF;                   // its channel-pair distance
+            const int tl = TAPS == 9 ? (u + PFB) % 9 : 0;                       // tap of the step being loaded
+            const int ds = TAPS == 9 ? (u + PFB) / 9 : u + PFB;                 // its channel-pair distance
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                B[st][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tl] + soff + (unsigned)ds * step_bytes);
+                B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tl] + soff + (unsigned)ds * step_bytes);
 #if MCQ_SCHED_FENCE
             // keep the software pipeline as written: without this fence the scheduler sinks the loads of all U
             // steps to the end of the (branch-free) body and waits for them one step later
             __builtin_amdgcn_sched_barrier(0);
 #endif
         }
-        soff += (TAPS == 9 ? 1u : (unsigned)PF) * step_bytes;
+        soff += (unsigned)PAIRS_PER_ITER * step_bytes;
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
@@ -360,7 +374,7 @@ inline int pairs_padded(int Cin, int ks) {        // 1x1 loops advance a whole p
 }
 inline int steps_padded(int Cin, int ks) { return pairs_padded(Cin, ks) * ks * ks; }
 
-template <int MB, int NB, int PF3, int PF1>
+template <int MB, int NB, int PF3A, int PF3B, int PF1>
 int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2, hipStream_t s) {
     // split-K: one 32-row band per owner wave (KS >= MB), whole channel pairs per slice, slices of >= 8 pairs of a
     // 3x3 conv (1x1 convs, 64 steps in all, are never split)
@@ -368,6 +382,7 @@ int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2
     if (k.ks == 1) ksplit_log2 = 0;
     while (ksplit_log2 > 0 && (k.S % (1 << ksplit_log2) != 0 || (k.S >> ksplit_log2) < 8)) --ksplit_log2;
     if ((1 << ksplit_log2) < MB) ksplit_log2 = 0;
+    constexpr int OCC = (MB == 2 && NB == 2) ? 3 : 2;      // waves per SIMD the register budget is sized for
     k.ks_log2 = ksplit_log2;
     k.slice_pairs = k.S >> ksplit_log2;
     k.tiles_log2 = ksplit_log2 >= 2 ? 0 : 2 - ksplit_log2;           // 4 waves per workgroup, 8 for 8-way split
@@ -376,12 +391,12 @@ int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2
     const dim3 grid((unsigned)((tiles + (1 << k.tiles_log2) - 1) >> k.tiles_log2), (unsigned)co_tiles);
     const dim3 block(64 * waves);
     if (k.ks == 3) {
-        if (pro == PRO_SILU) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF3, 9>), grid, block, lds, s, k);
-        else if (pro == PRO_NONE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF3, 9>), grid, block, lds, s, k);
+        if (pro == PRO_SILU) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF3A, PF3B, 9, OCC>), grid, block, lds, s, k);
+        else if (pro == PRO_NONE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF3A, PF3B, 9, OCC>), grid, block, lds, s, k);
         else return MCQ_EINVAL;
     } else {
-        if (pro == PRO_SQUARE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SQUARE, PF1, 1>), grid, block, lds, s, k);
-        else if (pro == PRO_NONE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF1, 1>), grid, block, lds, s, k);
+        if (pro == PRO_SQUARE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SQUARE, PF1, PF1, 1, OCC>), grid, block, lds, s, k);
+        else if (pro == PRO_NONE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF1, PF1, 1, OCC>), grid, block, lds, s, k);
         else return MCQ_EINVAL;
     }
     return mcq_check_launch();
@@ -482,11 +497,11 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     const long long ptiles = (tb + NB - 1) / NB;
     const int co_tiles = (co32 + MB - 1) / MB;
     hipStream_t s = (hipStream_t)stream;
-    if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42, 4>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, 8>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 2 && NB == 2) return launch_tile<2, 2, 9, 8>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 2 && NB == 1) return launch_tile<2, 1, 9, 16>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 1 && NB == 2) return launch_tile<1, 2, 9, 8>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 1 && NB == 1) return launch_tile<1, 1, 9, 16>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42A, MCQ_PF42B, 4>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 2 && NB == 2) return launch_tile<2, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 2 && NB == 1) return launch_tile<2, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 1 && NB == 2) return launch_tile<1, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 1 && NB == 1) return launch_tile<1, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
     return MCQ_EINVAL;
 }

@@ -209,6 +209,23 @@ int mcq_rans_decode_with_indexes(const uint8_t* in, int64_t nbytes, const int32_
                                  const uint32_t* cdfs, const int32_t* cdf_starts, const int32_t* cdf_sizes,
                                  const int32_t* offsets, int32_t n_cdfs, int32_t* out_symbols);
 
+/* ---- validation metrics (callers of the path: mcquic/validate/handlers.py:14-41) --------------------------------
+ * MS-SSIM of two uint8 batches x, y [N, C, H, W] as the reference's MsSSIM handler computes it
+ * (handlers.py:14-27 -> metrics.py:69-104 `_ssim`, :142-193 `ms_ssim`, module defaults metrics.py:222: 11-tap sigma-1.5
+ * window, K = (0.01, 0.03), data range 255, five levels with weights metrics.py:19).  out[N] receives the MS-SSIM VALUE
+ * in [0, 1] (the reference module returns 1 - value and the handler prints -10 log10 of that).  H and W must exceed 160
+ * (metrics.py:163-166), else MCQ_EINVAL.  `workspace` holds the pooled pyramids and partial sums:
+ * mcq_ms_ssim_workspace_bytes(N, C, H, W) bytes (0 for an invalid shape), 8-byte aligned, contents undefined after. */
+size_t mcq_ms_ssim_workspace_bytes(int32_t N, int32_t C, int32_t H, int32_t W);
+int mcq_ms_ssim_u8(const uint8_t* x, const uint8_t* y, float* out, void* workspace, int32_t N, int32_t C, int32_t H,
+                   int32_t W, void* stream);
+/* Host helper: the 11 float32 window taps the kernels use (metrics.py:22-37 for size 11, sigma 1.5). */
+void mcq_ms_ssim_window(float* out11);
+
+/* out[n] = sum over the per_image bytes of image n of (x - y)^2, exact (int64).  The reference's PSNR
+ * (metrics.py:264-274) is 10 log10(255^2 / (out[n] / per_image + 1e-4)) in float64. */
+int mcq_sqdiff_sum_u8(const uint8_t* x, const uint8_t* y, int64_t* out, int64_t per_image, int32_t N, void* stream);
+
 /* Library / build identification: returns a static string "mcquic_hip <ver> gfx950". */
 const char* mcq_version(void);
 

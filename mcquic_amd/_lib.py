@@ -70,6 +70,10 @@ SYMBOLS = {
                                                c_void_p, c_int64]),
     "mcq_rans_decode_with_indexes": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_int32, c_void_p]),
+    "mcq_ms_ssim_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "mcq_ms_ssim_u8": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "mcq_ms_ssim_window": (None, [c_void_p]),
+    "mcq_sqdiff_sum_u8": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "mcq_version": (c_char_p, []),
 }
 

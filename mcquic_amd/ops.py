@@ -254,6 +254,40 @@ def detransform(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ---- validation metrics (mcquic/validate/handlers.py) ----------------------------------------------------------
+def _u8_pair(x: torch.Tensor, y: torch.Tensor):
+    x, y = _dev(x, "x", torch.uint8), _dev(y, "y", torch.uint8)
+    if x.shape != y.shape or x.dim() != 4:
+        raise ValueError(f"expected two uint8 [N, C, H, W] batches of one shape, got {tuple(x.shape)} and {tuple(y.shape)}")
+    return x, y
+
+
+def ms_ssim(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """MS-SSIM value in [0, 1] per image of two uint8 batches (mcquic/validate/metrics.py:142-193 as called by
+    handlers.py:14-27).  Sides must exceed 160 pixels (metrics.py:163-166)."""
+    x, y = _u8_pair(x, y)
+    n, c, h, w = x.shape
+    lib = _lib.load()
+    nbytes = lib.mcq_ms_ssim_workspace_bytes(n, c, h, w)
+    if nbytes == 0:
+        raise ValueError(f"MS-SSIM needs image sides larger than 160 pixels, got {h}x{w}")
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.mcq_ms_ssim_u8(_ptr(x), _ptr(y), _ptr(out), _ptr(ws), n, c, h, w, _stream()), "mcq_ms_ssim_u8")
+    return out
+
+
+def sqdiff_sum(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """Exact per-image sum of squared differences of two uint8 batches, int64 [N]."""
+    x, y = _u8_pair(x, y)
+    n = x.shape[0]
+    out = torch.empty(n, dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().mcq_sqdiff_sum_u8(_ptr(x), _ptr(y), _ptr(out), x[0].numel(), n, _stream()), "mcq_sqdiff_sum_u8")
+    return out
+
+
 # ---- backward-pass kernels (training step) ---------------------------------------------------------------------
 def nchw_to_nhwc(x: torch.Tensor, square: bool = False) -> torch.Tensor:
     x = _dev(x, "x")

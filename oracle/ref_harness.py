@@ -132,6 +132,34 @@ def load():
     return C
 
 
+def load_validate_handlers():
+    """The reference's validation handlers (mcquic/validate/handlers.py: MsSSIM, PSNR, BPP, IdealBPP) and the Decibel
+    formatter (mcquic/validate/utils.py), imported unmodified.  handlers.py pulls torchvision and
+    vlutils.metrics.meter.Handler at import time: both are stubbed (Handler = the three members the handlers use)."""
+    load()
+
+    class _Handler:                                   # vlutils.metrics.meter.Handler as used by handlers.py
+        def __init__(self, format: str = r"%.2f"):
+            self._format = format
+            self.length = 0
+
+        def reset(self):
+            self.length = 0
+
+        def to(self, device):
+            return self
+
+    _stub("vlutils.metrics")
+    _stub("vlutils.metrics.meter", Handler=_Handler)
+    tf = sys.modules["torchvision.transforms.functional"]
+    tf.resize = tf.center_crop = tf.convert_image_dtype = None       # only InceptionScore (not used here) calls them
+    _stub("torchvision.models", inception_v3=None)
+    _pkg("mcquic.validate", REF + "/mcquic/validate")
+    import mcquic.validate.handlers as H
+    import mcquic.validate.utils as U
+    return {"MsSSIM": H.MsSSIM, "PSNR": H.PSNR, "BPP": H.BPP, "IdealBPP": H.IdealBPP, "Decibel": U.Decibel}
+
+
 def reference_compressor(channel, m, k, state_dict=None):
     """Construct the reference's Compressor (eval mode) and optionally load a state_dict into it."""
     C = load()

@@ -32,6 +32,9 @@ def sha(t: torch.Tensor) -> str:
     return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
 
 
+F7_CASES = [(1, 2, 200, 176), (2, 3, 193, 211), (3, 1, 768, 512), (4, 2, 161, 400)]   # (seed, n, h, w)
+
+
 def main():
     C = ref_harness.load()
     import mcquic.nn as RN                      # the reference's layers
@@ -188,6 +191,28 @@ def main():
         f8["bypass_sym"] = sym
         f8["bypass_bytes"] = np.frombuffer(by, dtype=np.uint8)
         np.savez_compressed(os.path.join(OUT, "f8_rans.npz"), **f8)
+    # ---- F7: validation metrics (MS-SSIM, PSNR, IdealBPP) from the reference's own validate/ code ---------
+    import importlib.util
+    from oracle import metrics_ref as MR        # generators only
+    spec = importlib.util.spec_from_file_location("ref_metrics", os.path.join(ref_harness.REF, "mcquic/validate/metrics.py"))
+    RM = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(RM)
+    RH = ref_harness.load_validate_handlers()
+    f7 = {"cases": np.array(F7_CASES, dtype=np.int64)}
+    msssim_mod, psnr_mod, decibel = RM.MsSSIM(sizeAverage=False), RM.PSNR(sizeAverage=False), RH["Decibel"](1.0)
+    for i, (seed, n, h, w) in enumerate(F7_CASES):
+        x, y = MR.make_u8_pair(seed, n, h, w)
+        out = msssim_mod(x.float(), y.float())                    # handlers.py:26 (1 - ms_ssim)
+        f7[f"msssim_{i}"] = (1.0 - out).numpy()
+        f7[f"msssim_db_{i}"] = decibel(out).numpy()
+        f7[f"psnr_{i}"] = psnr_mod(x.float(), y.float()).numpy()
+        f7[f"sha_{i}"] = np.frombuffer(bytes.fromhex(sha(x) + sha(y)), dtype=np.uint8)
+    ks, ms = list(MR.CODE_BATCH_KS), [2, 2, 2]
+    handler = RH["IdealBPP"](ms, ks)
+    for codes in MR.make_code_batches():                            # accumulated over two batches like a validation run
+        handler(codes=codes, images=torch.zeros(3, 3, 768, 512, dtype=torch.uint8))
+    f7["ideal_bpp"] = np.array([handler.Result], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "f7_metrics.npz"), **f7)
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -195,10 +195,16 @@ def test_validate_helpers(dev):
     model = Compressor(8, 2, [32, 16, 8]).eval()
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
-    x = R.make_images(3, 128, 128).to(dev)
+    from oracle import metrics_ref as M
+    x = R.make_images(3, 256, 256).to(dev)
     rows = validate.validate(model, x)
-    assert tuple(rows.shape) == (3, 2) and torch.isfinite(rows).all() and float(rows[:, 1].min()) > 0
-    want = R.psnr(R.detransform(x.cpu()), R.detransform(model.decode(model.encode(x)).cpu()))
-    assert torch.allclose(rows[:, 0].cpu(), want, atol=1e-9)
+    assert tuple(rows.shape) == (3, 3) and torch.isfinite(rows).all() and float(rows[:, 2].min()) > 0
+    a, b = R.detransform(x.cpu()), R.detransform(model.decode(model.encode(x)).cpu())
+    assert torch.allclose(rows[:, 0].cpu(), M.psnr_u8(a, b), rtol=1e-13, atol=0)   # exact integer error sums
+    assert torch.allclose(rows[:, 1].cpu(), M.ms_ssim_db(M.ms_ssim(a, b)).double(), atol=2e-3)
+    small = validate.validate(model, R.make_images(2, 128, 128).to(dev), msssim=False)
+    assert torch.isnan(small[:, 1]).all() and torch.isfinite(small[:, [0, 2]]).all()
+    with pytest.raises(ValueError):
+        validate.validate(model, R.make_images(1, 128, 128).to(dev))
     enc, dec = validate.speed(model, iters=2, batch=2, height=128, width=128)
     assert enc > 0 and dec > 0

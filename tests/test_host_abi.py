@@ -41,6 +41,26 @@ def test_size_queries_run_without_a_gpu():
     assert lib.mcq_packed_codebook_floats(2, 8192, 64) == (2 * 64 * 32 + 4) * 256 + 2 * 65 * 256
 
 
+def test_ms_ssim_host_side():
+    """Window taps equal the oracle's float32 window (= the reference's _fspecial_gauss_1d); shape rules."""
+    import ctypes
+    from mcquic_amd import _lib
+    from oracle import metrics_ref as M
+    lib = _lib.load()
+    buf = (ctypes.c_float * 11)()
+    lib.mcq_ms_ssim_window(buf)
+    assert list(buf) == M.gauss_window().tolist()
+    assert lib.mcq_ms_ssim_workspace_bytes(1, 3, 160, 512) == 0          # sides must exceed 160 (metrics.py:163-166)
+    assert lib.mcq_ms_ssim_workspace_bytes(1, 3, 512, 160) == 0
+    nbytes = lib.mcq_ms_ssim_workspace_bytes(2, 3, 161, 161)
+    assert nbytes > 0 and nbytes % 4 == 0
+    # pooled pyramid of a 768x512 pair: 4 levels x 2 images of floats, plus partial sums and level results
+    planes, pyr = 32 * 3, sum((768 >> l) * (512 >> l) for l in range(1, 5))
+    assert lib.mcq_ms_ssim_workspace_bytes(32, 3, 768, 512) >= 2 * planes * pyr * 4
+    assert lib.mcq_ms_ssim_u8(None, None, None, None, 1, 3, 256, 256, None) == _lib.MCQ_EINVAL
+    assert lib.mcq_sqdiff_sum_u8(None, None, None, 10, 1, None) == _lib.MCQ_EINVAL
+
+
 def test_invalid_arguments_return_einval():
     from mcquic_amd import _lib
     lib = _lib.load()

@@ -119,3 +119,33 @@ def test_training_forward_matches_repaired_reference():
         np.testing.assert_allclose(logits[lv].numpy(), z[f"logit{lv}"], rtol=1e-6, atol=1e-6)
         ema = R.freq_ema_update(sd[f"_quantizer._entropyCoder._freqEMA.{lv}"], counts[lv])
         np.testing.assert_allclose(ema.numpy(), z[f"ema{lv}"], rtol=0, atol=1e-7)
+
+
+def test_metrics_match_reference():
+    """MS-SSIM / PSNR / IdealBPP restatements (oracle/metrics_ref.py) against values from the reference's validate code."""
+    from oracle import metrics_ref as M
+    z = np.load(os.path.join(G, "f7_metrics.npz"))
+    for i, (seed, n, h, w) in enumerate(z["cases"].tolist()):
+        x, y = M.make_u8_pair(seed, n, h, w)
+        assert np.array_equal(np.concatenate([_sha(x), _sha(y)]), z[f"sha_{i}"]), "generator drifted"
+        v = M.ms_ssim(x, y)
+        np.testing.assert_allclose(v.numpy(), z[f"msssim_{i}"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(M.ms_ssim_db(v).numpy(), z[f"msssim_db_{i}"], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(M.psnr_u8(x, y).numpy(), z[f"psnr_{i}"], rtol=1e-14, atol=0)
+    ks, batches = list(M.CODE_BATCH_KS), M.make_code_batches()
+    hist = [torch.zeros(2, k) for k in ks]
+    count = [torch.zeros(2) for _ in ks]
+    for codes in batches:
+        for lv, (c, k) in enumerate(zip(codes, ks)):
+            for g in range(2):
+                hist[lv][g] += torch.bincount(c[:, g].flatten(), minlength=k)
+                count[lv][g] += c[:, g].numel()
+    got = M.ideal_bpp(hist, count, 2 * 3 * 768 * 512)
+    assert abs(got - float(z["ideal_bpp"][0])) <= 1e-6 * float(z["ideal_bpp"][0]), (got, z["ideal_bpp"])
+
+
+def test_ms_ssim_rejects_small_images():
+    from oracle import metrics_ref as M
+    x = torch.zeros(1, 3, 160, 300, dtype=torch.uint8)
+    with pytest.raises(ValueError):
+        M.ms_ssim(x, x)

@@ -37,3 +37,26 @@ def test_hip_module_tree_matches_reference_keys():
     assert list(mine.keys()) == list(ref.keys())
     for k in ref:
         assert tuple(mine[k].shape) == tuple(ref[k].shape), k
+
+
+def test_metrics_oracle_against_reference_handlers():
+    """oracle/metrics_ref.py against the reference's MsSSIM / PSNR / IdealBPP handlers, live (fresh seeds)."""
+    from oracle import metrics_ref as M
+    H = ref_harness.load_validate_handlers()
+    x, y = M.make_u8_pair(901, 2, 211, 180)
+    msssim, psnr = H["MsSSIM"](), H["PSNR"]()
+    want_db = torch.tensor(msssim.handle(images=x, restored=y))
+    assert torch.allclose(M.ms_ssim_db(M.ms_ssim(x, y)), want_db, atol=2e-3)
+    assert torch.allclose(M.psnr_u8(x, y), torch.tensor(psnr.handle(images=x, restored=y), dtype=torch.float64),
+                          rtol=1e-14, atol=0)
+    ks = list(M.CODE_BATCH_KS)
+    handler = H["IdealBPP"]([2, 2, 2], ks)
+    hist = [torch.zeros(2, k) for k in ks]
+    count = [torch.zeros(2) for _ in ks]
+    for codes in M.make_code_batches(seed=5, batches=3):
+        handler(codes=codes, images=torch.zeros(3, 3, 768, 512, dtype=torch.uint8))
+        for lv, (c, k) in enumerate(zip(codes, ks)):
+            for g in range(2):
+                hist[lv][g] += torch.bincount(c[:, g].flatten(), minlength=k)
+                count[lv][g] += c[:, g].numel()
+    assert abs(M.ideal_bpp(hist, count, 3 * 3 * 768 * 512) - handler.Result) <= 1e-6 * handler.Result

@@ -186,17 +186,33 @@ __global__ void ms_ssim_combine_kernel(const float* __restrict__ levels, int N, 
     out[n] = sum / (float)C;
 }
 
-constexpr int SQ_CHUNK = 65536;       // bytes per workgroup: 256 per thread, <= 2^24 per thread in uint32
+constexpr int SQ_CHUNK = 16384;       // bytes per workgroup (64 per thread: the uint32 partial cannot overflow)
 __global__ __launch_bounds__(256) void sqdiff_sum_u8_kernel(const uint8_t* __restrict__ x, const uint8_t* __restrict__ y,
-                                                            int64_t per_image, unsigned long long* __restrict__ out) {
+                                                            int64_t per_image, int vec4, unsigned long long* __restrict__ out) {
     const int n = blockIdx.y;
     const int64_t base = (int64_t)blockIdx.x * SQ_CHUNK;
     const uint8_t* xp = x + (size_t)n * per_image;
     const uint8_t* yp = y + (size_t)n * per_image;
+    const int64_t end = base + SQ_CHUNK < per_image ? base + SQ_CHUNK : per_image;
     unsigned acc = 0;
-    for (int64_t i = base + threadIdx.x; i < base + SQ_CHUNK && i < per_image; i += 256) {
-        const int d = (int)xp[i] - (int)yp[i];
-        acc += (unsigned)(d * d);
+    if (vec4) {                           // per_image % 16 == 0 and 16-byte aligned bases: 16 pixels per load
+        for (int64_t i = base + threadIdx.x * 16; i < end; i += 256 * 16) {
+            const uint4 a = *reinterpret_cast<const uint4*>(xp + i);
+            const uint4 b = *reinterpret_cast<const uint4*>(yp + i);
+            const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int sft = 0; sft < 32; sft += 8) {
+                    const int d = (int)((aw[k] >> sft) & 255u) - (int)((bw[k] >> sft) & 255u);
+                    acc += (unsigned)(d * d);
+                }
+        }
+    } else {
+        for (int64_t i = base + threadIdx.x; i < end; i += 256) {
+            const int d = (int)xp[i] - (int)yp[i];
+            acc += (unsigned)(d * d);
+        }
     }
     unsigned long long s = acc;
 #pragma unroll
@@ -310,6 +326,7 @@ extern "C" int mcq_sqdiff_sum_u8(const uint8_t* x, const uint8_t* y, int64_t* ou
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(out, 0, (size_t)N * sizeof(int64_t), s) != hipSuccess) return MCQ_ELAUNCH;
     const dim3 grid((unsigned)((per_image + SQ_CHUNK - 1) / SQ_CHUNK), (unsigned)N);
-    hipLaunchKernelGGL(sqdiff_sum_u8_kernel, grid, dim3(256), 0, s, x, y, per_image, (unsigned long long*)out);
+    const int vec4 = per_image % 16 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
+    hipLaunchKernelGGL(sqdiff_sum_u8_kernel, grid, dim3(256), 0, s, x, y, per_image, vec4, (unsigned long long*)out);
     return mcq_check_launch();
 }

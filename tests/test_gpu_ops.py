@@ -172,7 +172,9 @@ def _audit_codes(got, x, cb, eps, what):
 
 
 @pytest.mark.parametrize("shape", [(2, 8192, 64, 2, 12, 16), (2, 2048, 64, 2, 6, 8), (2, 512, 64, 3, 3, 5),
-                                   (4, 4096, 256, 1, 8, 8), (2, 32, 4, 2, 8, 8), (2, 200, 64, 1, 5, 7)])
+                                   (4, 4096, 256, 1, 8, 8), (2, 32, 4, 2, 8, 8), (2, 200, 64, 1, 5, 7),
+                                   (1, 4096, 8, 2, 16, 16),      # ResidualBackwardQuantizer geometry (quantizer.py:584-592)
+                                   (2, 64, 5, 1, 4, 4)])         # odd vector length
 def test_vq_assign(dev, shape):
     from mcquic_amd import ops
     m, k, d, n, h, w = shape

@@ -15,6 +15,8 @@
 // per k-step it issues one weight load (MB floats per lane) and NB activation loads (buffer
 // loads; out-of-image taps are turned into out-of-range offsets, for which the hardware returns
 // 0 = the conv's zero padding), PF steps ahead of the MFMAs that consume them.
+#include <type_traits>
+
 #include "mcq_common.h"
 #include "../../include/mcquic_hip.h"
 
@@ -50,6 +52,7 @@ struct ConvK {
 };
 
 constexpr int PRO_NONE = 0, PRO_SILU = 1, PRO_SQUARE = 2;
+constexpr unsigned RUNTIME_FLAGS = 0xffffffffu;    // epilogue instance that tests the flags at run time
 
 template <int MB> struct AVec;
 template <> struct AVec<4> { typedef f32x4v T; };
@@ -190,110 +193,130 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
-    // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row tile, the 16 output
-    // channels row(r) = (r & 3) + 8 (r >> 2) + 4 hi.  Side inputs are fetched 16 at a time so
-    // their latencies overlap.
+    // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row tile, the 16 output channels
+    // row(r) + 4 hi, row(r) = (r & 3) + 8 (r >> 2).  Element (co, pixel) of image n sits at byte (co HoWo + pixel) 4 of
+    // that image's [Cout, Ho, Wo] slab, for the output and for every side input (all have the output's shape).  All
+    // epilogue traffic goes through buffer instructions on a per-image descriptor: the per-lane part (pixel, the 4 hi
+    // rows) is the voffset, the row of register r the wave-uniform soffset.  Rows >= Cout land beyond num_records and
+    // lanes without a pixel carry the out-of-range marker, so loads return 0 and stores are dropped by the hardware:
+    // no predication, no branches, and hipcc is free to overlap the side loads of one tile with the math of another.
     const unsigned fl = p.flags;
-    const size_t HoWo = (size_t)p.Ho * p.Wo;
+    const unsigned HoWo = (unsigned)(p.Ho * p.Wo);
+    const unsigned slab_bytes = (unsigned)p.Cout * HoWo * 4u;
 
-    auto finish = [&](int mb, int nb, float (&v)[16], const float (&bias16)[16], const bool (&cok)[16]) {
-        const int co0 = co_base + mb * 32 + 4 * hi;      // channel of register 0
-        const bool vld = valid[nb];
+    auto epilogue = [&](auto tag, const bool tile_active, auto&& get_acc, const int mb_first, auto count_tag) {
+        constexpr unsigned EF = decltype(tag)::value;                 // compile-time flag set, or RUNTIME_FLAGS
+        constexpr int MC = decltype(count_tag)::value;                // 32-row bands this wave finishes
+        const unsigned f = EF == RUNTIME_FLAGS ? fl : EF;
+        if (!tile_active) return;
+        unsigned pvo[NB];
+        __amdgpu_buffer_rsrc_t yr[NB], y2r[NB], rr_[NB], mr[NB], gr[NB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = v[r] + bias16[r];
+        for (int nb = 0; nb < NB; ++nb) {
+            const size_t slab = (size_t)img[nb] * p.Cout * HoWo;
+            yr[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.y + slab), slab_bytes);
+            if (f & MCQ_CONV_DUAL_SILU) y2r[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.y2 + slab), slab_bytes);
+            if (f & MCQ_CONV_RESIDUAL) rr_[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.res + slab), slab_bytes);
+            if (f & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL))
+                mr[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.mul + slab), slab_bytes);
+            if (f & MCQ_CONV_GATE) gr[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.gid + slab), slab_bytes);
+            if (f & MCQ_CONV_SHUFFLE2)      // [Cout/4, 2 Ho, 2 Wo]: channel c = co / 4 -> rows of 2 Wo, this lane's 2x2 cell
+                pvo[nb] = valid[nb] ? ((unsigned)hi * 4u * HoWo + (unsigned)(2 * yo[nb]) * (unsigned)(2 * p.Wo) + (unsigned)(2 * xo[nb])) * 4u
+                                    : MCQ_OOB;
+            else
+                pvo[nb] = valid[nb] ? ((unsigned)(yo[nb] * p.Wo + xo[nb]) + 4u * (unsigned)hi * HoWo) * 4u : MCQ_OOB;
+        }
+        const __amdgpu_buffer_rsrc_t br = mcq_make_rsrc(mcq_uniform_ptr(p.bias ? p.bias : p.wp), p.bias ? (unsigned)p.Cout * 4u : 0u);
 
-        if (fl & MCQ_CONV_SHUFFLE2) {
-            // registers 4q..4q+3 are the 2x2 sub-pixels of output channel co/4: two float2 rows.
-            const int Co4 = p.Cout >> 2;
-            const size_t W2 = 2 * (size_t)p.Wo;
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                if (vld && cok[rq * 4]) {
-                    const int c = (co0 + 8 * rq) >> 2;
-                    float* o = p.y + (((size_t)img[nb] * Co4 + c) * (2 * (size_t)p.Ho) + 2 * (size_t)yo[nb]) * W2 +
-                               2 * (size_t)xo[nb];
-                    *reinterpret_cast<f32x2v*>(o) = f32x2v{v[rq * 4 + 0], v[rq * 4 + 1]};
-                    *reinterpret_cast<f32x2v*>(o + W2) = f32x2v{v[rq * 4 + 2], v[rq * 4 + 3]};
-                }
-            }
-            return;
-        }
-        const size_t idx0 = ((size_t)img[nb] * p.Cout + co0) * HoWo + (size_t)yo[nb] * p.Wo + xo[nb];
-        bool ok[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ok[r] = vld && cok[r];
-        if (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL)) {
-            float m[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m[r] = ok[r] ? p.mul[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
-            if (fl & MCQ_CONV_GDN) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = m[r] * (1.0f / sqrtf(v[r]));
-            } else if (fl & MCQ_CONV_IGDN) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = m[r] * sqrtf(v[r]);
-            } else if (fl & MCQ_CONV_MUL) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = m[r] * v[r];
-            } else {
-                float gi[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gi[r] = ok[r] ? p.gid[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = m[r] * mcq_sigmoid(v[r]) + gi[r];
-            }
-        }
-        if (fl & MCQ_CONV_RESIDUAL) {
-            float rr[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rr[r] = ok[r] ? p.res[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] + p.res_scale * rr[r];
-        }
-        if (fl & MCQ_CONV_SILU_OUT) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (ok[r]) p.y[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
-        if (fl & MCQ_CONV_DUAL_SILU) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (ok[r]) p.y2[idx0 + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = v[r];
-        }
-    };
-
-    auto load_bias = [&](int mb, float (&bias16)[16], bool (&cok)[16]) {
-        const int co0 = co_base + mb * 32 + 4 * hi;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            cok[r] = co0 + (r & 3) + 8 * (r >> 2) < p.Cout;
-            bias16[r] = 0.0f;
-        }
-        if (p.bias) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (cok[r]) bias16[r] = p.bias[co0 + (r & 3) + 8 * (r >> 2)];
-        }
-    };
-
-    if (KS == 1) {
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
+        for (int mi = 0; mi < MC; ++mi) {
+            const int mb = mb_first + mi;
+            const unsigned co_row0 = (unsigned)(co_base + mb * 32);   // wave-uniform
             float bias16[16];
-            bool cok[16];
-            load_bias(mb, bias16, cok);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bias16[r] = mcq_buffer_load_s(br, (unsigned)hi * 16u, (co_row0 + (unsigned)mcq_drow(r, 0)) * 4u);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 float v[16];
+                get_acc(mi, nb, v);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = acc[mb][nb][r];
-                finish(mb, nb, v, bias16, cok);
+                for (int r = 0; r < 16; ++r) v[r] = v[r] + bias16[r];
+                if (f & MCQ_CONV_SHUFFLE2) {
+                    // registers 4q..4q+3 are the 2x2 sub-pixels of output channel co / 4: two float2 rows
+                    const unsigned W2b = 2u * (unsigned)p.Wo * 4u;
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const unsigned so = ((co_row0 >> 2) + 2u * (unsigned)rq) * HoWo * 16u;
+                        mcq_buffer_store2_s(f32x2v{v[rq * 4 + 0], v[rq * 4 + 1]}, yr[nb], pvo[nb], so);
+                        mcq_buffer_store2_s(f32x2v{v[rq * 4 + 2], v[rq * 4 + 3]}, yr[nb], pvo[nb], so + W2b);
+                    }
+                    continue;
+                }
+                unsigned so[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) so[r] = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
+                if (f & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL)) {
+                    float m[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[r] = mcq_buffer_load_s(mr[nb], pvo[nb], so[r]);
+                    if (f & MCQ_CONV_GDN) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = m[r] * (1.0f / sqrtf(v[r]));
+                    } else if (f & MCQ_CONV_IGDN) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = m[r] * sqrtf(v[r]);
+                    } else if (f & MCQ_CONV_MUL) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = m[r] * v[r];
+                    } else {
+                        float gi[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) gi[r] = mcq_buffer_load_s(gr[nb], pvo[nb], so[r]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = m[r] * mcq_sigmoid(v[r]) + gi[r];
+                    }
+                }
+                if (f & MCQ_CONV_RESIDUAL) {
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = mcq_buffer_load_s(rr_[nb], pvo[nb], so[r]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = v[r] + p.res_scale * rv[r];
+                }
+                if (f & MCQ_CONV_SILU_OUT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = mcq_silu(v[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mcq_buffer_store_s(v[r], yr[nb], pvo[nb], so[r]);
+                if (f & MCQ_CONV_DUAL_SILU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mcq_buffer_store_s(mcq_silu(v[r]), y2r[nb], pvo[nb], so[r]);
+                }
             }
         }
+    };
+    // the flag sets the network issues most get their own branch-free instance; anything else takes the generic one
+    auto run_epilogue = [&](const bool tile_active, auto&& get_acc, const int mb_first, auto mb_count) {
+        const unsigned ef = fl & ~(unsigned)(MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN);
+        if (ef == (MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU))
+            epilogue(std::integral_constant<unsigned, MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU>{}, tile_active, get_acc, mb_first, mb_count);
+        else if (ef == MCQ_CONV_SILU_OUT)
+            epilogue(std::integral_constant<unsigned, MCQ_CONV_SILU_OUT>{}, tile_active, get_acc, mb_first, mb_count);
+        else if (ef == 0u)
+            epilogue(std::integral_constant<unsigned, 0u>{}, tile_active, get_acc, mb_first, mb_count);
+        else if (ef == MCQ_CONV_RESIDUAL)
+            epilogue(std::integral_constant<unsigned, MCQ_CONV_RESIDUAL>{}, tile_active, get_acc, mb_first, mb_count);
+        else
+            epilogue(std::integral_constant<unsigned, RUNTIME_FLAGS>{}, tile_active, get_acc, mb_first, mb_count);
+    };
+
+    if (KS == 1) {
+        run_epilogue(true, [&](int mi, int nb, float (&v)[16]) {           // (mi, nb are constants once unrolled)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[mi][nb][r];
+        }, 0, std::integral_constant<int, MB>{});
         return;
     }
 
@@ -328,13 +351,10 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
         }
         __syncthreads();
     }
-    if (active && kslice < MB) {
-        float bias16[16];
-        bool cok[16];
-        load_bias(kslice, bias16, cok);
+    run_epilogue(active && kslice < MB, [&](int, int nb, float (&v)[16]) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) finish(kslice, nb, own[nb], bias16, cok);
-    }
+        for (int r = 0; r < 16; ++r) v[r] = own[nb][r];
+    }, kslice, std::integral_constant<int, 1>{});
 }
 
 // OIHW -> [Cout/128][TP][64 lanes][4]: lane l, slot q holds W[co = 128 T + 32 q + (l & 31)][ci = 2 s + (l >> 5)][tap]
@@ -496,6 +516,9 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     const int pro = (fl & MCQ_CONV_SILU_IN) ? PRO_SILU : (fl & MCQ_CONV_SQUARE_IN) ? PRO_SQUARE : PRO_NONE;
     const long long ptiles = (tb + NB - 1) / NB;
     const int co_tiles = (co32 + MB - 1) / MB;
+    // the epilogue addresses one image of the output (and of every side input) through a 32-bit buffer offset,
+    // rows of the last cout tile included
+    if ((uint64_t)co_tiles * 32u * (unsigned)MB * (uint64_t)k.Ho * k.Wo * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
     hipStream_t s = (hipStream_t)stream;
     if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42A, MCQ_PF42B, 4>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);

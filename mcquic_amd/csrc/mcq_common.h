@@ -70,6 +70,19 @@ __device__ __forceinline__ float mcq_buffer_load(__amdgpu_buffer_rsrc_t r, uint3
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
 }
 
+// Buffer accesses with a wave-uniform byte offset in soffset next to the per-lane voffset (the hardware range-checks
+// their sum against num_records: out-of-range loads return 0, out-of-range stores are dropped).
+__device__ __forceinline__ float mcq_buffer_load_s(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void mcq_buffer_store_s(float v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, (int)voff, (int)soff, 0);
+}
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mcq_buffer_store2_s(f32x2v v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), r, (int)voff, (int)soff, 0);
+}
+
 // Uniform (SGPR) 64-bit pointer from a possibly lane-tainted one.
 template <typename T>
 __device__ __forceinline__ T* mcq_uniform_ptr(T* p) {

@@ -60,6 +60,51 @@ def test_conv_plain(dev, case, tile):
     _close(got, want, 2e-6, f"conv{case} tile={tile:#x}")
 
 
+@pytest.mark.parametrize("case", [(2, 32, 40, 9, 11, 1, 1), (1, 128, 128, 12, 8, 3, 1), (2, 16, 70, 10, 14, 3, 2)])
+def test_conv_without_bias_and_ragged_cout(dev, case):
+    """bias=None (conv1x1(..., bias=False), quantizer.py:606) and Cout that is not a multiple of the 32-row tile: the
+    rows past Cout and the missing bias are handled by out-of-range buffer accesses, not by predication."""
+    from mcquic_amd import ops
+    n, cin, cout, h, w, ks, stride = case
+    x = _rand((n, cin, h, w), 5)
+    wt = _rand((cout, cin, ks, ks), 6, 1.0 / np.sqrt(cin * ks * ks))
+    res = _rand((n, cout, (h + stride - 1) // stride, (w + stride - 1) // stride), 7)
+    want = F.conv2d(x, wt, None, stride=stride, padding=ks // 2)
+    pk = ops.PackedConv(wt.to(dev), None)
+    for tile in (0, 0x42, 0x11, 0x322):
+        if ((tile >> 4) & 15) * 32 > ((cout + 31) // 32) * 32:
+            continue
+        _close(ops.conv2d(x.to(dev), pk, stride, tile=tile), want, 2e-6, f"nobias{case} tile={tile:#x}")
+        got = ops.conv2d(x.to(dev), pk, stride, tile=tile, res=res.to(dev), dual_silu=True)
+        _close(got, want + res, 2e-6, f"nobias+res{case} tile={tile:#x}")
+        _close(ops.silu_twin(got), F.silu(want + res), 2e-6, f"nobias+twin{case} tile={tile:#x}")
+
+
+def test_conv_never_writes_outside_its_output(dev):
+    """Raw C-ABI call with the output placed inside a guard band: rows of the last cout tile past Cout, pixels past the
+    image and the second image's slab are all addressed through range-checked buffer stores."""
+    import ctypes
+    from mcquic_amd import _lib, ops
+    n, cin, cout, h, w = 2, 16, 70, 9, 13
+    x = _rand((n, cin, h, w), 8).to(dev)
+    wt = _rand((cout, cin, 3, 3), 9, 0.1)
+    pk = ops.PackedConv(wt.to(dev), None)
+    want = F.conv2d(x.cpu(), wt, None, padding=1)
+    guard, numel = 1 << 16, n * cout * h * w
+    for tile in (0, 0x42, 0x41, 0x11, 0x242):
+        buf = torch.full((guard + numel + guard,), 7.5, device=dev)
+        twin = torch.full((guard + numel + guard,), -3.25, device=dev)
+        y, y2 = buf[guard:guard + numel], twin[guard:guard + numel]
+        d = _lib.ConvDesc(x.data_ptr(), pk.wp.data_ptr(), None, y.data_ptr(), y2.data_ptr(), None, None, None,
+                          n, cin, h, w, cout, 3, 1, ops.CONV_DUAL_SILU, 1.0, tile)
+        assert _lib.load().mcq_conv2d_f32(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        torch.cuda.synchronize()
+        _close(y.view(n, cout, h, w), want, 2e-6, f"guarded conv tile={tile:#x}")
+        _close(y2.view(n, cout, h, w), F.silu(want), 2e-6, f"guarded twin tile={tile:#x}")
+        for t, fill in ((buf, 7.5), (twin, -3.25)):
+            assert bool((t[:guard] == fill).all()) and bool((t[guard + numel:] == fill).all()), f"tile={tile:#x}: guard band written"
+
+
 def test_conv_identity_weight_asymmetric(dev):
     """A = I with an asymmetric B catches row/col swaps of the MFMA fragment maps."""
     from mcquic_amd import ops

@@ -21,8 +21,12 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
     constexpr int MB = VQ_MB, NB = VQ_NB, PF = VQ_PF;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int gw = blockIdx.x * 4 + wave;
-    if (gw * NB >= p.total_blocks) return;
+    // 4 waves per workgroup = (4 >> cs_log2) vector tiles x (1 << cs_log2) slices of the codeword tiles
+    const int CS = 1 << p.cs_log2;
+    const int slice = wave & (CS - 1);
+    const int gw = blockIdx.x * (4 >> p.cs_log2) + (wave >> p.cs_log2);
+    const bool active = gw * NB < p.total_blocks;            // wave-uniform
+    if (CS == 1 && !active) return;                          // (sliced waves stay for the barrier)
     const int g = blockIdx.y;
     const int hi = lane >> 5, j = lane & 31;
     const int BW = 1 << p.bw_log2;
@@ -70,8 +74,11 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
 
     f32x4v A[PF];
     float B[PF][NB];
-    const float* wl = p.cbp + ((size_t)g * p.ntile * p.Sp * 64 + lane) * 4;
-    const f32x4v* c2l = reinterpret_cast<const f32x4v*>(p.c2p) + (size_t)g * (p.ntile + 1) * 64 + lane;
+    const int per_slice = (p.ntile + CS - 1) >> p.cs_log2;
+    const int tile0 = slice * per_slice;                     // this wave's codeword tiles: [tile0, tile1)
+    const int tile1 = active ? (tile0 + per_slice < p.ntile ? tile0 + per_slice : p.ntile) : tile0;
+    const float* wl = p.cbp + (((size_t)g * p.ntile + tile0) * p.Sp * 64 + lane) * 4;
+    const f32x4v* c2l = reinterpret_cast<const f32x4v*>(p.c2p) + ((size_t)g * (p.ntile + 1) + tile0) * 64 + lane;
     int ls = 0;
     unsigned soffL = 0;
     const unsigned step_bytes = 2u * (unsigned)HW * 4u;
@@ -95,12 +102,15 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
     for (int nb = 0; nb < NB; ++nb) { best[nb] = INFINITY; bidx[nb] = 0; }
     const float bone = hi == 0 ? 1.0f : 0.0f;
 
+    f32x4v c2a = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+    if (tile0 < tile1) {
 #pragma unroll
-    for (int st = 0; st < PF; ++st) issue(st);
-    f32x4v c2a = c2l[0];
+        for (int st = 0; st < PF; ++st) issue(st);
+        c2a = c2l[0];
+    }
 
-    for (int tile = 0; tile < p.ntile; ++tile) {
-        const f32x4v c2n = c2l[(size_t)(tile + 1) * 64];   // next tile's norms (one spare tile is allocated)
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const f32x4v c2n = c2l[(size_t)(tile - tile0 + 1) * 64];   // next tile's norms (one spare tile is allocated)
         f32x16 acc[MB][NB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
@@ -147,9 +157,32 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
         const float ob = __shfl_xor(best[nb], 32);
         const int oi = __shfl_xor(bidx[nb], 32);
         if (ob < best[nb] || (ob == best[nb] && oi < bidx[nb])) { best[nb] = ob; bidx[nb] = oi; }
+    }
+    if (CS > 1) {
+        // slices meet in LDS; slice 0 folds the others in slice order -- a later slice holds larger codeword indices,
+        // so it only wins with a strictly smaller distance (first index on ties, like torch.argmin)
+        __shared__ float s_best[4][NB][64];
+        __shared__ int s_idx[4][NB][64];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            s_best[wave][nb][lane] = best[nb];
+            s_idx[wave][nb][lane] = bidx[nb];
+        }
+        __syncthreads();
+        if (slice != 0 || !active) return;
+        for (int s = 1; s < CS; ++s) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float ob = s_best[wave + s][nb][lane];
+                const int oi = s_idx[wave + s][nb][lane];
+                if (ob < best[nb]) { best[nb] = ob; bidx[nb] = oi; }
+            }
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
         if (hi == 0 && valid[nb])
             p.codes[(((size_t)img[nb] * p.m + g) * p.h + yo[nb]) * p.w + xo[nb]] = (int64_t)bidx[nb];
-    }
 }
 
 // codebook [m, k, d] -> cbp [m][ntile][Sp][64][4] (+ zero tail) and c2p [m][ntile + 1][64][4]
@@ -289,7 +322,21 @@ extern "C" int mcq_vq_assign_f32(const float* x, const float* cb_packed, int64_t
     const long long tb = (long long)N * p.nbx * p.nby;
     if (tb > 0x7fffffffLL) return MCQ_ETOOLARGE;
     p.total_blocks = (int)tb;
-    const unsigned gx = (unsigned)(((tb + VQ_NB - 1) / VQ_NB + 3) / 4);
+    // Every wave walks all codeword tiles of its 64 vectors, so the launch has (vector tiles x m) waves whatever k is:
+    // too few for the 2048 wave slots (2 per SIMD) on the small levels, and 1.5 rounds for config #4.  Splitting the
+    // codeword tiles over 2 or 4 waves of a workgroup multiplies the waves and divides their length; pick the split
+    // with the fewest whole rounds of work.
+    const long long vtiles = (tb + VQ_NB - 1) / VQ_NB;
+    int cs_log2 = 0;
+    double best_cost = 1e30;
+    for (int lg = 0; lg <= 2 && (1 << lg) <= p.ntile; ++lg) {
+        const long long waves = vtiles * m << lg;
+        const double cost = (double)((waves + 2047) / 2048) / (double)(1 << lg);
+        if (cost < best_cost - 1e-12) { best_cost = cost; cs_log2 = lg; }
+    }
+    p.cs_log2 = cs_log2;
+    const int per_wg = 4 >> cs_log2;
+    const unsigned gx = (unsigned)((vtiles + per_wg - 1) / per_wg);
     hipLaunchKernelGGL(vq_assign_kernel, dim3(gx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, p);
     return mcq_check_launch();
 }

@@ -4,7 +4,10 @@
 
 namespace {
 
-constexpr int VQ_MB = 4, VQ_NB = 2, VQ_PF = 4;
+#ifndef MCQ_VQ_PF
+#define MCQ_VQ_PF 8
+#endif
+constexpr int VQ_MB = 4, VQ_NB = 2, VQ_PF = MCQ_VQ_PF;     // wave tile 128 codewords x 64 vectors; prefetch ring depth in k-steps
 
 struct VqK {
     const float* x; const float* cbp; const float* c2p; int64_t* codes;
@@ -12,6 +15,7 @@ struct VqK {
     int Sp;            // k-steps (channel pairs) per tile, padded to a multiple of VQ_PF
     int ntile;         // 128-codeword tiles
     int bw_log2, nbx, nby, total_blocks;
+    int cs_log2;       // vq_assign: 1 << cs_log2 waves of a workgroup share one vector tile, each a slice of the codeword tiles
 };
 
 inline void block_shape(int Ho, int Wo, int& lg_out) {

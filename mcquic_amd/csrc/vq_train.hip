@@ -127,6 +127,9 @@ __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
                     for (int wb = 0; wb < NW; ++wb)      // A operand = latent vectors (rows), B operand = codewords (cols)
                         acc[nb][wb] = __builtin_amdgcn_mfma_f32_32x32x2f32(B[st][nb], A[st][wb], acc[nb][wb], 0, 0, 0);
                 issue(st);
+                // keep the software pipeline as written (without the fence hipcc regroups the loads of the body and
+                // waits for nearly all of them at the loop head: the ring then hides one step instead of PF)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 

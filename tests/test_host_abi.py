@@ -38,7 +38,7 @@ def test_size_queries_run_without_a_gpu():
     assert lib.mcq_packed_conv_weight_floats(128, 3, 3) == (18 + 16) * 256      # 2 channel pairs x 9 taps
     assert lib.mcq_packed_conv_weight_floats(128, 8, 1) == (16 + 16) * 256      # 1x1: 4 pairs padded to one 16-deep ring
     assert lib.mcq_packed_conv_weight_floats(128, 128, 5) == 0                   # unsupported kernel size
-    assert lib.mcq_packed_codebook_floats(2, 8192, 64) == (2 * 64 * 32 + 4) * 256 + 2 * 65 * 256
+    assert lib.mcq_packed_codebook_floats(2, 8192, 64) == (2 * 64 * 32 + 8) * 256 + 2 * 65 * 256      # + the 8-step ring tail
 
 
 def test_ms_ssim_host_side():

@@ -24,7 +24,10 @@ import os
 import sys
 import time
 
-import torch
+# hardware queues for the branch streams next to RCCL's own streams (see mcquic_amd/__init__.py); must precede HIP init
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -230,7 +233,7 @@ def main():
                 "achieved": round(achieved_tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / FP32_MATRIX_PEAK_TFLOPS, 4),
                 "traffic": (lambda t: None if t is None else round(t["fetch_bytes_per_launch_x2_corrected"] + t["write_size_bytes_per_launch"]))(pmc_traffic()),
-                "traffic_unit": "HBM-side bytes per launch of conv_mfma_kernel<4,2,0,9,9> (PMC FETCH_SIZE x2-corrected + WRITE_SIZE, profiles/r01_pmc.json)",
+                "traffic_unit": "HBM-side bytes per launch of conv_mfma_kernel<4,2,0,...> (PMC FETCH_SIZE x2-corrected + WRITE_SIZE, profiles/r01_pmc.json)",
                 "algorithmic_bytes_per_launch": round(conv["bytes"] / max(conv["launches"], 1)),
                 "launches_per_step": conv["launches"] // max(args.steps, 1),
                 "avg_launch_ms": round(conv["sum_ms"] / max(conv["launches"], 1), 4),
@@ -247,10 +250,12 @@ def main():
             gpu_pix = model.decode([c.to(dev) for c in cpu_codes])
             out["cpu_baseline"] = base
             out["parity"] = parity_report([c[:nb] for c in codes], gpu_pix, cpu_codes, cpu_pix)
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)          # the ONE line, after anything RCCL prints on the way out
 
 
 if __name__ == "__main__":

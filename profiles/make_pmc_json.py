@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""profiles/pmc_stats.py writes /tmp/pmc_rows.json (per kernel x launch grid averages of the --pmc passes); this turns
+it into the summary bench.py reads for `roofline.traffic` (profiles/rNN_pmc.json).
+usage: python profiles/make_pmc_json.py gpurun_out/final/pmc_rows.json > profiles/r01_pmc.json"""
+import json
+import sys
+
+rows = json.load(open(sys.argv[1]))
+dom = max((r for r in rows if "conv_mfma" in r["kernel"]), key=lambda r: r["_dur_ns"] * r["launches"])["kernel"]
+sel = [r for r in rows if r["kernel"] == dom]
+n = sum(r["launches"] for r in sel)
+fetch = sum(r["FETCH_SIZE"] * 1024 * r["launches"] for r in sel) / n
+write = sum(r["WRITE_SIZE"] * 1024 * r["launches"] for r in sel) / n
+big = next(r for r in sel if r["wgs"] == 3072 and r["gy"] == 1)          # the 192x128 level, 128 -> 128 channels
+large = [r for r in sel if r["wgs"] >= 3072]
+busy = sum(r["SQ_VALU_MFMA_BUSY_CYCLES"] * r["launches"] for r in large)
+gui = sum(r["GRBM_GUI_ACTIVE"] * r["launches"] for r in large)
+dur = sum(r["_dur_ns"] * r["launches"] for r in large)
+out = {
+    "source": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE} --kernel-trace -- "
+              "python bench.py --steps 1 --warmup 1 --no-cpu-baseline (three separate passes, single stream; "
+              "tools/collect_profiles.sh, profiles/pmc_stats.py, profiles/make_pmc_json.py)",
+    "kernel": dom + " (128 co x 64 px wave tile, 3x3, no prologue)",
+    "units": "bytes per launch, averaged over the launches of the kernel in the run; FETCH_SIZE/WRITE_SIZE are KiB "
+             "counters; on gfx950 FETCH_SIZE tallies 64 B per 128-B request for wide coalesced reads "
+             "(MI355X_MICROARCH.md, HBM section), hence the x2-corrected figure; our reads are 4-byte-per-lane buffer "
+             "loads, for which the correction is uncalibrated",
+    "launches_summed_over_the_passes": n,
+    "fetch_size_bytes_per_launch": fetch,
+    "write_size_bytes_per_launch": write,
+    "fetch_bytes_per_launch_x2_corrected": 2 * fetch,
+    "fetch_size_bytes_192x128_layer": big["FETCH_SIZE"] * 1024,
+    "fetch_bytes_192x128_layer_x2_corrected": 2 * big["FETCH_SIZE"] * 1024,
+    "write_size_bytes_192x128_layer": big["WRITE_SIZE"] * 1024,
+    "avg_us_192x128_layer": big["_dur_ns"] / 1e3,
+    # SQ_VALU_MFMA_BUSY_CYCLES sums over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+    "mfma_pipe_utilisation_large_layers": busy / (gui / 8 * 1024),
+    "effective_clock_ghz_large_layers": (gui / 8) / dur,
+    "algorithmic_bytes_192x128_layer": {"input": 402653184, "output": 402653184,
+                                         "note": "+ one more output-sized read (residual) and write (SiLU twin) on the closing conv of a block"},
+}
+json.dump(out, sys.stdout, indent=1)

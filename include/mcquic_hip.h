@@ -150,13 +150,19 @@ int mcq_vq_soft_bwd_f32(const float* ddist, const float* rowsum, const float* x,
 
 /* out[n][p][c] = x[n][c][p] (squared if `square`): channel-major copies feeding the weight-gradient GEMM. */
 int mcq_nchw_to_nhwc_f32(const float* x, float* out, int32_t N, int32_t C, int32_t HW, int32_t square, void* stream);
+/* The same for the two operands of one weight-gradient GEMM (x [N,Cx,HWx], squared if `square_x`, and y [N,Cy,HWy]) in
+ * a single launch. */
+int mcq_nchw_to_nhwc_pair_f32(const float* x, float* x_out, int32_t Cx, int32_t HWx, int32_t square_x, const float* y,
+                              float* y_out, int32_t Cy, int32_t HWy, int32_t N, void* stream);
 
 /* dW[co][ci][ky][kx] = sum_{n,yo,xo} dY[n][co][yo][xo] * X[n][ci][yo*stride + ky - k/2][xo*stride + kx - k/2]
- * from NHWC copies of X [N,H,W,Cin] and dY [N,Ho,Wo,Cout]; `workspace` holds the per-range partial sums. */
+ * from NHWC copies of X [N,H,W,Cin] and dY [N,Ho,Wo,Cout]; `workspace` holds the per-range partial sums.  If `dbias` is
+ * not NULL it also receives db[co] = sum_{n,yo,xo} dY[n][co][yo][xo] (the bias gradient of the same conv, summed by the
+ * waves that stream dY anyway). */
 size_t mcq_conv2d_wgrad_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize,
                                          int32_t stride);
-int mcq_conv2d_wgrad_f32(const float* x_nhwc, const float* dy_nhwc, float* dw, float* workspace, int32_t N, int32_t Cin,
-                         int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, void* stream);
+int mcq_conv2d_wgrad_f32(const float* x_nhwc, const float* dy_nhwc, float* dw, float* dbias, float* workspace, int32_t N,
+                         int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, void* stream);
 
 /* out[c] = sum_{n,p} x[n][c][p]   (bias / beta gradients); optional workspace of min(N, 16) * C floats. */
 int mcq_channel_sum_f32(const float* x, float* out, float* workspace, int32_t N, int32_t C, int32_t HW, void* stream);

@@ -53,8 +53,10 @@ SYMBOLS = {
     "mcq_vq_soft_bwd_f32": (c_int32, [c_void_p] * 10 + [c_int32] * 6 + [c_void_p]),
     "mcq_nchw_to_nhwc_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_conv2d_wgrad_workspace_floats": (c_size_t, [c_int32] * 7),
-    "mcq_conv2d_wgrad_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                       c_int32, c_int32, c_void_p]),
+    "mcq_conv2d_wgrad_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                       c_int32, c_int32, c_int32, c_void_p]),
+    "mcq_nchw_to_nhwc_pair_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32,
+                                            c_int32, c_void_p]),
     "mcq_channel_sum_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_silu_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_gate_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

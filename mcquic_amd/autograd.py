@@ -76,9 +76,13 @@ class ConvFn(torch.autograd.Function):
                 dx = ops.conv2d(dyc, wt, shuffle2=True)
                 if dx.shape[-2] != x.shape[-2] or dx.shape[-1] != x.shape[-1]:
                     dx = dx[..., :x.shape[-2], :x.shape[-1]].contiguous()
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = ops.conv2d_wgrad(x, dyc, conv.kernelSize, conv.stride)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_db:
+                dw, db = ops.conv2d_wgrad(x, dyc, conv.kernelSize, conv.stride, want_bias=True)   # one kernel for both
+            else:
+                dw = ops.conv2d_wgrad(x, dyc, conv.kernelSize, conv.stride)
+        elif want_db:
             db = ops.channel_sum(dyc)
         return dx, dw, db, (dy if ctx.has_res else None), None, None
 
@@ -161,8 +165,8 @@ class GdnFn(torch.autograd.Function):
         dxd, ds = ops.gdn_bwd_prep(x, s, dy, ctx.inverse)
         back = ops.PackedConv((2.0 * gamma.detach().t().contiguous())[..., None, None], None)
         dx = ops.conv2d(ds, back, mul=x, res=dxd)                              # dy f(s) + 2 x (gamma^T ds)
-        dbeta = ops.channel_sum(ds)
-        dgamma = ops.conv2d_wgrad(x, ds, 1, 1, square_x=True)[:, :, 0, 0]
+        dgamma, dbeta = ops.conv2d_wgrad(x, ds, 1, 1, square_x=True, want_bias=True)
+        dgamma = dgamma[:, :, 0, 0]
         return dx, dbeta, dgamma, None
 
 

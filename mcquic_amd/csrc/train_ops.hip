@@ -39,9 +39,37 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
+// the two operands of one weight-gradient GEMM in a single launch: blockIdx.z < N transposes x, >= N transposes dy
+__global__ void nchw_to_nhwc_pair_kernel(const float* __restrict__ x, float* __restrict__ xo, int Cx, int HWx, int square,
+                                         const float* __restrict__ y, float* __restrict__ yo, int Cy, int HWy, int N) {
+    __shared__ float tile[32][33];
+    const bool second = (int)blockIdx.z >= N;
+    const int n = second ? blockIdx.z - N : blockIdx.z;
+    const int C = second ? Cy : Cx, HW = second ? HWy : HWx;
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    if (c0 >= C || p0 >= HW) return;                              // the grid covers the larger of the two shapes
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* xi = (second ? y : x) + (size_t)n * C * HW;
+    float* oi = (second ? yo : xo) + (size_t)n * C * HW;
+    const bool sq = !second && square;
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int c = c0 + ty + r, p = p0 + tx;
+        float v = (c < C && p < HW) ? xi[(size_t)c * HW + p] : 0.0f;
+        if (sq) v = v * v;
+        tile[ty + r][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int p = p0 + ty + r, c = c0 + tx;
+        if (c < C && p < HW) oi[(size_t)p * C + c] = tile[tx][ty + r];
+    }
+}
+
 // ---- weight gradient -------------------------------------------------------------------------------------------
 struct WgradK {
-    const float* xt; const float* dyt; float* part;
+    const float* xt; const float* dyt; float* part; float* bias_part;
     int N, Cin, H, W, Cout, Ho, Wo, ks, stride;
     int splits;          // number of pixel ranges
     int chunk;           // output pixels per range (even)
@@ -49,9 +77,15 @@ struct WgradK {
     long long P;         // N * Ho * Wo
 };
 
-constexpr int WG_MB = 4, WG_NB = 2, WG_PF = 4;
+constexpr int WG_MB = 4, WG_NB = 2, WG_PF = 8;
 
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
+// dW partials of one (pixel range, tap, 64-ci tile, 128-co tile) per wave: D[co][ci] += dy^T[p][co] * x^T[p + tap][ci],
+// two output pixels per k-step (lane half hi takes pixel 2t + hi).  Both operands are NHWC copies, so a lane's 32
+// channels are one 128-byte line.  Addressing is branch-free: the dy offset is linear in the pixel index and ends at the
+// per-wave num_records (range end), channel / image-border predicates become the out-of-range marker, and the
+// (n, y, x) walk of the input pixel uses selects.  The waves of tap 0 / ci-tile 0 also sum their dy operand over the
+// pixels: that is the bias gradient of the same conv (bias_part[split][co]).
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradK p) {
     constexpr int MB = WG_MB, NB = WG_NB, PF = WG_PF;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -66,40 +100,51 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
     const long long p_begin = (long long)split * p.chunk;
     long long p_end = p_begin + p.chunk;
     if (p_end > p.P) p_end = p.P;
+    const bool want_bias = p.bias_part != nullptr && blockIdx.y == 0;        // wave-uniform
 
     const __amdgpu_buffer_rsrc_t rx = mcq_make_rsrc(mcq_uniform_ptr(p.xt), (uint32_t)((size_t)p.N * p.H * p.W * p.Cin * 4));
-    const __amdgpu_buffer_rsrc_t rd = mcq_make_rsrc(mcq_uniform_ptr(p.dyt), (uint32_t)((size_t)p.P * p.Cout * 4));
+    // dy^T rows [p_begin, p_end) of this wave: pixels past the range end are out of range = 0
+    // (the last ranges can start at or past P when chunk was rounded up: empty descriptor)
+    const long long d_begin = p_begin < p.P ? p_begin : p.P, d_len = p_end > p_begin ? p_end - p_begin : 0;
+    const __amdgpu_buffer_rsrc_t rd = mcq_make_rsrc(mcq_uniform_ptr(p.dyt + (size_t)d_begin * p.Cout),
+                                                    (uint32_t)((size_t)d_len * p.Cout * 4));
 
     // this lane's pixel: p_begin + hi, advancing by 2 per k-step
-    long long pp = p_begin + hi;
+    const long long pp0 = p_begin + hi;
     const int HoWo = p.Ho * p.Wo;
-    int n = (int)(pp / HoWo);
-    int rem = (int)(pp - (long long)n * HoWo);
+    int n = (int)(pp0 / HoWo);
+    const int rem = (int)(pp0 - (long long)n * HoWo);
     int yo = rem / p.Wo, xo = rem - yo * p.Wo;
 
-    bool cok[MB], iok[NB];
+    unsigned dbase[MB], xbase[NB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) cok[mb] = co_base + 32 * mb + j < p.Cout;
+    for (int mb = 0; mb < MB; ++mb)
+        dbase[mb] = co_base + 32 * mb + j < p.Cout ? (unsigned)(((size_t)hi * p.Cout + co_base + 32 * mb + j) * 4) : MCQ_OOB;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) iok[nb] = ci_base + 32 * nb + j < p.Cin;
+    for (int nb = 0; nb < NB; ++nb) xbase[nb] = ci_base + 32 * nb + j < p.Cin ? (unsigned)((ci_base + 32 * nb + j) * 4) : MCQ_OOB;
+    unsigned dstep = 0;                                      // bytes from the range start to this k-step's pixel pair
+    const unsigned dinc = 2u * (unsigned)p.Cout * 4u;
 
     float A[PF][MB], B[PF][NB];
     auto issue = [&](int st) {
-        const bool live = pp < p_end;
-        const unsigned doff = (unsigned)(((size_t)pp * p.Cout + co_base + j) * 4);
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-            A[st][mb] = mcq_buffer_load(rd, (live && cok[mb]) ? doff + (unsigned)(128 * mb) : MCQ_OOB);
+        for (int mb = 0; mb < MB; ++mb) A[st][mb] = mcq_buffer_load(rd, dbase[mb] + dstep);
+        dstep += dinc;
         const int yi = yo * p.stride + dy - pad, xi = xo * p.stride + dx - pad;
-        const bool inb = live && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
-        const unsigned xoff = (unsigned)(((((size_t)n * p.H + yi) * p.W + xi) * p.Cin + ci_base + j) * 4);
+        const bool inb = n < p.N && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
+        const unsigned xpix = inb ? (unsigned)(((n * p.H + yi) * p.W + xi) * p.Cin) * 4u : MCQ_OOB;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            B[st][nb] = mcq_buffer_load(rx, (inb && iok[nb]) ? xoff + (unsigned)(128 * nb) : MCQ_OOB);
-        pp += 2;
+        for (int nb = 0; nb < NB; ++nb) B[st][nb] = mcq_buffer_load(rx, ((xpix | xbase[nb]) >> 31) ? MCQ_OOB : xpix + xbase[nb]);
+        // advance two output pixels (select form: no divergent branches; Wo == 1 and Ho == 1 wrap twice)
         xo += 2;
-        if (xo >= p.Wo) { xo -= p.Wo; ++yo; if (xo >= p.Wo) { xo -= p.Wo; ++yo; } }
-        if (yo >= p.Ho) { yo -= p.Ho; ++n; if (yo >= p.Ho) { yo -= p.Ho; ++n; } }
+        int w = xo >= p.Wo ? 1 : 0;
+        xo -= w ? p.Wo : 0; yo += w;
+        w = xo >= p.Wo ? 1 : 0;
+        xo -= w ? p.Wo : 0; yo += w;
+        w = yo >= p.Ho ? 1 : 0;
+        yo -= w ? p.Ho : 0; n += w;
+        w = yo >= p.Ho ? 1 : 0;
+        yo -= w ? p.Ho : 0; n += w;
     };
 
     f32x16 acc[MB][NB];
@@ -109,10 +154,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+    float bsum[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) bsum[mb] = 0.0f;
 
 #pragma unroll
     for (int st = 0; st < PF; ++st) issue(st);
-    const int steps = (p.chunk / 2 + PF - 1) / PF * PF;        // whole prefetch rounds; the tail loads are masked to 0
+    const int steps = (p.chunk / 2 + PF - 1) / PF * PF;        // whole prefetch rounds; the tail loads are out of range = 0
     for (int t = 0; t < steps; t += PF) {
 #pragma unroll
         for (int st = 0; st < PF; ++st) {
@@ -121,7 +169,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st][mb], B[st][nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) bsum[mb] = bsum[mb] + A[st][mb];     // (every wave: cheaper than a branch per step)
             issue(st);
+            __builtin_amdgcn_sched_barrier(0);                  // keep the software pipeline as written
         }
     }
 
@@ -139,13 +190,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
                 if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Cin + ci] = acc[mb][nb][r];
             }
         }
+    if (want_bias) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const float s = bsum[mb] + __shfl_xor(bsum[mb], 32);       // even + odd pixels
+            const int co = co_base + 32 * mb + j;
+            if (hi == 0 && co < p.Cout) p.bias_part[(size_t)split * p.Cout + co] = s;
+        }
+    }
 }
 
-// dW[co][ci][tap] = sum_split part[split][tap][co][ci]   (fixed order: deterministic)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int taps, int Cout, int Cin) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // index into [tap][co][ci]
+// dW[co][ci][tap] = sum_split part[split][tap][co][ci]; db[co] = sum_split bias_part[split][co]   (fixed order: deterministic)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int taps, int Cout, int Cin,
+                                    const float* __restrict__ bias_part, float* __restrict__ dbias) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // index into [tap][co][ci], then [co] of the bias
     const size_t per = (size_t)taps * Cout * Cin;
-    if (i >= per) return;
+    if (i >= per) {
+        const size_t co = i - per;
+        if (dbias && co < (size_t)Cout) {
+            float s = 0.0f;
+            for (int sp = 0; sp < splits; ++sp) s += bias_part[(size_t)sp * Cout + co];
+            dbias[co] = s;
+        }
+        return;
+    }
     float s = 0.0f;
     for (int sp = 0; sp < splits; ++sp) s += part[(size_t)sp * per + i];
     const int ci = (int)(i % Cin);
@@ -266,6 +334,16 @@ extern "C" int mcq_nchw_to_nhwc_f32(const float* x, float* out, int32_t N, int32
     return mcq_check_launch();
 }
 
+extern "C" int mcq_nchw_to_nhwc_pair_f32(const float* x, float* x_out, int32_t Cx, int32_t HWx, int32_t square_x, const float* y,
+                                        float* y_out, int32_t Cy, int32_t HWy, int32_t N, void* stream) {
+    if (!x || !x_out || !y || !y_out || N <= 0 || Cx <= 0 || Cy <= 0 || HWx <= 0 || HWy <= 0 || N > 32767) return MCQ_EINVAL;
+    const int hw = HWx > HWy ? HWx : HWy, c = Cx > Cy ? Cx : Cy;
+    const dim3 grid((unsigned)((hw + 31) / 32), (unsigned)((c + 31) / 32), (unsigned)(2 * N));
+    hipLaunchKernelGGL(nchw_to_nhwc_pair_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_out, Cx, HWx, square_x, y, y_out, Cy,
+                       HWy, N);
+    return mcq_check_launch();
+}
+
 extern "C" size_t mcq_conv2d_wgrad_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize,
                                                     int32_t stride) {
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
@@ -277,11 +355,11 @@ extern "C" size_t mcq_conv2d_wgrad_workspace_floats(int32_t N, int32_t Cin, int3
     if (splits < 1) splits = 1;
     const long long max_splits = (P + 63) / 64;                 // at least 64 pixels per range
     if (splits > max_splits) splits = max_splits;
-    return (size_t)splits * taps * Cout * Cin;
+    return (size_t)splits * taps * Cout * Cin + (size_t)splits * Cout;      // dW partials + bias partials
 }
 
-extern "C" int mcq_conv2d_wgrad_f32(const float* x_nhwc, const float* dy_nhwc, float* dw, float* workspace, int32_t N, int32_t Cin,
-                                    int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, void* stream) {
+extern "C" int mcq_conv2d_wgrad_f32(const float* x_nhwc, const float* dy_nhwc, float* dw, float* dbias, float* workspace, int32_t N,
+                                    int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, void* stream) {
     if (!x_nhwc || !dy_nhwc || !dw || !workspace) return MCQ_EINVAL;
     const size_t wsf = mcq_conv2d_wgrad_workspace_floats(N, Cin, H, W, Cout, ksize, stride);
     if (wsf == 0) return MCQ_EINVAL;
@@ -296,15 +374,17 @@ extern "C" int mcq_conv2d_wgrad_f32(const float* x_nhwc, const float* dy_nhwc, f
     const int taps = ksize * ksize;
     p.ci_tiles = (Cin + 63) / 64;
     const int co_tiles = (Cout + 127) / 128;
-    p.splits = (int)(wsf / ((size_t)taps * Cout * Cin));
+    p.splits = (int)(wsf / ((size_t)taps * Cout * Cin + (size_t)Cout));
+    p.bias_part = dbias ? workspace + (size_t)p.splits * taps * Cout * Cin : nullptr;
     long long chunk = (p.P + p.splits - 1) / p.splits;
     chunk = (chunk + 1) & ~1LL;                                 // even: a k-step covers two pixels
     p.chunk = (int)chunk;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((p.splits + 3) / 4), (unsigned)(taps * p.ci_tiles), (unsigned)co_tiles);
     hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
-    const size_t per = (size_t)taps * Cout * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, workspace, dw, p.splits, taps, Cout, Cin);   // dW in OIHW order
+    const size_t per = (size_t)taps * Cout * Cin + (dbias ? (size_t)Cout : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, workspace, dw, p.splits, taps, Cout, Cin,
+                       (const float*)p.bias_part, dbias);   // dW in OIHW order
     return mcq_check_launch();
 }
 

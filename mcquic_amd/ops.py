@@ -298,19 +298,24 @@ def nchw_to_nhwc(x: torch.Tensor, square: bool = False) -> torch.Tensor:
     return out
 
 
-def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, square_x: bool = False) -> torch.Tensor:
-    """dW [Cout, Cin, k, k] of y = conv(x, W) from NCHW x and dy (channel-major copies are made here)."""
+def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, square_x: bool = False, want_bias: bool = False):
+    """dW [Cout, Cin, k, k] of y = conv(x, W) + b from NCHW x and dy (channel-major copies are made here, one launch for
+    the pair); with `want_bias` returns (dW, db) where db[co] = sum of dy over images and pixels, from the same kernel."""
     x, dy = _dev(x, "x"), _dev(dy, "dy")
     n, cin, h, w = x.shape
-    cout = dy.shape[1]
+    cout, ho, wo = dy.shape[1], dy.shape[2], dy.shape[3]
     lib = _lib.load()
-    xt, dyt = nchw_to_nhwc(x, square_x), nchw_to_nhwc(dy)
+    xt = torch.empty((n, h, w, cin), dtype=torch.float32, device=x.device)
+    dyt = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
     ws = torch.empty(lib.mcq_conv2d_wgrad_workspace_floats(n, cin, h, w, cout, ksize, stride), dtype=torch.float32, device=x.device)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
     with torch.cuda.device(x.device):
-        check(lib.mcq_conv2d_wgrad_f32(_ptr(xt), _ptr(dyt), _ptr(dw), _ptr(ws), n, cin, h, w, cout, ksize, stride, _stream()),
-              "mcq_conv2d_wgrad_f32")
-    return dw
+        check(lib.mcq_nchw_to_nhwc_pair_f32(_ptr(x), _ptr(xt), cin, h * w, int(square_x), _ptr(dy), _ptr(dyt), cout, ho * wo, n,
+                                            _stream()), "mcq_nchw_to_nhwc_pair_f32")
+        check(lib.mcq_conv2d_wgrad_f32(_ptr(xt), _ptr(dyt), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, ksize, stride,
+                                       _stream()), "mcq_conv2d_wgrad_f32")
+    return (dw, db) if want_bias else dw
 
 
 def channel_sum(x: torch.Tensor) -> torch.Tensor:

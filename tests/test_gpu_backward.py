@@ -25,7 +25,9 @@ def _close(got, want, tol, what):
 
 @pytest.mark.parametrize("case", [(2, 128, 128, 12, 16, 3, 1), (1, 128, 128, 9, 7, 3, 1), (2, 128, 128, 12, 16, 3, 2),
                                   (1, 128, 128, 9, 7, 3, 2), (2, 128, 128, 10, 6, 1, 1), (2, 3, 128, 16, 12, 3, 2),
-                                  (1, 8, 8, 11, 13, 3, 1), (2, 128, 12, 8, 8, 3, 1)])
+                                  (1, 8, 8, 11, 13, 3, 1), (2, 128, 12, 8, 8, 3, 1),
+                                  (1, 128, 128, 87, 167, 3, 1),   # 14529 pixels: 227 ranges of 66, the last seven empty
+                                  (1, 64, 40, 1, 300, 3, 1), (3, 16, 24, 33, 1, 1, 1)])     # one-pixel-wide / -high maps
 def test_conv_backward(dev, case):
     from mcquic_amd.nn import Conv2d
     n, cin, cout, h, w, ks, stride = case

@@ -77,6 +77,9 @@ struct WgradK {
     long long P;         // N * Ho * Wo
 };
 
+#ifndef MCQ_WGRAD_WAVES
+#define MCQ_WGRAD_WAVES 4096      // ~4 waves per SIMD in all
+#endif
 constexpr int WG_MB = 4, WG_NB = 2, WG_PF = 8;
 
 // dW partials of one (pixel range, tap, 64-ci tile, 128-co tile) per wave: D[co][ci] += dy^T[p][co] * x^T[p + tap][ci],
@@ -351,7 +354,7 @@ extern "C" size_t mcq_conv2d_wgrad_workspace_floats(int32_t N, int32_t Cin, int3
     const long long Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const long long P = (long long)N * Ho * Wo;
     const int taps = ksize * ksize, ci_tiles = (Cin + 63) / 64, co_tiles = (Cout + 127) / 128;
-    long long splits = 4096 / ((long long)taps * ci_tiles * co_tiles);      // ~4 waves per SIMD in all
+    long long splits = MCQ_WGRAD_WAVES / ((long long)taps * ci_tiles * co_tiles);      // waves in all
     if (splits < 1) splits = 1;
     const long long max_splits = (P + 63) / 64;                 // at least 64 pixels per range
     if (splits > max_splits) splits = max_splits;

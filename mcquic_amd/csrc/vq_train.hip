@@ -25,6 +25,7 @@ struct VqLogitK {
     float scale;                // sqrt(k)
     float* logits;              // [N, m, h, w, k]
     int raw;                    // 1: store the inner products <x_v, c_k> themselves (backward: dSample = dDeq . C^T)
+    int tiles_per_z;            // codeword tiles per blockIdx.z (the logits of different tiles are independent)
 };
 
 __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
@@ -85,7 +86,9 @@ __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
 
     f32x4v A[PF];
     float B[PF][NP];
-    const float* wl = p.cbp + ((size_t)g * p.ntile * p.Sp * 64 + lane) * 4;
+    const int tile_lo = blockIdx.z * q.tiles_per_z;
+    const int tile_hi = tile_lo + q.tiles_per_z < p.ntile ? tile_lo + q.tiles_per_z : p.ntile;
+    const float* wl = p.cbp + (((size_t)g * p.ntile + tile_lo) * p.Sp * 64 + lane) * 4;
     const f32x4v* c2l = reinterpret_cast<const f32x4v*>(p.c2p) + (size_t)g * (p.ntile + 1) * 64 + j;   // lane j of BOTH halves
     int ls = 0;
     unsigned soffL = 0;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
 #pragma unroll
     for (int st = 0; st < PF; ++st) issue(st);
 
-    for (int tile = 0; tile < p.ntile; ++tile) {
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
         const f32x4v c2t = c2l[(size_t)tile * 64];
         f32x16 acc[NP][NW];
 #pragma unroll
@@ -347,7 +350,15 @@ extern "C" int mcq_vq_logits_f32(const float* x, const float* cb_packed, const f
     // sqrt(k) as the reference computes it: math.sqrt (double) then used as a Python float in a float32 division
     q.scale = (float)sqrt((double)k);
     const unsigned gx = (unsigned)(((q.v.total_blocks + VQ_NB - 1) / VQ_NB + 3) / 4);
-    hipLaunchKernelGGL(vq_logits_kernel, dim3(gx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, q);
+    // (vector tiles x m) waves walk all codeword tiles otherwise: split the tiles over grid.z until ~2048 waves exist
+    {
+        const long long waves = (long long)gx * 4 * m;
+        int zs = 1;
+        while (zs < q.v.ntile && waves * zs < 2048) zs *= 2;
+        q.tiles_per_z = (q.v.ntile + zs - 1) / zs;
+        const unsigned gz = (unsigned)((q.v.ntile + q.tiles_per_z - 1) / q.tiles_per_z);
+        hipLaunchKernelGGL(vq_logits_kernel, dim3(gx, (unsigned)m, gz), dim3(256), 0, (hipStream_t)stream, q);
+    }
     return mcq_check_launch();
 }
 
@@ -360,7 +371,15 @@ extern "C" int mcq_vq_inner_f32(const float* x, const float* cb_packed, float* o
     q.v.codes = nullptr;
     q.temperature = nullptr; q.bound = 0.0f; q.scale = 1.0f; q.logits = out; q.raw = 1;
     const unsigned gx = (unsigned)(((q.v.total_blocks + VQ_NB - 1) / VQ_NB + 3) / 4);
-    hipLaunchKernelGGL(vq_logits_kernel, dim3(gx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, q);
+    // (vector tiles x m) waves walk all codeword tiles otherwise: split the tiles over grid.z until ~2048 waves exist
+    {
+        const long long waves = (long long)gx * 4 * m;
+        int zs = 1;
+        while (zs < q.v.ntile && waves * zs < 2048) zs *= 2;
+        q.tiles_per_z = (q.v.ntile + zs - 1) / zs;
+        const unsigned gz = (unsigned)((q.v.ntile + q.tiles_per_z - 1) / q.tiles_per_z);
+        hipLaunchKernelGGL(vq_logits_kernel, dim3(gx, (unsigned)m, gz), dim3(256), 0, (hipStream_t)stream, q);
+    }
     return mcq_check_launch();
 }
 

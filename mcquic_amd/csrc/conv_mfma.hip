@@ -33,6 +33,9 @@
 #ifndef MCQ_PFB
 #define MCQ_PFB 18
 #endif
+#ifndef MCQ_XCD_REMAP
+#define MCQ_XCD_REMAP 1
+#endif
 
 namespace {
 
@@ -73,7 +76,18 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     const int KS = 1 << p.ks_log2;
     const int tile_in_wg = wave >> p.ks_log2;       // which output tile of this workgroup
     const int kslice = wave & (KS - 1);             // which slice of the k-steps
-    const int gw = (blockIdx.x << p.tiles_log2) + tile_in_wg;   // tile index along the pixel-block axis
+    // XCD-aware tile order: the dispatcher deals workgroups round-robin to the 8 XCDs (linear id % 8), each with its own
+    // L2.  Taking the id as is, vertically adjacent pixel rows -- which share two of their three input rows -- always sit
+    // on different XCDs and every XCD pulls the halo rows through the fabric again (FETCH_SIZE 3.1x the input on the
+    // 384x256 level).  Remapped, XCD k walks the contiguous k-th eighth of the tiles, so the halo of one workgroup is the
+    // row its own XCD touched a moment ago.
+    unsigned wg = blockIdx.x;
+    if (MCQ_XCD_REMAP) {
+        const unsigned nwg = gridDim.x, xcd = wg & 7u, slot = wg >> 3;
+        const unsigned base = xcd * (nwg >> 3) + (xcd < (nwg & 7u) ? xcd : (nwg & 7u));      // workgroups of the XCDs before this one
+        wg = base + slot;
+    }
+    const int gw = (int)(wg << p.tiles_log2) + tile_in_wg;       // tile index along the pixel-block axis
     const bool active = gw * NB < p.total_blocks;   // wave-uniform
     if (KS == 1 && !active) return;                 // (split-K waves stay for the barriers)
     const int co_base = blockIdx.y * (32 * MB);     // first output channel of this wave

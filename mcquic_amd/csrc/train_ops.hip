@@ -78,7 +78,8 @@ struct WgradK {
 };
 
 #ifndef MCQ_WGRAD_WAVES
-#define MCQ_WGRAD_WAVES 4096      // ~4 waves per SIMD in all
+#define MCQ_WGRAD_WAVES 1024      // one wave per SIMD in all: fewer, longer pixel ranges beat 2048 / 4096 (57 -> 54 ms per
+                                  // training step) and 512 (61 ms) -- less partial-sum traffic, fixed costs paid once
 #endif
 constexpr int WG_MB = 4, WG_NB = 2, WG_PF = 8;
 

@@ -416,6 +416,128 @@ extern "C" int mcq_vq_softmax_bwd_f32(const float* logits, const float* u_gumbel
     return mcq_check_launch();
 }
 
+namespace {
+
+// ---- tiled forms of the two kernels above for d <= 64 (the training geometry: d = 64) ---------------------------------
+// Both put the channel j on the lane axis, so codebook rows / latent vectors are coalesced 256-byte loads, and take the
+// dDist factors -- which are the same for every channel -- from wave-uniform (scalar) loads.  Enough waves are created
+// (4 per workgroup, each a slice of the contraction) that their latencies overlap; the slices meet in LDS and are added
+// in slice order, so both results are deterministic.
+
+// dx: a workgroup owns DX_R consecutive latent vectors of one (image, group); wave w contracts codewords
+// [w k/4, (w+1) k/4): DX_R FMAs per codebook-row load.
+constexpr int DX_R = 8;
+__global__ __launch_bounds__(256) void vq_dx_tiled_kernel(const float* __restrict__ ddist, const float* __restrict__ rowsum,
+                                                          const float* __restrict__ x, const float* __restrict__ cb,
+                                                          float* __restrict__ dx, int rows, int m, int d, int hw, int k) {
+    __shared__ float part[3][DX_R][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int row0 = blockIdx.x * DX_R;                           // hw % DX_R == 0: the DX_R rows share (n, g)
+    const int pix0 = row0 % hw;
+    const int ng = row0 / hw;
+    const int g = ng % m;
+    const int kq = k >> 2;                                        // k % 16 == 0
+    const float* dr = ddist + (size_t)row0 * k + (size_t)wave * kq;
+    const float* cg = cb + ((size_t)g * k + (size_t)wave * kq) * d;
+    const bool jok = lane < d;
+    float acc[DX_R];
+#pragma unroll
+    for (int r = 0; r < DX_R; ++r) acc[r] = 0.0f;
+    for (int c = 0; c < kq; c += 4) {
+        float cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cv[u] = jok ? cg[(size_t)(c + u) * d + lane] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < DX_R; ++r) {
+            const f32x4v gq = *reinterpret_cast<const f32x4v*>(dr + (size_t)r * k + c);   // wave-uniform address
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[r] = __builtin_fmaf(gq[u], cv[u], acc[r]);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < DX_R; ++r) part[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0 && jok) {
+#pragma unroll
+        for (int r = 0; r < DX_R; ++r) {
+            const float t = ((acc[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane];
+            const size_t xi = ((size_t)ng * d + lane) * hw + pix0 + r;
+            dx[xi] = 2.0f * x[xi] * rowsum[row0 + r] - 2.0f * t;
+        }
+    }
+}
+
+// dcodebook: a workgroup owns DC_W consecutive codewords of one group; wave w contracts the latent vectors
+// [w V/4, (w+1) V/4): per vector one load of its channel row and DC_W scalar dDist values -> DC_W FMAs per lane.  The
+// sampled codeword of a vector (index / hot, the straight-through path of the soft dequantisation) is wave-uniform:
+// its term is added by a rare uniform branch.
+constexpr int DC_W = 16;
+__global__ __launch_bounds__(256) void vq_dc_tiled_kernel(const float* __restrict__ ddist, const float* __restrict__ xt,
+                                                          const float* __restrict__ dqt, const int64_t* __restrict__ index,
+                                                          const float* __restrict__ hot, const float* __restrict__ cb,
+                                                          float* __restrict__ dcb, int N, int m, int d, int hw, int k) {
+    __shared__ float part[3][2 * DC_W + 1][64];                   // waves 1..3: acc[c], sc[c] per lane; row 2 DC_W: column sums
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = blockIdx.y;
+    const int c0 = blockIdx.x * DC_W;                             // k % DC_W == 0
+    const int C = m * d;
+    const int V = N * hw;
+    const int per = (V + 3) / 4;
+    const int v0 = wave * per, v1 = v0 + per < V ? v0 + per : V;
+    const bool jok = lane < d;
+    float acc[DC_W], sc[DC_W], cs[DC_W];
+#pragma unroll
+    for (int u = 0; u < DC_W; ++u) { acc[u] = 0.0f; sc[u] = 0.0f; cs[u] = 0.0f; }
+    for (int v = v0; v < v1; ++v) {
+        const int n = v / hw, pp = v - n * hw;
+        const size_t row = ((size_t)n * m + g) * hw + pp;
+        const float xv = jok ? xt[((size_t)n * hw + pp) * C + (size_t)g * d + lane] : 0.0f;
+        const float* gr = ddist + row * k + c0;                   // wave-uniform: DC_W consecutive floats
+#pragma unroll
+        for (int q = 0; q < DC_W / 4; ++q) {
+            const f32x4v gq = *reinterpret_cast<const f32x4v*>(gr + 4 * q);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[4 * q + u] = __builtin_fmaf(gq[u], xv, acc[4 * q + u]);
+                cs[4 * q + u] += gq[u];
+            }
+        }
+        const int idx = (int)index[row] - c0;                     // wave-uniform
+        if (idx >= 0 && idx < DC_W) {
+            const float t = jok ? hot[row] * dqt[((size_t)n * hw + pp) * C + (size_t)g * d + lane] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < DC_W; ++u) sc[u] = u == idx ? sc[u] + t : sc[u];
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int u = 0; u < DC_W; ++u) { part[wave - 1][u][lane] = acc[u]; part[wave - 1][DC_W + u][lane] = sc[u]; }
+        if (lane < DC_W) {
+            float mine = 0.0f;
+#pragma unroll
+            for (int u = 0; u < DC_W; ++u) mine = lane == u ? cs[u] : mine;
+            part[wave - 1][2 * DC_W][lane] = mine;
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && jok) {
+#pragma unroll
+        for (int u = 0; u < DC_W; ++u) {
+            const float a = ((acc[u] + part[0][u][lane]) + part[1][u][lane]) + part[2][u][lane];
+            const float s2 = ((sc[u] + part[0][DC_W + u][lane]) + part[1][DC_W + u][lane]) + part[2][DC_W + u][lane];
+            const float col = ((cs[u] + part[0][2 * DC_W][u]) + part[1][2 * DC_W][u]) + part[2][2 * DC_W][u];
+            const size_t ci = ((size_t)g * k + c0 + u) * d + lane;
+            dcb[ci] = 2.0f * cb[ci] * col - 2.0f * a + s2;
+        }
+    }
+}
+
+}  // namespace
+
 extern "C" int mcq_vq_soft_bwd_f32(const float* ddist, const float* rowsum, const float* x, const float* x_nhwc,
                                    const float* ddeq_nhwc, const int64_t* sample_index, const float* sample_hot,
                                    const float* codebook, float* dx, float* dcodebook, int32_t N, int32_t m, int32_t d, int32_t h,
@@ -426,9 +548,18 @@ extern "C" int mcq_vq_soft_bwd_f32(const float* ddist, const float* rowsum, cons
     const long long rows = (long long)N * m * h * w;
     if (rows > 0x7fffffffLL) return MCQ_ETOOLARGE;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(vq_dx_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ddist, rowsum, x, codebook, dx, (int)rows, m, d,
-                       h * w, k);
-    hipLaunchKernelGGL(vq_dc_kernel, dim3((unsigned)((k + 3) / 4), (unsigned)m), dim3(256), 0, s, ddist, x_nhwc, ddeq_nhwc, sample_index,
-                       sample_hot, codebook, dcodebook, N, m, d, h * w, k);
+    const int hw = h * w;
+    if (d <= 64 && hw % DX_R == 0 && k % 16 == 0)
+        hipLaunchKernelGGL(vq_dx_tiled_kernel, dim3((unsigned)(rows / DX_R)), dim3(256), 0, s, ddist, rowsum, x, codebook, dx,
+                           (int)rows, m, d, hw, k);
+    else
+        hipLaunchKernelGGL(vq_dx_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ddist, rowsum, x, codebook, dx, (int)rows, m, d,
+                           hw, k);
+    if (d <= 64 && k % DC_W == 0)
+        hipLaunchKernelGGL(vq_dc_tiled_kernel, dim3((unsigned)(k / DC_W), (unsigned)m), dim3(256), 0, s, ddist, x_nhwc, ddeq_nhwc,
+                           sample_index, sample_hot, codebook, dcodebook, N, m, d, hw, k);
+    else
+        hipLaunchKernelGGL(vq_dc_kernel, dim3((unsigned)((k + 3) / 4), (unsigned)m), dim3(256), 0, s, ddist, x_nhwc, ddeq_nhwc, sample_index,
+                           sample_hot, codebook, dcodebook, N, m, d, hw, k);
     return mcq_check_launch();
 }

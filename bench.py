@@ -67,7 +67,11 @@ class ConvProfiler:
             ho = (h + 2 * pad - w.ksize) // stride + 1
             wo = (wd + 2 * pad - w.ksize) // stride + 1
             flops = 2.0 * n * ho * wo * w.cout * cin * w.ksize * w.ksize
-            nbytes = 4.0 * (x.numel() + y.numel())
+            # algorithmic HBM bytes of the fused op: input and output once, plus every output-shaped side tensor its
+            # contract needs (residual / multiplier / gate reads, the SiLU twin write)
+            sides = sum(1 for key in ("res", "gdn_mul", "igdn_mul", "gate_mul", "gate_id", "mul") if kw.get(key) is not None)
+            sides += 1 if kw.get("dual_silu") else 0
+            nbytes = 4.0 * (x.numel() + y.numel() * (1 + sides))
             prof.records.append((s, e, flops, nbytes))
             return y
 
@@ -232,8 +236,8 @@ def main():
                 "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM, all tile variants)",
                 "achieved": round(achieved_tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / FP32_MATRIX_PEAK_TFLOPS, 4),
-                "traffic": (lambda t: None if t is None else round(t["fetch_bytes_per_launch_x2_corrected"] + t["write_size_bytes_per_launch"]))(pmc_traffic()),
-                "traffic_unit": "HBM-side bytes per launch of conv_mfma_kernel<4,2,0,...> (PMC FETCH_SIZE x2-corrected + WRITE_SIZE, profiles/r01_pmc.json)",
+                "traffic": (lambda t: None if t is None else round(t["all_conv_launches"]["fetch_bytes_per_launch_x2_corrected"] + t["all_conv_launches"]["write_size_bytes_per_launch"]))(pmc_traffic()),
+                "traffic_unit": "HBM-side bytes per conv_mfma_kernel launch, averaged over all conv launches of a step like algorithmic_bytes_per_launch (PMC FETCH_SIZE x2-corrected + WRITE_SIZE, separate passes, profiles/r01_pmc.json)",
                 "algorithmic_bytes_per_launch": round(conv["bytes"] / max(conv["launches"], 1)),
                 "launches_per_step": conv["launches"] // max(args.steps, 1),
                 "avg_launch_ms": round(conv["sum_ms"] / max(conv["launches"], 1), 4),

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     for (int sp = 0; sp < npairs; sp += PAIRS_PER_ITER) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (TAPS == 9 && u == 9 && sp + 1 >= npairs) break;     // odd slice: the second pair of the body is past it
+            if (TAPS == 9 && u > 0 && u % 9 == 0 && sp + u / 9 >= npairs) break;   // the slice ends inside the body
             const int sa = u % PFA, sb = u % PFB;
             float bv[NB];
 #pragma unroll

@@ -14,12 +14,19 @@ import sys
 
 REPS = 24
 CONFIGS = []          # (n, cin, h, w, tile, flags)
-for n in (1, 32):
-    for (h, w) in ((12, 8), (24, 16), (48, 32)):
-        for cin in (16, 128):
-            for tile in (0, 0x42, 0x11, 0x311, 0x241):
-                for flags in ("plain", "res"):
-                    CONFIGS.append((n, cin, h, w, tile, flags))
+if os.environ.get("PROBE_SHAPES"):      # e.g. PROBE_SHAPES="8,16,16;8,8,8" PROBE_TILES="0,0x11,0x311,0x241"
+    tiles = [int(t, 0) for t in os.environ.get("PROBE_TILES", "0,0x311,0x211,0x241,0x341,0x222,0x322,0x221,0x321,0x121").split(",")]
+    for shp in os.environ["PROBE_SHAPES"].split(";"):
+        n, h, w = (int(v) for v in shp.split(","))
+        for tile in tiles:
+            CONFIGS.append((n, 128, h, w, tile, "res"))
+else:
+    for n in (1, 32):
+        for (h, w) in ((12, 8), (24, 16), (48, 32)):
+            for cin in (16, 128):
+                for tile in (0, 0x42, 0x11, 0x311, 0x241):
+                    for flags in ("plain", "res"):
+                        CONFIGS.append((n, cin, h, w, tile, flags))
 
 
 def run():

@@ -81,7 +81,10 @@ struct WgradK {
 #define MCQ_WGRAD_WAVES 1024      // one wave per SIMD in all: fewer, longer pixel ranges beat 2048 / 4096 (57 -> 54 ms per
                                   // training step) and 512 (61 ms) -- less partial-sum traffic, fixed costs paid once
 #endif
-constexpr int WG_MB = 4, WG_NB = 2, WG_PF = 8;
+#ifndef MCQ_WGRAD_PF
+#define MCQ_WGRAD_PF 8
+#endif
+constexpr int WG_MB = 4, WG_NB = 2, WG_PF = MCQ_WGRAD_PF;
 
 // dW partials of one (pixel range, tap, 64-ci tile, 128-co tile) per wave: D[co][ci] += dy^T[p][co] * x^T[p + tap][ci],
 // two output pixels per k-step (lane half hi takes pixel 2t + hi).  Both operands are NHWC copies, so a lane's 32
@@ -89,6 +92,10 @@ constexpr int WG_MB = 4, WG_NB = 2, WG_PF = 8;
 // per-wave num_records (range end), channel / image-border predicates become the out-of-range marker, and the
 // (n, y, x) walk of the input pixel uses selects.  The waves of tap 0 / ci-tile 0 also sum their dy operand over the
 // pixels: that is the bias gradient of the same conv (bias_part[split][co]).
+// EVEN (Wo even, the usual case): the two pixels of a k-step sit in one output row, so the (n, y, x) walk, the row part
+// of the input offset and the image-border tests are wave-uniform and run on the scalar unit; a step then costs four
+// vector instructions of addressing instead of ~55 (which, at one wave per SIMD, sat between the MFMAs: 38 % -> of peak).
+template <bool EVEN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradK p) {
     constexpr int MB = WG_MB, NB = WG_NB, PF = WG_PF;
     const int lane = threadIdx.x & 63;
@@ -129,8 +136,43 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradK p) {
     unsigned dstep = 0;                                      // bytes from the range start to this k-step's pixel pair
     const unsigned dinc = 2u * (unsigned)p.Cout * 4u;
 
+    // EVEN: wave-uniform walk of the pixel PAIR (p_begin is even, so is xo_u; lane half hi takes xo_u + hi, same row)
+    int n_u = (int)(p_begin / HoWo);
+    const int rem_u = (int)(p_begin - (long long)n_u * HoWo);
+    int yo_u = rem_u / p.Wo, xo_u = rem_u - yo_u * p.Wo;
+    unsigned xlane[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) xlane[nb] = xbase[nb] + (unsigned)(hi * p.stride * p.Cin) * 4u;   // (marker + small stays a marker)
+    int xi0 = xo_u * p.stride + dx - pad;                         // input column of the pair's first pixel
+    const int yi_first = yo_u * p.stride + dy - pad;
+    bool row_ok = n_u < p.N && yi_first >= 0 && yi_first < p.H;
+    unsigned row_base = row_ok ? (unsigned)(((n_u * p.H + yi_first) * p.W) * p.Cin * 4) : 0u;
+
     float A[PF][MB], B[PF][NB];
     auto issue = [&](int st) {
+        if (EVEN) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) A[st][mb] = mcq_buffer_load_s(rd, dbase[mb], dstep);
+            dstep += dinc;
+            // row_ok / row_base only change when the walk wraps to a new row: kept in scalar registers, updated there
+            const bool ok0 = row_ok && xi0 >= 0 && xi0 < p.W;
+            const bool ok1 = row_ok && xi0 + p.stride >= 0 && xi0 + p.stride < p.W;
+            const unsigned base_u = row_base + (unsigned)(xi0 * p.Cin * 4);        // (may be -Cin*4 in all: wraps back)
+            const bool ok = hi ? ok1 : ok0;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) B[st][nb] = mcq_buffer_load(rx, ok ? xlane[nb] + base_u : MCQ_OOB);
+            xo_u += 2;
+            xi0 += 2 * p.stride;
+            if (xo_u >= p.Wo) {
+                xo_u = 0; ++yo_u;
+                if (yo_u >= p.Ho) { yo_u = 0; ++n_u; }
+                xi0 = dx - pad;
+                const int yi = yo_u * p.stride + dy - pad;
+                row_ok = n_u < p.N && yi >= 0 && yi < p.H;
+                row_base = row_ok ? (unsigned)(((n_u * p.H + yi) * p.W) * p.Cin * 4) : 0u;
+            }
+            return;
+        }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) A[st][mb] = mcq_buffer_load(rd, dbase[mb] + dstep);
         dstep += dinc;
@@ -385,7 +427,8 @@ extern "C" int mcq_conv2d_wgrad_f32(const float* x_nhwc, const float* dy_nhwc, f
     p.chunk = (int)chunk;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((p.splits + 3) / 4), (unsigned)(taps * p.ci_tiles), (unsigned)co_tiles);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
+    if (p.Wo % 2 == 0) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, s, p);
     const size_t per = (size_t)taps * Cout * Cin + (dbias ? (size_t)Cout : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, workspace, dw, p.splits, taps, Cout, Cin,
                        (const float*)p.bias_part, dbias);   // dW in OIHW order

@@ -42,6 +42,9 @@
 #ifndef MCQ_TILE_22A
 #define MCQ_TILE_22A 0
 #endif
+#ifndef MCQ_TILE_14
+#define MCQ_TILE_14 1
+#endif
 
 namespace {
 
@@ -517,7 +520,11 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     int MB, NB, ksl = 0;
     const int forced = d->tile & 0xff;
     if (forced) { MB = forced >> 4; NB = forced & 15; ksl = (d->tile >> 8) & 3; }
-    else if (co32 == 1) { MB = 1; NB = 2; }
+    else if (co32 == 1) {
+        // <= 32 output channels (the 12-channel head, the tiny fixture models): one weight load feeds NB MFMAs, so the
+        // widest pixel tile that still leaves >= 2048 waves amortises it best (head conv 2.34 -> 2.05 ms with NB = 4)
+        MB = 1; NB = (MCQ_TILE_14 && tb >= 4 * 2048) ? 4 : 2;
+    }
     else {
         // (the 128 x 32 tile <4, 1> is instantiated and reachable through `tile`; an automatic rule preferring it on
         //  the 24x16 / 12x8 levels gained 0.4 % at batch 32 and lost 8 % on the batch-8 training step: not used)
@@ -552,6 +559,7 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 2) return launch_tile<2, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 1) return launch_tile<2, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 1 && NB == 4) return launch_tile<1, 4, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 1 && NB == 2) return launch_tile<1, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 1 && NB == 1) return launch_tile<1, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
     return MCQ_EINVAL;

@@ -43,7 +43,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 0x42, 0x41, 0x22, 0x21, 0x12, 0x11, 0x142, 0x242, 0x342, 0x241, 0x222, 0x311, 0x321])
+@pytest.mark.parametrize("tile", [0, 0x42, 0x41, 0x22, 0x21, 0x12, 0x14, 0x11, 0x142, 0x242, 0x342, 0x241, 0x222, 0x311, 0x321])
 def test_conv_plain(dev, case, tile):
     """tile = (log2 split-K << 8) | (MB << 4) | NB; 0 = the library's own choice."""
     from mcquic_amd import ops

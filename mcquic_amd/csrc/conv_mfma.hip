@@ -45,6 +45,9 @@
 #ifndef MCQ_TILE_14
 #define MCQ_TILE_14 1
 #endif
+#ifndef MCQ_HEAD16
+#define MCQ_HEAD16 1
+#endif
 
 namespace {
 
@@ -65,6 +68,12 @@ struct ConvK {
 
 constexpr int PRO_NONE = 0, PRO_SILU = 1, PRO_SQUARE = 2;
 constexpr unsigned RUNTIME_FLAGS = 0xffffffffu;    // epilogue instance that tests the flags at run time
+
+}  // namespace
+
+#include "conv_head16.h"
+
+namespace {
 
 template <int MB> struct AVec;
 template <> struct AVec<4> { typedef f32x4v T; };
@@ -416,6 +425,10 @@ inline int pairs_padded(int Cin, int ks) {        // 1x1 loops advance a whole p
     return ks == 1 ? (S + 15) & ~15 : S;
 }
 inline int steps_padded(int Cin, int ks) { return pairs_padded(Cin, ks) * ks * ks; }
+inline size_t general_floats(int Cout, int Cin, int ks) {      // operand stream of conv_mfma_kernel
+    const size_t ntile = (size_t)(Cout + 127) / 128;
+    return (ntile * (size_t)steps_padded(Cin, ks) + 16) * 256;   // + 16 zero steps read by the prefetch tail
+}
 
 template <int MB, int NB, int PF3A, int PF3B, int PF1>
 int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2, hipStream_t s) {
@@ -449,18 +462,22 @@ int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2
 
 extern "C" size_t mcq_packed_conv_weight_floats(int32_t Cout, int32_t Cin, int32_t ksize) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
-    const size_t ntile = (size_t)(Cout + 127) / 128;
-    return (ntile * (size_t)steps_padded(Cin, ksize) + 16) * 256;   // + 16 zero steps read by the prefetch tail
+    return general_floats(Cout, Cin, ksize) + (MCQ_HEAD16 && head16_shape(Cout, ksize) ? head16_floats(Cin) : 0);
 }
 
 extern "C" int mcq_pack_conv_weight_f32(const float* w, int32_t Cout, int32_t Cin, int32_t ksize, float* out,
                                         void* stream) {
     if (!w || !out || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return MCQ_EINVAL;
-    const size_t total = mcq_packed_conv_weight_floats(Cout, Cin, ksize);
+    const size_t total = general_floats(Cout, Cin, ksize);
     const int S = pairs_padded(Cin, ksize), TP = steps_padded(Cin, ksize), ntile = (Cout + 127) / 128;
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, ksize, S,
                        TP, ntile, out, total);
+    if (MCQ_HEAD16 && head16_shape(Cout, ksize)) {      // second copy in the 16-row operand order of conv_head16_kernel
+        const size_t t16 = head16_floats(Cin);
+        hipLaunchKernelGGL(pack_head16_kernel, dim3((unsigned)((t16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
+                           (Cin + 3) / 4, out + total, t16);
+    }
     return mcq_check_launch();
 }
 
@@ -496,6 +513,25 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     k.S = pairs_padded(d->Cin, d->ksize);
     k.TP = steps_padded(d->Cin, d->ksize);
     k.flags = fl; k.res_scale = d->res_scale;
+
+    // <= 16 output channels, 3x3, stride 1, nothing but bias / PixelShuffle in the epilogue: the 16-row MFMA kernel
+    if (MCQ_HEAD16 && head16_shape(d->Cout, d->ksize) && d->stride == 1 && (d->tile & 0xff) == 0 &&
+        (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN)) == 0) {
+        if ((uint64_t)d->Cout * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
+        Head16K h;
+        h.x = d->x; h.wp16 = d->w_packed + general_floats(d->Cout, d->Cin, d->ksize); h.bias = d->bias; h.y = d->y;
+        h.N = d->N; h.Cin = d->Cin; h.H = d->H; h.W = d->W; h.Cout = d->Cout;
+        h.S4 = (d->Cin + 3) / 4;
+        h.gpr = (d->W + 15) / 16;
+        h.total_groups = (long long)d->N * d->H * h.gpr;
+        h.flags = fl;
+        const long long waves = (h.total_groups + H16_NB - 1) / H16_NB;
+        if ((waves + 3) / 4 > 0x7fffffffLL) return MCQ_ETOOLARGE;
+        const dim3 grid((unsigned)((waves + 3) / 4));
+        if (fl & MCQ_CONV_SILU_IN) hipLaunchKernelGGL(conv_head16_kernel<PRO_SILU>, grid, dim3(256), 0, (hipStream_t)stream, h);
+        else hipLaunchKernelGGL(conv_head16_kernel<PRO_NONE>, grid, dim3(256), 0, (hipStream_t)stream, h);
+        return mcq_check_launch();
+    }
 
     // pixel-block shape: the power-of-two width that wastes the fewest lanes (wider wins ties)
     int best_log2 = 5; double best_util = -1.0;

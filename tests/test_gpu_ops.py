@@ -105,6 +105,32 @@ def test_conv_never_writes_outside_its_output(dev):
             assert bool((t[:guard] == fill).all()) and bool((t[guard + numel:] == fill).all()), f"tile={tile:#x}: guard band written"
 
 
+@pytest.mark.parametrize("case", [(2, 128, 12, 24, 32, True), (1, 128, 12, 13, 37, True), (2, 6, 3, 9, 50, False),
+                                  (1, 8, 8, 17, 16, False), (3, 16, 16, 5, 7, True), (1, 3, 4, 20, 33, True)])
+def test_conv_narrow_cout_16row_kernel(dev, case):
+    """<= 16 output channels, 3x3, stride 1, bias / PixelShuffle only: conv_head16_kernel (v_mfma_f32_16x16x4_f32); any
+    other epilogue, or a forced tile, takes the general kernel -- all must agree with torch."""
+    from mcquic_amd import ops
+    n, cin, cout, h, w, shuffle = case
+    x = _rand((n, cin, h, w), 11)
+    wt = _rand((cout, cin, 3, 3), 12, 1.0 / np.sqrt(cin * 9))
+    b = _rand((cout,), 13, 0.1)
+    want = F.conv2d(x, wt, b, padding=1)
+    want_ps = F.pixel_shuffle(want, 2) if shuffle else want
+    pk = ops.PackedConv(wt.to(dev), b.to(dev))
+    got = ops.conv2d(x.to(dev), pk, 1, shuffle2=shuffle)                       # 16-row kernel
+    _close(got, want_ps, 2e-6, f"head16 {case}")
+    _close(ops.conv2d(x.to(dev), pk, 1, shuffle2=shuffle, tile=0x12), want_ps, 2e-6, f"general kernel {case}")
+    _close(ops.conv2d(x.to(dev), ops.PackedConv(wt.to(dev), None), 1, shuffle2=shuffle), F.pixel_shuffle(want - b[None, :, None, None], 2)
+           if shuffle else want - b[None, :, None, None], 2e-6, f"head16 no bias {case}")
+    want_silu = F.conv2d(F.silu(x), wt, b, padding=1)
+    _close(ops.conv2d(x.to(dev), pk, 1, silu_in=True, shuffle2=shuffle), F.pixel_shuffle(want_silu, 2) if shuffle else want_silu, 2e-6,
+           f"head16 silu_in {case}")
+    res = _rand(tuple(want.shape), 14)
+    if not shuffle:                                                             # residual epilogue -> general kernel
+        _close(ops.conv2d(x.to(dev), pk, 1, res=res.to(dev)), want + res, 2e-6, f"narrow + residual {case}")
+
+
 def test_conv_identity_weight_asymmetric(dev):
     """A = I with an asymmetric B catches row/col swaps of the MFMA fragment maps."""
     from mcquic_amd import ops

@@ -233,11 +233,11 @@ def main():
             "encode_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3),
             "encode_mpps": round(args.batch * H * W / 1e3 / enc_ms, 3), "decode_mpps": round(args.batch * H * W / 1e3 / dec_ms, 3),
             "roofline": {
-                "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM, all tile variants)",
+                "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM, all tile variants; + the 16-row conv_head16_kernel of the image head)",
                 "achieved": round(achieved_tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / FP32_MATRIX_PEAK_TFLOPS, 4),
                 "traffic": (lambda t: None if t is None else round(t["all_conv_launches"]["fetch_bytes_per_launch_x2_corrected"] + t["all_conv_launches"]["write_size_bytes_per_launch"]))(pmc_traffic()),
-                "traffic_unit": "HBM-side bytes per conv_mfma_kernel launch, averaged over all conv launches of a step like algorithmic_bytes_per_launch (PMC FETCH_SIZE x2-corrected + WRITE_SIZE, separate passes, profiles/r01_pmc.json)",
+                "traffic_unit": "HBM-side bytes per conv kernel launch, averaged over all conv launches of a step like algorithmic_bytes_per_launch (PMC FETCH_SIZE x2-corrected + WRITE_SIZE, separate passes, profiles/r01_pmc.json)",
                 "algorithmic_bytes_per_launch": round(conv["bytes"] / max(conv["launches"], 1)),
                 "launches_per_step": conv["launches"] // max(args.steps, 1),
                 "avg_launch_ms": round(conv["sum_ms"] / max(conv["launches"], 1), 4),

@@ -16,7 +16,7 @@ large = [r for r in sel if r["wgs"] >= 3072]
 busy = sum(r["SQ_VALU_MFMA_BUSY_CYCLES"] * r["launches"] for r in large)
 gui = sum(r["GRBM_GUI_ACTIVE"] * r["launches"] for r in large)
 dur = sum(r["_dur_ns"] * r["launches"] for r in large)
-allc = [r for r in rows if "conv_mfma" in r["kernel"]]
+allc = [r for r in rows if "conv_mfma" in r["kernel"] or "conv_head16" in r["kernel"]]
 na = sum(r["launches"] for r in allc)
 out = {
     "source": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE} --kernel-trace -- "
@@ -38,7 +38,7 @@ out = {
     "mfma_pipe_utilisation_large_layers": busy / (gui / 8 * 1024),
     "effective_clock_ghz_large_layers": (gui / 8) / dur,
     "all_conv_launches": {
-        "note": "every conv_mfma_kernel instance, averaged per launch (the population bench.py averages its algorithmic bytes over)",
+        "note": "every conv_mfma_kernel / conv_head16_kernel instance, averaged per launch (the population bench.py averages its algorithmic bytes over)",
         "fetch_size_bytes_per_launch": sum(r["FETCH_SIZE"] * 1024 * r["launches"] for r in allc) / na,
         "fetch_bytes_per_launch_x2_corrected": 2 * sum(r["FETCH_SIZE"] * 1024 * r["launches"] for r in allc) / na,
         "write_size_bytes_per_launch": sum(r["WRITE_SIZE"] * 1024 * r["launches"] for r in allc) / na,

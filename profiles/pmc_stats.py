@@ -16,7 +16,7 @@ for path in sys.argv[1:]:
     meta = {}
     for did, name, gx, gy, wx, cname, val, dur in cur.execute(
             "select dispatch_id, kernel_name, grid_size_x, grid_size_y, workgroup_size_x, counter_name, value, duration from counters_collection"):
-        if "conv_mfma" not in name and "vq_assign" not in name:
+        if "conv_mfma" not in name and "conv_head16" not in name and "vq_assign" not in name:
             continue
         per[(did, cname)] += val
         meta[did] = (name, gx, gy, wx, dur)

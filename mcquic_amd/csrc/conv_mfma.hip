@@ -52,7 +52,7 @@
 namespace {
 
 struct ConvK {
-    const float* x; const float* wp; const float* bias; float* y; float* y2;
+    const float* x; const float* wp; const float* wp64; const float* wp32; const float* bias; float* y; float* y2;
     const float* res; const float* mul; const float* gid;
     int N, Cin, H, W, Cout, Ho, Wo;
     int ks, stride;
@@ -159,7 +159,12 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     float B[PFB][NB];
     const int tile128 = co_base >> 7, q0 = (co_base & 127) >> 5;
     const int s0 = kslice * p.slice_pairs;          // first channel pair of this wave's slice
-    const float* wl = p.wp + (((size_t)tile128 * p.TP + (size_t)s0 * TAPS) * 64 + lane) * 4 + q0;
+    // weights: the copy packed for this tile height, so that a wave-wide load is one dense run of 64 * MB floats
+    // (reading the 32- / 64-row tiles out of the 128-row copy -- 4 / 8 bytes per lane at a 16-byte stride -- touched
+    // four / two times the cache lines and made a 12x8-level launch 30 instead of 21 us)
+    const float* wl = MB == 4 ? p.wp + (((size_t)tile128 * p.TP + (size_t)s0 * TAPS) * 64 + lane) * 4 + q0
+                    : MB == 2 ? p.wp64 + (((size_t)(co_base >> 6) * p.TP + (size_t)s0 * TAPS) * 64 + lane) * 2
+                              : p.wp32 + ((size_t)(co_base >> 5) * p.TP + (size_t)s0 * TAPS) * 64 + lane;
     const unsigned step_bytes = 2u * (unsigned)HW * 4u;     // one channel pair further
     unsigned soff = (unsigned)s0 * step_bytes;
 
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
         for (int st = 0; st < PFA; ++st) {          // weights of steps 0 .. PFA-1 of the slice
             A[st] = *reinterpret_cast<const avec_t*>(wl);
-            wl += 256;
+            wl += 64 * MB;
         }
 #pragma unroll
         for (int st = 0; st < PFB; ++st) {          // activations of steps 0 .. PFB-1
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
             // refill the slots with the steps PFA / PFB ahead (over-reads past the slice: the packed weights carry
             // a zero tail, and activation offsets past the last channel are out of range = 0)
             A[sa] = *reinterpret_cast<const avec_t*>(wl);
-            wl += 256;
+            wl += 64 * MB;
             const int tl = TAPS == 9 ? (u + PFB) % 9 : 0;                       // tap of the step being loaded
             const int ds = TAPS == 9 ? (u + PFB) / 9 : u + PFB;                 // its channel-pair distance
 #pragma unroll
@@ -389,26 +394,32 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     }, kslice, std::integral_constant<int, 1>{});
 }
 
-// OIHW -> [Cout/128][TP][64 lanes][4]: lane l, slot q holds W[co = 128 T + 32 q + (l & 31)][ci = 2 s + (l >> 5)][tap]
+// OIHW -> [Cout/(32 bands)][TP][64 lanes][bands]: lane l, slot q holds W[co = 32 bands T + 32 q + (l & 31)][ci = 2 s + (l >> 5)][tap]
 // for k-step = s * taps + tap (channel-major, tap-inner); zero beyond Cout / Cin and in the 16-step tail.
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, int S, int TP,
-                                        int ntile, float* __restrict__ out, size_t total) {
+                                        float* __restrict__ out, size_t sec4, size_t sec2, size_t total) {
+    // three copies back to back, `bands` = 32-row bands per tile (4 / 2 / 1 for the 128- / 64- / 32-row copies), each
+    // laid out [tile][step][lane][band] and followed by its zero tail
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int q = (int)(i & 3);
-    const int lane = (int)((i >> 2) & 63);
-    const size_t stepg = i >> 8;
+    const size_t at = i;
+    int bands = 4;
+    if (i >= sec4) { i -= sec4; bands = 2; if (i >= sec2) { i -= sec2; bands = 1; } }
+    const int ntile = (Cout + 32 * bands - 1) / (32 * bands);
+    const int q = (int)(i % bands);
+    const int lane = (int)((i / bands) & 63);
+    const size_t stepg = i / ((size_t)bands * 64);
     const int tile = (int)(stepg / TP);
     const int step = (int)(stepg - (size_t)tile * TP);
     float v = 0.0f;
     const int taps = ks * ks;
     if (tile < ntile && step < TP) {
         const int s = step / taps, tap = step - s * taps;
-        const int co = tile * 128 + 32 * q + (lane & 31);
+        const int co = tile * 32 * bands + 32 * q + (lane & 31);
         const int ci = 2 * s + (lane >> 5);
         if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * (ks * ks) + tap];
     }
-    out[i] = v;
+    out[at] = v;
 }
 
 __global__ void nonneg_reparam_kernel(const float* __restrict__ p, float bound, float pedestal, float* __restrict__ out,
@@ -425,9 +436,14 @@ inline int pairs_padded(int Cin, int ks) {        // 1x1 loops advance a whole p
     return ks == 1 ? (S + 15) & ~15 : S;
 }
 inline int steps_padded(int Cin, int ks) { return pairs_padded(Cin, ks) * ks * ks; }
-inline size_t general_floats(int Cout, int Cin, int ks) {      // operand stream of conv_mfma_kernel
-    const size_t ntile = (size_t)(Cout + 127) / 128;
-    return (ntile * (size_t)steps_padded(Cin, ks) + 16) * 256;   // + 16 zero steps read by the prefetch tail
+// The operand stream of conv_mfma_kernel exists once per tile height: 128-, 64- and 32-row copies, each with its own
+// 16 zero steps for the prefetch tail.
+inline size_t section_floats(int Cout, int Cin, int ks, int bands) {
+    const size_t ntile = (size_t)(Cout + 32 * bands - 1) / (32 * bands);
+    return (ntile * (size_t)steps_padded(Cin, ks) + 16) * 64 * bands;
+}
+inline size_t general_floats(int Cout, int Cin, int ks) {
+    return section_floats(Cout, Cin, ks, 4) + section_floats(Cout, Cin, ks, 2) + section_floats(Cout, Cin, ks, 1);
 }
 
 template <int MB, int NB, int PF3A, int PF3B, int PF1>
@@ -469,10 +485,9 @@ extern "C" int mcq_pack_conv_weight_f32(const float* w, int32_t Cout, int32_t Ci
                                         void* stream) {
     if (!w || !out || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return MCQ_EINVAL;
     const size_t total = general_floats(Cout, Cin, ksize);
-    const int S = pairs_padded(Cin, ksize), TP = steps_padded(Cin, ksize), ntile = (Cout + 127) / 128;
-    const unsigned blocks = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, ksize, S,
-                       TP, ntile, out, total);
+    const int S = pairs_padded(Cin, ksize), TP = steps_padded(Cin, ksize);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
+                       ksize, S, TP, out, section_floats(Cout, Cin, ksize, 4), section_floats(Cout, Cin, ksize, 2), total);
     if (MCQ_HEAD16 && head16_shape(Cout, ksize)) {      // second copy in the 16-row operand order of conv_head16_kernel
         const size_t t16 = head16_floats(Cin);
         hipLaunchKernelGGL(pack_head16_kernel, dim3((unsigned)((t16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
@@ -504,7 +519,10 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     if ((uint64_t)d->Cin * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
 
     ConvK k;
-    k.x = d->x; k.wp = d->w_packed; k.bias = d->bias; k.y = d->y; k.y2 = d->y_silu; k.res = d->res; k.mul = d->mul; k.gid = d->gate_id;
+    k.x = d->x; k.wp = d->w_packed;
+    k.wp64 = k.wp + section_floats(d->Cout, d->Cin, d->ksize, 4);
+    k.wp32 = k.wp64 + section_floats(d->Cout, d->Cin, d->ksize, 2);
+    k.bias = d->bias; k.y = d->y; k.y2 = d->y_silu; k.res = d->res; k.mul = d->mul; k.gid = d->gate_id;
     k.N = d->N; k.Cin = d->Cin; k.H = d->H; k.W = d->W; k.Cout = d->Cout;
     k.ks = d->ksize; k.stride = d->stride;
     const int pad = d->ksize / 2;

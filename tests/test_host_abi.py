@@ -32,11 +32,16 @@ def test_library_exports_every_declared_symbol():
 def test_size_queries_run_without_a_gpu():
     from mcquic_amd import _lib
     lib = _lib.load()
-    # 128 -> 128 3x3: 576 k-steps (+16 tail) x 64 lanes x 4 floats
-    assert lib.mcq_packed_conv_weight_floats(128, 128, 3) == (576 + 16) * 256
-    assert lib.mcq_packed_conv_weight_floats(512, 128, 3) == (4 * 576 + 16) * 256
-    assert lib.mcq_packed_conv_weight_floats(128, 3, 3) == (18 + 16) * 256      # 2 channel pairs x 9 taps
-    assert lib.mcq_packed_conv_weight_floats(128, 8, 1) == (16 + 16) * 256      # 1x1: 4 pairs padded to one 16-deep ring
+    # the operand stream exists once per tile height (128 / 64 / 32 rows = 4 / 2 / 1 bands of 64 lanes), each copy with
+    # 16 zero tail steps; 128 -> 128 3x3 has 576 k-steps
+    def sections(cout, steps):
+        return sum(((cout + 32 * b - 1) // (32 * b) * steps + 16) * 64 * b for b in (4, 2, 1))
+    assert lib.mcq_packed_conv_weight_floats(128, 128, 3) == sections(128, 576)
+    assert lib.mcq_packed_conv_weight_floats(512, 128, 3) == sections(512, 576)
+    assert lib.mcq_packed_conv_weight_floats(128, 3, 3) == sections(128, 18)         # 2 channel pairs x 9 taps
+    assert lib.mcq_packed_conv_weight_floats(128, 8, 1) == sections(128, 16)         # 1x1: 4 pairs padded to one 16-deep ring
+    # <= 16 output channels, 3x3: + the 16-row copy of the image-head kernel (32 four-channel groups x 9 taps + 16 tail steps)
+    assert lib.mcq_packed_conv_weight_floats(12, 128, 3) == sections(12, 576) + (32 * 9 + 16) * 64
     assert lib.mcq_packed_conv_weight_floats(128, 128, 5) == 0                   # unsupported kernel size
     assert lib.mcq_packed_codebook_floats(2, 8192, 64) == (2 * 64 * 32 + 8) * 256 + 2 * 65 * 256      # + the 8-step ring tail
 

@@ -36,8 +36,43 @@ def tensor_version(t: torch.Tensor) -> int:
         return -1
 
 
-def _stream() -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+# Host-side cost matters where launches are ~10 us of GPU work (batch 1, the training step's ~4700 launches): the raw
+# stream handle and a device guard that does nothing when the tensor already lives on the current device replace
+# torch.cuda.current_stream() / torch.cuda.device(), which cost ~4 us and ~3 us per call.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _stream() -> int:
+    """hipStream_t of the current device's current stream (call inside `_guard`)."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _guard:
+    """`with _guard(t.device):` makes t's device current for the launch, like torch.cuda.device, but free when it already is."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device: torch.device):
+        self.idx = device.index
+        self.prev = -1
+
+    def __enter__(self):
+        if self.idx is not None and _cur_device is not None:
+            cur = _cur_device()
+            if cur != self.idx:
+                torch.cuda.set_device(self.idx)
+                self.prev = cur
+        elif self.idx is not None:
+            self.prev = torch.cuda.current_device()
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
@@ -50,7 +85,8 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device address for a `void*` parameter / struct field (ctypes converts the int; None = NULL)."""
+    return None if t is None else t.data_ptr()
 
 
 class PackedConv:
@@ -66,7 +102,7 @@ class PackedConv:
         lib = _lib.load()
         n = lib.mcq_packed_conv_weight_floats(cout, cin, kh)
         self.wp = torch.empty(n, dtype=torch.float32, device=weight.device)
-        with torch.cuda.device(weight.device):
+        with _guard(weight.device):
             check(lib.mcq_pack_conv_weight_f32(_ptr(weight), cout, cin, kh, _ptr(self.wp), _stream()), "mcq_pack_conv_weight_f32")
         self.bias = None if bias is None else _dev(bias.detach(), "bias").clone()
         self.cout, self.cin, self.ksize = cout, cin, kh
@@ -125,7 +161,7 @@ def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = F
     d = ConvDesc(_ptr(x), _ptr(w.wp), _ptr(w.bias), _ptr(y), _ptr(y2), _ptr(res), _ptr(mul), _ptr(gate_id),
                  n, cin, h, wd, w.cout, w.ksize, stride, flags, float(res_scale), tile)
     lib = _lib.load()
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(lib.mcq_conv2d_f32(ctypes.byref(d), _stream()), "mcq_conv2d_f32")
     if y2 is not None:
         setattr(y, _TWIN, y2)
@@ -136,7 +172,7 @@ def nonneg_reparam(p: torch.Tensor, bound: float, pedestal: float) -> torch.Tens
     """max(p, bound)^2 - pedestal (mcquic/nn/base.py:81-84), folded once per weight version."""
     p = _dev(p.detach(), "p")
     out = torch.empty_like(p)
-    with torch.cuda.device(p.device):
+    with _guard(p.device):
         check(_lib.load().mcq_nonneg_reparam_f32(_ptr(p), float(bound), float(pedestal), _ptr(out), p.numel(), _stream()),
               "mcq_nonneg_reparam_f32")
     return out
@@ -153,7 +189,7 @@ class PackedCodebook:
         lib = _lib.load()
         n = lib.mcq_packed_codebook_floats(m, k, d)
         self.packed = torch.empty(n, dtype=torch.float32, device=cb.device)
-        with torch.cuda.device(cb.device):
+        with _guard(cb.device):
             check(lib.mcq_vq_pack_codebook_f32(_ptr(cb), m, k, d, _ptr(self.packed), _stream()), "mcq_vq_pack_codebook_f32")
         self.codebook, self.m, self.k, self.d = cb, m, k, d
 
@@ -165,7 +201,7 @@ def vq_assign(x: torch.Tensor, cb: PackedCodebook) -> torch.Tensor:
     if c != cb.m * cb.d:
         raise ValueError(f"latent has {c} channels, codebook expects {cb.m}*{cb.d}")
     codes = torch.empty((n, cb.m, h, w), dtype=torch.int64, device=x.device)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(_lib.load().mcq_vq_assign_f32(_ptr(x), _ptr(cb.packed), _ptr(codes), n, cb.m, cb.d, h, w, cb.k, _stream()),
               "mcq_vq_assign_f32")
     return codes
@@ -179,7 +215,7 @@ def vq_gather(codes: torch.Tensor, cb: PackedCodebook, dual_silu: bool = False) 
         raise RuntimeError(f"codes carry m={m}, codebook has m={cb.m}")
     out = torch.empty((n, m * cb.d, h, w), dtype=torch.float32, device=codes.device)
     out2 = torch.empty_like(out) if dual_silu else None
-    with torch.cuda.device(codes.device):
+    with _guard(codes.device):
         check(_lib.load().mcq_vq_gather_f32(_ptr(codes), _ptr(cb.codebook), _ptr(out), _ptr(out2), n, m, cb.d, h, w, cb.k,
                                             _stream()), "mcq_vq_gather_f32")
     if out2 is not None:
@@ -195,7 +231,7 @@ def vq_logits(x: torch.Tensor, cb: PackedCodebook, temperature: torch.Tensor, bo
         raise ValueError(f"latent has {c} channels, codebook expects {cb.m}*{cb.d}")
     t = _dev(temperature.detach().reshape(-1), "temperature")
     logits = torch.empty((n, cb.m, h, w, cb.k), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(_lib.load().mcq_vq_logits_f32(_ptr(x), _ptr(cb.packed), _ptr(t), float(bound), _ptr(logits), n, cb.m, cb.d, h, w,
                                             cb.k, _stream()), "mcq_vq_logits_f32")
     return logits
@@ -214,7 +250,7 @@ def vq_gumbel_sample(logits: torch.Tensor, u_drop: torch.Tensor, u_gumbel: torch
     codes = torch.empty((n, m, h, w), dtype=torch.int64, device=logits.device)
     index = torch.empty_like(codes)
     hot = torch.empty((n, m, h, w), dtype=torch.float32, device=logits.device)
-    with torch.cuda.device(logits.device):
+    with _guard(logits.device):
         check(_lib.load().mcq_vq_gumbel_sample_f32(_ptr(logits), _ptr(u_drop), _ptr(u_gumbel), _ptr(freq), _ptr(expo), _ptr(codes),
                                                    _ptr(index), _ptr(hot), n, m, h, w, k, _stream()), "mcq_vq_gumbel_sample_f32")
     return codes, index, hot
@@ -226,7 +262,7 @@ def vq_dequant_soft(index: torch.Tensor, hot: torch.Tensor, cb: PackedCodebook) 
     hot = _dev(hot, "sample_hot")
     n, m, h, w = index.shape
     out = torch.empty((n, m * cb.d, h, w), dtype=torch.float32, device=index.device)
-    with torch.cuda.device(index.device):
+    with _guard(index.device):
         check(_lib.load().mcq_vq_dequant_soft_f32(_ptr(index), _ptr(hot), _ptr(cb.codebook), _ptr(out), n, m, cb.d, h, w, cb.k,
                                                   _stream()), "mcq_vq_dequant_soft_f32")
     return out
@@ -238,7 +274,7 @@ def add(a: torch.Tensor, b: torch.Tensor, dual_silu: bool = False) -> torch.Tens
         raise ValueError("add: shape mismatch")
     out = torch.empty_like(a)
     out2 = torch.empty_like(a) if dual_silu else None
-    with torch.cuda.device(a.device):
+    with _guard(a.device):
         check(_lib.load().mcq_add_f32(_ptr(a), _ptr(b), _ptr(out), _ptr(out2), a.numel(), _stream()), "mcq_add_f32")
     if out2 is not None:
         setattr(out, _TWIN, out2)
@@ -249,7 +285,7 @@ def detransform(x: torch.Tensor) -> torch.Tensor:
     """[-1, 1] fp32 -> uint8 (mcquic/utils/vision.py:143-146)."""
     x = _dev(x, "x")
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(_lib.load().mcq_detransform_u8(_ptr(x), _ptr(out), x.numel(), _stream()), "mcq_detransform_u8")
     return out
 
@@ -273,7 +309,7 @@ def ms_ssim(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         raise ValueError(f"MS-SSIM needs image sides larger than 160 pixels, got {h}x{w}")
     ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
     out = torch.empty(n, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(lib.mcq_ms_ssim_u8(_ptr(x), _ptr(y), _ptr(out), _ptr(ws), n, c, h, w, _stream()), "mcq_ms_ssim_u8")
     return out
 
@@ -283,7 +319,7 @@ def sqdiff_sum(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     x, y = _u8_pair(x, y)
     n = x.shape[0]
     out = torch.empty(n, dtype=torch.int64, device=x.device)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(_lib.load().mcq_sqdiff_sum_u8(_ptr(x), _ptr(y), _ptr(out), x[0].numel(), n, _stream()), "mcq_sqdiff_sum_u8")
     return out
 
@@ -293,7 +329,7 @@ def nchw_to_nhwc(x: torch.Tensor, square: bool = False) -> torch.Tensor:
     x = _dev(x, "x")
     n, c, h, w = x.shape
     out = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(_lib.load().mcq_nchw_to_nhwc_f32(_ptr(x), _ptr(out), n, c, h * w, int(square), _stream()), "mcq_nchw_to_nhwc_f32")
     return out
 
@@ -310,7 +346,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
     ws = torch.empty(lib.mcq_conv2d_wgrad_workspace_floats(n, cin, h, w, cout, ksize, stride), dtype=torch.float32, device=x.device)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(lib.mcq_nchw_to_nhwc_pair_f32(_ptr(x), _ptr(xt), cin, h * w, int(square_x), _ptr(dy), _ptr(dyt), cout, ho * wo, n,
                                             _stream()), "mcq_nchw_to_nhwc_pair_f32")
         check(lib.mcq_conv2d_wgrad_f32(_ptr(xt), _ptr(dyt), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, ksize, stride,
@@ -323,7 +359,7 @@ def channel_sum(x: torch.Tensor) -> torch.Tensor:
     n, c, h, w = x.shape
     out = torch.empty((c,), dtype=torch.float32, device=x.device)
     ws = torch.empty((min(n, 16) * c,), dtype=torch.float32, device=x.device) if n > 1 else None
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(_lib.load().mcq_channel_sum_f32(_ptr(x), _ptr(out), _ptr(ws), n, c, h * w, _stream()), "mcq_channel_sum_f32")
     return out
 
@@ -331,7 +367,7 @@ def channel_sum(x: torch.Tensor) -> torch.Tensor:
 def silu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     x, dy = _dev(x, "x"), _dev(dy, "dy")
     dx = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(_lib.load().mcq_silu_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _stream()), "mcq_silu_bwd_f32")
     return dx
 
@@ -339,7 +375,7 @@ def silu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
 def gate_bwd(a: torch.Tensor, b: torch.Tensor, dout: torch.Tensor):
     a, b, dout = _dev(a, "a"), _dev(b, "b"), _dev(dout, "dout")
     da, db = torch.empty_like(a), torch.empty_like(a)
-    with torch.cuda.device(a.device):
+    with _guard(a.device):
         check(_lib.load().mcq_gate_bwd_f32(_ptr(a), _ptr(b), _ptr(dout), _ptr(da), _ptr(db), a.numel(), _stream()), "mcq_gate_bwd_f32")
     return da, db
 
@@ -347,7 +383,7 @@ def gate_bwd(a: torch.Tensor, b: torch.Tensor, dout: torch.Tensor):
 def gdn_bwd_prep(x: torch.Tensor, s: torch.Tensor, dy: torch.Tensor, inverse: bool):
     x, s, dy = _dev(x, "x"), _dev(s, "s"), _dev(dy, "dy")
     dxd, ds = torch.empty_like(x), torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(_lib.load().mcq_gdn_bwd_prep_f32(_ptr(x), _ptr(s), _ptr(dy), int(inverse), _ptr(dxd), _ptr(ds), x.numel(), _stream()),
               "mcq_gdn_bwd_prep_f32")
     return dxd, ds
@@ -357,7 +393,7 @@ def pixel_unshuffle2(x: torch.Tensor) -> torch.Tensor:
     x = _dev(x, "x")
     n, c, h2, w2 = x.shape
     out = torch.empty((n, c * 4, h2 // 2, w2 // 2), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(_lib.load().mcq_pixel_unshuffle2_f32(_ptr(x), _ptr(out), n, c, h2 // 2, w2 // 2, _stream()), "mcq_pixel_unshuffle2_f32")
     return out
 
@@ -365,7 +401,7 @@ def pixel_unshuffle2(x: torch.Tensor) -> torch.Tensor:
 def silu(x: torch.Tensor) -> torch.Tensor:
     x = _dev(x, "x")
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(_lib.load().mcq_silu_f32(_ptr(x), _ptr(y), x.numel(), _stream()), "mcq_silu_f32")
     return y
 
@@ -373,7 +409,7 @@ def silu(x: torch.Tensor) -> torch.Tensor:
 def gate(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     a, b, x = _dev(a, "a"), _dev(b, "b"), _dev(x, "x")
     out = torch.empty_like(a)
-    with torch.cuda.device(a.device):
+    with _guard(a.device):
         check(_lib.load().mcq_gate_f32(_ptr(a), _ptr(b), _ptr(x), _ptr(out), a.numel(), _stream()), "mcq_gate_f32")
     return out
 
@@ -381,7 +417,7 @@ def gate(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 def axpby(a: torch.Tensor, b: torch.Tensor, alpha: float, beta: float) -> torch.Tensor:
     a, b = _dev(a, "a"), _dev(b, "b")
     out = torch.empty_like(a)
-    with torch.cuda.device(a.device):
+    with _guard(a.device):
         check(_lib.load().mcq_axpby_f32(_ptr(a), _ptr(b), float(alpha), float(beta), _ptr(out), a.numel(), _stream()), "mcq_axpby_f32")
     return out
 
@@ -391,7 +427,7 @@ def vq_inner(x: torch.Tensor, cb: PackedCodebook) -> torch.Tensor:
     x = _dev(x, "x")
     n, c, h, w = x.shape
     out = torch.empty((n, cb.m, h, w, cb.k), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(_lib.load().mcq_vq_inner_f32(_ptr(x), _ptr(cb.packed), _ptr(out), n, cb.m, cb.d, h, w, cb.k, _stream()), "mcq_vq_inner_f32")
     return out
 
@@ -403,7 +439,7 @@ def vq_softmax_bwd(logits: torch.Tensor, u_gumbel: torch.Tensor, ds: torch.Tenso
     t = _dev(temperature.detach().reshape(-1), "temperature")
     rowsum = torch.empty((n, m, h, w), dtype=torch.float32, device=logits.device)
     dtrow = torch.empty_like(rowsum)
-    with torch.cuda.device(logits.device):
+    with _guard(logits.device):
         check(_lib.load().mcq_vq_softmax_bwd_f32(_ptr(logits), _ptr(u_gumbel), _ptr(ds), _ptr(t), float(bound), _ptr(rowsum), _ptr(dtrow),
                                                  n, m, h, w, k, _stream()), "mcq_vq_softmax_bwd_f32")
     return rowsum, dtrow
@@ -417,7 +453,7 @@ def vq_soft_bwd(ddist: torch.Tensor, rowsum: torch.Tensor, x: torch.Tensor, ddeq
     xt, dqt = nchw_to_nhwc(x), nchw_to_nhwc(ddeq)
     dx = torch.empty_like(x)
     dcb = torch.empty_like(cb.codebook)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         check(_lib.load().mcq_vq_soft_bwd_f32(_ptr(ddist), _ptr(rowsum), _ptr(x), _ptr(xt), _ptr(dqt), _ptr(index), _ptr(hot),
                                               _ptr(cb.codebook), _ptr(dx), _ptr(dcb), n, m, cb.d, h, w, k, _stream()), "mcq_vq_soft_bwd_f32")
     return dx, dcb

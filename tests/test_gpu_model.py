@@ -55,6 +55,13 @@ def test_qp2_model_one_image(dev):
     _compare(dev, 128, 2, [8192, 2048, 512], n=1, h=256, w=384, seed=0, pix_tol=1e-4)
 
 
+def test_qp2_model_kodak_shape_batch(dev):
+    """The BASELINE geometry itself: three 768x512 images through the qp=2 model against the CPU oracle (~20 s of CPU) --
+    every tile variant of the three latent levels and the image-head kernel at the size the benchmark runs them."""
+    mism, err = _compare(dev, 128, 2, [8192, 2048, 512], n=3, h=768, w=512, seed=5, pix_tol=1e-4)
+    assert mism == 0, f"{mism} audited near-tie code mismatches (none has been observed so far)"
+
+
 def test_encode_is_batch_invariant(dev):
     from mcquic_amd import Compressor
     sd = R.make_state_dict(128, 2, [8192, 2048, 512], seed=0)

@@ -73,27 +73,14 @@ class FileHeader:
     imageSize: ImageSize
 
     def __init__(self, version: str, qp: str, codeSize: CodeSize, imageSize: ImageSize):
-        if versionCheck(version):
-            self.qp = qp
-            self.version = version
-            self.codeSize = codeSize
-            self.imageSize = imageSize
+        versionCheck(version)                      # raises for files this build cannot read
+        self.qp, self.version, self.codeSize, self.imageSize = qp, version, codeSize, imageSize
 
-    @property
-    def QuantizationParameter(self) -> str:
-        return str(self.qp)
-
-    @property
-    def Version(self) -> str:
-        return self.version
-
-    @property
-    def CodeSize(self) -> CodeSize:
-        return self.codeSize
-
-    @property
-    def ImageSize(self) -> ImageSize:
-        return self.imageSize
+    # the reference's read-only aliases of the four fields
+    QuantizationParameter = property(lambda self: str(self.qp))
+    Version = property(lambda self: self.version)
+    CodeSize = property(lambda self: self.codeSize)
+    ImageSize = property(lambda self: self.imageSize)
 
 
 @dataclass
@@ -101,13 +88,8 @@ class File:
     fileHeader: FileHeader
     contents: List[bytes]
 
-    @property
-    def FileHeader(self) -> FileHeader:
-        return self.fileHeader
-
-    @property
-    def Content(self) -> List[bytes]:
-        return self.contents
+    FileHeader = property(lambda self: self.fileHeader)
+    Content = property(lambda self: self.contents)
 
     def serialize(self) -> bytes:
         import msgpack
@@ -135,9 +117,7 @@ class File:
             raise ValueError(f"not a .mcq document: {e}") from e
         return File(header, contents)
 
-    @property
-    def BPP(self) -> float:
-        return sum(len(x) for x in self.contents) * 8 / self.FileHeader.ImageSize.Pixels
+    BPP = property(lambda self: self.size() * 8 / self.fileHeader.imageSize.Pixels)      # bits per image pixel
 
     def size(self, human: bool = False) -> Union[int, str]:
         size = sum(len(x) for x in self.contents)

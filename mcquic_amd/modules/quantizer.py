@@ -10,7 +10,7 @@ the epilogue of latentHead's last conv.
 from __future__ import annotations
 
 import math
-from typing import Callable, Dict, List, Optional, Tuple, Union
+from typing import Callable, Dict, List, Optional, Union
 
 import torch
 from torch import nn

@@ -22,7 +22,7 @@ import torch
 from torch import nn
 
 from .. import autograd as AG
-from .convs import Conv2d, PixelShuffle3x3, conv1x1, conv3x3, pixelShuffle3x3
+from .convs import conv1x1, conv3x3, pixelShuffle3x3
 from .gdn import GenDivNorm, InvGenDivNorm
 
 __all__ = ["ResidualBlockWithStride", "ResidualBlockShuffle", "ResidualBlock", "AttentionBlock"]

@@ -17,7 +17,7 @@ the reference, this oracle and the HIP implementation.
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional
 
 import torch
 import torch.nn.functional as F

@@ -1,6 +1,5 @@
 """GPU: backward kernels of the training step against torch.autograd on the CPU (the same formulas the reference
 gets from autograd over nn.Conv2d / SiLU / GDN / sigmoid)."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

@@ -63,8 +63,10 @@ typedef struct mcq_conv_desc {
 /* Number of floats mcq_pack_conv_weight_f32 writes for a [Cout, Cin, ks, ks] weight. */
 size_t mcq_packed_conv_weight_floats(int32_t Cout, int32_t Cin, int32_t ksize);
 
-/* Re-lay a dense OIHW weight (nn.Conv2d.weight, mcquic/nn/convs.py:77-100,257-276) into the
- * MFMA operand stream the conv kernel reads: [Cout/128][tap][Cin/2][64 lanes][4] (zero padded). */
+/* Re-lay a dense OIHW weight (nn.Conv2d.weight, mcquic/nn/convs.py:77-100,257-276) into the MFMA operand streams the
+ * conv kernels read: [Cout/128][Cin/2 x taps][64 lanes][4] followed by dense copies for the 64- and 32-row wave tiles
+ * ([Cout/64][..][64][2], [Cout/32][..][64][1]) and, for 3x3 layers with <= 16 output channels, the operand order of the
+ * 16-row image-head kernel; every copy zero padded (one launch). */
 int mcq_pack_conv_weight_f32(const float* w_oihw, int32_t Cout, int32_t Cin, int32_t ksize,
                              float* w_packed, void* stream);
 

@@ -12,9 +12,12 @@
 //           of a channel pair re-read the same rows back to back, so they hit L1 instead of being nine separate
 //           sweeps over the whole activation (tap-major measured 2.4-4.8x the algorithmic bytes at the L2 fabric).
 // A wave owns MB x NB accumulator tiles of 32 couts x 32 pixels and is a self-contained stream:
-// per k-step it issues one weight load (MB floats per lane) and NB activation loads (buffer
-// loads; out-of-image taps are turned into out-of-range offsets, for which the hardware returns
-// 0 = the conv's zero padding), PF steps ahead of the MFMAs that consume them.
+// per k-step it issues one weight load (MB floats per lane, from the copy packed for its tile height) and NB
+// activation loads (buffer loads; out-of-image taps are turned into out-of-range offsets, for which the hardware
+// returns 0 = the conv's zero padding), 9 resp. 18 k-steps ahead of the MFMAs that consume them.  Small layers split
+// the k-steps of a tile over 2 / 4 / 8 waves of a workgroup (LDS reduction); the epilogue (bias, GDN / IGDN, gate,
+// residual, SiLU, SiLU twin, PixelShuffle store) runs on buffer instructions without predication.
+// Build switches below (all measured on MI355X): ring depths, XCD-aware tile order, tile rules.
 #include <type_traits>
 
 #include "mcq_common.h"

@@ -64,17 +64,21 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
     }
 
     // |x_v|^2, sequential over the d channels of the group (both half-waves compute it redundantly)
+    // (sixteen independent loads per batch, both blocks together; the additions keep the channel order)
     float x2[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        float s = 0.0f;
-        unsigned off = pixoff[nb];
-        for (int c = 0; c < p.d; ++c) {
-            const float v = mcq_buffer_load(rsrc[nb], off);
-            s = s + v * v;
-            off += (unsigned)HW * 4u;
-        }
-        x2[nb] = s;
+    for (int nb = 0; nb < NB; ++nb) x2[nb] = 0.0f;
+    for (int c0 = 0; c0 < p.d; c0 += 16) {
+        float v[NB][16];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)      // channels past d are out of range = 0: they add +0
+                v[nb][i] = mcq_buffer_load(rsrc[nb], pixoff[nb] + (unsigned)(c0 + i) * (unsigned)HW * 4u);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x2[nb] = x2[nb] + v[nb][i] * v[nb][i];
     }
 
     f32x4v A[PF];

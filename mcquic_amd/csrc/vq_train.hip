@@ -72,11 +72,12 @@ __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
 #pragma unroll
     for (int nb = 0; nb < NP; ++nb) {
         float s = 0.0f;
-        unsigned off = pixoff[nb];
-        for (int c = 0; c < p.d; ++c) {
-            const float v = mcq_buffer_load(rsrc[nb], off);
-            s = s + v * v;
-            off += (unsigned)HW * 4u;
+        for (int c0 = 0; c0 < p.d; c0 += 16) {          // sixteen independent loads per batch, additions in channel order
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = mcq_buffer_load(rsrc[nb], pixoff[nb] + (unsigned)(c0 + i) * (unsigned)HW * 4u);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s = s + v[i] * v[i];
         }
         f32x16 z;
 #pragma unroll

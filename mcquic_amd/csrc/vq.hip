@@ -21,8 +21,13 @@ namespace {
 // tile fully unrolled the whole tile body is straight-line code and hipcc counts the prefetch ring exactly
 // (`s_waitcnt vmcnt(N)` per step); around a run-time inner loop it merges the loop-entry and back-edge states
 // conservatively and drains the ring at every loop head (112 -> 117 TFLOP/s on config #4).
-template <int SPC>
+// XLDS (d = 256): a wave re-reads its 64 vectors (64 KB) for each of its codeword tiles; that does not fit L1, and
+// taking it from L2 every time cost 7 % (ablation: activation loads forced to one hot line 122 -> 130 TFLOP/s).  In this
+// mode the four waves of a workgroup are the four codeword slices of ONE vector tile, which they stage in LDS once
+// ([channel][64 vectors]: the B operand of a k-step is then two conflict-free ds_read_b32 per lane).
+template <int SPC, bool XLDS>
 __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
+    __shared__ float xs[XLDS ? 2 * SPC * 64 : 1];
     constexpr int MB = VQ_MB, NB = VQ_NB, PF = VQ_PF;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -63,6 +68,16 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
         rsrc[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.x + ((size_t)n * p.m + g) * (size_t)p.d * HW), group_bytes);
     }
 
+    if (XLDS) {
+        // wave w stages channels w, w + 4, ... of the tile (its own lanes' pixels: every slice has the same geometry)
+        for (int c = wave; c < 2 * SPC; c += 4) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                if (hi == 0) xs[c * 64 + nb * 32 + j] = mcq_buffer_load(rsrc[nb], pixoff[nb] + (unsigned)c * (unsigned)HW * 4u);
+        }
+        __syncthreads();
+    }
+
     // |x_v|^2, sequential over the d channels of the group (both half-waves compute it redundantly)
     // (sixteen independent loads per batch, both blocks together; the additions keep the channel order)
     float x2[NB];
@@ -99,7 +114,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
         A[st] = *reinterpret_cast<const f32x4v*>(wl);
         wl += 256;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) B[st][nb] = mcq_buffer_load(rsrc[nb], voffL[nb] + soffL);
+        for (int nb = 0; nb < NB; ++nb)
+            B[st][nb] = XLDS ? xs[(2 * ls + hi) * 64 + nb * 32 + j] : mcq_buffer_load(rsrc[nb], voffL[nb] + soffL);
         ++ls;
         soffL += step_bytes;
         if (ls == p.Sp) { ls = 0; soffL = 0; }
@@ -354,13 +370,15 @@ extern "C" int mcq_vq_assign_f32(const float* x, const float* cb_packed, int64_t
         const double cost = (double)((waves + 2047) / 2048) / (double)(1 << lg);
         if (cost < best_cost - 1e-12) { best_cost = cost; cs_log2 = lg; }
     }
+    if (p.Sp == 128 && p.ntile >= 4) cs_log2 = 2;          // the LDS-staged mode: four slices share one vector tile
     p.cs_log2 = cs_log2;
     const int per_wg = 4 >> cs_log2;
     const unsigned gx = (unsigned)((vtiles + per_wg - 1) / per_wg);
     const dim3 grid(gx, (unsigned)m);
-    if (p.Sp == 32) hipLaunchKernelGGL(vq_assign_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, p);          // d = 64
-    else if (p.Sp == 128) hipLaunchKernelGGL(vq_assign_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, p);   // d = 256
-    else hipLaunchKernelGGL(vq_assign_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (p.Sp == 32) hipLaunchKernelGGL((vq_assign_kernel<32, false>), grid, dim3(256), 0, (hipStream_t)stream, p);          // d = 64
+    else if (p.Sp == 128 && cs_log2 == 2) hipLaunchKernelGGL((vq_assign_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, p);   // d = 256
+    else if (p.Sp == 128) hipLaunchKernelGGL((vq_assign_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((vq_assign_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     return mcq_check_launch();
 }
 

@@ -274,8 +274,15 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        # RCCL writes its version banner through C stdio, which a pipe only sees at exit: flush it out first so that the
+        # ONE line below is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)          # the ONE line, after anything RCCL prints on the way out
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

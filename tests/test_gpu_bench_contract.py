@@ -1,0 +1,54 @@
+"""GPU: the bench.py output contract (one JSON line, required keys, roofline / cpu_baseline objects) on a tiny run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
+                          *extra], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert lines, "no output"
+    return json.loads(lines[-1])                 # the JSON line is the last thing printed
+
+
+def test_bench_line_has_the_contract_fields(dev):
+    d = _run()
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-2 * d["value"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+    assert d["parity"]["code_mismatches"] == 0
+
+
+def test_bench_under_a_process_group(dev):
+    """RANK / WORLD_SIZE in the environment (what torch.distributed.run sets): RCCL path at world size 1."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
+                          "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "cpu_baseline" not in d
+
+
+def test_import_sets_hw_queue_default():
+    out = subprocess.run([sys.executable, "-c", "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import mcquic_amd; "
+                          "print(os.environ['GPU_MAX_HW_QUEUES'])"], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "8", out.stderr[-500:]

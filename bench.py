@@ -270,18 +270,18 @@ def main():
             gpu_pix = model.decode([c.to(dev) for c in cpu_codes])
             out["cpu_baseline"] = base
             out["parity"] = parity_report([c[:nb] for c in codes], gpu_pix, cpu_codes, cpu_pix)
+    # RCCL writes its version banner through C stdio, which a pipe only sees at exit: every rank flushes it out before the
+    # last barrier so that rank 0's ONE line below is the last thing on stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # RCCL writes its version banner through C stdio, which a pipe only sees at exit: flush it out first so that the
-        # ONE line below is the last thing on stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        sys.stdout.flush()
         print(json.dumps(out), flush=True)
 
 

@@ -208,21 +208,21 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
                 if (PRO == PRO_SQUARE) v = v * v;
                 bv[nb] = v;
             }
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[sa], mb), bv[nb],
-                                                                       acc[mb][nb], 0, 0, 0);
-            // refill the slots with the steps PFA / PFB ahead (over-reads past the slice: the packed weights carry
-            // a zero tail, and activation offsets past the last channel are out of range = 0)
-            A[sa] = *reinterpret_cast<const avec_t*>(wl);
-            wl += 64 * MB;
+            // MFMAs pixel-block major, and each activation slot refilled right after its last use: the refill of block 0
+            // issues while the MFMAs of block 1 run instead of queueing behind all MB x NB of them together with the
+            // other loads (+1.6 % on the large layers); over-reads past the slice are harmless (the packed weights carry a
+            // zero tail, activation offsets past the last channel are out of range = 0)
             const int tl = TAPS == 9 ? (u + PFB) % 9 : 0;                       // tap of the step being loaded
             const int ds = TAPS == 9 ? (u + PFB) / 9 : u + PFB;                 // its channel-pair distance
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[sa], mb), bv[nb], acc[mb][nb], 0, 0, 0);
                 B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tl] + soff + (unsigned)ds * step_bytes);
+            }
+            A[sa] = *reinterpret_cast<const avec_t*>(wl);
+            wl += 64 * MB;
 #if MCQ_SCHED_FENCE
             // keep the software pipeline as written: without this fence the scheduler sinks the loads of all U
             // steps to the end of the (branch-free) body and waits for them one step later

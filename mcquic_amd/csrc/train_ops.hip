@@ -210,14 +210,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradK p) {
     for (int t = 0; t < steps; t += PF) {
 #pragma unroll
         for (int st = 0; st < PF; ++st) {
+            if (EVEN) {
+                // ci-block major, every operand slot refilled right after its last use (the loads spread between the
+                // MFMAs instead of queueing behind all eight); same addressing as issue()
+                const bool ok0 = row_ok && xi0 >= 0 && xi0 < p.W;
+                const bool ok1 = row_ok && xi0 + p.stride >= 0 && xi0 + p.stride < p.W;
+                const unsigned base_u = row_base + (unsigned)(xi0 * p.Cin * 4);
+                const bool ok = hi ? ok1 : ok0;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+                for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st][mb], B[st][nb], acc[mb][nb], 0, 0, 0);
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st][mb], B[st][nb], acc[mb][nb], 0, 0, 0);
+                    B[st][nb] = mcq_buffer_load(rx, ok ? xlane[nb] + base_u : MCQ_OOB);
+                }
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) bsum[mb] = bsum[mb] + A[st][mb];     // (every wave: cheaper than a branch per step)
-            issue(st);
+                for (int mb = 0; mb < MB; ++mb) {
+                    bsum[mb] = bsum[mb] + A[st][mb];                 // (every wave: cheaper than a branch per step)
+                    A[st][mb] = mcq_buffer_load_s(rd, dbase[mb], dstep);
+                }
+                dstep += dinc;
+                xo_u += 2;
+                xi0 += 2 * p.stride;
+                if (xo_u >= p.Wo) {
+                    xo_u = 0; ++yo_u;
+                    if (yo_u >= p.Ho) { yo_u = 0; ++n_u; }
+                    xi0 = dx - pad;
+                    const int yi = yo_u * p.stride + dy - pad;
+                    row_ok = n_u < p.N && yi >= 0 && yi < p.H;
+                    row_base = row_ok ? (unsigned)(((n_u * p.H + yi) * p.W) * p.Cin * 4) : 0u;
+                }
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st][mb], B[st][nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) bsum[mb] = bsum[mb] + A[st][mb];
+                issue(st);
+            }
             __builtin_amdgcn_sched_barrier(0);                  // keep the software pipeline as written
         }
     }

@@ -145,12 +145,19 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
                 for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
         auto step = [&](int st) {
+            // vector-block major, each activation slot refilled right after its last use (as in conv_mfma_kernel)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+            for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                for (int mb = 0; mb < MB; ++mb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st][mb], B[st][nb], acc[mb][nb], 0, 0, 0);
-            issue(st);
+                B[st][nb] = XLDS ? xs[(2 * ls + hi) * 64 + nb * 32 + j] : mcq_buffer_load(rsrc[nb], voffL[nb] + soffL);
+            }
+            A[st] = *reinterpret_cast<const f32x4v*>(wl);
+            wl += 256;
+            ++ls;
+            soffL += step_bytes;
+            if (ls == p.Sp) { ls = 0; soffL = 0; }
             // keep the software pipeline as written (without the fence hipcc regroups the loads of the body)
             __builtin_amdgcn_sched_barrier(0);
         };

@@ -126,11 +126,17 @@ __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
 #pragma unroll
             for (int st = 0; st < PF; ++st) {
 #pragma unroll
-                for (int nb = 0; nb < NP; ++nb)
+                for (int nb = 0; nb < NP; ++nb) {        // vector-block major; the slot is refilled right after its last use
 #pragma unroll
                     for (int wb = 0; wb < NW; ++wb)      // A operand = latent vectors (rows), B operand = codewords (cols)
                         acc[nb][wb] = __builtin_amdgcn_mfma_f32_32x32x2f32(B[st][nb], A[st][wb], acc[nb][wb], 0, 0, 0);
-                issue(st);
+                    B[st][nb] = mcq_buffer_load(rsrc[nb], voffL[nb] + soffL);
+                }
+                A[st] = *reinterpret_cast<const f32x4v*>(wl);
+                wl += 256;
+                ++ls;
+                soffL += step_bytes;
+                if (ls == p.Sp) { ls = 0; soffL = 0; }
                 // keep the software pipeline as written (without the fence hipcc regroups the loads of the body and
                 // waits for nearly all of them at the loop head: the ring then hides one step instead of PF)
                 __builtin_amdgcn_sched_barrier(0);

@@ -23,6 +23,11 @@
 #include "mcq_common.h"
 #include "../../include/mcquic_hip.h"
 
+// tuning ablations (never shipped): 1 = every activation load hits the same line, 2 = and every weight load, 3 = no
+// loads in the k-loop at all (the MFMA-issue bound of this loop structure); DESIGN.md section 4 has the numbers
+#ifndef MCQ_ABLATE
+#define MCQ_ABLATE 0
+#endif
 #ifndef MCQ_SCHED_FENCE
 #define MCQ_SCHED_FENCE 1
 #endif
@@ -219,10 +224,20 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[sa], mb), bv[nb], acc[mb][nb], 0, 0, 0);
+#if MCQ_ABLATE >= 3
+                asm volatile("" : "+v"(B[sb][nb]));
+#elif MCQ_ABLATE >= 1
+                B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][TAPS == 9 ? 4 : 0]);
+#else
                 B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tl] + soff + (unsigned)ds * step_bytes);
+#endif
             }
+#if MCQ_ABLATE < 3
             A[sa] = *reinterpret_cast<const avec_t*>(wl);
+#endif
+#if MCQ_ABLATE < 2
             wl += 64 * MB;
+#endif
 #if MCQ_SCHED_FENCE
             // keep the software pipeline as written: without this fence the scheduler sinks the loads of all U
             // steps to the end of the (branch-free) body and waits for them one step later

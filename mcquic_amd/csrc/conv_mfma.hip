@@ -28,6 +28,18 @@
 #ifndef MCQ_ABLATE
 #define MCQ_ABLATE 0
 #endif
+#ifndef MCQ_SALU_ADDR
+#define MCQ_SALU_ADDR 1
+#endif
+#ifndef MCQ_ABLATE_X
+#define MCQ_ABLATE_X 0
+#endif
+#ifndef MCQ_ABLATE_EPI
+#define MCQ_ABLATE_EPI 0     // 1 = skip the epilogue (no side loads, no stores)
+#endif
+#ifndef MCQ_PRIO
+#define MCQ_PRIO 0
+#endif
 #ifndef MCQ_SCHED_FENCE
 #define MCQ_SCHED_FENCE 1
 #endif
@@ -93,10 +105,42 @@ template <> __device__ __forceinline__ float a_elem<1>(const float& v, int) { re
 
 extern __shared__ __attribute__((aligned(16))) float mcq_lds[];
 
+// weight-ring load: 4 * MB bytes per lane from a buffer descriptor, per-lane byte offset + wave-uniform byte offset
+template <int MB> __device__ __forceinline__ typename AVec<MB>::T mcq_wload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ f32x4v mcq_wload<4>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+template <> __device__ __forceinline__ f32x2v mcq_wload<2>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+template <> __device__ __forceinline__ float mcq_wload<1>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
+#if MCQ_STAMPS
+// tuning aid (never shipped): per-wave s_memrealtime stamps (100 MHz) at entry / ring filled / k-loop done / stores issued
+__device__ unsigned long long* mcq_stamp_buf = nullptr;      // [0] = record counter, then 6 words per record
+__device__ __forceinline__ void mcq_stamp_write(unsigned long long t0, unsigned long long t1, unsigned long long t2, unsigned long long t3) {
+    if (mcq_stamp_buf == nullptr || (threadIdx.x & 63) != 0) return;
+    const unsigned long long rec = atomicAdd(mcq_stamp_buf, 1ull);
+    if (rec >= (1ull << 20)) return;
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* o = mcq_stamp_buf + 1 + rec * 6;
+    o[0] = hw; o[1] = xcc; o[2] = t0; o[3] = t1; o[4] = t2; o[5] = t3;
+}
+#define MCQ_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#else
+#define MCQ_STAMP(var)
+#endif
+
 template <int MB, int NB, int PRO, int PFA, int PFB, int TAPS, int OCC>
 __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     static_assert(TAPS == 1 ? PFA == PFB : ((9 % PFA == 0 || PFA % 9 == 0) && PFB % 9 == 0 && PFB % PFA == 0),
                   "ring depths must tile the unrolled body");
+    MCQ_STAMP(st0);
+    if (MCQ_PRIO) __builtin_amdgcn_s_setprio(MCQ_PRIO);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int KS = 1 << p.ks_log2;
@@ -129,6 +173,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     int img[NB], yo[NB], xo[NB];
     bool valid[NB];
     __amdgpu_buffer_rsrc_t rsrc[NB];
+    const char* xb[NB];                             // (wave-uniform) first byte of the block's image
     unsigned voff[NB][TAPS];                        // per-tap byte offset of this lane's pixel, or the OOB marker
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -144,7 +189,8 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
         yo[nb] = by * BH + ly;
         xo[nb] = bx * BW + lx;
         valid[nb] = pbv && yo[nb] < p.Ho && xo[nb] < p.Wo;
-        rsrc[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.x + (size_t)n * p.Cin * HW), plane_bytes);
+        xb[nb] = reinterpret_cast<const char*>(mcq_uniform_ptr(p.x + (size_t)n * p.Cin * HW));
+        rsrc[nb] = mcq_make_rsrc(xb[nb], plane_bytes);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
@@ -173,6 +219,15 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     const float* wl = MB == 4 ? p.wp + (((size_t)tile128 * p.TP + (size_t)s0 * TAPS) * 64 + lane) * 4 + q0
                     : MB == 2 ? p.wp64 + (((size_t)(co_base >> 6) * p.TP + (size_t)s0 * TAPS) * 64 + lane) * 2
                               : p.wp32 + ((size_t)(co_base >> 5) * p.TP + (size_t)s0 * TAPS) * 64 + lane;
+#if MCQ_SALU_ADDR
+    // the same stream as a wave-uniform base (SGPR pair, advanced by the scalar unit) plus a constant per-lane offset
+    const float* wbu = MB == 4 ? p.wp + ((size_t)tile128 * p.TP + (size_t)s0 * TAPS) * 256 + q0
+                     : MB == 2 ? p.wp64 + ((size_t)(co_base >> 6) * p.TP + (size_t)s0 * TAPS) * 128
+                               : p.wp32 + ((size_t)(co_base >> 5) * p.TP + (size_t)s0 * TAPS) * 64;
+    const __amdgpu_buffer_rsrc_t wr = mcq_make_rsrc(wbu, 0x7fffffffu);   // (the packed copies end in a zero tail: over-reads are in bounds)
+    const unsigned wlane = (unsigned)lane * (unsigned)(4 * MB);
+    unsigned wso = 0;
+#endif
     const unsigned step_bytes = 2u * (unsigned)HW * 4u;     // one channel pair further
     unsigned soff = (unsigned)s0 * step_bytes;
 
@@ -188,8 +243,13 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     if (active) {
 #pragma unroll
         for (int st = 0; st < PFA; ++st) {          // weights of steps 0 .. PFA-1 of the slice
+#if MCQ_SALU_ADDR
+            A[st] = mcq_wload<MB>(wr, wlane, wso);
+            wso += 256 * MB;
+#else
             A[st] = *reinterpret_cast<const avec_t*>(wl);
             wl += 64 * MB;
+#endif
         }
 #pragma unroll
         for (int st = 0; st < PFB; ++st) {          // activations of steps 0 .. PFB-1
@@ -200,7 +260,25 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
         }
     }
 
+    MCQ_STAMP(st1);
+    if (MCQ_PRIO) __builtin_amdgcn_s_setprio(0);
     for (int sp = 0; sp < npairs; sp += PAIRS_PER_ITER) {
+#if MCQ_SALU_ADDR
+        // Every VALU instruction between two MFMAs costs the matrix pipe ~10 cycles (tools/probes/mfma_issue.hip), so
+        // the k-loop has none: the channel-pair offset of an activation load lives in its buffer descriptor -- one per
+        // pixel block and channel pair of the body, rebuilt by the scalar unit each iteration with num_records shrunk
+        // accordingly (reads past the last channel stay out of range = 0) -- and the voffset is the bare tap offset.
+        constexpr int PFBP = TAPS == 9 ? PFB / 9 : PFB;      // look-ahead in channel pairs
+        __amdgpu_buffer_rsrc_t rB[NB][PAIRS_PER_ITER];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < PAIRS_PER_ITER; ++j) {
+                const unsigned off = soff + (unsigned)(PFBP + j) * step_bytes;
+                const int left = (int)plane_bytes - (int)off;      // (signed max: the unsigned saturating form is VALU-only)
+                rB[nb][j] = mcq_make_rsrc(xb[nb] + off, (unsigned)(left > 0 ? left : 0));
+            }
+#endif
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (TAPS == 9 && u > 0 && u % 9 == 0 && sp + u / 9 >= npairs) break;   // the slice ends inside the body
@@ -228,15 +306,26 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
                 asm volatile("" : "+v"(B[sb][nb]));
 #elif MCQ_ABLATE >= 1
                 B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][TAPS == 9 ? 4 : 0]);
+#elif MCQ_ABLATE_X == 1      /* no per-step address add */
+                B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tl]);
+#elif MCQ_ABLATE_X == 2      /* no activation loads */
+                asm volatile("" : "+v"(B[sb][nb]));
+#elif MCQ_SALU_ADDR
+                B[sb][nb] = mcq_buffer_load(rB[nb][ds - PFBP], voff[nb][tl]);
 #else
                 B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tl] + soff + (unsigned)ds * step_bytes);
 #endif
             }
-#if MCQ_ABLATE < 3
+#if MCQ_SALU_ADDR
+            A[sa] = mcq_wload<MB>(wr, wlane, wso);
+            wso += 256 * MB;
+#else
+#if MCQ_ABLATE < 3 && MCQ_ABLATE_X != 3      /* X == 3: no weight loads */
             A[sa] = *reinterpret_cast<const avec_t*>(wl);
 #endif
 #if MCQ_ABLATE < 2
             wl += 64 * MB;
+#endif
 #endif
 #if MCQ_SCHED_FENCE
             // keep the software pipeline as written: without this fence the scheduler sinks the loads of all U
@@ -247,6 +336,8 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
         soff += (unsigned)PAIRS_PER_ITER * step_bytes;
     }
 
+    MCQ_STAMP(st2);
+    if (MCQ_PRIO) __builtin_amdgcn_s_setprio(MCQ_PRIO);
     // ---- epilogue ---------------------------------------------------------------------------
     // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row tile, the 16 output channels
     // row(r) + 4 hi, row(r) = (r & 3) + 8 (r >> 2).  Element (co, pixel) of image n sits at byte (co HoWo + pixel) 4 of
@@ -368,10 +459,19 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     };
 
     if (KS == 1) {
+#if MCQ_ABLATE_EPI
+        float keep = 0.0f;
+        for (int mb = 0; mb < MB; ++mb) for (int nb = 0; nb < NB; ++nb) for (int r = 0; r < 16; ++r) keep += acc[mb][nb][r];
+        run_epilogue(keep == 12345.678f, [&](int mi, int nb, float (&v)[16]) {
+#else
         run_epilogue(true, [&](int mi, int nb, float (&v)[16]) {           // (mi, nb are constants once unrolled)
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = acc[mi][nb][r];
         }, 0, std::integral_constant<int, MB>{});
+#if MCQ_STAMPS
+        { MCQ_STAMP(st3); mcq_stamp_write(st0, st1, st2, st3); }
+#endif
         return;
     }
 
@@ -636,3 +736,9 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     if (MB == 1 && NB == 1) return launch_tile<1, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
     return MCQ_EINVAL;
 }
+
+#if MCQ_STAMPS
+extern "C" int mcq_stamp_buffer(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(mcq_stamp_buf), &buf, sizeof(buf));
+}
+#endif

@@ -101,7 +101,12 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
     const int per_slice = (p.ntile + CS - 1) >> p.cs_log2;
     const int tile0 = slice * per_slice;                     // this wave's codeword tiles: [tile0, tile1)
     const int tile1 = active ? (tile0 + per_slice < p.ntile ? tile0 + per_slice : p.ntile) : tile0;
-    const float* wl = p.cbp + (((size_t)g * p.ntile + tile0) * p.Sp * 64 + lane) * 4;
+    // operand addresses stay off the vector ALU inside the k-loop (a VALU instruction between two MFMAs costs the
+    // matrix pipe ~10 cycles, tools/probes/mfma_issue.hip): per-lane offsets are loop constants, the running part is
+    // a wave-uniform soffset advanced by the scalar unit
+    const __amdgpu_buffer_rsrc_t wr = mcq_make_rsrc(p.cbp + ((size_t)g * p.ntile + tile0) * p.Sp * 256, 0x7fffffffu);
+    const unsigned wlane = (unsigned)lane * 16u;
+    unsigned wso = 0;
     const f32x4v* c2l = reinterpret_cast<const f32x4v*>(p.c2p) + ((size_t)g * (p.ntile + 1) + tile0) * 64 + lane;
     int ls = 0;
     unsigned soffL = 0;
@@ -111,11 +116,11 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
     for (int nb = 0; nb < NB; ++nb) voffL[nb] = valid[nb] ? pixoff[nb] + (unsigned)(hi * HW) * 4u : MCQ_OOB;
 
     auto issue = [&](int st) {
-        A[st] = *reinterpret_cast<const f32x4v*>(wl);
-        wl += 256;
+        A[st] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)wlane, (int)wso, 0));
+        wso += 1024;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-            B[st][nb] = XLDS ? xs[(2 * ls + hi) * 64 + nb * 32 + j] : mcq_buffer_load(rsrc[nb], voffL[nb] + soffL);
+            B[st][nb] = XLDS ? xs[(2 * ls + hi) * 64 + nb * 32 + j] : mcq_buffer_load_s(rsrc[nb], voffL[nb], soffL);
         ++ls;
         soffL += step_bytes;
         if (ls == p.Sp) { ls = 0; soffL = 0; }
@@ -144,17 +149,21 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
-        auto step = [&](int st) {
+        auto step = [&](int st, int t) {
+            // fully unrolled variants: the slot being refilled belongs to k-step (t + PF) % SPC of the tile -- a
+            // compile-time number, so the LDS read takes an immediate offset and nothing is computed per lane
+            const int lsn = SPC ? (t + PF) % (SPC ? SPC : 1) : ls;
+            const unsigned son = SPC ? (unsigned)lsn * step_bytes : soffL;
             // vector-block major, each activation slot refilled right after its last use (as in conv_mfma_kernel)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st][mb], B[st][nb], acc[mb][nb], 0, 0, 0);
-                B[st][nb] = XLDS ? xs[(2 * ls + hi) * 64 + nb * 32 + j] : mcq_buffer_load(rsrc[nb], voffL[nb] + soffL);
+                B[st][nb] = XLDS ? xs[(2 * lsn + hi) * 64 + nb * 32 + j] : mcq_buffer_load_s(rsrc[nb], voffL[nb], son);
             }
-            A[st] = *reinterpret_cast<const f32x4v*>(wl);
-            wl += 256;
+            A[st] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)wlane, (int)wso, 0));
+            wso += 1024;
             ++ls;
             soffL += step_bytes;
             if (ls == p.Sp) { ls = 0; soffL = 0; }
@@ -165,12 +174,12 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
 #pragma unroll
             for (int t = 0; t < SPC; t += PF) {
 #pragma unroll
-                for (int st = 0; st < PF; ++st) step(st);
+                for (int st = 0; st < PF; ++st) step(st, t + st);
             }
         } else {
             for (int t = 0; t < p.Sp; t += PF) {
 #pragma unroll
-                for (int st = 0; st < PF; ++st) step(st);
+                for (int st = 0; st < PF; ++st) step(st, 0);
             }
         }
 

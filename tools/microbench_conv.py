@@ -24,6 +24,9 @@ SHAPES = [  # n, cin, cout, h, w, ks, stride
     (32, 128, 128, 24, 16, 3, 1),
     (32, 128, 128, 12, 8, 3, 1),
     (32, 128, 128, 48, 32, 1, 1),
+    (32, 128, 128, 96, 64, 1, 1),
+    (32, 128, 128, 192, 128, 1, 1),
+    (32, 128, 128, 384, 256, 1, 1),
 ]
 TILES = [0, 0x42, 0x242, 0x342, 0x41, 0x241, 0x341, 0x22, 0x122, 0x222, 0x322, 0x11, 0x311]
 
@@ -35,23 +38,26 @@ def main():
     ap.add_argument("--flags", default="res")
     ap.add_argument("--small", action="store_true", help="only the three small levels")
     ap.add_argument("--big", action="store_true", help="only the two largest levels")
+    ap.add_argument("--k1", action="store_true", help="only the 1x1 shapes")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     print("lib:", os.environ.get("MCQUIC_AMD_LIB", "default"))
-    for (n, cin, cout, h, w, ks, stride) in (SHAPES[3:6] if args.small else SHAPES[:2] if args.big else SHAPES):
+    for (n, cin, cout, h, w, ks, stride) in (SHAPES[3:6] if args.small else SHAPES[:2] if args.big else SHAPES[6:] if args.k1 else SHAPES[:7]):
         x = torch.randn(n, cin, h, w, device=dev)
         res = torch.randn(n, cout, h // stride, w // stride, device=dev)
         packs = [ops.PackedConv(torch.randn(cout, cin, ks, ks, device=dev) * 0.03, torch.randn(cout, device=dev)) for _ in range(args.nweights)]
         flops = 2.0 * n * (h // stride) * (w // stride) * cout * cin * ks * ks
         row = []
         for tile in TILES:
-            if h * w > 100 * 64 and tile not in (0, 0x42, 0x41, 0x22):
+            if h * w > 100 * 64 and tile not in (0, 0x42, 0x41, 0x22, 0x11):
                 continue
             kw = dict(tile=tile)
             if args.flags == "res":
                 kw.update(res=res, dual_silu=True)
             elif args.flags == "resonly":
                 kw.update(res=res)
+            elif args.flags == "gdn":
+                kw.update(square_in=True, gdn_mul=x)
             elif args.flags == "silu_out":
                 kw.update(silu_out=True)
             for i in range(3):

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256, MCQ_H16_OCC) void conv_head16_kernel(Head16K p
     int img[NB], yy[NB], xx[NB];
     bool valid[NB];
     __amdgpu_buffer_rsrc_t rsrc[NB];
+    const char* xb[NB];
     unsigned voff[NB][9];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(256, MCQ_H16_OCC) void conv_head16_kernel(Head16K p
         const int xg = rem - y * p.gpr;
         img[nb] = n; yy[nb] = y; xx[nb] = xg * 16 + j;
         valid[nb] = gv && xx[nb] < p.W;
-        rsrc[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.x + (size_t)n * p.Cin * HW), plane_bytes);
+        xb[nb] = reinterpret_cast<const char*>(mcq_uniform_ptr(p.x + (size_t)n * p.Cin * HW));
+        rsrc[nb] = mcq_make_rsrc(xb[nb], plane_bytes);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int yi = y + tap / 3 - 1, xi = xx[nb] + tap % 3 - 1;
@@ -78,7 +80,11 @@ __global__ __launch_bounds__(256, MCQ_H16_OCC) void conv_head16_kernel(Head16K p
 
     float A[PFA];
     float B[PFB][NB];
-    const float* wl = p.wp16 + lane;
+    // no VALU instructions in the k-loop (as in conv_mfma_kernel): weights through a buffer load with a scalar offset,
+    // the 4-channel-group offset of the activations in per-iteration descriptors built by the scalar unit
+    const __amdgpu_buffer_rsrc_t wr = mcq_make_rsrc(p.wp16, 0x7fffffffu);
+    const unsigned wlane = (unsigned)lane * 4u;
+    unsigned wso = 0;
     const unsigned step_bytes = 4u * (unsigned)HW * 4u;      // one 4-channel group further
     unsigned soff = 0;
     f32x4acc acc[NB];
@@ -86,14 +92,24 @@ __global__ __launch_bounds__(256, MCQ_H16_OCC) void conv_head16_kernel(Head16K p
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4acc{0.0f, 0.0f, 0.0f, 0.0f};
 
 #pragma unroll
-    for (int st = 0; st < PFA; ++st) { A[st] = *wl; wl += 64; }
+    for (int st = 0; st < PFA; ++st) { A[st] = mcq_buffer_load_s(wr, wlane, wso); wso += 256; }
 #pragma unroll
     for (int st = 0; st < PFB; ++st) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) B[st][nb] = mcq_buffer_load(rsrc[nb], voff[nb][st % 9] + (unsigned)(st / 9) * step_bytes);
     }
 
+    static_assert(PFB % 9 == 0, "whole channel groups per body");
     for (int s = 0; s < p.S4; s += U / 9) {
+        __amdgpu_buffer_rsrc_t rB[NB][U / 9];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int jg = 0; jg < U / 9; ++jg) {
+                const unsigned off = soff + (unsigned)(PFB / 9 + jg) * step_bytes;
+                const int left = (int)plane_bytes - (int)off;
+                rB[nb][jg] = mcq_make_rsrc(xb[nb] + off, (unsigned)(left > 0 ? left : 0));
+            }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (u > 0 && u % 9 == 0 && s + u / 9 >= p.S4) break;     // odd group count: the second half of the body is past it
@@ -104,11 +120,11 @@ __global__ __launch_bounds__(256, MCQ_H16_OCC) void conv_head16_kernel(Head16K p
                 if (PRO == PRO_SILU) v = mcq_silu(v);
                 acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[sa], v, acc[nb], 0, 0, 0);
             }
-            A[sa] = *wl;
-            wl += 64;
+            A[sa] = mcq_buffer_load_s(wr, wlane, wso);
+            wso += 256;
             const int tl = (u + PFB) % 9, ds = (u + PFB) / 9;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tl] + soff + (unsigned)ds * step_bytes);
+            for (int nb = 0; nb < NB; ++nb) B[sb][nb] = mcq_buffer_load(rB[nb][ds - PFB / 9], voff[nb][tl]);
             __builtin_amdgcn_sched_barrier(0);                      // keep the software pipeline as written
         }
         soff += (unsigned)(U / 9) * step_bytes;

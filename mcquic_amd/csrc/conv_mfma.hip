@@ -60,7 +60,7 @@
 #define MCQ_TILE_41 1
 #endif
 #ifndef MCQ_TILE_22A
-#define MCQ_TILE_22A 0
+#define MCQ_TILE_22A 1
 #endif
 #ifndef MCQ_TILE_14
 #define MCQ_TILE_14 1
@@ -713,9 +713,9 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
         while (ksl < 3 && (tiles << ksl) < 2048) ++ksl;
         // an 8-way split of the 128 x 64 tile runs as a 4-way split of the 128 x 32 tile instead: the same number of
         // waves, half the LDS reduction depth, 3 waves / SIMD resident (8 x 128 x 32 x 32 layer: 50 -> 28 us)
-        // (tried, MCQ_TILE_22A: a 4-way split 128 x 64 tile that needs 1.5 rounds at 2 waves / SIMD -- the 48x32 level --
-        //  as the 64 x 64 tile split 2 ways, all waves resident at 3 / SIMD: 135 -> 127 us in isolation, but -0.4 % images/s in
-        //  the network, with and without branch streams: the two cout halves read the cold activations twice.  Off.)
+        // MCQ_TILE_22A: a 4-way split 128 x 64 tile that needs 1.5 rounds at 2 waves / SIMD -- the 48x32 level -- runs as
+        // the 64 x 64 tile split 2 ways, all waves resident at 3 / SIMD (120 -> 111 us per launch, +0.4 % images/s; with
+        // the earlier k-loop, whose address arithmetic weighed twice as much on the smaller tile, it cost 0.4 %)
         if (MCQ_TILE_22A && MB == 4 && NB == 2 && ksl == 2 && tiles * 4 > 2048 && tiles * 4 <= 3072 && d->ksize == 3 &&
             k.S % 2 == 0 && (k.S >> 1) >= 8) { MB = 2; NB = 2; ksl = 1; }
         if (MCQ_TILE_41 && MB == 4 && NB == 2 && ksl == 3 && d->ksize == 3 && k.S % 4 == 0 && (k.S >> 2) >= 8) { NB = 1; ksl = 2; }

@@ -11,6 +11,8 @@
 //     forward kernel's; the pixel range is split over waves and the partial sums are reduced in a second,
 //     deterministic pass (no atomics);
 //   * small element-wise backward kernels (SiLU, gate, GDN) and reductions (bias / beta gradients).
+#include <type_traits>
+
 #include "mcq_common.h"
 #include "../../include/mcquic_hip.h"
 
@@ -114,6 +116,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradK p) {
     const bool want_bias = p.bias_part != nullptr && blockIdx.y == 0;        // wave-uniform
 
     const __amdgpu_buffer_rsrc_t rx = mcq_make_rsrc(mcq_uniform_ptr(p.xt), (uint32_t)((size_t)p.N * p.H * p.W * p.Cin * 4));
+    // EVEN walk: the wave-uniform part of an x address goes into the load's soffset (scalar unit); the descriptor starts
+    // `pad` pixels before the tensor so that this part is never negative (the lanes that would read there are masked)
+    const unsigned pad_bytes = (unsigned)((p.ks >> 1) * p.Cin * 4);
+    const __amdgpu_buffer_rsrc_t rxs = mcq_make_rsrc(reinterpret_cast<const char*>(mcq_uniform_ptr(p.xt)) - pad_bytes,
+                                                     (uint32_t)((size_t)p.N * p.H * p.W * p.Cin * 4) + pad_bytes);
     // dy^T rows [p_begin, p_end) of this wave: pixels past the range end are out of range = 0
     // (the last ranges can start at or past P when chunk was rounded up: empty descriptor)
     const long long d_begin = p_begin < p.P ? p_begin : p.P, d_len = p_end > p_begin ? p_end - p_begin : 0;
@@ -157,10 +164,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradK p) {
             // row_ok / row_base only change when the walk wraps to a new row: kept in scalar registers, updated there
             const bool ok0 = row_ok && xi0 >= 0 && xi0 < p.W;
             const bool ok1 = row_ok && xi0 + p.stride >= 0 && xi0 + p.stride < p.W;
-            const unsigned base_u = row_base + (unsigned)(xi0 * p.Cin * 4);        // (may be -Cin*4 in all: wraps back)
+            const unsigned base_u = row_base + (unsigned)(xi0 * p.Cin * 4) + pad_bytes;   // >= 0 relative to rxs
             const bool ok = hi ? ok1 : ok0;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) B[st][nb] = mcq_buffer_load(rx, ok ? xlane[nb] + base_u : MCQ_OOB);
+            for (int nb = 0; nb < NB; ++nb) B[st][nb] = mcq_buffer_load_s(rxs, ok ? xlane[nb] : MCQ_OOB, base_u);
             xo_u += 2;
             xi0 += 2 * p.stride;
             if (xo_u >= p.Wo) {
@@ -207,6 +214,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradK p) {
 #pragma unroll
     for (int st = 0; st < PF; ++st) issue(st);
     const int steps = (p.chunk / 2 + PF - 1) / PF * PF;        // whole prefetch rounds; the tail loads are out of range = 0
+    auto k_loop = [&](auto bias_tag) {
+    constexpr bool BIAS = decltype(bias_tag)::value;
     for (int t = 0; t < steps; t += PF) {
 #pragma unroll
         for (int st = 0; st < PF; ++st) {
@@ -215,18 +224,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradK p) {
                 // MFMAs instead of queueing behind all eight); same addressing as issue()
                 const bool ok0 = row_ok && xi0 >= 0 && xi0 < p.W;
                 const bool ok1 = row_ok && xi0 + p.stride >= 0 && xi0 + p.stride < p.W;
-                const unsigned base_u = row_base + (unsigned)(xi0 * p.Cin * 4);
+                const unsigned base_u = row_base + (unsigned)(xi0 * p.Cin * 4) + pad_bytes;
                 const bool ok = hi ? ok1 : ok0;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st][mb], B[st][nb], acc[mb][nb], 0, 0, 0);
-                    B[st][nb] = mcq_buffer_load(rx, ok ? xlane[nb] + base_u : MCQ_OOB);
+                    B[st][nb] = mcq_buffer_load_s(rxs, ok ? xlane[nb] : MCQ_OOB, base_u);
                 }
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    bsum[mb] = bsum[mb] + A[st][mb];                 // (every wave: cheaper than a branch per step)
+                    if (BIAS) bsum[mb] = bsum[mb] + A[st][mb];       // only the waves of tap 0 / ci tile 0 (VALU work costs MFMA issue slots)
                     A[st][mb] = mcq_buffer_load_s(rd, dbase[mb], dstep);
                 }
                 dstep += dinc;
@@ -246,13 +255,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradK p) {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st][mb], B[st][nb], acc[mb][nb], 0, 0, 0);
+                if (BIAS) {
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) bsum[mb] = bsum[mb] + A[st][mb];
+                    for (int mb = 0; mb < MB; ++mb) bsum[mb] = bsum[mb] + A[st][mb];
+                }
                 issue(st);
             }
             __builtin_amdgcn_sched_barrier(0);                  // keep the software pipeline as written
         }
     }
+    };
+    if (want_bias) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 
     // partial sums: part[split][tap][co][ci] (ci contiguous: 32 lanes = 128 B)
     const int taps = p.ks * p.ks;

@@ -23,22 +23,14 @@
 #include "mcq_common.h"
 #include "../../include/mcquic_hip.h"
 
-// tuning ablations (never shipped): 1 = every activation load hits the same line, 2 = and every weight load, 3 = no
-// loads in the k-loop at all (the MFMA-issue bound of this loop structure); DESIGN.md section 4 has the numbers
+// tuning ablations of the k-loop (never shipped; DESIGN.md section 4 has the numbers): 1 = every activation load reads
+// the same cache line, 2 = no activation loads, 3 = no weight loads, 4 = no loads at all (MFMAs + loop control: the
+// issue bound of this loop structure); MCQ_ABLATE_EPI = 1 skips the epilogue (no side loads, no stores)
 #ifndef MCQ_ABLATE
 #define MCQ_ABLATE 0
 #endif
-#ifndef MCQ_SALU_ADDR
-#define MCQ_SALU_ADDR 1
-#endif
-#ifndef MCQ_ABLATE_X
-#define MCQ_ABLATE_X 0
-#endif
 #ifndef MCQ_ABLATE_EPI
-#define MCQ_ABLATE_EPI 0     // 1 = skip the epilogue (no side loads, no stores)
-#endif
-#ifndef MCQ_PRIO
-#define MCQ_PRIO 0
+#define MCQ_ABLATE_EPI 0
 #endif
 #ifndef MCQ_SCHED_FENCE
 #define MCQ_SCHED_FENCE 1
@@ -140,7 +132,6 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     static_assert(TAPS == 1 ? PFA == PFB : ((9 % PFA == 0 || PFA % 9 == 0) && PFB % 9 == 0 && PFB % PFA == 0),
                   "ring depths must tile the unrolled body");
     MCQ_STAMP(st0);
-    if (MCQ_PRIO) __builtin_amdgcn_s_setprio(MCQ_PRIO);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int KS = 1 << p.ks_log2;
@@ -216,18 +207,14 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     // weights: the copy packed for this tile height, so that a wave-wide load is one dense run of 64 * MB floats
     // (reading the 32- / 64-row tiles out of the 128-row copy -- 4 / 8 bytes per lane at a 16-byte stride -- touched
     // four / two times the cache lines and made a 12x8-level launch 30 instead of 21 us)
-    const float* wl = MB == 4 ? p.wp + (((size_t)tile128 * p.TP + (size_t)s0 * TAPS) * 64 + lane) * 4 + q0
-                    : MB == 2 ? p.wp64 + (((size_t)(co_base >> 6) * p.TP + (size_t)s0 * TAPS) * 64 + lane) * 2
-                              : p.wp32 + ((size_t)(co_base >> 5) * p.TP + (size_t)s0 * TAPS) * 64 + lane;
-#if MCQ_SALU_ADDR
-    // the same stream as a wave-uniform base (SGPR pair, advanced by the scalar unit) plus a constant per-lane offset
+    // -- as a wave-uniform base plus a constant per-lane offset, read through a buffer load whose running offset is
+    // the scalar soffset (no per-lane pointer arithmetic in the k-loop)
     const float* wbu = MB == 4 ? p.wp + ((size_t)tile128 * p.TP + (size_t)s0 * TAPS) * 256 + q0
                      : MB == 2 ? p.wp64 + ((size_t)(co_base >> 6) * p.TP + (size_t)s0 * TAPS) * 128
                                : p.wp32 + ((size_t)(co_base >> 5) * p.TP + (size_t)s0 * TAPS) * 64;
     const __amdgpu_buffer_rsrc_t wr = mcq_make_rsrc(wbu, 0x7fffffffu);   // (the packed copies end in a zero tail: over-reads are in bounds)
     const unsigned wlane = (unsigned)lane * (unsigned)(4 * MB);
     unsigned wso = 0;
-#endif
     const unsigned step_bytes = 2u * (unsigned)HW * 4u;     // one channel pair further
     unsigned soff = (unsigned)s0 * step_bytes;
 
@@ -243,13 +230,8 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     if (active) {
 #pragma unroll
         for (int st = 0; st < PFA; ++st) {          // weights of steps 0 .. PFA-1 of the slice
-#if MCQ_SALU_ADDR
             A[st] = mcq_wload<MB>(wr, wlane, wso);
             wso += 256 * MB;
-#else
-            A[st] = *reinterpret_cast<const avec_t*>(wl);
-            wl += 64 * MB;
-#endif
         }
 #pragma unroll
         for (int st = 0; st < PFB; ++st) {          // activations of steps 0 .. PFB-1
@@ -261,9 +243,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     }
 
     MCQ_STAMP(st1);
-    if (MCQ_PRIO) __builtin_amdgcn_s_setprio(0);
     for (int sp = 0; sp < npairs; sp += PAIRS_PER_ITER) {
-#if MCQ_SALU_ADDR
         // Every VALU instruction between two MFMAs costs the matrix pipe ~10 cycles (tools/probes/mfma_issue.hip), so
         // the k-loop has none: the channel-pair offset of an activation load lives in its buffer descriptor -- one per
         // pixel block and channel pair of the body, rebuilt by the scalar unit each iteration with num_records shrunk
@@ -278,7 +258,6 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
                 const int left = (int)plane_bytes - (int)off;      // (signed max: the unsigned saturating form is VALU-only)
                 rB[nb][j] = mcq_make_rsrc(xb[nb] + off, (unsigned)(left > 0 ? left : 0));
             }
-#endif
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (TAPS == 9 && u > 0 && u % 9 == 0 && sp + u / 9 >= npairs) break;   // the slice ends inside the body
@@ -302,30 +281,17 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[sa], mb), bv[nb], acc[mb][nb], 0, 0, 0);
-#if MCQ_ABLATE >= 3
+#if MCQ_ABLATE == 2 || MCQ_ABLATE == 4
                 asm volatile("" : "+v"(B[sb][nb]));
-#elif MCQ_ABLATE >= 1
+#elif MCQ_ABLATE == 1
                 B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][TAPS == 9 ? 4 : 0]);
-#elif MCQ_ABLATE_X == 1      /* no per-step address add */
-                B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tl]);
-#elif MCQ_ABLATE_X == 2      /* no activation loads */
-                asm volatile("" : "+v"(B[sb][nb]));
-#elif MCQ_SALU_ADDR
-                B[sb][nb] = mcq_buffer_load(rB[nb][ds - PFBP], voff[nb][tl]);
 #else
-                B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tl] + soff + (unsigned)ds * step_bytes);
+                B[sb][nb] = mcq_buffer_load(rB[nb][ds - PFBP], voff[nb][tl]);
 #endif
             }
-#if MCQ_SALU_ADDR
+#if MCQ_ABLATE < 3
             A[sa] = mcq_wload<MB>(wr, wlane, wso);
             wso += 256 * MB;
-#else
-#if MCQ_ABLATE < 3 && MCQ_ABLATE_X != 3      /* X == 3: no weight loads */
-            A[sa] = *reinterpret_cast<const avec_t*>(wl);
-#endif
-#if MCQ_ABLATE < 2
-            wl += 64 * MB;
-#endif
 #endif
 #if MCQ_SCHED_FENCE
             // keep the software pipeline as written: without this fence the scheduler sinks the loads of all U
@@ -337,7 +303,6 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     }
 
     MCQ_STAMP(st2);
-    if (MCQ_PRIO) __builtin_amdgcn_s_setprio(MCQ_PRIO);
     // ---- epilogue ---------------------------------------------------------------------------
     // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row tile, the 16 output channels
     // row(r) + 4 hi, row(r) = (r & 3) + 8 (r >> 2).  Element (co, pixel) of image n sits at byte (co HoWo + pixel) 4 of

@@ -56,6 +56,8 @@ def main():
                 kw.update(res=res, dual_silu=True)
             elif args.flags == "resonly":
                 kw.update(res=res)
+            elif args.flags == "dual":
+                kw.update(dual_silu=True)
             elif args.flags == "gdn":
                 kw.update(square_in=True, gdn_mul=x)
             elif args.flags == "silu_out":

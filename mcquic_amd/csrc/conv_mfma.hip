@@ -599,7 +599,9 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     if (fl & MCQ_CONV_SHUFFLE2) {
         if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN))) return MCQ_EINVAL;
     }
-    if ((uint64_t)d->Cin * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
+    // one image's input slab plus the prefetch rings' over-read (up to 8 channels) must stay below 2 GiB: byte offsets and
+    // the descriptors' shrinking num_records are 32-bit (signed in the scalar arithmetic of the k-loop)
+    if ((uint64_t)(d->Cin + 8) * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
 
     ConvK k;
     k.x = d->x; k.wp = d->w_packed;

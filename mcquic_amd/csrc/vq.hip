@@ -193,11 +193,17 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    // (x2 + c2) - 2 * inter ; 2 * inter is exact, so the fused form rounds identically
-                    const float dv = __builtin_fmaf(-2.0f, acc[mb][nb][r], x2[nb] + c2d[r]);
-                    const int word = word0 + mb * 32 + mcq_drow(r, hi);
-                    if (dv < best[nb]) { best[nb] = dv; bidx[nb] = word; }
+                for (int r = 0; r < 16; r += 2) {
+                    // (x2 + c2) - 2 * inter ; 2 * inter is exact, so the fused form rounds identically.  Two distances per
+                    // instruction (v_pk_add_f32 / v_pk_fma_f32: same IEEE operations, half the issue slots)
+                    const f32x2v s2 = f32x2v{x2[nb], x2[nb]} + f32x2v{c2d[r], c2d[r + 1]};
+                    const f32x2v dv2 = __builtin_elementwise_fma(f32x2v{-2.0f, -2.0f}, f32x2v{acc[mb][nb][r], acc[mb][nb][r + 1]}, s2);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float dv = dv2[e];
+                        const int word = word0 + mb * 32 + mcq_drow(r + e, hi);
+                        if (dv < best[nb]) { best[nb] = dv; bidx[nb] = word; }
+                    }
                 }
         }
         c2a = c2n;

@@ -10,6 +10,7 @@
 //   extra 2: the conv k-step's memory instructions: 1 x buffer_load_dwordx4 + 2 x buffer_load_dword (cache-resident
 //            lines, wave-uniform offset from the scalar unit) whose results are the MFMA operands two iterations later
 //   extra 3: extra 2 + the two v_add_u32 of the address arithmetic
+// The last lines repeat the 32x32x2 cases with 256 / 512 workgroups, i.e. 1 / 2 waves per SIMD in a single round.
 // Prints TFLOP/s per combination:   hipcc --offload-arch=gfx950 -O3 -o mfma_issue mfma_issue.hip && ./mfma_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -73,8 +74,7 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ src, float
 }
 
 template <int SHAPE, int EXTRA>
-void run(const float* src, float* out) {
-    const int steps = 6000, wgs = 2048;           // 2048 workgroups x 4 waves = 4 rounds of the 2048 resident waves
+void run(const float* src, float* out, int wgs = 2048, int steps = 6000) {   // 2048 workgroups x 4 waves = 4 rounds of the 2048 resident waves
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((k<SHAPE, EXTRA>), dim3(wgs), dim3(256), 65536, 0, src, out, steps, 0u);
@@ -85,7 +85,7 @@ void run(const float* src, float* out) {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double flops = 3.0 * wgs * 4 * (double)steps * 8 * 4096;     // 512 MFMA cycles x 64 flops / cycle per wave-step
-    printf("shape %s extra %d: %8.3f ms  %7.1f TFLOP/s\n", SHAPE ? "16x16x4" : "32x32x2", EXTRA, ms / 3, flops / (ms * 1e-3) / 1e12);
+    printf("shape %s extra %d, %4d workgroups: %8.3f ms  %7.1f TFLOP/s\n", SHAPE ? "16x16x4" : "32x32x2", EXTRA, wgs, ms / 3, flops / (ms * 1e-3) / 1e12);
 }
 
 int main() {
@@ -94,5 +94,8 @@ int main() {
     hipMalloc(&out, 1 << 16);
     run<0, 0>(src, out); run<0, 1>(src, out); run<0, 2>(src, out); run<0, 3>(src, out);
     run<1, 0>(src, out); run<1, 1>(src, out); run<1, 2>(src, out); run<1, 3>(src, out);
+    // one workgroup per CU = a LONE wave on every SIMD (what a wave's neighbour sees while it is in its epilogue)
+    run<0, 0>(src, out, 256, 24000); run<0, 2>(src, out, 256, 24000); run<0, 3>(src, out, 256, 24000);
+    run<0, 0>(src, out, 512, 12000); run<0, 2>(src, out, 512, 12000);
     return 0;
 }

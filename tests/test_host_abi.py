@@ -138,4 +138,8 @@ def test_oversized_planes_are_rejected_before_any_launch():
     d.x = d.w_packed = d.y = 1                      # never dereferenced: the size check comes first
     d.N, d.Cin, d.H, d.W, d.Cout, d.ksize, d.stride = 1, 128, 4096, 1024, 128, 3, 1
     assert lib.mcq_conv2d_f32(d, None) == _lib.MCQ_ETOOLARGE
+    # the limit includes the 8 channels the operand rings may read past the last one (their offsets are 32-bit too):
+    # 120 channels of 4096 x 1024 floats are 1.875 GiB, with the over-read exactly 2 GiB
+    d.Cin = 120
+    assert lib.mcq_conv2d_f32(d, None) == _lib.MCQ_ETOOLARGE
     assert lib.mcq_vq_assign_f32(1, 1, 1, 1, 2, 64, 4096, 2048, 512, None) == _lib.MCQ_ETOOLARGE

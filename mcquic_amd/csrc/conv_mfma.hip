@@ -356,7 +356,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
             // instead of block by block with loads, activation and stores alternating (measured: +1.8 % on a 384x256 layer
             // with the twin epilogue, +0.9 % images/s)
             constexpr unsigned SIMPLE = MCQ_CONV_SILU_OUT | MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU;
-            if (EF != RUNTIME_FLAGS && (EF & ~SIMPLE) == 0u) {
+            if (EF != RUNTIME_FLAGS && (EF & ~SIMPLE) == 0u && NB <= 2) {     // (NB = 4: 192 temporaries, spills)
                 unsigned sob[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sob[r] = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;

@@ -114,16 +114,17 @@ template <> __device__ __forceinline__ float mcq_wload<1>(__amdgpu_buffer_rsrc_t
 
 #if MCQ_STAMPS
 // tuning aid (never shipped): per-wave s_memrealtime stamps (100 MHz) at entry / ring filled / k-loop done / stores issued
-__device__ unsigned long long* mcq_stamp_buf = nullptr;      // [0] = record counter, then 6 words per record
-__device__ __forceinline__ void mcq_stamp_write(unsigned long long t0, unsigned long long t1, unsigned long long t2, unsigned long long t3) {
+__device__ unsigned long long* mcq_stamp_buf = nullptr;      // [0] = record counter, then 9 words per record
+__device__ __forceinline__ void mcq_stamp_write(unsigned long long t0, unsigned long long t1, unsigned long long t2, unsigned long long t3,
+                                                unsigned long long dA = 0, unsigned long long dB = 0, unsigned long long dC = 0) {
     if (mcq_stamp_buf == nullptr || (threadIdx.x & 63) != 0) return;
     const unsigned long long rec = atomicAdd(mcq_stamp_buf, 1ull);
     if (rec >= (1ull << 20)) return;
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    unsigned long long* o = mcq_stamp_buf + 1 + rec * 6;
-    o[0] = hw; o[1] = xcc; o[2] = t0; o[3] = t1; o[4] = t2; o[5] = t3;
+    unsigned long long* o = mcq_stamp_buf + 1 + rec * 9;
+    o[0] = hw; o[1] = xcc; o[2] = t0; o[3] = t1; o[4] = t2; o[5] = t3; o[6] = dA; o[7] = dB; o[8] = dC;
 }
 #define MCQ_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
 #else
@@ -306,6 +307,9 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     }
 
     MCQ_STAMP(st2);
+#if MCQ_STAMPS
+    unsigned long long ph_a = 0, ph_b = 0, ph_c = 0;     // band epilogue: side loads issued / arithmetic done / stores issued
+#endif
     // ---- epilogue ---------------------------------------------------------------------------
     // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row tile, the 16 output channels
     // row(r) + 4 hi, row(r) = (r & 3) + 8 (r >> 2).  Element (co, pixel) of image n sits at byte (co HoWo + pixel) 4 of
@@ -361,12 +365,14 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sob[r] = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
                 float vv[NB][16], rvv[NB][16], tw[NB][16];
+                MCQ_STAMP(pe0);
                 if (EF & MCQ_CONV_RESIDUAL) {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) rvv[nb][r] = mcq_buffer_load_s(rr_[nb], pvo[nb], sob[r]);
                 }
+                MCQ_STAMP(pe1);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     get_acc(mi, nb, vv[nb]);
@@ -385,6 +391,10 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
                         for (int r = 0; r < 16; ++r) tw[nb][r] = mcq_silu(vv[nb][r]);
                     }
                 }
+#if MCQ_STAMPS
+                asm volatile("" :: "v"(vv[0][0]), "v"(vv[NB - 1][15]), "v"(tw[0][0]), "v"(tw[NB - 1][15]));
+#endif
+                MCQ_STAMP(pe2);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -394,6 +404,9 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
                         for (int r = 0; r < 16; ++r) mcq_buffer_store_s(tw[nb][r], y2r[nb], pvo[nb], sob[r]);
                     }
                 }
+#if MCQ_STAMPS
+                { MCQ_STAMP(pe3); ph_a += pe1 - pe0; ph_b += pe2 - pe1; ph_c += pe3 - pe2; }
+#endif
                 continue;
             }
 #endif
@@ -485,7 +498,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
             for (int r = 0; r < 16; ++r) v[r] = acc[mi][nb][r];
         }, 0, std::integral_constant<int, MB>{});
 #if MCQ_STAMPS
-        { MCQ_STAMP(st3); mcq_stamp_write(st0, st1, st2, st3); }
+        { MCQ_STAMP(st3); mcq_stamp_write(st0, st1, st2, st3, ph_a, ph_b, ph_c); }
 #endif
         return;
     }

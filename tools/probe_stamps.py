@@ -23,7 +23,7 @@ from mcquic_amd import ops, _lib  # noqa: E402
 def main():
     dev = torch.device("cuda:0")
     lib = ctypes.CDLL(os.path.abspath(os.environ["MCQUIC_AMD_LIB"]))
-    buf = torch.zeros(1 + 6 * (1 << 20), dtype=torch.int64, device=dev)
+    buf = torch.zeros(1 + 9 * (1 << 20), dtype=torch.int64, device=dev)
     assert lib.mcq_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
     shapes = [(32, 128, 128, 192, 128)] if len(sys.argv) < 2 else [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
     for (n, cin, cout, h, w) in shapes:
@@ -40,12 +40,15 @@ def main():
             ops.conv2d(x, packs[0], 1, **kw)
             torch.cuda.synchronize()
             cnt = int(buf[0].item())
-            rec = buf[1:1 + 6 * cnt].cpu().numpy().reshape(cnt, 6)
-            hw, xcc, t0, t1, t2, t3 = (rec[:, i] for i in range(6))
+            rec = buf[1:1 + 9 * cnt].cpu().numpy().reshape(cnt, 9)
+            hw, xcc, t0, t1, t2, t3, da, db, dc = (rec[:, i] for i in range(9))
             tick = 0.01    # us
             print(f"\n== {n}x{cin}->{cout} {h}x{w} {flags}: {cnt} waves, kernel span {(t3.max() - t0.min()) * tick:.1f} us")
             for name, d in (("entry -> ring requested", t1 - t0), ("k-loop", t2 - t1), ("epilogue (to last store issued)", t3 - t2)):
                 print(f"  {name:34s} median {np.median(d) * tick:8.2f} us   p10 {np.percentile(d, 10) * tick:8.2f}   p90 {np.percentile(d, 90) * tick:8.2f}")
+            if dc.any():
+                print(f"  band epilogue phases, summed over the bands: side loads issued {np.median(da) * tick:.2f} us, arithmetic (incl. waiting for them) "
+                      f"{np.median(db) * tick:.2f} us, stores issued {np.median(dc) * tick:.2f} us")
             slot = (xcc.astype(np.int64) & 0xF) << 16 | (hw.astype(np.int64) & 0xFFFF)
             simd = slot >> 4
             by_slot = defaultdict(list)

@@ -175,22 +175,30 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=4, help="images in the CPU-oracle sample (SURVEY 8(d): batch 4)")
     ap.add_argument("--graphs", action="store_true", help="replay encode/decode as captured hipGraphs (small-batch latency)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from mcquic_amd import launch
+    # `--gpus N` IS the world size: without a launcher's environment the script re-executes itself under
+    # torch.distributed.run with N ranks (one per GPU); a launcher whose WORLD_SIZE disagrees is an error (exit 2)
+    rank, local_rank, world, use_dist = launch.ensure_world(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    if world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: --gpus {world} but this node has {torch.cuda.device_count()} HIP devices")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cores = launch.pin_rank_cores(local_rank, local_world)  # disjoint host cores per rank, from the GPU's NUMA node
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run: take the RCCL path even at N=1
-    if use_dist:
+    rccl_world = None
+    if use_dist:                                             # launched by torch.distributed.run: the RCCL path even at N=1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        rccl_world = launch.rccl_check(dist, dev)           # an actual all-reduce: the ranks RCCL really connected
+        if rccl_world != world or dist.get_world_size() != world:
+            raise SystemExit(f"bench.py: RCCL spans {rccl_world} ranks, expected {world}")
 
     from mcquic_amd import Compressor
     torch.manual_seed(3407)                                   # same random-init weights on every rank
@@ -242,6 +250,7 @@ def main():
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (uniform [-1,1) images, random-init weights)",
+            "rccl_world": rccl_world, "rank0_cores": None if cores is None else len(cores),
             "config": {"workload": f"qp=2 reference model Compressor(128, 2, [8192, 2048, 512]), batch={args.batch} "
                                    f"768x512 random images per GPU, encode+decode tensor path (BASELINE configs[1])",
                        "images_per_gpu": args.batch, "parallelism": f"dp{world} (independent image shards, no data-path collective)"},

@@ -46,6 +46,19 @@ def test_bench_under_a_process_group(dev):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["rccl_world"] == 1                              # an RCCL all-reduce actually ran over the process group
+
+
+def test_bench_without_a_launcher_takes_no_process_group(dev):
+    d = _run("--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and d["rccl_world"] is None
+
+
+def test_bench_gpus_must_match_the_launcher(dev):
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29579")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    assert out.returncode == 2
 
 
 def test_import_sets_hw_queue_default():

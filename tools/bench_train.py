@@ -19,18 +19,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU); > 1 re-executes under torch.distributed.run")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--crop", type=int, default=256)
     ap.add_argument("--graph", action="store_true", help="capture forward+backward in one hipGraph and replay it (single GPU)")
     args = ap.parse_args()
-    rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    from mcquic_amd import launch
+    rank, local, world, launched = launch.ensure_world(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    launch.pin_rank_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+        if launch.rccl_check(dist, dev) != world:
+            raise SystemExit("bench_train.py: RCCL does not span the requested ranks")
     from mcquic_amd import Compressor
     torch.manual_seed(3407)
     model = Compressor(128, 2, [8192, 2048, 512]).to(dev).train()

@@ -203,19 +203,38 @@ int mcq_detransform_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 int mcq_pmf_to_quantized_cdf(const float* pmf, int32_t k, int32_t precision, uint32_t* cdf);
 
 /* One rANS stream over symbols[0..n): symbol i is coded with CDF number indexes[i]; CDF c occupies
- * cdfs[cdf_starts[c] ...], cdf_sizes[c] follows the reference's convention (sentinel slot = cdf_sizes[c] - 2,
- * the reference passes k + 2), offsets[c] is subtracted from the symbol.  Returns the number of bytes written to
- * `out`, or a negative MCQ_E* (MCQ_ETOOLARGE if `capacity` is too small: 4 * n + 8 always suffices without
- * bypass symbols).  Bit-identical to RansEncoder.encodeWithIndexes
- * (cpp_exts/buffered_rans_encoder.cpp:104-196 over ryg_rans/rans64.h). */
+ * cdfs[cdf_starts[c] ...] with cdf_lens[c] entries actually present; cdf_sizes[c] follows the reference's convention
+ * (sentinel slot = cdf_sizes[c] - 2; the reference's caller passes k + 2 over k + 1 entries,
+ * mcquic/modules/entropyCoder.py:121), offsets[c] is subtracted from the symbol.  A symbol whose table slot would lie
+ * beyond cdf_lens[c] is MCQ_EINVAL (the reference reads past the table there).  Returns the number of bytes written to
+ * `out`, or a negative MCQ_E* (MCQ_ETOOLARGE if `capacity` is too small: 4 * n + 8 always suffices without bypass
+ * symbols).  Bit-identical to RansEncoder.encodeWithIndexes (cpp_exts/buffered_rans_encoder.cpp:104-196 over
+ * ryg_rans/rans64.h). */
 int64_t mcq_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexes, int64_t n,
                                      const uint32_t* cdfs, const int32_t* cdf_starts, const int32_t* cdf_sizes,
-                                     const int32_t* offsets, int32_t n_cdfs, uint8_t* out, int64_t capacity);
+                                     const int32_t* cdf_lens, const int32_t* offsets, int32_t n_cdfs, uint8_t* out, int64_t capacity);
 
 /* Inverse of the above (cpp_exts/rans_decoder.cpp:104-167); MCQ_EINVAL on a truncated / malformed stream. */
 int mcq_rans_decode_with_indexes(const uint8_t* in, int64_t nbytes, const int32_t* indexes, int64_t n,
                                  const uint32_t* cdfs, const int32_t* cdf_starts, const int32_t* cdf_sizes,
-                                 const int32_t* offsets, int32_t n_cdfs, int32_t* out_symbols);
+                                 const int32_t* cdf_lens, const int32_t* offsets, int32_t n_cdfs, int32_t* out_symbols);
+
+/* All images of one level in ONE call (replaces the reference's Python loop `for code in codes: for codePerImage in
+ * code: encoder.encodeWithIndexes(...)`, mcquic/modules/entropyCoder.py:108-126): n_streams independent streams of n
+ * symbols each (symbols[n_streams][n], one shared `indexes[n]`), stream i written to out + i * stride (stride >= 4 n + 8
+ * without bypass symbols) with its length in out_nbytes[i].  Streams are spread over `n_threads` host threads (<= 0: one
+ * per hardware thread); the bytes of a stream do not depend on the thread count.  Returns MCQ_OK or the first failing
+ * stream's error. */
+int mcq_rans_encode_batch_with_indexes(const int32_t* symbols, int64_t n_streams, int64_t n, const int32_t* indexes,
+                                       const uint32_t* cdfs, const int32_t* cdf_starts, const int32_t* cdf_sizes,
+                                       const int32_t* cdf_lens, const int32_t* offsets, int32_t n_cdfs, uint8_t* out,
+                                       int64_t stride, int64_t* out_nbytes, int32_t n_threads);
+
+/* Inverse (entropyCoder.py:141-154): stream i = in[in_offsets[i] .. in_offsets[i + 1]), decoded into out_symbols[i][n]. */
+int mcq_rans_decode_batch_with_indexes(const uint8_t* in, const int64_t* in_offsets, int64_t n_streams, const int32_t* indexes,
+                                       int64_t n, const uint32_t* cdfs, const int32_t* cdf_starts, const int32_t* cdf_sizes,
+                                       const int32_t* cdf_lens, const int32_t* offsets, int32_t n_cdfs, int32_t* out_symbols,
+                                       int32_t n_threads);
 
 /* ---- validation metrics (callers of the path: mcquic/validate/handlers.py:14-41) --------------------------------
  * MS-SSIM of two uint8 batches x, y [N, C, H, W] as the reference's MsSSIM handler computes it

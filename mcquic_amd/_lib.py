@@ -68,10 +68,14 @@ SYMBOLS = {
     "mcq_add_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_detransform_u8": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_pmf_to_quantized_cdf": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
-    "mcq_rans_encode_with_indexes": (c_int64, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+    "mcq_rans_encode_with_indexes": (c_int64, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                                c_void_p, c_int64]),
-    "mcq_rans_decode_with_indexes": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+    "mcq_rans_decode_with_indexes": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_int32, c_void_p]),
+    "mcq_rans_encode_batch_with_indexes": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                     c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int32]),
+    "mcq_rans_decode_batch_with_indexes": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                                     c_void_p, c_void_p, c_int32, c_void_p, c_int32]),
     "mcq_ms_ssim_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "mcq_ms_ssim_u8": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_ms_ssim_window": (None, [c_void_p]),

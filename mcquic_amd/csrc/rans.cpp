@@ -12,11 +12,16 @@
 // branch is kept for format completeness.
 //
 // Unlike the reference (Python lists -> std::vector copies, one call per image and level) the entry points take
-// flat int32 arrays; one call codes one stream, and streams are independent (image x level), so callers may
-// fan them out over host threads.
+// flat int32 arrays.  Streams are independent (image x level): the *_batch_* entry points code all images of one level
+// in ONE call, spread over a pool of host threads (one stream per task, tasks handed out through an atomic counter).
+// Every table access is range-checked against `cdf_lens` (entries actually present per CDF): with the reference's
+// `cdfSizes = k + 2` over k + 1 entries a symbol outside [0, k) would index one past the table (the reference reads
+// out of bounds there, assert compiled out) -- here it is MCQ_EINVAL.
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/mcquic_hip.h"
@@ -84,10 +89,21 @@ extern "C" int mcq_pmf_to_quantized_cdf(const float* pmf, int32_t k, int32_t pre
     return MCQ_OK;
 }
 
-extern "C" int64_t mcq_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexes, int64_t n,
-                                                const uint32_t* cdfs, const int32_t* cdf_starts, const int32_t* cdf_sizes,
-                                                const int32_t* offsets, int32_t n_cdfs, uint8_t* out, int64_t capacity) {
-    if (!symbols || !indexes || !cdfs || !cdf_starts || !cdf_sizes || !offsets || !out || n < 0 || n_cdfs <= 0) return MCQ_EINVAL;
+namespace {
+
+struct Tables {
+    const uint32_t* cdfs; const int32_t* starts; const int32_t* sizes; const int32_t* lens; const int32_t* offsets; int32_t n_cdfs;
+    bool ok() const {
+        if (!cdfs || !starts || !sizes || !lens || !offsets || n_cdfs <= 0) return false;
+        for (int32_t c = 0; c < n_cdfs; ++c)
+            if (starts[c] < 0 || lens[c] < 2 || sizes[c] < 2) return false;
+        return true;
+    }
+};
+
+int64_t encode_stream(const int32_t* symbols, const int32_t* indexes, int64_t n, const Tables& t, uint8_t* out, int64_t capacity) {
+    const uint32_t* cdfs = t.cdfs; const int32_t* cdf_starts = t.starts; const int32_t* cdf_sizes = t.sizes;
+    const int32_t* offsets = t.offsets; const int32_t n_cdfs = t.n_cdfs;
     std::vector<Sym> syms;
     syms.reserve((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
@@ -100,6 +116,7 @@ extern "C" int64_t mcq_rans_encode_with_indexes(const int32_t* symbols, const in
         uint32_t raw = 0;
         if (value < 0) { raw = (uint32_t)(-2 * value - 1); value = max_value; }
         else if (value >= max_value) { raw = (uint32_t)(2 * (value - max_value)); value = max_value; }
+        if (value + 1 >= t.lens[ci]) return MCQ_EINVAL;         // no sentinel slot in this table: the symbol is out of range
         syms.push_back({(uint16_t)cdf[value], (uint16_t)(cdf[value + 1] - cdf[value]), false});
         if (value == max_value) {                 // bypass: digit count, then the raw value in 4-bit digits
             int32_t n_bypass = 0;
@@ -134,10 +151,9 @@ extern "C" int64_t mcq_rans_encode_with_indexes(const int32_t* symbols, const in
     return nbytes;
 }
 
-extern "C" int mcq_rans_decode_with_indexes(const uint8_t* in, int64_t nbytes, const int32_t* indexes, int64_t n,
-                                            const uint32_t* cdfs, const int32_t* cdf_starts, const int32_t* cdf_sizes,
-                                            const int32_t* offsets, int32_t n_cdfs, int32_t* out_symbols) {
-    if (!in || !indexes || !cdfs || !cdf_starts || !cdf_sizes || !offsets || !out_symbols || n < 0 || n_cdfs <= 0) return MCQ_EINVAL;
+int decode_stream(const uint8_t* in, int64_t nbytes, const int32_t* indexes, int64_t n, const Tables& t, int32_t* out_symbols) {
+    const uint32_t* cdfs = t.cdfs; const int32_t* cdf_starts = t.starts; const int32_t* cdf_sizes = t.sizes;
+    const int32_t* offsets = t.offsets; const int32_t n_cdfs = t.n_cdfs;
     if (nbytes < 8 || (nbytes & 3)) return MCQ_EINVAL;
     std::vector<uint32_t> words((size_t)nbytes / 4);
     std::memcpy(words.data(), in, (size_t)nbytes);
@@ -151,13 +167,13 @@ extern "C" int mcq_rans_decode_with_indexes(const uint8_t* in, int64_t nbytes, c
         if (ci < 0 || ci >= n_cdfs) return MCQ_EINVAL;
         const uint32_t* cdf = cdfs + cdf_starts[ci];
         const int32_t max_value = cdf_sizes[ci] - 2;
-        if (max_value < 0) return MCQ_EINVAL;
+        if (max_value < 0 || max_value >= t.lens[ci]) return MCQ_EINVAL;       // the bisection reads entries 0 .. max_value
         const uint32_t cum = (uint32_t)(x & ((1u << kPrecision) - 1));
         // first entry strictly above cum (the reference scans linearly; CDFs are increasing, so bisect)
         int32_t lo = 0, hi = max_value + 1;      // entries 0 .. max_value + 1 hold cdf[0] = 0 .. 2^16 (or the sentinel)
         while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cdf[mid] > cum) hi = mid; else lo = mid + 1; }
         const int32_t s = lo - 1;
-        if (s < 0 || s > max_value) return MCQ_EINVAL;
+        if (s < 0 || s > max_value || s + 1 >= t.lens[ci]) return MCQ_EINVAL;
         const uint32_t start = cdf[s], freq = cdf[s + 1] - cdf[s];
         x = (uint64_t)freq * (x >> kPrecision) + (x & ((1u << kPrecision) - 1)) - start;
         if (x < kRansL) {
@@ -178,4 +194,77 @@ extern "C" int mcq_rans_decode_with_indexes(const uint8_t* in, int64_t nbytes, c
         out_symbols[i] = value + offsets[ci];
     }
     return MCQ_OK;
+}
+
+// run task(i) for i in [0, n_tasks) on up to n_threads host threads; returns the first non-zero status in task order
+template <typename F>
+int run_pool(int64_t n_tasks, int32_t n_threads, F&& task) {
+    if (n_tasks <= 0) return MCQ_OK;
+    std::vector<int> status((size_t)n_tasks, MCQ_OK);
+    int64_t workers = n_threads <= 0 ? (int64_t)std::thread::hardware_concurrency() : n_threads;
+    if (workers < 1) workers = 1;
+    if (workers > n_tasks) workers = n_tasks;
+    std::atomic<int64_t> next{0};
+    auto loop = [&]() {
+        for (;;) {
+            const int64_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_tasks) return;
+            status[(size_t)i] = task(i);
+        }
+    };
+    if (workers == 1) loop();
+    else {
+        std::vector<std::thread> pool;
+        pool.reserve((size_t)workers - 1);
+        for (int64_t w = 1; w < workers; ++w) pool.emplace_back(loop);
+        loop();
+        for (auto& th : pool) th.join();
+    }
+    for (int st : status) if (st != MCQ_OK) return st;
+    return MCQ_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t mcq_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexes, int64_t n,
+                                                const uint32_t* cdfs, const int32_t* cdf_starts, const int32_t* cdf_sizes,
+                                                const int32_t* cdf_lens, const int32_t* offsets, int32_t n_cdfs, uint8_t* out,
+                                                int64_t capacity) {
+    const Tables t{cdfs, cdf_starts, cdf_sizes, cdf_lens, offsets, n_cdfs};
+    if (!symbols || !indexes || !out || n < 0 || !t.ok()) return MCQ_EINVAL;
+    return encode_stream(symbols, indexes, n, t, out, capacity);
+}
+
+extern "C" int mcq_rans_decode_with_indexes(const uint8_t* in, int64_t nbytes, const int32_t* indexes, int64_t n,
+                                            const uint32_t* cdfs, const int32_t* cdf_starts, const int32_t* cdf_sizes,
+                                            const int32_t* cdf_lens, const int32_t* offsets, int32_t n_cdfs, int32_t* out_symbols) {
+    const Tables t{cdfs, cdf_starts, cdf_sizes, cdf_lens, offsets, n_cdfs};
+    if (!in || !indexes || !out_symbols || n < 0 || !t.ok()) return MCQ_EINVAL;
+    return decode_stream(in, nbytes, indexes, n, t, out_symbols);
+}
+
+extern "C" int mcq_rans_encode_batch_with_indexes(const int32_t* symbols, int64_t n_streams, int64_t n, const int32_t* indexes,
+                                                  const uint32_t* cdfs, const int32_t* cdf_starts, const int32_t* cdf_sizes,
+                                                  const int32_t* cdf_lens, const int32_t* offsets, int32_t n_cdfs, uint8_t* out,
+                                                  int64_t stride, int64_t* out_nbytes, int32_t n_threads) {
+    const Tables t{cdfs, cdf_starts, cdf_sizes, cdf_lens, offsets, n_cdfs};
+    if (!symbols || !indexes || !out || !out_nbytes || n_streams < 0 || n < 0 || stride < 8 || !t.ok()) return MCQ_EINVAL;
+    return run_pool(n_streams, n_threads, [&](int64_t i) -> int {
+        const int64_t nb = encode_stream(symbols + i * n, indexes, n, t, out + i * stride, stride);
+        out_nbytes[i] = nb < 0 ? 0 : nb;
+        return nb < 0 ? (int)nb : MCQ_OK;
+    });
+}
+
+extern "C" int mcq_rans_decode_batch_with_indexes(const uint8_t* in, const int64_t* in_offsets, int64_t n_streams,
+                                                  const int32_t* indexes, int64_t n, const uint32_t* cdfs, const int32_t* cdf_starts,
+                                                  const int32_t* cdf_sizes, const int32_t* cdf_lens, const int32_t* offsets,
+                                                  int32_t n_cdfs, int32_t* out_symbols, int32_t n_threads) {
+    const Tables t{cdfs, cdf_starts, cdf_sizes, cdf_lens, offsets, n_cdfs};
+    if (!in || !in_offsets || !indexes || !out_symbols || n_streams < 0 || n < 0 || !t.ok()) return MCQ_EINVAL;
+    for (int64_t i = 0; i < n_streams; ++i)
+        if (in_offsets[i + 1] < in_offsets[i]) return MCQ_EINVAL;
+    return run_pool(n_streams, n_threads, [&](int64_t i) -> int {
+        return decode_stream(in + in_offsets[i], in_offsets[i + 1] - in_offsets[i], indexes, n, t, out_symbols + i * n);
+    });
 }

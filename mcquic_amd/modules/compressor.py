@@ -11,6 +11,7 @@ reference checkpoint's `model` dict loads with `load_state_dict(strict=True)`.
 """
 from __future__ import annotations
 
+import operator
 from typing import List, Tuple
 
 import torch
@@ -22,6 +23,9 @@ from ..utils.specification import FileHeader, ImageSize
 from .quantizer import BaseQuantizer, UMGMQuantizer
 
 from ..utils.specification import VERSION as __version__   # the reference snapshot's mcquic.__version__ (FileHeader)
+
+
+_VERSION_OF = operator.attrgetter("_version")
 
 
 class _GraphedCall:
@@ -78,14 +82,44 @@ class BaseCompressor(nn.Module):
         self._qp = "-1"
         self._padding = AlignedPadding()
         self._graphs = None          # {(kind, shapes, device): _GraphedCall} once enableGraphs(True)
+        self._graphStamp = None      # fingerprint of the weights the captures were taken under
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._forgetCaptures())
 
     def enableGraphs(self, enabled: bool = True):
-        """Replay `encode` / `decode` as captured hipGraphs (one per input shape).  For latency-bound small batches;
-        call again (or change weights through load_state_dict) to drop the captures."""
+        """Replay `encode` / `decode` as captured hipGraphs (one per input shape).  For latency-bound small batches.
+        A capture bakes in the addresses of the packed weights / codebooks it ran on, so every captured call first
+        compares a fingerprint of all parameters and buffers (version counters + storage addresses, ~0.1 ms) with the one
+        the captures were taken under: an optimizer step, `load_state_dict`, `reAssignCodebook`, `.to(...)` or any
+        other in-place update drops all captures before anything is replayed."""
         self._graphs = {} if enabled else None
+        self._graphStamp = None
         return self
 
+    def _weightStamp(self):
+        from .. import ops
+        tensors = self.__dict__.get("_stampTensors")
+        if tensors is None:                      # (walking the module tree costs ~3 ms: done once, redone after _apply)
+            tensors = self.__dict__["_stampTensors"] = list(self.parameters()) + list(self.buffers())
+        try:                                     # version counters only: storage moves come through _apply / load hooks
+            return tuple(map(_VERSION_OF, tensors))
+        except RuntimeError:                     # tensors created under torch.inference_mode() carry no counter
+            return tuple((ops.tensor_version(t), t.data_ptr()) for t in tensors)
+
+    def _forgetCaptures(self):
+        self.__dict__.pop("_stampTensors", None)
+        if self._graphs is not None:
+            self._graphs.clear()
+
+    def _apply(self, fn, *args, **kwargs):
+        """`.to()` / `.cuda()` / `.float()` replace storages (and buffer objects): forget the captures and the tensor list."""
+        self._forgetCaptures()
+        return super()._apply(fn, *args, **kwargs)
+
     def _graphed(self, kind: str, fn, inputs):
+        stamp = self._weightStamp()
+        if stamp != self._graphStamp:            # weights changed since the captures: their packed operands are stale
+            self._graphs.clear()
+            self._graphStamp = stamp
         key = (kind, tuple(tuple(t.shape) for t in inputs), inputs[0].device)
         g = self._graphs.get(key)
         if g is None:

@@ -16,6 +16,7 @@ cannot execute.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Tuple
 
 import numpy as np
@@ -49,6 +50,7 @@ class _Tables:
         self.cdfs = np.ascontiguousarray(np.asarray(cdfs, dtype=np.uint32).reshape(-1))
         self.starts = np.ascontiguousarray(np.arange(m, dtype=np.int32) * (k + 1))
         self.sizes = np.full(m, k + 2, dtype=np.int32)           # the reference's convention (entropyCoder.py:121)
+        self.lens = np.full(m, k + 1, dtype=np.int32)            # entries actually present per CDF (range checks in C)
         self.offsets = np.zeros(m, dtype=np.int32)
         self.m = m
 
@@ -59,9 +61,9 @@ def ransEncodeWithIndexes(symbols: np.ndarray, indexes: np.ndarray, t: _Tables) 
     cap = 4 * symbols.size + 64
     out = np.empty(cap, dtype=np.uint8)
     n = _lib.load().mcq_rans_encode_with_indexes(_vp(symbols), _vp(indexes), symbols.size, _vp(t.cdfs), _vp(t.starts),
-                                                 _vp(t.sizes), _vp(t.offsets), t.m, _vp(out), cap)
+                                                 _vp(t.sizes), _vp(t.lens), _vp(t.offsets), t.m, _vp(out), cap)
     if n < 0:
-        raise RuntimeError(f"rANS encode failed ({n})")
+        raise RuntimeError(f"rANS encode failed ({n}): a symbol outside its CDF's range, or a malformed table")
     return out[:n].tobytes()
 
 
@@ -70,7 +72,48 @@ def ransDecodeWithIndexes(binary: bytes, indexes: np.ndarray, t: _Tables) -> np.
     buf = np.frombuffer(binary, dtype=np.uint8)
     out = np.empty(indexes.size, dtype=np.int32)
     rc = _lib.load().mcq_rans_decode_with_indexes(_vp(buf), buf.size, _vp(indexes), indexes.size, _vp(t.cdfs), _vp(t.starts),
-                                                  _vp(t.sizes), _vp(t.offsets), t.m, _vp(out))
+                                                  _vp(t.sizes), _vp(t.lens), _vp(t.offsets), t.m, _vp(out))
+    if rc != 0:
+        raise RuntimeError("Got a truncated or malformed rANS stream.")
+    return out
+
+
+def hostThreads() -> int:
+    """Host threads for the batched coder: the cores this process may use (affinity mask; MCQUIC_AMD_RANS_THREADS overrides)."""
+    env = os.environ.get("MCQUIC_AMD_RANS_THREADS")
+    if env:
+        return max(1, int(env))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, 32))
+
+
+def ransEncodeBatchWithIndexes(symbols: np.ndarray, indexes: np.ndarray, t: _Tables, threads: int = 0) -> List[bytes]:
+    """symbols [n_streams, n] (one stream per row, all coded with the same `indexes[n]`) -> one byte string per row.
+    ONE C call; rows are spread over a pool of host threads (mcq_rans_encode_batch_with_indexes)."""
+    symbols = np.ascontiguousarray(symbols, dtype=np.int32)
+    indexes = np.ascontiguousarray(indexes, dtype=np.int32)
+    ns, n = symbols.shape
+    stride = 4 * n + 64
+    out = np.empty((ns, stride), dtype=np.uint8)
+    sizes = np.zeros(ns, dtype=np.int64)
+    rc = _lib.load().mcq_rans_encode_batch_with_indexes(_vp(symbols), ns, n, _vp(indexes), _vp(t.cdfs), _vp(t.starts), _vp(t.sizes),
+                                                        _vp(t.lens), _vp(t.offsets), t.m, _vp(out), stride, _vp(sizes),
+                                                        threads or hostThreads())
+    if rc != 0:
+        raise RuntimeError(f"rANS encode failed ({rc}): a code index outside [0, k), or a malformed table")
+    return [out[i, :sizes[i]].tobytes() for i in range(ns)]
+
+
+def ransDecodeBatchWithIndexes(binaries: List[bytes], indexes: np.ndarray, t: _Tables, threads: int = 0) -> np.ndarray:
+    """One byte string per stream -> int32 [n_streams, n]; ONE C call over a pool of host threads."""
+    indexes = np.ascontiguousarray(indexes, dtype=np.int32)
+    offs = np.zeros(len(binaries) + 1, dtype=np.int64)
+    np.cumsum([len(b) for b in binaries], out=offs[1:])
+    buf = np.frombuffer(b"".join(binaries), dtype=np.uint8)
+    out = np.empty((len(binaries), indexes.size), dtype=np.int32)
+    rc = _lib.load().mcq_rans_decode_batch_with_indexes(_vp(buf), _vp(offs), len(binaries), _vp(indexes), indexes.size, _vp(t.cdfs),
+                                                        _vp(t.starts), _vp(t.sizes), _vp(t.lens), _vp(t.offsets), t.m, _vp(out),
+                                                        threads or hostThreads())
     if rc != 0:
         raise RuntimeError("Got a truncated or malformed rANS stream.")
     return out
@@ -154,34 +197,62 @@ class EntropyCoder(nn.Module):
     # ---- byte streams (entropyCoder.py:95-154) ----------------------------------------------------------------
     @torch.inference_mode()
     def compress(self, codes: List[torch.Tensor]) -> Tuple[List[List[bytes]], List[CodeSize]]:
-        """codes: level-length list of [n, m, h, w] -> (binaries[n][level], CodeSize per image)."""
+        """codes: level-length list of [n, m, h, w] -> (binaries[n][level], CodeSize per image).
+        Per level: one device-to-host copy (all levels' copies are enqueued before the first one is waited for) and ONE
+        call into the host coder, which spreads the n images' streams over a thread pool."""
         n, m = self._checkShape(codes)
         self.CDFs  # refresh the tables if the EMA changed
+        if len(codes) != len(self._tables):
+            raise RuntimeError(f"expected {len(self._tables)} code levels, got {len(codes)}")
+        hosts = []
+        for code in codes:
+            c32 = code.detach().to(torch.int32)
+            if c32.is_cuda:
+                pinned = torch.empty(c32.shape, dtype=torch.int32, pin_memory=True)
+                pinned.copy_(c32, non_blocking=True)
+                c32 = pinned
+            hosts.append(c32)
+        if codes[0].is_cuda:
+            torch.cuda.current_stream(codes[0].device).synchronize()
         compressed: List[List[bytes]] = [[] for _ in range(n)]
         heights, widths = [], []
-        for code, table in zip(codes, self._tables):
-            _, _, h, w = code.shape
+        for host, table, k in zip(hosts, self._tables, self._k):
+            _, _, h, w = host.shape
             heights.append(h)
             widths.append(w)
-            host = code.detach().to("cpu", torch.int32).numpy()            # one D2H copy per level
             idx = np.repeat(np.arange(m, dtype=np.int32), h * w)            # group id per symbol, [m, h, w] order
-            for i in range(n):
-                compressed[i].append(ransEncodeWithIndexes(host[i].reshape(-1), idx, table))
+            for i, b in enumerate(ransEncodeBatchWithIndexes(host.numpy().reshape(n, m * h * w), idx, table)):
+                compressed[i].append(b)
         return compressed, [CodeSize([m] * len(codes), heights, widths, list(self._k)) for _ in range(n)]
+
+    # what a header may ask the decoder to allocate: a side of 2^15 latent positions is a 2-megapixel-wide image 64 times over
+    _MAX_SIDE = 1 << 15
 
     @torch.inference_mode()
     def decompress(self, binaries: List[List[bytes]], codeSizes: List[CodeSize]) -> List[torch.Tensor]:
-        """binaries[n][level] -> level-length list of int64 [n, m, h, w] on the coder's device."""
+        """binaries[n][level] -> level-length list of int64 [n, m, h, w] on the coder's device.  Header fields are
+        untrusted input (they come out of a `.mcq` file): m / k must be this model's, sizes positive and bounded, all
+        images of a batch alike -- checked before anything is allocated."""
         if len(binaries) < 1 or len(binaries) != len(codeSizes):
             raise RuntimeError("`binaries` and `codeSizes` must be non-empty and of equal length.")
         self.CDFs
-        levels = len(binaries[0])
-        out = [[] for _ in range(levels)]
+        levels = len(self._tables)
+        first = codeSizes[0]
         for binary, codeSize in zip(binaries, codeSizes):
-            if len(binary) != levels or len(codeSize.heights) != levels:
-                raise RuntimeError("Every image must carry one stream per level.")
-            for lv, (b, table, mi, h, w) in enumerate(zip(binary, self._tables, codeSize.m, codeSize.heights, codeSize.widths)):
-                idx = np.repeat(np.arange(mi, dtype=np.int32), h * w)
-                out[lv].append(torch.from_numpy(ransDecodeWithIndexes(b, idx, table).reshape(mi, h, w).astype(np.int64)))
+            if len(binary) != levels or len(codeSize.heights) != levels or len(codeSize.widths) != levels or len(codeSize.m) != levels:
+                raise RuntimeError(f"Every image must carry one stream per level ({levels} for this model).")
+            if list(codeSize.m) != [self._m] * levels or list(codeSize.k) != list(self._k):
+                raise RuntimeError(f"The header's code size (m = {list(codeSize.m)}, k = {list(codeSize.k)}) is not this model's "
+                                   f"(m = {self._m}, k = {list(self._k)}).")
+            if any(not (0 < int(v) <= self._MAX_SIDE) for v in list(codeSize.heights) + list(codeSize.widths)):
+                raise RuntimeError("The header's code heights / widths are out of range.")
+            if list(codeSize.heights) != list(first.heights) or list(codeSize.widths) != list(first.widths):
+                raise RuntimeError("All images of one batch must share their code sizes.")
         device = self._freqEMA[0].device
-        return [torch.stack(c, 0).to(device) for c in out]
+        out = []
+        for lv, table in enumerate(self._tables):
+            h, w = int(first.heights[lv]), int(first.widths[lv])
+            idx = np.repeat(np.arange(self._m, dtype=np.int32), h * w)
+            sym = ransDecodeBatchWithIndexes([binary[lv] for binary in binaries], idx, table)
+            out.append(torch.from_numpy(sym.reshape(len(binaries), self._m, h, w).astype(np.int64)).to(device))
+        return out

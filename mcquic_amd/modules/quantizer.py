@@ -28,6 +28,9 @@ class _CodebookCache:
         self._packed: Optional[ops.PackedCodebook] = None
         self._key = None
 
+    def invalidate(self):
+        self._packed, self._key = None, None
+
     def get(self, codebook: torch.Tensor) -> ops.PackedCodebook:
         key = (ops.tensor_version(codebook), codebook.data_ptr())
         if self._packed is None or key != self._key:
@@ -55,35 +58,57 @@ class _multiCodebookQuantization(nn.Module):
         self._cache = [cache]          # list: keep the cache out of nn.Module's attribute registration
 
     @torch.no_grad()
-    def reAssignCodebook(self, freq: torch.Tensor) -> torch.Tensor:
-        """Replace never-assigned codewords by copies of the most used ones (reference: quantizer.py:111-136).
-        Parameter-sized host logic (torch ops on [k, d]); returns the per-codeword "changed" mask, flattened."""
-        codebook = self._codebook.detach().clone()
-        freq = freq.to(self._codebook.device).detach().clone()
-        for m, (codebookGroup, freqGroup) in enumerate(zip(self._codebook, freq)):
-            neverAssignedLoc = freqGroup < EPS
-            totalNeverAssigned = int(neverAssignedLoc.sum())
-            if totalNeverAssigned > self._k // 2:          # more than half never assigned: drop a random part of them
-                mask = torch.zeros((totalNeverAssigned,), device=self._codebook.device)
-                maskIdx = torch.randperm(len(mask), device=mask.device)[self._k // 2:]
-                mask[maskIdx] = -1.
-                freqGroup[neverAssignedLoc] = mask
-                neverAssignedLoc = (freqGroup < EPS) * (freqGroup > (-EPS))
-                totalNeverAssigned = int(neverAssignedLoc.sum())
-            argIdx = torch.argsort(freqGroup, descending=True)
-            mostAssigned = codebookGroup[argIdx]
-            codebook.data[m, neverAssignedLoc] = mostAssigned[:totalNeverAssigned]
-        diff = ((codebook - self._codebook) ** 2).sum(-1) > 1e-4
-        self._codebook.data.copy_(codebook)
-        return diff.flatten()
+    def reAssignCodebook(self, freq: torch.Tensor, priority: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Dead codewords (normalised frequency < 1e-6) are overwritten by the most used ones: the i-th dead codeword in
+        index order receives the i-th most frequent codeword of its group; when more than k // 2 of a group are dead only
+        a random k // 2 of them are refilled (reference behaviour: mcquic/modules/quantizer.py:111-136, driven by the
+        CodebookReassign hook, mcquic/train/hooks.py:100-121).  Returns the flattened [m * k] mask of codewords that moved
+        by more than 1e-4 in squared distance.
+
+        One batched device-side pass over all m groups -- two sorts, a cumulative count and a gather -- with no host
+        read-back (the reference loops over groups and syncs twice per group).  `priority` [m, k]: the dead codewords with
+        the smallest priorities are the ones refilled when there are too many (default: fresh uniform draws; the parity
+        test passes the ranks of the reference's `torch.randperm` draw)."""
+        old = self._codebook.detach()
+        dev = old.device
+        freq = freq.detach().to(dev, torch.float32)
+        m, k, d = old.shape
+        half = k // 2
+        dead = freq < EPS                                                       # [m, k]
+        if priority is None:
+            priority = torch.rand((m, k), device=dev)
+        # rank of every codeword when the dead ones are lined up by priority (live ones pushed behind them)
+        lineup = torch.where(dead, priority.to(dev, torch.float32), torch.full_like(freq, float("inf"))).argsort(dim=-1, stable=True)
+        place = torch.empty_like(lineup).scatter_(-1, lineup, torch.arange(k, device=dev).expand(m, k))
+        refill = dead & (place < half)                                          # at most k // 2 per group
+        # popularity order: live codewords by frequency, then the refilled dead ones (0), then the skipped dead ones (-1);
+        # a group with few dead codewords keeps its measured frequencies untouched, like the reference
+        crowded = dead.sum(-1, keepdim=True) > half
+        score = torch.where(crowded & dead, torch.where(refill, torch.zeros_like(freq), -torch.ones_like(freq)), freq)
+        donors = score.argsort(dim=-1, descending=True, stable=True)                # [m, k] codeword indices, most used first
+        slot = (refill.cumsum(-1) - 1).clamp_(min=0)                            # i for the i-th refilled codeword of a group
+        source = donors.gather(-1, slot)                                        # donor index per codeword position
+        moved = old.gather(1, source[..., None].expand(m, k, d))
+        fresh = torch.where(refill[..., None], moved, old)
+        changed = ((fresh - old) ** 2).sum(-1) > 1e-4
+        self._store(fresh)
+        return changed.flatten()
 
     @torch.no_grad()
     def syncCodebook(self):
-        """Broadcast rank 0's codebook (reference: quantizer.py:138-142)."""
+        """Every rank takes rank 0's codebook (reference: quantizer.py:138-142): one broadcast of a detached copy, written
+        back in place so the Parameter object (and the optimizer state keyed on it) stays the same."""
         import torch.distributed as dist
-        codebook = self._codebook.detach().clone()
-        dist.broadcast(codebook, 0)
-        self._codebook.data.copy_(codebook)
+        buf = self._codebook.detach().clone()
+        dist.broadcast(buf, 0)
+        self._store(buf)
+
+    def _store(self, value: torch.Tensor):
+        """In-place update of the shared codebook Parameter that the packed-operand cache notices: `copy_` on the Parameter
+        itself bumps its version counter (`.data.copy_` does not), and the cache is dropped explicitly as well, for
+        parameters created under torch.inference_mode(), which carry no version counter."""
+        self._codebook.copy_(value)
+        self._cache[0].invalidate()
 
     def encode(self, x: torch.Tensor) -> torch.Tensor:
         """[n, m*d, h, w] -> int64 [n, m, h, w] = argmin_k ((x2 + c2) - 2 x.c), first index on ties (:144-179)."""

@@ -484,3 +484,50 @@ def freq_ema_update(freq_ema: torch.Tensor, total_count: torch.Tensor, ema: floa
     """entropyCoder.py:38-43 after the all_reduce: normalise the counts, blend with the running EMA."""
     normalized = total_count / total_count.sum(-1, keepdim=True)
     return (1 - ema) * normalized + ema * freq_ema
+
+
+# ----------------------------------------------------------------------------------------------
+# inputs of the reAssignCodebook fixtures (tests/golden/f9_reassign.npz); generators only
+def reassign_case(m: int, k: int, d: int, dead_frac, seed: int):
+    """One `reAssignCodebook` case (mcquic/modules/quantizer.py:111-136): a codebook [m, k, d], normalised frequencies
+    [m, k] with a share of dead (< 1e-6) entries per group, and the permutation each group's `torch.randperm` call is
+    made to return when the group is crowded (more than k // 2 dead)."""
+    g = torch.Generator().manual_seed(seed)
+    cb = torch.randn((m, k, d), generator=g)
+    f = torch.rand((m, k), generator=g) + 0.01
+    dead = torch.rand((m, k), generator=g) < torch.tensor(dead_frac)[:, None]
+    tiny = torch.rand((m, k), generator=g) * 1e-9 * (torch.rand((m, k), generator=g) < 0.5)
+    f = torch.where(dead, tiny, f)
+    f = f / f.sum(-1, keepdim=True)
+    perms = [torch.randperm(int((f[gi] < 1e-6).sum()), generator=g) for gi in range(m)]
+    return cb, f, perms
+
+
+REASSIGN_CASES = [(2, 32, 4, [0.2, 0.3], 1), (2, 32, 4, [0.7, 0.2], 2), (2, 32, 4, [0.9, 0.95], 3), (2, 512, 64, [0.6, 0.4], 4),
+                  (3, 64, 8, [0.0, 0.6, 0.5], 6)]
+
+
+def reassign_priority(freq: torch.Tensor, perms) -> torch.Tensor:
+    """The recorded permutations as refill priorities [m, k]: the dead codeword the reference's permutation lists i-th
+    gets priority i (the reference keeps the first k // 2 of the permutation)."""
+    m, k = freq.shape
+    pr = torch.full((m, k), float(k + 1))
+    for g in range(m):
+        idx = torch.nonzero(freq[g] < 1e-6).flatten()
+        pr[g, idx[perms[g]]] = torch.arange(len(idx), dtype=torch.float32)
+    return pr
+
+
+def reassign_defined_mask(freq: torch.Tensor, priority: torch.Tensor) -> torch.Tensor:
+    """[m, k] bool: positions whose new codeword the reference defines.  When a group has more refilled slots than live
+    codewords, the donors past the live ones are dead codewords tied at frequency 0, which the reference orders with an
+    unstable `torch.argsort` -- implementation-defined, so those slots are only checked to hold SOME refilled dead codeword."""
+    m, k = freq.shape
+    out = torch.ones((m, k), dtype=torch.bool)
+    for g in range(m):
+        dead = freq[g] < 1e-6
+        idx = torch.nonzero(dead).flatten()
+        keep = idx[torch.argsort(priority[g, idx])[: k // 2]].sort().values if len(idx) > k // 2 else idx
+        live = k - len(idx)
+        out[g, keep[min(len(keep), live):]] = False
+    return out

@@ -35,6 +35,12 @@ def sha(t: torch.Tensor) -> str:
 F7_CASES = [(1, 2, 200, 176), (2, 3, 193, 211), (3, 1, 768, 512), (4, 2, 161, 400)]   # (seed, n, h, w)
 
 
+def want(tag: str) -> bool:
+    """`python make_golden.py f9 f10` regenerates only the named fixture sets (default: all of them)."""
+    sel = [a.lower() for a in sys.argv[1:]]
+    return not sel or tag in sel
+
+
 def main():
     C = ref_harness.load()
     import mcquic.nn as RN                      # the reference's layers
@@ -44,175 +50,249 @@ def main():
     torch.set_num_threads(8)
 
     # ---- F1: per-block I/O at C = 8 (odd sizes) -------------------------------------------------------
-    blocks = {}
-    c = 8
-    x = rand((2, c, 13, 18), 101)
-    blocks["x"] = x.numpy()
-    for name, ctor, mk in [("ResidualBlock", lambda: RN.ResidualBlock(c, c), R._rb),
-                           ("ResidualBlockWithStride", lambda: RN.ResidualBlockWithStride(c, c), R._rb_stride),
-                           ("ResidualBlockShuffle", lambda: RN.ResidualBlockShuffle(c, c), R._rb_shuffle),
-                           ("AttentionBlock", lambda: RN.blocks.AttentionBlock(c), R._attn)]:
-        sd = {}
-        mk(sd, "", c, 11)
-        mod = ctor().eval()
-        mod.load_state_dict(sd, strict=True)
-        with torch.inference_mode():
-            blocks[name] = mod(x.clone()).numpy()
-    for name, cls in [("GenDivNorm", RN.GenDivNorm), ("InvGenDivNorm", RN.InvGenDivNorm)]:
-        sd = {}
-        R._gdn_params(sd, "", c, 12)
-        mod = cls(c).eval()
-        mod.load_state_dict(sd, strict=True)
-        with torch.inference_mode():
-            blocks[name] = mod(x.clone() * 2).numpy()
-    np.savez_compressed(os.path.join(OUT, "f1_blocks_c8.npz"), **blocks)
+    if want("f1"):
+        blocks = {}
+        c = 8
+        x = rand((2, c, 13, 18), 101)
+        blocks["x"] = x.numpy()
+        for name, ctor, mk in [("ResidualBlock", lambda: RN.ResidualBlock(c, c), R._rb),
+                               ("ResidualBlockWithStride", lambda: RN.ResidualBlockWithStride(c, c), R._rb_stride),
+                               ("ResidualBlockShuffle", lambda: RN.ResidualBlockShuffle(c, c), R._rb_shuffle),
+                               ("AttentionBlock", lambda: RN.blocks.AttentionBlock(c), R._attn)]:
+            sd = {}
+            mk(sd, "", c, 11)
+            mod = ctor().eval()
+            mod.load_state_dict(sd, strict=True)
+            with torch.inference_mode():
+                blocks[name] = mod(x.clone()).numpy()
+        for name, cls in [("GenDivNorm", RN.GenDivNorm), ("InvGenDivNorm", RN.InvGenDivNorm)]:
+            sd = {}
+            R._gdn_params(sd, "", c, 12)
+            mod = cls(c).eval()
+            mod.load_state_dict(sd, strict=True)
+            with torch.inference_mode():
+                blocks[name] = mod(x.clone() * 2).numpy()
+        np.savez_compressed(os.path.join(OUT, "f1_blocks_c8.npz"), **blocks)
 
     # ---- F2 / F3: VQ distance + argmin, gather (the reference's _multiCodebookQuantization) -------------
-    vq = {}
-    for tag, (m, k, d, n, h, w) in {"qp2_l2": (2, 512, 64, 2, 6, 8), "qp2_l1": (2, 2048, 64, 1, 6, 8),
-                                    "small": (2, 32, 4, 2, 8, 8)}.items():
-        g = torch.Generator().manual_seed(7)
-        cb = torch.randn((m, k, d), generator=g) * np.sqrt(2 / (5 * d))
-        xx = torch.randn((n, m * d, h, w), generator=g) * 0.1
-        q = RQ._multiCodebookQuantization(torch.nn.Parameter(cb), 0.0)
-        dq = RQ._multiCodebookDeQuantization(torch.nn.Parameter(cb))
-        with torch.inference_mode():
-            dist = q._distance(xx)
-            code = q.encode(xx)
-            deq = dq.decode(code)
-        top2 = torch.topk(dist, 2, dim=-1, largest=False).values
-        vq[tag + "_shape"] = np.array([m, k, d, n, h, w])
-        vq[tag + "_code"] = code.numpy().astype(np.int16)
-        vq[tag + "_gap"] = (top2[..., 1] - top2[..., 0]).numpy()
-        vq[tag + "_mindist"] = top2[..., 0].numpy()
-        vq[tag + "_deq_sha"] = np.frombuffer(bytes.fromhex(sha(deq)), dtype=np.uint8)
-    np.savez_compressed(os.path.join(OUT, "f2_vq.npz"), **vq)
+    if want("f2"):
+        vq = {}
+        for tag, (m, k, d, n, h, w) in {"qp2_l2": (2, 512, 64, 2, 6, 8), "qp2_l1": (2, 2048, 64, 1, 6, 8),
+                                        "small": (2, 32, 4, 2, 8, 8)}.items():
+            g = torch.Generator().manual_seed(7)
+            cb = torch.randn((m, k, d), generator=g) * np.sqrt(2 / (5 * d))
+            xx = torch.randn((n, m * d, h, w), generator=g) * 0.1
+            q = RQ._multiCodebookQuantization(torch.nn.Parameter(cb), 0.0)
+            dq = RQ._multiCodebookDeQuantization(torch.nn.Parameter(cb))
+            with torch.inference_mode():
+                dist = q._distance(xx)
+                code = q.encode(xx)
+                deq = dq.decode(code)
+            top2 = torch.topk(dist, 2, dim=-1, largest=False).values
+            vq[tag + "_shape"] = np.array([m, k, d, n, h, w])
+            vq[tag + "_code"] = code.numpy().astype(np.int16)
+            vq[tag + "_gap"] = (top2[..., 1] - top2[..., 0]).numpy()
+            vq[tag + "_mindist"] = top2[..., 0].numpy()
+            vq[tag + "_deq_sha"] = np.frombuffer(bytes.fromhex(sha(deq)), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, "f2_vq.npz"), **vq)
 
     # ---- F4: the full small model Compressor(8, 2, [32, 16, 8]) ----------------------------------------
-    small = {}
-    sd = R.make_state_dict(8, 2, [32, 16, 8], seed=1)
-    model = ref_harness.reference_compressor(8, 2, [32, 16, 8], sd)
-    for tag, (n, h, w) in {"pad": (2, 200, 136), "aligned": (1, 128, 256)}.items():
-        xi = R.make_images(n, h, w)
+    if want("f4"):
+        small = {}
+        sd = R.make_state_dict(8, 2, [32, 16, 8], seed=1)
+        model = ref_harness.reference_compressor(8, 2, [32, 16, 8], sd)
+        for tag, (n, h, w) in {"pad": (2, 200, 136), "aligned": (1, 128, 256)}.items():
+            xi = R.make_images(n, h, w)
+            with torch.inference_mode():
+                codes = model.encode(xi)
+                rec = model.decode(codes)
+            small[tag + "_shape"] = np.array([n, h, w])
+            for lv, cd in enumerate(codes):
+                small[f"{tag}_code{lv}"] = cd.numpy().astype(np.int16)
+            small[tag + "_rec_strided"] = rec[..., ::4, ::4].numpy()
+            small[tag + "_rec_crop"] = rec[..., 32:96, 32:96].numpy()
+            small[tag + "_rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
+            small[tag + "_padded_sha"] = np.frombuffer(bytes.fromhex(sha(AlignedPadding()(xi))), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, "f4_small_model.npz"), **small)
+
+    # ---- F5: the qp=2 model Compressor(128, 2, [8192, 2048, 512]) on one 256x384 image -----------------
+    if want("f5"):
+        qp2 = {}
+        sd = R.make_state_dict(128, 2, [8192, 2048, 512], seed=0)
+        model = ref_harness.reference_compressor(128, 2, [8192, 2048, 512], sd)
+        xi = R.make_images(1, 256, 384)
         with torch.inference_mode():
             codes = model.encode(xi)
             rec = model.decode(codes)
-        small[tag + "_shape"] = np.array([n, h, w])
+        qp2["shape"] = np.array([1, 256, 384])
+        qp2["n_state_dict_entries"] = np.array([len(model.state_dict())])
         for lv, cd in enumerate(codes):
-            small[f"{tag}_code{lv}"] = cd.numpy().astype(np.int16)
-        small[tag + "_rec_strided"] = rec[..., ::4, ::4].numpy()
-        small[tag + "_rec_crop"] = rec[..., 32:96, 32:96].numpy()
-        small[tag + "_rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
-        small[tag + "_padded_sha"] = np.frombuffer(bytes.fromhex(sha(AlignedPadding()(xi))), dtype=np.uint8)
-    np.savez_compressed(os.path.join(OUT, "f4_small_model.npz"), **small)
-
-    # ---- F5: the qp=2 model Compressor(128, 2, [8192, 2048, 512]) on one 256x384 image -----------------
-    qp2 = {}
-    sd = R.make_state_dict(128, 2, [8192, 2048, 512], seed=0)
-    model = ref_harness.reference_compressor(128, 2, [8192, 2048, 512], sd)
-    xi = R.make_images(1, 256, 384)
-    with torch.inference_mode():
-        codes = model.encode(xi)
-        rec = model.decode(codes)
-    qp2["shape"] = np.array([1, 256, 384])
-    qp2["n_state_dict_entries"] = np.array([len(model.state_dict())])
-    for lv, cd in enumerate(codes):
-        qp2[f"code{lv}"] = cd.numpy().astype(np.int16)
-    qp2["rec_crop"] = rec[:, :, 96:160, 160:224].numpy()
-    qp2["rec_mean_abs"] = np.array([rec.abs().mean().item()])
-    qp2["rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
-    np.savez_compressed(os.path.join(OUT, "f5_qp2_model.npz"), **qp2)
+            qp2[f"code{lv}"] = cd.numpy().astype(np.int16)
+        qp2["rec_crop"] = rec[:, :, 96:160, 160:224].numpy()
+        qp2["rec_mean_abs"] = np.array([rec.abs().mean().item()])
+        qp2["rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, "f5_qp2_model.npz"), **qp2)
     # ---- F6: training-mode forward of the small model (reference with its one broken attribute repaired:
-    #          _multiCodebookQuantization._freqEMA = the level's entropy-coder EMA, see oracle/mcquic_ref.py) -----
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group("gloo", rank=0, world_size=1)
-    ch, m, ks = 8, 2, [32, 16, 8]
-    sd = R.make_state_dict(ch, m, ks, seed=2)
-    g = torch.Generator().manual_seed(3)
-    for lv, k in enumerate(ks):
-        f = torch.rand((m, k), generator=g) ** 3 + 1e-3
-        sd[f"_quantizer._entropyCoder._freqEMA.{lv}"] = f / f.sum(-1, keepdim=True)
-    model = ref_harness.reference_compressor(ch, m, ks, sd)
-    for lv, enc in enumerate(model._quantizer._encoders):
-        enc._quantizer._freqEMA = model._quantizer._entropyCoder._freqEMA[lv]
-    model.train()
-    xi = R.make_images(2, 128, 128, seed=4)
-    shapes = [(2, m, 8, 8, 32), (2, m, 4, 4, 16), (2, m, 2, 2, 8)]
-    us = [(torch.rand(sh, generator=g), torch.rand(sh, generator=g)) for sh in shapes]
-    it = iter([u for pair in us for u in pair])
-    orig = torch.rand_like
-    torch.rand_like = lambda t, **kw: next(it).clone()
-    try:
-        xHat, yHat, codes, logits = model(xi.clone())
-    finally:
-        torch.rand_like = orig
-    f6 = {"xHat_strided": xHat.detach()[..., ::2, ::2].numpy(), "yHat": yHat.detach().numpy()}
-    for lv in range(3):
-        f6[f"code{lv}"] = codes[lv].numpy().astype(np.int16)
-        f6[f"logit{lv}"] = logits[lv].detach().numpy()
-        f6[f"ema{lv}"] = model._quantizer._entropyCoder._freqEMA[lv].detach().numpy()
-    np.savez_compressed(os.path.join(OUT, "f6_train_forward.npz"), **f6)
+    if want("f6"):
+        #          _multiCodebookQuantization._freqEMA = the level's entropy-coder EMA, see oracle/mcquic_ref.py) -----
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("gloo", rank=0, world_size=1)
+        ch, m, ks = 8, 2, [32, 16, 8]
+        sd = R.make_state_dict(ch, m, ks, seed=2)
+        g = torch.Generator().manual_seed(3)
+        for lv, k in enumerate(ks):
+            f = torch.rand((m, k), generator=g) ** 3 + 1e-3
+            sd[f"_quantizer._entropyCoder._freqEMA.{lv}"] = f / f.sum(-1, keepdim=True)
+        model = ref_harness.reference_compressor(ch, m, ks, sd)
+        for lv, enc in enumerate(model._quantizer._encoders):
+            enc._quantizer._freqEMA = model._quantizer._entropyCoder._freqEMA[lv]
+        model.train()
+        xi = R.make_images(2, 128, 128, seed=4)
+        shapes = [(2, m, 8, 8, 32), (2, m, 4, 4, 16), (2, m, 2, 2, 8)]
+        us = [(torch.rand(sh, generator=g), torch.rand(sh, generator=g)) for sh in shapes]
+        it = iter([u for pair in us for u in pair])
+        orig = torch.rand_like
+        torch.rand_like = lambda t, **kw: next(it).clone()
+        try:
+            xHat, yHat, codes, logits = model(xi.clone())
+        finally:
+            torch.rand_like = orig
+        f6 = {"xHat_strided": xHat.detach()[..., ::2, ::2].numpy(), "yHat": yHat.detach().numpy()}
+        for lv in range(3):
+            f6[f"code{lv}"] = codes[lv].numpy().astype(np.int16)
+            f6[f"logit{lv}"] = logits[lv].detach().numpy()
+            f6[f"ema{lv}"] = model._quantizer._entropyCoder._freqEMA[lv].detach().numpy()
+        np.savez_compressed(os.path.join(OUT, "f6_train_forward.npz"), **f6)
 
     # ---- F8: rANS byte streams + quantized CDFs from the reference's native coder (oracle/_ref, built from the
-    #          reference's own sources by oracle/Makefile) ---------------------------------------------------------
-    import glob
-    import importlib.util
-    so = glob.glob(os.path.join(ROOT, "oracle", "_ref", "rans*.so"))
-    if so:
-        spec = importlib.util.spec_from_file_location("rans", so[0])
-        RA = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(RA)
-        rng = np.random.default_rng(0)
-        f8 = {}
-        for tag, k, m, h, w in (("k8", 8, 2, 5, 7), ("k512", 512, 2, 12, 8), ("k8192", 8192, 2, 48, 32)):
-            pmfs = []
-            for g in range(m):
-                pm = rng.random(k).astype(np.float32) ** (4 if g == 0 else 1)
-                pmfs.append((pm / pm.sum()).astype(np.float32))
-            cdfs = [RA.pmfToQuantizedCDF(pm.tolist(), 16) for pm in pmfs]
-            sym = rng.integers(0, k, m * h * w).astype(np.int32)
-            idx = np.repeat(np.arange(m, dtype=np.int32), h * w)
-            by = RA.RansEncoder().encodeWithIndexes(sym.tolist(), idx.tolist(), cdfs, [k + 2] * m, [0] * m)
-            f8[tag + "_pmf"] = np.stack(pmfs)
-            f8[tag + "_cdf"] = np.asarray(cdfs, dtype=np.uint32)
-            f8[tag + "_sym"] = sym
-            f8[tag + "_shape"] = np.array([m, h, w, k])
-            f8[tag + "_bytes"] = np.frombuffer(by, dtype=np.uint8)
-        # bypass path: CompressAI's own convention cdfSizes = len(cdf) (sentinel = last slot), symbols beyond it / negative
-        k = 16
-        pm = (np.ones(k) / k).astype(np.float32)
-        cdf = RA.pmfToQuantizedCDF(pm.tolist(), 16)
-        sym = np.array([0, 3, 14, 15, 16, 40, 1000, -1, -7, 5], dtype=np.int32)
-        by = RA.RansEncoder().encodeWithIndexes(sym.tolist(), [0] * len(sym), [cdf], [k + 1], [0])
-        f8["bypass_cdf"] = np.asarray(cdf, dtype=np.uint32)
-        f8["bypass_sym"] = sym
-        f8["bypass_bytes"] = np.frombuffer(by, dtype=np.uint8)
-        np.savez_compressed(os.path.join(OUT, "f8_rans.npz"), **f8)
+    if want("f8"):
+        #          reference's own sources by oracle/Makefile) ---------------------------------------------------------
+        import glob
+        import importlib.util
+        so = glob.glob(os.path.join(ROOT, "oracle", "_ref", "rans*.so"))
+        if so:
+            spec = importlib.util.spec_from_file_location("rans", so[0])
+            RA = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(RA)
+            rng = np.random.default_rng(0)
+            f8 = {}
+            for tag, k, m, h, w in (("k8", 8, 2, 5, 7), ("k512", 512, 2, 12, 8), ("k8192", 8192, 2, 48, 32)):
+                pmfs = []
+                for g in range(m):
+                    pm = rng.random(k).astype(np.float32) ** (4 if g == 0 else 1)
+                    pmfs.append((pm / pm.sum()).astype(np.float32))
+                cdfs = [RA.pmfToQuantizedCDF(pm.tolist(), 16) for pm in pmfs]
+                sym = rng.integers(0, k, m * h * w).astype(np.int32)
+                idx = np.repeat(np.arange(m, dtype=np.int32), h * w)
+                by = RA.RansEncoder().encodeWithIndexes(sym.tolist(), idx.tolist(), cdfs, [k + 2] * m, [0] * m)
+                f8[tag + "_pmf"] = np.stack(pmfs)
+                f8[tag + "_cdf"] = np.asarray(cdfs, dtype=np.uint32)
+                f8[tag + "_sym"] = sym
+                f8[tag + "_shape"] = np.array([m, h, w, k])
+                f8[tag + "_bytes"] = np.frombuffer(by, dtype=np.uint8)
+            # bypass path: CompressAI's own convention cdfSizes = len(cdf) (sentinel = last slot), symbols beyond it / negative
+            k = 16
+            pm = (np.ones(k) / k).astype(np.float32)
+            cdf = RA.pmfToQuantizedCDF(pm.tolist(), 16)
+            sym = np.array([0, 3, 14, 15, 16, 40, 1000, -1, -7, 5], dtype=np.int32)
+            by = RA.RansEncoder().encodeWithIndexes(sym.tolist(), [0] * len(sym), [cdf], [k + 1], [0])
+            f8["bypass_cdf"] = np.asarray(cdf, dtype=np.uint32)
+            f8["bypass_sym"] = sym
+            f8["bypass_bytes"] = np.frombuffer(by, dtype=np.uint8)
+            np.savez_compressed(os.path.join(OUT, "f8_rans.npz"), **f8)
     # ---- F7: validation metrics (MS-SSIM, PSNR, IdealBPP) from the reference's own validate/ code ---------
-    import importlib.util
-    from oracle import metrics_ref as MR        # generators only
-    spec = importlib.util.spec_from_file_location("ref_metrics", os.path.join(ref_harness.REF, "mcquic/validate/metrics.py"))
-    RM = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(RM)
-    RH = ref_harness.load_validate_handlers()
-    f7 = {"cases": np.array(F7_CASES, dtype=np.int64)}
-    msssim_mod, psnr_mod, decibel = RM.MsSSIM(sizeAverage=False), RM.PSNR(sizeAverage=False), RH["Decibel"](1.0)
-    for i, (seed, n, h, w) in enumerate(F7_CASES):
-        x, y = MR.make_u8_pair(seed, n, h, w)
-        out = msssim_mod(x.float(), y.float())                    # handlers.py:26 (1 - ms_ssim)
-        f7[f"msssim_{i}"] = (1.0 - out).numpy()
-        f7[f"msssim_db_{i}"] = decibel(out).numpy()
-        f7[f"psnr_{i}"] = psnr_mod(x.float(), y.float()).numpy()
-        f7[f"sha_{i}"] = np.frombuffer(bytes.fromhex(sha(x) + sha(y)), dtype=np.uint8)
-    ks, ms = list(MR.CODE_BATCH_KS), [2, 2, 2]
-    handler = RH["IdealBPP"](ms, ks)
-    for codes in MR.make_code_batches():                            # accumulated over two batches like a validation run
-        handler(codes=codes, images=torch.zeros(3, 3, 768, 512, dtype=torch.uint8))
-    f7["ideal_bpp"] = np.array([handler.Result], dtype=np.float64)
-    np.savez_compressed(os.path.join(OUT, "f7_metrics.npz"), **f7)
+    if want("f7"):
+        import importlib.util
+        from oracle import metrics_ref as MR        # generators only
+        spec = importlib.util.spec_from_file_location("ref_metrics", os.path.join(ref_harness.REF, "mcquic/validate/metrics.py"))
+        RM = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(RM)
+        RH = ref_harness.load_validate_handlers()
+        f7 = {"cases": np.array(F7_CASES, dtype=np.int64)}
+        msssim_mod, psnr_mod, decibel = RM.MsSSIM(sizeAverage=False), RM.PSNR(sizeAverage=False), RH["Decibel"](1.0)
+        for i, (seed, n, h, w) in enumerate(F7_CASES):
+            x, y = MR.make_u8_pair(seed, n, h, w)
+            out = msssim_mod(x.float(), y.float())                    # handlers.py:26 (1 - ms_ssim)
+            f7[f"msssim_{i}"] = (1.0 - out).numpy()
+            f7[f"msssim_db_{i}"] = decibel(out).numpy()
+            f7[f"psnr_{i}"] = psnr_mod(x.float(), y.float()).numpy()
+            f7[f"sha_{i}"] = np.frombuffer(bytes.fromhex(sha(x) + sha(y)), dtype=np.uint8)
+        ks, ms = list(MR.CODE_BATCH_KS), [2, 2, 2]
+        handler = RH["IdealBPP"](ms, ks)
+        for codes in MR.make_code_batches():                            # accumulated over two batches like a validation run
+            handler(codes=codes, images=torch.zeros(3, 3, 768, 512, dtype=torch.uint8))
+        f7["ideal_bpp"] = np.array([handler.Result], dtype=np.float64)
+        np.savez_compressed(os.path.join(OUT, "f7_metrics.npz"), **f7)
+
+    # ---- F1b: per-block I/O at C = 128, the network's width ------------------------------
+    if want("f1b"):
+        blocks = {}
+        c = 128
+        x = rand((1, c, 9, 10), 131)
+        blocks["x"] = x.numpy()
+        for name, ctor, mk in [("ResidualBlock", lambda: RN.ResidualBlock(c, c), R._rb),
+                               ("ResidualBlockWithStride", lambda: RN.ResidualBlockWithStride(c, c), R._rb_stride),
+                               ("ResidualBlockShuffle", lambda: RN.ResidualBlockShuffle(c, c), R._rb_shuffle),
+                               ("AttentionBlock", lambda: RN.blocks.AttentionBlock(c), R._attn)]:
+            sd = {}
+            mk(sd, "", c, 21)
+            mod = ctor().eval()
+            mod.load_state_dict(sd, strict=True)
+            with torch.inference_mode():
+                blocks[name] = mod(x.clone()).numpy()
+        for name, cls in [("GenDivNorm", RN.GenDivNorm), ("InvGenDivNorm", RN.InvGenDivNorm)]:
+            sd = {}
+            R._gdn_params(sd, "", c, 22)
+            mod = cls(c).eval()
+            mod.load_state_dict(sd, strict=True)
+            with torch.inference_mode():
+                blocks[name] = mod(x.clone() * 2).numpy()
+        np.savez_compressed(os.path.join(OUT, "f1b_blocks_c128.npz"), **blocks)
+
+    # ---- F5b: the qp=2 model at BASELINE's sizes: 2 x 3 x 768 x 512 and 1 x 3 x 1152 x 2048 (assets/sample.png's
+    #           geometry, no padding): every code index, the reconstruction's SHA, a strided view and a crop -------
+    if want("f5b"):
+        big = {}
+        sd = R.make_state_dict(128, 2, [8192, 2048, 512], seed=0)
+        model = ref_harness.reference_compressor(128, 2, [8192, 2048, 512], sd)
+        for tag, (n, h, w, seed) in {"kodak": (2, 768, 512, 3407), "sample": (1, 1152, 2048, 11)}.items():
+            xi = R.make_images(n, h, w, seed=seed)
+            with torch.inference_mode():
+                codes = model.encode(xi)
+                rec = model.decode(codes)
+            big[tag + "_shape"] = np.array([n, h, w, seed])
+            for lv, cd in enumerate(codes):
+                big[f"{tag}_code{lv}"] = cd.numpy().astype(np.int16)
+            big[tag + "_rec_strided"] = rec[..., ::16, ::16].numpy()
+            big[tag + "_rec_crop"] = rec[:, :, h // 2 - 32:h // 2 + 32, w // 2 - 32:w // 2 + 32].numpy()
+            big[tag + "_rec_mean_abs"] = np.array([rec.abs().mean().item()])
+            big[tag + "_rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, "f5b_qp2_fullsize.npz"), **big)
+
+    # ---- F9: reAssignCodebook (mcquic/modules/quantizer.py:111-136) with torch.randperm made to return a recorded
+    #          permutation per crowded group ---------------------------------------------------------------------
+    if want("f9"):
+        f9 = {"cases": np.array([(m, k, d, seed) for m, k, d, _, seed in R.REASSIGN_CASES], dtype=np.int64)}
+        for ci, (m, k, d, dead_frac, seed) in enumerate(R.REASSIGN_CASES):
+            cb, f, perms = R.reassign_case(m, k, d, dead_frac, seed)
+            q = RQ._multiCodebookQuantization(torch.nn.Parameter(cb.clone()), 0.0)
+            crowded = [int((f[gi] < 1e-6).sum()) > k // 2 for gi in range(m)]
+            it = iter([perms[gi] for gi in range(m) if crowded[gi]])
+            orig = torch.randperm
+            torch.randperm = lambda n, **kw: next(it).clone()
+            try:
+                changed = q.reAssignCodebook(f.clone())
+            finally:
+                torch.randperm = orig
+            f9[f"freq_{ci}"] = f.numpy()
+            for gi in range(m):
+                f9[f"perm_{ci}_{gi}"] = perms[gi].numpy().astype(np.int32)
+            f9[f"new_codebook_{ci}"] = q._codebook.detach().numpy()
+            f9[f"changed_{ci}"] = changed.numpy()
+        np.savez_compressed(os.path.join(OUT, "f9_reassign.npz"), **f9)
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

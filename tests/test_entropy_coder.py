@@ -92,3 +92,59 @@ def test_against_compiled_reference_extension():
         t = E._Tables(cdfs, k)
         assert E.ransEncodeWithIndexes(sym, idx, t) == ref
         assert RA.RansDecoder().decodeWithIndexes(ref, idx.tolist(), cdfs, [k + 2] * m, [0] * m) == E.ransDecodeWithIndexes(ref, idx, t).tolist()
+
+
+def test_batched_coder_equals_one_stream_at_a_time():
+    """All images of a level in one C call over a thread pool: the bytes of every stream are those of the single-stream
+    entry point (which is pinned to the reference's coder above), whatever the thread count."""
+    z = np.load(G)
+    m, h, w, k = [int(v) for v in z["k512_shape"]]
+    t = E._Tables([E.pmfToQuantizedCDF(pm.tolist(), 16) for pm in z["k512_pmf"]], k)
+    idx = np.repeat(np.arange(m, dtype=np.int32), h * w)
+    rng = np.random.default_rng(3)
+    sym = rng.integers(0, k, (37, m * h * w)).astype(np.int32)
+    sym[0] = z["k512_sym"]                                                   # the golden stream rides along
+    one = [E.ransEncodeWithIndexes(row, idx, t) for row in sym]
+    assert one[0] == z["k512_bytes"].tobytes()
+    for threads in (1, 2, 5, 64):
+        assert E.ransEncodeBatchWithIndexes(sym, idx, t, threads=threads) == one
+        assert np.array_equal(E.ransDecodeBatchWithIndexes(one, idx, t, threads=threads), sym)
+    assert E.ransEncodeBatchWithIndexes(sym[:0], idx, t) == []
+
+
+def test_out_of_range_symbols_are_errors_not_overreads():
+    """with `cdfSizes = k + 2` over k + 1 entries a symbol >= k (or < 0) would index past the table."""
+    k = 8
+    t = E._Tables([E.pmfToQuantizedCDF([1.0 / k] * k)], k)
+    idx = np.zeros(4, dtype=np.int32)
+    for bad in (k, k + 5, -1):
+        with pytest.raises(RuntimeError):
+            E.ransEncodeWithIndexes(np.array([0, 1, bad, 2], dtype=np.int32), idx, t)
+        with pytest.raises(RuntimeError):
+            E.ransEncodeBatchWithIndexes(np.array([[0, 1, 2, 3], [0, 1, bad, 2]], dtype=np.int32), idx, t)
+    coder = E.EntropyCoder(2, [32, 16, 8])
+    codes = [torch.zeros((1, 2, s, s), dtype=torch.int64) for s in (4, 2, 1)]
+    codes[1][0, 1, 0, 0] = 16
+    with pytest.raises(RuntimeError):
+        coder.compress(codes)
+
+
+def test_decompress_rejects_hostile_headers():
+    """Header fields come out of a `.mcq` file: wrong m / k, non-positive or absurd sizes, truncated streams -> RuntimeError
+    before anything is allocated."""
+    m, ks = 2, [32, 16, 8]
+    coder = E.EntropyCoder(m, ks)
+    codes = [torch.randint(0, k, (2, m, s, s), generator=torch.Generator().manual_seed(1)) for k, s in zip(ks, (4, 2, 1))]
+    binaries, sizes = coder.compress(codes)
+    good = sizes[0]
+    for bad in (CodeSize([3, 3, 3], good.heights, good.widths, good.k), CodeSize(good.m, [-4, 2, 1], good.widths, good.k),
+                CodeSize(good.m, [1 << 30, 2, 1], good.widths, good.k), CodeSize(good.m, good.heights, good.widths, [64, 16, 8]),
+                CodeSize(good.m[:2], good.heights[:2], good.widths[:2], good.k[:2])):
+        with pytest.raises(RuntimeError):
+            coder.decompress(binaries, [bad, bad])
+    with pytest.raises(RuntimeError):
+        coder.decompress([[b[:8] for b in binaries[0]], binaries[1]], sizes)
+    with pytest.raises(RuntimeError):
+        coder.decompress(binaries, [good, CodeSize(good.m, [8, 2, 1], good.widths, good.k)])
+    for a, b in zip(codes, coder.decompress(binaries, sizes)):
+        assert torch.equal(a, b)

@@ -80,3 +80,48 @@ def test_qp2_model_against_reference_vectors(dev):
     rec = model.decode([c.to(dev) for c in want]).cpu()
     np.testing.assert_allclose(rec[:, :, 96:160, 160:224].numpy(), z["rec_crop"], rtol=0, atol=1e-4)
     assert abs(rec.abs().mean().item() - float(z["rec_mean_abs"][0])) < 1e-5
+
+
+def test_blocks_c128_against_reference_vectors(dev):
+    """F1 at the network's width: every block type at C = 128 against the reference's outputs."""
+    from mcquic_amd import nn as N
+    z = np.load(os.path.join(G, "f1b_blocks_c128.npz"))
+    c = 128
+    x = torch.from_numpy(z["x"]).to(dev)
+    for name, ctor, mk in [("ResidualBlock", lambda: N.ResidualBlock(c, c), R._rb),
+                           ("ResidualBlockWithStride", lambda: N.ResidualBlockWithStride(c, c), R._rb_stride),
+                           ("ResidualBlockShuffle", lambda: N.ResidualBlockShuffle(c, c), R._rb_shuffle),
+                           ("AttentionBlock", lambda: N.AttentionBlock(c), R._attn)]:
+        sd = {}
+        mk(sd, "", c, 21)
+        mod = ctor()
+        mod.load_state_dict(sd, strict=True)
+        got = mod.to(dev).eval()(x).cpu().numpy()
+        np.testing.assert_allclose(got, z[name], rtol=0, atol=2e-5, err_msg=name)
+    for name, cls in [("GenDivNorm", N.GenDivNorm), ("InvGenDivNorm", N.InvGenDivNorm)]:
+        sd = {}
+        R._gdn_params(sd, "", c, 22)
+        mod = cls(c)
+        mod.load_state_dict(sd, strict=True)
+        np.testing.assert_allclose(mod.to(dev).eval()(x * 2).cpu().numpy(), z[name], rtol=0, atol=2e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("tag", ["kodak", "sample"])
+def test_qp2_fullsize_against_reference_vectors(dev, tag):
+    """F5 at BASELINE's sizes, straight against the reference (no oracle in between): 2 x 3 x 768 x 512 (configs[1]'s
+    geometry) and 1 x 3 x 1152 x 2048 (configs[0]: assets/sample.png's geometry) -- every code index exact, pixels 1e-4."""
+    from mcquic_amd import Compressor
+    z = np.load(os.path.join(G, "f5b_qp2_fullsize.npz"))
+    n, h, w, seed = [int(v) for v in z[tag + "_shape"]]
+    sd = R.make_state_dict(128, 2, [8192, 2048, 512], seed=0)
+    model = Compressor(128, 2, [8192, 2048, 512]).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    codes = model.encode(R.make_images(n, h, w, seed=seed).to(dev))
+    want = [torch.from_numpy(z[f"{tag}_code{lv}"].astype(np.int64)) for lv in range(3)]
+    for lv, (c, wc) in enumerate(zip(codes, want)):
+        assert torch.equal(c.cpu(), wc), f"level {lv}: {(c.cpu() != wc).sum()} mismatches"
+    rec = model.decode([c.to(dev) for c in want]).cpu()
+    np.testing.assert_allclose(rec[..., ::16, ::16].numpy(), z[tag + "_rec_strided"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(rec[:, :, h // 2 - 32:h // 2 + 32, w // 2 - 32:w // 2 + 32].numpy(), z[tag + "_rec_crop"], rtol=0, atol=1e-4)
+    assert abs(rec.abs().mean().item() - float(z[tag + "_rec_mean_abs"][0])) < 1e-5

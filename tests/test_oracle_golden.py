@@ -149,3 +149,35 @@ def test_ms_ssim_rejects_small_images():
     x = torch.zeros(1, 3, 160, 300, dtype=torch.uint8)
     with pytest.raises(ValueError):
         M.ms_ssim(x, x)
+
+
+def test_blocks_c128_match_reference():
+    """F1 at the network's width (C = 128)."""
+    z = np.load(os.path.join(G, "f1b_blocks_c128.npz"))
+    c = 128
+    x = torch.from_numpy(z["x"])
+    for name, mk, fn in [("ResidualBlock", R._rb, R.residual_block),
+                         ("ResidualBlockWithStride", R._rb_stride, R.residual_block_with_stride),
+                         ("ResidualBlockShuffle", R._rb_shuffle, R.residual_block_shuffle),
+                         ("AttentionBlock", R._attn, R.attention_block)]:
+        sd = {}
+        mk(sd, "", c, 21)
+        np.testing.assert_allclose(fn(sd, "", x.clone()).numpy(), z[name], rtol=0, atol=2e-6, err_msg=name)
+    for name, inv in [("GenDivNorm", False), ("InvGenDivNorm", True)]:
+        sd = {}
+        R._gdn_params(sd, "", c, 22)
+        np.testing.assert_allclose(R.gdn(sd, "", x.clone() * 2, inv).numpy(), z[name], rtol=0, atol=2e-6, err_msg=name)
+
+
+def test_qp2_model_kodak_batch_matches_reference():
+    """F5 at BASELINE's geometry: 2 x 3 x 768 x 512 through the qp=2 model, every code index against the reference."""
+    z = np.load(os.path.join(G, "f5b_qp2_fullsize.npz"))
+    n, h, w, seed = [int(v) for v in z["kodak_shape"]]
+    sd = R.make_state_dict(128, 2, [8192, 2048, 512], seed=0)
+    codes = R.encode(sd, R.make_images(n, h, w, seed=seed))
+    want = [torch.from_numpy(z[f"kodak_code{lv}"].astype(np.int64)) for lv in range(3)]
+    for lv, (c, wc) in enumerate(zip(codes, want)):
+        assert torch.equal(c, wc), f"level {lv}: {(c != wc).sum()} mismatches"
+    rec = R.decode(sd, want)
+    np.testing.assert_allclose(rec[..., ::16, ::16].numpy(), z["kodak_rec_strided"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(rec[:, :, h // 2 - 32:h // 2 + 32, w // 2 - 32:w // 2 + 32].numpy(), z["kodak_rec_crop"], rtol=0, atol=2e-6)

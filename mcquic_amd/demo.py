@@ -29,7 +29,9 @@ def loadModel(qp: int, local, device) -> Compressor:
     params = dict(QP2)
     state = None
     if local is not None:
-        ckpt = torch.load(str(local), map_location="cpu")
+        # weights_only: a checkpoint is tensors + plain containers; never unpickle arbitrary objects from a path that may
+        # have come out of a file header
+        ckpt = torch.load(str(local), map_location="cpu", weights_only=True)
         state = ckpt.get("model", ckpt) if isinstance(ckpt, dict) else ckpt
         cfg = ckpt.get("config") if isinstance(ckpt, dict) else None
         if isinstance(cfg, dict) and "model" in cfg and "params" in cfg["model"]:
@@ -42,6 +44,18 @@ def loadModel(qp: int, local, device) -> Compressor:
         model.load_state_dict(state)
     model.QuantizationParameter = str(local) if local is not None else f"qp_{qp}_msssim"
     return model.to(device).eval()
+
+
+def detectLocalFile(qp: str):
+    """The header's `qp` string names a local checkpoint only if it is an existing file whose suffix contains "mcquic"
+    (reference: demo.py:93-97); anything else in that untrusted field is never opened."""
+    try:
+        path = pathlib.Path(qp)
+        if path.exists() and path.is_file() and "mcquic" in path.suffix.lower():
+            return path
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def compressImage(image: torch.Tensor, model: Compressor, crop: bool) -> File:
@@ -93,8 +107,12 @@ def main(argv=None) -> int:
         elif a.input.suffix.lower() == ".mcq":
             from PIL import Image
             source = File.deserialize(a.input.read_bytes())
-            qp = source.FileHeader.QuantizationParameter
-            local = pathlib.Path(qp) if pathlib.Path(qp).is_file() else a.local      # demo.py:87-106 detectModelFromFile
+            local = detectLocalFile(source.FileHeader.QuantizationParameter) or a.local
+            if local is None:
+                # the reference would now download the model its header names; without a network the restore can only
+                # exercise the plumbing -- say so instead of silently decoding with random weights
+                print("warning: no checkpoint resolved for this file (pass --local); restoring with the seeded random-weight "
+                      "qp=2 model: the output is not the original picture", file=sys.stderr)
             model = loadModel(a.qp, local, device)
             restored = decompressImage(source, model)
             say(f"{source.FileHeader.ImageSize}, {source.BPP:.4f} bpp")

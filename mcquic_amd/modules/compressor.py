@@ -138,7 +138,11 @@ class BaseCompressor(nn.Module):
         """Training-mode forward (compressor.py:35-43): (xHat, yHat, codes, logits); None in eval mode like the
         reference.  With grad enabled the step runs through mcquic_amd.autograd (HIP kernels in both directions:
         xHat.backward(...) fills every parameter's .grad); under torch.no_grad() the fused inference kernels are used.
-        `uniforms`: optional per-level (u_drop, u_gumbel) draws replacing the two `torch.rand_like(logit)` calls."""
+        `uniforms`: optional per-level (u_drop, u_gumbel) draws replacing the two `torch.rand_like(logit)` calls.
+        Divergence from the reference: the returned `logits` are VALUES only (marked non-differentiable by
+        autograd.SoftQuantizeFn).  In the reference they carry a graph back to the latents, codebooks and temperatures;
+        its shipped losses (mcquic/loss/__init__.py:47-62) never differentiate them, so the config-#5 step is the same,
+        but a logit-based regulariser would receive no gradient here -- it must be added inside SoftQuantizeFn.backward."""
         if not self.training:
             return None
         self._check(x)

@@ -6,7 +6,9 @@ reference's marshmallow `FileSchema().dump()` + `msgpack.packb(use_bin_type=True
     {"fileHeader": {"qp", "version", "codeSize": {"m", "heights", "widths", "k"}, "imageSize": {"height", "width", "channel"}},
      "contents": [bytes, ...]}
 (marshmallow is not installed here, so the reference's serializer cannot be run: the layout is restated from the
-schema declarations, specification.py:22-53; format parity with files written by the reference is unpinned.)
+schema declarations, specification.py:22-53, and pinned byte for byte by a document derived by hand from those
+declarations and the msgpack format, tests/test_mcq_container.py; a cross-read of files written by the reference itself
+stays unexecuted.)
 """
 from __future__ import annotations
 

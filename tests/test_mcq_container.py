@@ -1,0 +1,88 @@
+"""The `.mcq` container byte for byte.  marshmallow is absent here, so the reference's serializer
+cannot run; the expected document below is derived BY HAND from its schema declarations
+(mcquic/utils/specification.py:22-53: FileSchema{fileHeader, contents}, FileHeaderSchema{qp, version, codeSize, imageSize},
+CodeSizeSchema{m, heights, widths, k}, ImageSizeSchema{height, width, channel}; `dump` emits the fields in declaration
+order) and from the msgpack format itself (`msgpack.packb(..., use_bin_type=True)`, specification.py:149-151) -- no
+msgpack library is involved in building the expectation."""
+import pytest
+
+from mcquic_amd.utils.specification import CodeSize, File, FileHeader, ImageSize
+
+
+def _s(text: str) -> bytes:                 # msgpack fixstr: 0xa0 | length, then the UTF-8 bytes (length < 32)
+    raw = text.encode()
+    assert len(raw) < 32
+    return bytes([0xA0 | len(raw)]) + raw
+
+
+EXPECTED = b"".join([
+    b"\x82",                                                    # map of 2: fileHeader, contents
+    _s("fileHeader"), b"\x84",                                   # map of 4: qp, version, codeSize, imageSize
+    _s("qp"), _s("2"),
+    _s("version"), _s("0.1.40"),
+    _s("codeSize"), b"\x84",
+    _s("m"), b"\x93\x02\x02\x02",                                # fixarray(3) of positive fixints
+    _s("heights"), b"\x93\x30\x18\x0c",                          # 48, 24, 12
+    _s("widths"), b"\x93\x20\x10\x08",                           # 32, 16, 8
+    _s("k"), b"\x93\xcd\x20\x00\xcd\x08\x00\xcd\x02\x00",        # uint16 8192, 2048, 512
+    _s("imageSize"), b"\x83",
+    _s("height"), b"\xcd\x03\x00",                               # 768
+    _s("width"), b"\xcd\x02\x00",                                # 512
+    _s("channel"), b"\x03",
+    _s("contents"), b"\x92",                                     # fixarray(2) of bin8
+    b"\xc4\x03\x01\x02\x03",
+    b"\xc4\x01\xff",
+])
+
+
+def _file():
+    header = FileHeader("0.1.40", "2", CodeSize([2, 2, 2], [48, 24, 12], [32, 16, 8], [8192, 2048, 512]), ImageSize(768, 512, 3))
+    return File(header, [b"\x01\x02\x03", b"\xff"])
+
+
+def test_serialize_writes_the_schema_document_byte_for_byte():
+    assert _file().serialize() == EXPECTED
+    assert len(EXPECTED) == 141
+
+
+def test_deserialize_reads_the_hand_written_document():
+    f = File.deserialize(EXPECTED)
+    assert f.FileHeader.QuantizationParameter == "2" and f.FileHeader.Version == "0.1.40"
+    assert f.FileHeader.CodeSize == CodeSize([2, 2, 2], [48, 24, 12], [32, 16, 8], [8192, 2048, 512])
+    assert f.FileHeader.ImageSize == ImageSize(768, 512, 3)
+    assert f.Content == [b"\x01\x02\x03", b"\xff"]
+    assert f.size() == 4 and f.BPP == 4 * 8 / (768 * 512)
+
+
+def test_larger_streams_use_bin16():
+    """A level-0 stream of a 768x512 image is ~5000 bytes: bin16 (0xc5 + big-endian length)."""
+    f = _file()
+    f.contents = [bytes(range(256)) * 20, b"\x00" * 300]
+    data = f.serialize()
+    tail = b"\x92" + b"\xc5\x14\x00" + bytes(range(256)) * 20 + b"\xc5\x01\x2c" + b"\x00" * 300
+    assert data.endswith(tail) and data[:len(EXPECTED) - 9] == EXPECTED[:-9]
+
+
+def test_empty_or_non_bytes_contents_are_invalid():
+    """BytesField._validate (specification.py:13-19): bytes only, never empty."""
+    import msgpack
+    doc = msgpack.unpackb(EXPECTED, raw=False)
+    for bad in ([], [b""], ["text"]):
+        doc["contents"] = bad
+        with pytest.raises(ValueError):
+            File.deserialize(msgpack.packb(doc, use_bin_type=True))
+
+
+def test_header_qp_is_only_opened_when_it_names_a_mcquic_file(tmp_path):
+    """the untrusted `qp` string of a `.mcq` header is a checkpoint path only under the reference's rule
+    (existing file, "mcquic" in the suffix; mcquic/demo.py:93-97)."""
+    from mcquic_amd.demo import detectLocalFile
+    other = tmp_path / "secret.pt"
+    other.write_bytes(b"x")
+    ckpt = tmp_path / "qp_2_msssim_8e954998.mcquic"
+    ckpt.write_bytes(b"x")
+    assert detectLocalFile(str(other)) is None
+    assert detectLocalFile("qp_2_msssim") is None
+    assert detectLocalFile(str(tmp_path)) is None
+    assert detectLocalFile("\x00bad") is None
+    assert detectLocalFile(str(ckpt)) == ckpt

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Index / pixel parity of the HIP path against the CPU oracle at BASELINE configs[1]'s full workload: 32 images of
+768x512 through the qp=2 model.  Writes one JSON record (profiles/r02_parity_b32.json is a committed copy).
+
+    python tools/parity_b32.py [--images 32] [--out gpurun_out/parity_b32.json]
+
+The oracle runs in chunks of 4 images on the host cores (~0.7 s per image on 16 cores).  For every level the record
+holds the mismatch count and, where a code differs, the oracle's own distance gap between the two candidates."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=32)
+    ap.add_argument("--chunk", type=int, default=4)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_b32.json"))
+    a = ap.parse_args()
+    from mcquic_amd import Compressor
+    from oracle import mcquic_ref as R
+    dev = torch.device("cuda:0")
+    ks = [8192, 2048, 512]
+    sd = R.make_state_dict(128, 2, ks, seed=0)
+    model = Compressor(128, 2, ks).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    x = R.make_images(a.images, 768, 512, seed=3407)
+    codes = [c.cpu() for c in model.encode(x.to(dev))]           # ONE batch of `images` on the GPU
+    t0 = time.time()
+    mism, worst_gap, total = [0, 0, 0], [0.0, 0.0, 0.0], [0, 0, 0]
+    pix_err, psnr_min = 0.0, float("inf")
+    for lo in range(0, a.images, a.chunk):
+        xs = x[lo:lo + a.chunk]
+        collect = {}
+        want = R.quantizer_encode(sd, R.encoder(sd, R.aligned_padding(xs)), collect)
+        for lv, wc in enumerate(want):
+            g = codes[lv][lo:lo + a.chunk]
+            bad = g != wc
+            total[lv] += wc.numel()
+            if bad.any():
+                dist = R.vq_distance(collect["q"][lv], sd[f"_quantizer._encoders.{lv}._quantizer._codebook"]).double()
+                dg = torch.gather(dist, -1, g.unsqueeze(-1)).squeeze(-1)
+                dw = torch.gather(dist, -1, wc.unsqueeze(-1)).squeeze(-1)
+                worst_gap[lv] = max(worst_gap[lv], float((dg - dw).abs()[bad].max()))
+                mism[lv] += int(bad.sum())
+        rec_cpu = R.decode(sd, want)
+        rec_gpu = model.decode([c.to(dev) for c in want]).cpu()  # pixels from the ORACLE's codes
+        pix_err = max(pix_err, float((rec_gpu - rec_cpu).abs().max()))
+        psnr_min = min(psnr_min, float(R.psnr(R.detransform(rec_gpu), R.detransform(rec_cpu)).min()))
+    rec = {"workload": f"qp=2 model, {a.images} x 3 x 768 x 512, seed 3407 (BASELINE configs[1])",
+           "codes_per_level": total, "code_mismatches_per_level": mism, "code_mismatches": sum(mism),
+           "worst_oracle_gap_at_a_mismatch": worst_gap, "decode_max_abs_err": pix_err,
+           "psnr_gpu_vs_cpu_u8_min_db": round(psnr_min, 2), "oracle_seconds": round(time.time() - t0, 1),
+           "device": torch.cuda.get_device_name(0)}
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(rec, open(a.out, "w"), indent=1)
+    print(json.dumps(rec))
+    return 0 if sum(mism) == 0 and pix_err <= 1e-4 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -260,12 +260,26 @@ def main():
         model = ref_harness.reference_compressor(128, 2, [8192, 2048, 512], sd)
         for tag, (n, h, w, seed) in {"kodak": (2, 768, 512, 3407), "sample": (1, 1152, 2048, 11)}.items():
             xi = R.make_images(n, h, w, seed=seed)
+            gaps = []                           # the reference's own top-2 distance gap per vector (near-tie audit)
+            orig_distance = RQ._multiCodebookQuantization._distance
+
+            def recording_distance(self, x):
+                dist = orig_distance(self, x)
+                top2 = torch.topk(dist, 2, dim=-1, largest=False).values
+                gaps.append((top2[..., 1] - top2[..., 0]).clone())
+                return dist
+            RQ._multiCodebookQuantization._distance = recording_distance
+            try:
+                with torch.inference_mode():
+                    codes = model.encode(xi)
+            finally:
+                RQ._multiCodebookQuantization._distance = orig_distance
             with torch.inference_mode():
-                codes = model.encode(xi)
                 rec = model.decode(codes)
             big[tag + "_shape"] = np.array([n, h, w, seed])
             for lv, cd in enumerate(codes):
                 big[f"{tag}_code{lv}"] = cd.numpy().astype(np.int16)
+                big[f"{tag}_gap{lv}"] = gaps[lv].numpy()
             big[tag + "_rec_strided"] = rec[..., ::16, ::16].numpy()
             big[tag + "_rec_crop"] = rec[:, :, h // 2 - 32:h // 2 + 32, w // 2 - 32:w // 2 + 32].numpy()
             big[tag + "_rec_mean_abs"] = np.array([rec.abs().mean().item()])

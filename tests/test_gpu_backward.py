@@ -111,10 +111,12 @@ def _train_setup(ch, m, ks, n, hw, seed):
     return sd, x, us
 
 
-@pytest.mark.parametrize("cfg", [(8, 2, [32, 16, 8], 2, 128), (128, 2, [512, 64, 16], 1, 128)])
+@pytest.mark.parametrize("cfg", [(8, 2, [32, 16, 8], 2, 128), (128, 2, [512, 64, 16], 1, 128),
+                                 (128, 2, [8192, 2048, 512], 8, 256)])      # BASELINE configs[4] itself: qp=2 codebooks, 8 x 256 x 256
 def test_full_training_step_gradients(dev, cfg):
     """forward + backward of Compressor in training mode: every parameter gradient against CPU autograd through the
-    oracle's forward_train (same weights, same uniform draws, loss = <xHat, G>)."""
+    oracle's forward_train (same weights, same uniform draws, loss = <xHat, G>).  The last case is config #5's own
+    workload (8192-codeword soft assignment, logits [8, 2, 16, 16, 8192]; ~20 s of CPU autograd)."""
     from mcquic_amd import Compressor
     ch, m, ks, n, hw = cfg
     sd, x, us = _train_setup(ch, m, ks, n, hw, 21)

@@ -106,10 +106,30 @@ def test_blocks_c128_against_reference_vectors(dev):
         np.testing.assert_allclose(mod.to(dev).eval()(x * 2).cpu().numpy(), z[name], rtol=0, atol=2e-5, err_msg=name)
 
 
+def _audit_codes(got, want, gaps, tie=1e-5):
+    """Index parity with the near-tie protocol of DESIGN section 6: a code may differ from the reference's only where the
+    reference's OWN top-2 distance gap at that vector is below `tie` (fp32 reassociation noise is ~1e-6 of distances of
+    order 1: which of two codewords that close wins depends on the summation order of the conv stack, here as between
+    two CPU BLAS builds).  A flipped code changes the residual the deeper levels quantize, so an image is only compared
+    down to its first excused flip.  Returns (flips, images cut short)."""
+    n = want[0].shape[0]
+    alive = torch.ones(n, dtype=torch.bool)
+    flips = 0
+    for lv, (g, w_, gap) in enumerate(zip(got, want, gaps)):
+        bad = (g != w_) & alive[:, None, None, None]
+        if bad.any():
+            worst = float(torch.from_numpy(gap)[bad].max())
+            assert worst < tie, f"level {lv}: {int(bad.sum())} code mismatches, reference gap there up to {worst:.3e}"
+            flips += int(bad.sum())
+            alive &= ~bad.flatten(1).any(1)
+    return flips, int((~alive).sum())
+
+
 @pytest.mark.parametrize("tag", ["kodak", "sample"])
 def test_qp2_fullsize_against_reference_vectors(dev, tag):
     """F5 at BASELINE's sizes, straight against the reference (no oracle in between): 2 x 3 x 768 x 512 (configs[1]'s
-    geometry) and 1 x 3 x 1152 x 2048 (configs[0]: assets/sample.png's geometry) -- every code index exact, pixels 1e-4."""
+    geometry) and 1 x 3 x 1152 x 2048 (configs[0]: assets/sample.png's geometry) -- code indices exact up to audited
+    near-ties (the fixture carries the reference's own top-2 gaps), pixels from the reference's codes within 1e-4."""
     from mcquic_amd import Compressor
     z = np.load(os.path.join(G, "f5b_qp2_fullsize.npz"))
     n, h, w, seed = [int(v) for v in z[tag + "_shape"]]
@@ -117,10 +137,11 @@ def test_qp2_fullsize_against_reference_vectors(dev, tag):
     model = Compressor(128, 2, [8192, 2048, 512]).eval()
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
-    codes = model.encode(R.make_images(n, h, w, seed=seed).to(dev))
+    codes = [c.cpu() for c in model.encode(R.make_images(n, h, w, seed=seed).to(dev))]
     want = [torch.from_numpy(z[f"{tag}_code{lv}"].astype(np.int64)) for lv in range(3)]
-    for lv, (c, wc) in enumerate(zip(codes, want)):
-        assert torch.equal(c.cpu(), wc), f"level {lv}: {(c.cpu() != wc).sum()} mismatches"
+    flips, cut = _audit_codes(codes, want, [z[f"{tag}_gap{lv}"] for lv in range(3)])
+    total = sum(c.numel() for c in want)
+    assert flips <= max(1, total // 20000), f"{flips} audited near-tie flips in {total} codes: more than fp32 noise explains"
     rec = model.decode([c.to(dev) for c in want]).cpu()
     np.testing.assert_allclose(rec[..., ::16, ::16].numpy(), z[tag + "_rec_strided"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(rec[:, :, h // 2 - 32:h // 2 + 32, w // 2 - 32:w // 2 + 32].numpy(), z[tag + "_rec_crop"], rtol=0, atol=1e-4)

@@ -17,19 +17,24 @@ def _compare(dev, channel, m, k, n, h, w, seed, pix_tol):
     collect = {}
     want_codes = R.quantizer_encode(sd, R.encoder(sd, R.aligned_padding(x)), collect)
     got_codes = model.encode(x.to(dev))
+    # Near-tie protocol: a code may differ from the oracle's only where the oracle's own distance gap
+    # between the two candidates is below 1e-5 (fp32 summation-order noise is ~1e-6); such a flip changes the residual
+    # the deeper levels see, so an image is compared down to its first excused flip only.
     mism = 0
+    alive = torch.ones(n, dtype=torch.bool)
     for lv, (g, wc) in enumerate(zip(got_codes, want_codes)):
         assert g.dtype == torch.int64 and g.shape == wc.shape
-        bad = g.cpu() != wc
+        bad = (g.cpu() != wc) & alive[:, None, None, None]
         if bad.any():
-            # near-tie audit on the oracle's own distances at this level
             cb = sd[f"_quantizer._encoders.{lv}._quantizer._codebook"]
-            dist = R.vq_distance(collect["q"][lv], cb).double()
-            dg = torch.gather(dist, -1, g.cpu().unsqueeze(-1)).squeeze(-1)
-            dw = torch.gather(dist, -1, wc.unsqueeze(-1)).squeeze(-1)
-            gap = (dg - dw).abs()[bad].max().item()
+            rows = torch.nonzero(bad.flatten(1).any(1)).flatten()
+            dist = R.vq_distance(collect["q"][lv][rows], cb).double()
+            dg = torch.gather(dist, -1, g.cpu()[rows].unsqueeze(-1)).squeeze(-1)
+            dw = torch.gather(dist, -1, wc[rows].unsqueeze(-1)).squeeze(-1)
+            gap = (dg - dw).abs()[bad[rows]].max().item()
             assert gap < 1e-5, f"level {lv}: {int(bad.sum())} code mismatches, worst oracle gap {gap:.3e}"
             mism += int(bad.sum())
+            alive &= ~bad.flatten(1).any(1)
     # decode parity is checked from the ORACLE's codes so that an audited near-tie does not leak into pixels
     want = R.decode(sd, want_codes)
     got = model.decode([c.to(dev) for c in want_codes]).cpu()

@@ -35,16 +35,21 @@ def main():
     x = R.make_images(a.images, 768, 512, seed=3407)
     codes = [c.cpu() for c in model.encode(x.to(dev))]           # ONE batch of `images` on the GPU
     t0 = time.time()
-    mism, worst_gap, total = [0, 0, 0], [0.0, 0.0, 0.0], [0, 0, 0]
+    # first flips = codes that differ although everything upstream of them agreed (near-ties); downstream = differences
+    # on deeper levels of an image after a first flip (conditioned on different codes: not comparable)
+    mism, worst_gap, total, downstream = [0, 0, 0], [0.0, 0.0, 0.0], [0, 0, 0], [0, 0, 0]
     pix_err, psnr_min = 0.0, float("inf")
     for lo in range(0, a.images, a.chunk):
         xs = x[lo:lo + a.chunk]
         collect = {}
         want = R.quantizer_encode(sd, R.encoder(sd, R.aligned_padding(xs)), collect)
+        alive = torch.ones(len(xs), dtype=torch.bool)
         for lv, wc in enumerate(want):
             g = codes[lv][lo:lo + a.chunk]
-            bad = g != wc
+            downstream[lv] += int(((g != wc) & ~alive[:, None, None, None]).sum())
+            bad = (g != wc) & alive[:, None, None, None]
             total[lv] += wc.numel()
+            alive &= ~bad.flatten(1).any(1)
             if bad.any():
                 dist = R.vq_distance(collect["q"][lv], sd[f"_quantizer._encoders.{lv}._quantizer._codebook"]).double()
                 dg = torch.gather(dist, -1, g.unsqueeze(-1)).squeeze(-1)
@@ -56,14 +61,16 @@ def main():
         pix_err = max(pix_err, float((rec_gpu - rec_cpu).abs().max()))
         psnr_min = min(psnr_min, float(R.psnr(R.detransform(rec_gpu), R.detransform(rec_cpu)).min()))
     rec = {"workload": f"qp=2 model, {a.images} x 3 x 768 x 512, seed 3407 (BASELINE configs[1])",
-           "codes_per_level": total, "code_mismatches_per_level": mism, "code_mismatches": sum(mism),
-           "worst_oracle_gap_at_a_mismatch": worst_gap, "decode_max_abs_err": pix_err,
+           "codes_per_level": total, "first_flips_per_level": mism, "first_flips": sum(mism),
+           "worst_oracle_gap_at_a_first_flip": worst_gap, "downstream_differences_per_level": downstream,
+           "note": "a first flip = a code that differs although all codes upstream of it agree; excused only if the oracle's own "
+                   "distance gap between the two candidates is < 1e-5; deeper levels of that image then quantize a different residual", "decode_max_abs_err": pix_err,
            "psnr_gpu_vs_cpu_u8_min_db": round(psnr_min, 2), "oracle_seconds": round(time.time() - t0, 1),
            "device": torch.cuda.get_device_name(0)}
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(rec, open(a.out, "w"), indent=1)
     print(json.dumps(rec))
-    return 0 if sum(mism) == 0 and pix_err <= 1e-4 else 1
+    return 0 if max(worst_gap) < 1e-5 and pix_err <= 1e-4 else 1
 
 
 if __name__ == "__main__":

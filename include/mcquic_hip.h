@@ -41,6 +41,8 @@ extern "C" {
 #define MCQ_CONV_GATE       0x040u /* y = mul * sigmoid(acc) + gate_id  (blocks.py:281-288 AttentionBlock.forward) */
 #define MCQ_CONV_SHUFFLE2   0x080u /* store through nn.PixelShuffle(2)  (mcquic/nn/convs.py:221-255 pixelShuffle3x3) */
 #define MCQ_CONV_MUL        0x200u /* y = mul * acc                     (GDN backward: 2 x * (gamma^T ds))                    */
+#define MCQ_CONV_DSILU_MUL  0x400u /* y = acc * silu'(mul)              (backward of SiLU fused into the input-gradient conv:  */
+                                   /*                                    mul = the SiLU's input; then + res as usual)           */
 #define MCQ_CONV_DUAL_SILU  0x100u /* also store silu(y) to y_silu: the next block's act1(x), computed once per element */
 
 typedef struct mcq_conv_desc {
@@ -69,6 +71,16 @@ size_t mcq_packed_conv_weight_floats(int32_t Cout, int32_t Cin, int32_t ksize);
  * 16-row image-head kernel; every copy zero padded (one launch). */
 int mcq_pack_conv_weight_f32(const float* w_oihw, int32_t Cout, int32_t Cin, int32_t ksize,
                              float* w_packed, void* stream);
+
+/* The operand stream of a layer's INPUT-GRADIENT convolution, packed straight from the layer's own OIHW weight
+ * [Cout, Cin, k, k] in one launch (what torch.autograd derives for nn.Conv2d, mcquic/nn/convs.py:77-100):
+ *   stride 1:          dX = conv(dY, W'),  W'[ci][co][tap] = W[co][ci][flipped tap]          -> a [Cin, Cout, k, k] conv
+ *   stride 2 (3x3):    dX = PixelShuffle2(conv3x3(dY, W')), W' holding per input phase the taps that reach it
+ *                                                                                            -> a [4 Cin, Cout, 3, 3] conv
+ * mcq_dgrad_weight_shape gives that conv's (Cout_d, Cin_d); `out` holds mcq_packed_conv_weight_floats(Cout_d, Cin_d, k)
+ * floats and is used with mcq_conv2d_f32 like any packed weight (MCQ_CONV_SHUFFLE2 for stride 2). */
+int mcq_dgrad_weight_shape(int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t* Cout_d, int32_t* Cin_d);
+int mcq_pack_conv_dgrad_weight_f32(const float* w, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, float* out, void* stream);
 
 /* Dense 2-D convolution (zeros padding ksize/2) + fused prologue/epilogue.
  * Replaces nn.Conv2d.forward for conv3x3 / conv1x1 / pixelShuffle3x3 (mcquic/nn/convs.py:77-100,
@@ -165,6 +177,22 @@ size_t mcq_conv2d_wgrad_workspace_floats(int32_t N, int32_t Cin, int32_t H, int3
                                          int32_t stride);
 int mcq_conv2d_wgrad_f32(const float* x_nhwc, const float* dy_nhwc, float* dw, float* dbias, float* workspace, int32_t N,
                          int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, void* stream);
+
+/* The same gradient for 3x3 stride-1 convolutions straight from the NCHW tensors X [N,Cin,H,W] and dY [N,Cout,H,W], W a
+ * multiple of 8, each tensor below 1 GiB (mcq_conv2d_wgrad_nchw_workspace_floats returns 0 for any other shape: use the
+ * NHWC entry point then).  No channel-major copies: a wave walks an 8-pixel strip down the rows with a three-row window of
+ * X in registers, all nine taps per dY operand (csrc/wgrad_rows.hip).  Deterministic. */
+size_t mcq_conv2d_wgrad_nchw_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout);
+int mcq_conv2d_wgrad_nchw_f32(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int32_t N, int32_t Cin,
+                              int32_t H, int32_t W, int32_t Cout, void* stream);
+/* `nconv` (1 .. mcq_conv2d_wgrad_nchw_max_group()) convolutions of ONE shape in one launch pair: x[c], dy[c] -> dw[c], dbias[c]
+ * (dbias NULL, or NULL entries, for none).  The pointer tables are host arrays read during the call; `workspace` holds
+ * nconv * mcq_conv2d_wgrad_nchw_workspace_floats(...) floats.  The 16x16 ... 8x8 levels of a training step are
+ * launch-bound: a block's weight gradients go out together (mcquic_amd/autograd.py). */
+int32_t mcq_conv2d_wgrad_nchw_max_group(void);
+int mcq_conv2d_wgrad_nchw_group_f32(const float* const* x, const float* const* dy, float* const* dw, float* const* dbias,
+                                    int32_t nconv, float* workspace, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout,
+                                    void* stream);
 
 /* out[c] = sum_{n,p} x[n][c][p]   (bias / beta gradients); optional workspace of min(N, 16) * C floats. */
 int mcq_channel_sum_f32(const float* x, float* out, float* workspace, int32_t N, int32_t C, int32_t HW, void* stream);

@@ -17,7 +17,7 @@ _ERR = {MCQ_EINVAL: "MCQ_EINVAL (invalid argument)", MCQ_ELAUNCH: "MCQ_ELAUNCH (
         MCQ_ETOOLARGE: "MCQ_ETOOLARGE (tensor exceeds the addressing window)"}
 
 CONV_SILU_IN, CONV_SQUARE_IN, CONV_SILU_OUT, CONV_RESIDUAL = 0x1, 0x2, 0x4, 0x8
-CONV_GDN, CONV_IGDN, CONV_GATE, CONV_SHUFFLE2, CONV_DUAL_SILU, CONV_MUL = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
+CONV_GDN, CONV_IGDN, CONV_GATE, CONV_SHUFFLE2, CONV_DUAL_SILU, CONV_MUL, CONV_DSILU_MUL = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200, 0x400
 
 
 class ConvDesc(Structure):
@@ -33,6 +33,8 @@ class ConvDesc(Structure):
 SYMBOLS = {
     "mcq_packed_conv_weight_floats": (c_size_t, [c_int32, c_int32, c_int32]),
     "mcq_pack_conv_weight_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "mcq_dgrad_weight_shape": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "mcq_pack_conv_dgrad_weight_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "mcq_conv2d_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
     "mcq_nonneg_reparam_f32": (c_int32, [c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
     "mcq_packed_codebook_floats": (c_size_t, [c_int32, c_int32, c_int32]),
@@ -55,6 +57,12 @@ SYMBOLS = {
     "mcq_conv2d_wgrad_workspace_floats": (c_size_t, [c_int32] * 7),
     "mcq_conv2d_wgrad_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_void_p]),
+    "mcq_conv2d_wgrad_nchw_workspace_floats": (c_size_t, [c_int32] * 5),
+    "mcq_conv2d_wgrad_nchw_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                            c_int32, c_void_p]),
+    "mcq_conv2d_wgrad_nchw_max_group": (c_int32, []),
+    "mcq_conv2d_wgrad_nchw_group_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
+                                                  c_int32, c_int32, c_void_p]),
     "mcq_nchw_to_nhwc_pair_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32,
                                             c_int32, c_void_p]),
     "mcq_channel_sum_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),

@@ -19,24 +19,7 @@ import torch
 from . import ops
 
 
-# ---- weight transforms for input gradients (parameter-sized tensors; cached per weight version) -----------------
-def _dgrad_weight(weight: torch.Tensor, stride: int) -> torch.Tensor:
-    cout, cin, k, _ = weight.shape
-    if stride == 1:
-        return weight.flip(2, 3).transpose(0, 1).contiguous()                 # [cin, cout, k, k]
-    if k != 3 or stride != 2:
-        raise NotImplementedError("dgrad: only stride-2 3x3 convolutions are on the path")
-    # dX[2a + i][2b + j] = sum_{ty,tx} dY[a + ty][b + tx] * W[ky(i, ty)][kx(j, tx)]:  i = 0 -> (ty 0, ky 1);
-    # i = 1 -> (ty 0, ky 2), (ty +1, ky 0).  Laid out as a 3x3 conv with 4 * cin outputs followed by PixelShuffle(2).
-    w2 = torch.zeros((cin, 2, 2, cout, 3, 3), dtype=weight.dtype, device=weight.device)
-    kmap = {(0, 0): 1, (1, 0): 2, (1, 1): 0}                                  # (phase, tap offset) -> kernel index
-    wt = weight.permute(1, 0, 2, 3)                                           # [cin, cout, ky, kx]
-    for (i, ty), ky in kmap.items():
-        for (j, tx), kx in kmap.items():
-            w2[:, i, j, :, ty + 1, tx + 1] = wt[:, :, ky, kx]
-    return w2.reshape(cin * 4, cout, 3, 3).contiguous()
-
-
+# ---- input-gradient operand streams (packed straight from the OIHW parameter, cached per weight version) ----------
 class _DgradCache:
     def __init__(self):
         self.key, self.packed = None, None
@@ -44,9 +27,16 @@ class _DgradCache:
     def get(self, weight: torch.Tensor, stride: int) -> ops.PackedConv:
         key = (ops.tensor_version(weight), weight.data_ptr(), stride)
         if key != self.key:
-            self.packed = ops.PackedConv(_dgrad_weight(weight.detach(), stride), None)
+            self.packed = ops.PackedConv.dgrad(weight, stride)      # one pack launch (flip / transpose / sub-pixel scatter inside)
             self.key = key
         return self.packed
+
+
+def _dgrad_packed(conv, weight: torch.Tensor) -> ops.PackedConv:
+    cache = conv.__dict__.get("_dgradCache")
+    if cache is None:
+        cache = conv.__dict__["_dgradCache"] = _DgradCache()
+    return cache.get(weight, conv.stride)
 
 
 class ConvFn(torch.autograd.Function):
@@ -67,9 +57,7 @@ class ConvFn(torch.autograd.Function):
         dyc = ops.pixel_unshuffle2(dy) if ctx.shuffle2 else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if not hasattr(conv, "_dgradCache"):
-                conv._dgradCache = _DgradCache()
-            wt = conv._dgradCache.get(weight, conv.stride)
+            wt = _dgrad_packed(conv, weight)
             if conv.stride == 1:
                 dx = ops.conv2d(dyc, wt)
             else:
@@ -91,12 +79,130 @@ class SiluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         ctx.save_for_backward(x)
-        return ops.silu(x)
+        twin = ops.silu_twin(x)                     # the producer may have stored silu(x) beside x already
+        return twin if twin is not None else ops.silu(x)
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         return ops.silu_bwd(x, dy.contiguous())
+
+
+# ---- ResidualBlock / AttentionBlock as whole autograd nodes ---------------------------------------------------------
+def _rb_forward(block, x, sx):
+    """y = conv2(silu(conv1(silu(x)))) + x in two fused launches; returns (y, silu(y), what backward needs)."""
+    c1, c2 = block._branch[1], block._branch[3]
+    t1 = ops.conv2d(sx, c1.packed(), dual_silu=True)           # t1 and silu(t1) from one launch
+    s1 = ops.silu_twin(t1)
+    y = ops.conv2d(s1, c2.packed(), res=x, dual_silu=True)      # + x; silu(y) for the next block
+    return y, ops.silu_twin(y), (x, sx, t1, s1)
+
+
+def _rb_backward(block, saved, dy, pairs, need_dx: bool = True):
+    """Input gradient of a ResidualBlock in two fused launches; the two weight-gradient operand pairs are appended to
+    `pairs` for a grouped launch:  d_t1 = conv(dy, W2^T) * silu'(t1);  dx = conv(d_t1, W1^T) * silu'(x) + dy."""
+    x, sx, t1, s1 = saved
+    c1, c2 = block._branch[1], block._branch[3]
+    d_t1 = ops.conv2d(dy, _dgrad_packed(c2, c2.weight), dsilu_mul=t1)
+    dx = ops.conv2d(d_t1, _dgrad_packed(c1, c1.weight), dsilu_mul=x, res=dy) if need_dx else None
+    pairs.append((sx, d_t1))
+    pairs.append((s1, dy))
+    return dx
+
+
+def _wgrads(pairs):
+    """[(dW, db), ...] of the 3x3 stride-1 convs whose (input, output-gradient) pairs are given: one grouped launch."""
+    return ops.conv2d_wgrad_group([a for a, _ in pairs], [b for _, b in pairs], want_bias=True)
+
+
+class ResidualBlockFn(torch.autograd.Function):
+    """y = conv2(silu(conv1(silu(x)))) + x  (mcquic/nn/blocks.py:179-200) as two fused launches each way:
+         forward   t1, silu(t1) = conv1(silu(x))                      (SiLU twin stored by the producing launch)
+                   y,  silu(y)  = conv2(silu(t1)) + x
+         backward  d_t1 = conv(dy, W2^T) * silu'(t1)                   (MCQ_CONV_DSILU_MUL epilogue)
+                   dx   = conv(d_t1, W1^T) * silu'(x) + dy             (... + MCQ_CONV_RESIDUAL: the skip path's gradient)
+                   dW1, db1, dW2, db2: ONE grouped weight-gradient launch over (silu(x), d_t1) and (silu(t1), dy)
+       No stand-alone SiLU / SiLU-backward / add kernels, no channel-major copies.  `sx` = silu(x) is an input so that a
+       producer's twin is reused; the second output silu(y) is the next block's `sx` (no gradient flows through it: every
+       consumer differentiates through y itself)."""
+
+    @staticmethod
+    def forward(ctx, x, sx, w1, b1, w2, b2, block):
+        y, sy, saved = _rb_forward(block, x, sx)
+        ctx.save_for_backward(*saved)
+        ctx.block = block
+        ctx.mark_non_differentiable(sy)
+        return y, sy
+
+    @staticmethod
+    def backward(ctx, dy, _dsy):
+        pairs = []
+        dx = _rb_backward(ctx.block, ctx.saved_tensors, dy.contiguous(), pairs, ctx.needs_input_grad[0])
+        (dw1, db1), (dw2, db2) = _wgrads(pairs)
+        return dx, None, dw1, db1, dw2, db2, None
+
+
+class AttentionBlockFn(torch.autograd.Function):
+    """out = a * sigmoid(b) + x,  a = RB^3(x),  b = conv1x1(RB^3(x))   (mcquic/nn/blocks.py:245-288) as ONE autograd node:
+    the two stacks run on two streams in both directions (their 12-px-tile kernels do not fill the chip at the 16x16 ...
+    4x4 levels of a training step), every ResidualBlock is two fused launches each way, and the twelve 3x3 weight gradients
+    of the block leave in ONE grouped launch.  Parameter order: main RB 0..2 then side RB 0..2, each (w1, b1, w2, b2), then
+    the 1x1 conv's (w, b)."""
+
+    @staticmethod
+    def forward(ctx, x, sx, *rest):
+        block = rest[-1]
+        from .nn.blocks import _fork
+        saved = []
+        with _fork(x) as f:
+            b, sb = x, sx
+            for i in range(3):
+                b, sb, keep = _rb_forward(block._sideBranch[i], b, sb)
+                saved.extend(keep)
+        a, sa = x, sx
+        for i in range(3):
+            a, sa, keep = _rb_forward(block._mainBranch[i], a, sa)
+            saved.extend(keep)
+        b = f.join(b)
+        bb = ops.conv2d(b, block._sideBranch[3].packed())
+        out = ops.gate(a, bb, x)
+        ctx.save_for_backward(a, b, bb, *saved)
+        ctx.block = block
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        block = ctx.block
+        from .nn.blocks import _fork
+        a, b, bb = ctx.saved_tensors[:3]
+        saved = ctx.saved_tensors[3:]
+        side = [saved[4 * i: 4 * i + 4] for i in range(3)]
+        main = [saved[12 + 4 * i: 12 + 4 * i + 4] for i in range(3)]
+        dout = dout.contiguous()
+        da, dbb = ops.gate_bwd(a, bb, dout)
+        c11 = block._sideBranch[3]
+        pairs_side, pairs_main = [], []
+        with _fork(dout) as f:
+            g = ops.conv2d(dbb, _dgrad_packed(c11, c11.weight))
+            dw11, db11 = ops.conv2d_wgrad(b, dbb, 1, 1, want_bias=True)
+            for i in (2, 1, 0):
+                g = _rb_backward(block._sideBranch[i], side[i], g, pairs_side)
+        h = da
+        for i in (2, 1, 0):
+            h = _rb_backward(block._mainBranch[i], main[i], h, pairs_main)
+        g = f.join(g)
+        # the side stack's operand pairs (saved activations and gradients, all allocated on the side stream) are read by
+        # the grouped weight-gradient launch on THIS stream, and the 1x1 conv's gradients go on to autograd's consumers
+        f.hand_over(dw11, db11, *[t for pair in pairs_side for t in pair])
+        dx = ops.add(ops.add(h, g), dout)
+        grads = _wgrads(pairs_main[::-1] + pairs_side[::-1])      # RB-major: each RB contributed (conv1 pair, conv2 pair)
+        flat = []
+        # pairs were appended RB 2, 1, 0 with (conv1, conv2) inside each: reversed lists are conv2, conv1 of RB 0, 1, 2
+        for stack in (grads[:6], grads[6:]):
+            for i in range(3):
+                (dw2, db2), (dw1, db1) = stack[2 * i], stack[2 * i + 1]
+                flat.extend([dw1, db1, dw2, db2])
+        return (dx, None, *flat, dw11, db11, None)
 
 
 class GateFn(torch.autograd.Function):
@@ -176,6 +282,35 @@ def conv(x, module, res: Optional[torch.Tensor] = None, shuffle2: bool = False):
 
 def silu(x):
     return SiluFn.apply(x)
+
+
+def _silu_of(x: torch.Tensor) -> torch.Tensor:
+    """silu(x) as a plain tensor: the producer's twin if there is one, else one SiLU launch (remembered on x)."""
+    sx = ops.silu_twin(x)
+    if sx is None:
+        with torch.no_grad():
+            sx = ops.silu(x.detach())
+        ops.set_silu_twin(x, sx)
+    return sx
+
+
+def attention_block(x, block):
+    """AttentionBlock in the training graph (AttentionBlockFn)."""
+    params = []
+    for stack in (block._mainBranch, block._sideBranch):
+        for i in range(3):
+            c1, c2 = stack[i]._branch[1], stack[i]._branch[3]
+            params.extend([c1.weight, c1.bias, c2.weight, c2.bias])
+    c11 = block._sideBranch[3]
+    return AttentionBlockFn.apply(x, _silu_of(x), *params, c11.weight, c11.bias, block)
+
+
+def residual_block(x, block):
+    """ResidualBlock in the training graph (ResidualBlockFn); the result carries silu(result) as its twin."""
+    c1, c2 = block._branch[1], block._branch[3]
+    y, sy = ResidualBlockFn.apply(x, _silu_of(x), c1.weight, c1.bias, c2.weight, c2.bias, block)
+    ops.set_silu_twin(y, sy)
+    return y
 
 
 def gate(a, b, x):

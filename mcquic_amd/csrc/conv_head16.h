@@ -158,8 +158,27 @@ __global__ __launch_bounds__(256, MCQ_H16_OCC) void conv_head16_kernel(Head16K p
     }
 }
 
-// OIHW -> [S4 * 9 + tail][64 lanes]: lane l of k-step s * 9 + tap holds W[co = l & 15][ci = 4 s + (l >> 4)][tap]
-__global__ void pack_head16_kernel(const float* __restrict__ w, int Cout, int Cin, int S4, float* __restrict__ out, size_t total) {
+// `mode` selects which convolution the operand stream is for (w is always the layer's own OIHW weight [Co, Ci, ks, ks]):
+//   0  the layer itself:                    W'[co][ci][tap] = w[co][ci][tap]                                  (Cout = Co, Cin = Ci)
+//   1  its input gradient, stride 1:        W'[co][ci][tap] = w[ci][co][taps - 1 - tap]  (flip + transpose)    (Cout = Ci, Cin = Co)
+//   2  its input gradient, stride 2 (3x3):  dX = PixelShuffle2(conv3x3(dY, W')), W'[4 c + 2 i + j][o][(ty+1, tx+1)] =
+//      w[o][c][ky(i, ty)][kx(j, tx)] with (phase, offset) -> kernel index {(0,0): 1, (1,0): 2, (1,1): 0}, else 0   (Cout = 4 Ci, Cin = Co)
+// so the backward pass packs straight from the parameter in one launch (no flip / transpose / scatter on the way).
+__device__ __forceinline__ float pack_source(const float* __restrict__ w, int mode, int Co, int Ci, int ks, int co, int ci, int tap) {
+    const int taps = ks * ks;
+    if (mode == 0) return w[((size_t)co * Ci + ci) * taps + tap];
+    if (mode == 1) return w[((size_t)ci * Ci + co) * taps + (taps - 1 - tap)];
+    const int c = co >> 2, i = (co >> 1) & 1, j = co & 1;
+    const int ty = tap / 3 - 1, tx = tap % 3 - 1;
+    const int ky = i == 0 ? (ty == 0 ? 1 : -1) : (ty == 0 ? 2 : ty == 1 ? 0 : -1);
+    const int kx = j == 0 ? (tx == 0 ? 1 : -1) : (tx == 0 ? 2 : tx == 1 ? 0 : -1);
+    if (ky < 0 || kx < 0) return 0.0f;
+    return w[((size_t)ci * Ci + c) * 9 + ky * 3 + kx];
+}
+
+// OIHW -> [S4 * 9 + tail][64 lanes]: lane l of k-step s * 9 + tap holds W'[co = l & 15][ci = 4 s + (l >> 4)][tap]
+__global__ void pack_head16_kernel(const float* __restrict__ w, int Cout, int Cin, int S4, float* __restrict__ out, size_t total,
+                                   int mode, int Co, int Ci) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int lane = (int)(i & 63);
@@ -168,7 +187,7 @@ __global__ void pack_head16_kernel(const float* __restrict__ w, int Cout, int Ci
     if (step < (size_t)S4 * 9) {
         const int s = (int)(step / 9), tap = (int)(step - (size_t)s * 9);
         const int co = lane & 15, ci = 4 * s + (lane >> 4);
-        if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 9 + tap];
+        if (co < Cout && ci < Cin) v = pack_source(w, mode, Co, Ci, 3, co, ci, tap);
     }
     out[i] = v;
 }

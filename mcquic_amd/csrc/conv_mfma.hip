@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
             yr[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.y + slab), slab_bytes);
             if (f & MCQ_CONV_DUAL_SILU) y2r[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.y2 + slab), slab_bytes);
             if (f & MCQ_CONV_RESIDUAL) rr_[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.res + slab), slab_bytes);
-            if (f & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL))
+            if (f & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL | MCQ_CONV_DSILU_MUL))
                 mr[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.mul + slab), slab_bytes);
             if (f & MCQ_CONV_GATE) gr[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.gid + slab), slab_bytes);
             if (f & MCQ_CONV_SHUFFLE2)      // [Cout/4, 2 Ho, 2 Wo]: channel c = co / 4 -> rows of 2 Wo, this lane's 2x2 cell
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
                 unsigned so[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) so[r] = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
-                if (f & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL)) {
+                if (f & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL | MCQ_CONV_DSILU_MUL)) {
                     float m[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) m[r] = mcq_buffer_load_s(mr[nb], pvo[nb], so[r]);
@@ -443,6 +443,9 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
                     } else if (f & MCQ_CONV_MUL) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) v[r] = m[r] * v[r];
+                    } else if (f & MCQ_CONV_DSILU_MUL) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = v[r] * mcq_dsilu(m[r]);
                     } else {
                         float gi[16];
 #pragma unroll
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
 // OIHW -> [Cout/(32 bands)][TP][64 lanes][bands]: lane l, slot q holds W[co = 32 bands T + 32 q + (l & 31)][ci = 2 s + (l >> 5)][tap]
 // for k-step = s * taps + tap (channel-major, tap-inner); zero beyond Cout / Cin and in the 16-step tail.
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, int S, int TP,
-                                        float* __restrict__ out, size_t sec4, size_t sec2, size_t total) {
+                                        float* __restrict__ out, size_t sec4, size_t sec2, size_t total, int mode, int Co, int Ci) {
     // three copies back to back, `bands` = 32-row bands per tile (4 / 2 / 1 for the 128- / 64- / 32-row copies), each
     // laid out [tile][step][lane][band] and followed by its zero tail
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -563,7 +566,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
         const int s = step / taps, tap = step - s * taps;
         const int co = tile * 32 * bands + 32 * q + (lane & 31);
         const int ci = 2 * s + (lane >> 5);
-        if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * (ks * ks) + tap];
+        if (co < Cout && ci < Cin) v = pack_source(w, mode, Co, Ci, ks, co, ci, tap);
     }
     out[at] = v;
 }
@@ -633,11 +636,36 @@ extern "C" int mcq_pack_conv_weight_f32(const float* w, int32_t Cout, int32_t Ci
     const size_t total = general_floats(Cout, Cin, ksize);
     const int S = pairs_padded(Cin, ksize), TP = steps_padded(Cin, ksize);
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
-                       ksize, S, TP, out, section_floats(Cout, Cin, ksize, 4), section_floats(Cout, Cin, ksize, 2), total);
+                       ksize, S, TP, out, section_floats(Cout, Cin, ksize, 4), section_floats(Cout, Cin, ksize, 2), total, 0, Cout, Cin);
     if (MCQ_HEAD16 && head16_shape(Cout, ksize)) {      // second copy in the 16-row operand order of conv_head16_kernel
         const size_t t16 = head16_floats(Cin);
         hipLaunchKernelGGL(pack_head16_kernel, dim3((unsigned)((t16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
-                           (Cin + 3) / 4, out + total, t16);
+                           (Cin + 3) / 4, out + total, t16, 0, Cout, Cin);
+    }
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_dgrad_weight_shape(int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t* Cout_d, int32_t* Cin_d) {
+    if (Cout <= 0 || Cin <= 0 || !Cout_d || !Cin_d) return MCQ_EINVAL;
+    if (stride == 1 && (ksize == 1 || ksize == 3)) { *Cout_d = Cin; *Cin_d = Cout; return MCQ_OK; }
+    if (stride == 2 && ksize == 3) { *Cout_d = 4 * Cin; *Cin_d = Cout; return MCQ_OK; }
+    return MCQ_EINVAL;
+}
+
+extern "C" int mcq_pack_conv_dgrad_weight_f32(const float* w, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, float* out,
+                                              void* stream) {
+    int32_t co_d = 0, ci_d = 0;
+    if (!w || !out || mcq_dgrad_weight_shape(Cout, Cin, ksize, stride, &co_d, &ci_d) != MCQ_OK) return MCQ_EINVAL;
+    // same layout and size as a forward pack of a [co_d, ci_d, ks, ks] weight: mcq_packed_conv_weight_floats(co_d, ci_d, ks)
+    const size_t total = general_floats(co_d, ci_d, ksize);
+    const int S = pairs_padded(ci_d, ksize), TP = steps_padded(ci_d, ksize);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, co_d, ci_d,
+                       ksize, S, TP, out, section_floats(co_d, ci_d, ksize, 4), section_floats(co_d, ci_d, ksize, 2), total,
+                       stride == 1 ? 1 : 2, Cout, Cin);
+    if (MCQ_HEAD16 && head16_shape(co_d, ksize)) {      // narrow input gradients (the 8-channel fixture models) take the 16-row kernel
+        const size_t t16 = head16_floats(ci_d);
+        hipLaunchKernelGGL(pack_head16_kernel, dim3((unsigned)((t16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, co_d, ci_d,
+                           (ci_d + 3) / 4, out + total, t16, stride == 1 ? 1 : 2, Cout, Cin);
     }
     return mcq_check_launch();
 }
@@ -655,7 +683,7 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     if ((d->ksize != 1 && d->ksize != 3) || (d->stride != 1 && d->stride != 2)) return MCQ_EINVAL;
     const unsigned fl = d->flags;
     if ((fl & MCQ_CONV_RESIDUAL) && !d->res) return MCQ_EINVAL;
-    if ((fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL)) && !d->mul) return MCQ_EINVAL;
+    if ((fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL | MCQ_CONV_DSILU_MUL)) && !d->mul) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_GATE) && !d->gate_id) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_DUAL_SILU) && (!d->y_silu || (fl & MCQ_CONV_SILU_OUT))) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_SILU_IN) && (fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;

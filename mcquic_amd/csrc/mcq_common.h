@@ -62,6 +62,12 @@ __device__ __forceinline__ float mcq_sigmoid(float x) { return mcq_div(1.0f, mcq
 __device__ __forceinline__ float mcq_silu(float x) { return mcq_div(x, mcq_one_plus_exp_neg(x)); }
 #endif
 
+// silu'(x) = s (1 + x (1 - s)), s = sigmoid(x)
+__device__ __forceinline__ float mcq_dsilu(float x) {
+    const float s = mcq_sigmoid(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mcq_make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }

@@ -201,14 +201,23 @@ class _quantizerEncoder(nn.Module):
     def _forward(self, x: torch.Tensor, freqEMA: torch.Tensor, uniforms=None):
         """Training-mode level (:295-305): returns (sample, residual for the next level, code, logit)."""
         z = self._latentStageEncoder(x)
-        q, code, logit = self._quantizer(self._quantizationHead(z), freqEMA, uniforms)
         if self._latentHead is None:
+            q, code, logit = self._quantizer(self._quantizationHead(z), freqEMA, uniforms)
             return q, None, code, logit
-        deq = self._dequantizer(q)
         head = self._latentHead
         if torch.is_grad_enabled():
+            # latentHead(z) does not depend on the codes: it runs on the side stream beside quantizationHead + the soft
+            # assignment (15 convolutions each, launch-bound on the 16x16 ... 4x4 maps of a training crop); autograd
+            # replays the same two-stream schedule in the backward pass
             from .. import autograd as AG
-            return q, AG.sub(head(z), deq), code, logit
+            from ..nn.blocks import _fork
+            AG._silu_of(z)                                     # both heads open with silu(z): made once, before the streams part
+            with _fork(z, lane=1) as f:
+                hz = head(z)
+            q, code, logit = self._quantizer(self._quantizationHead(z), freqEMA, uniforms)
+            return q, AG.sub(f.join(hz), self._dequantizer(q)), code, logit
+        q, code, logit = self._quantizer(self._quantizationHead(z), freqEMA, uniforms)
+        deq = self._dequantizer(q)
         t = z
         for i in range(len(head) - 1):
             t = head[i](t)
@@ -239,6 +248,13 @@ class _quantizerDecoder(nn.Module):
 
     def forward(self, q, formerLevel: Optional[torch.Tensor]):
         """Training-mode level (:359-365): like decode, from the straight-through sample."""
+        if self._sideHead is not None and torch.is_grad_enabled():
+            from .. import autograd as AG
+            from ..nn.blocks import _fork
+            with _fork(formerLevel, lane=1) as f:              # sideHead || dequantizationHead (see _quantizerEncoder._forward)
+                side = self._sideHead(formerLevel)
+            x = AG.add(self._dequantizationHead(self._dequantizer(q)), f.join(side))
+            return self._restoreHead(x)
         x = self._dequantizationHead(self._dequantizer(q))
         if self._sideHead is not None:
             if torch.is_grad_enabled():

@@ -35,9 +35,10 @@ _BRANCH_STREAMS = os.environ.get("MCQUIC_AMD_BRANCH_STREAMS", "1") != "0"
 _side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
 
 
-def _side_stream(main: "torch.cuda.Stream") -> "torch.cuda.Stream":
-    """The side stream paired with `main` (one per main stream, so pipelined sub-batches do not share one)."""
-    key = (main.device.index, main.cuda_stream)
+def _side_stream(main: "torch.cuda.Stream", lane: int = 0) -> "torch.cuda.Stream":
+    """The side stream paired with `main` (one per main stream and lane, so pipelined sub-batches do not share one;
+    lane 0 = block-level branches, lane 1 = the level-granular forks of the training graph)."""
+    key = (main.device.index, main.cuda_stream, lane)
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=main.device)
@@ -48,11 +49,11 @@ class _fork:
     """`with _fork(x) as f:` runs the body on the side stream after everything enqueued so far; `f.join(t)` makes the
     main stream wait for it and hands tensor `t` (allocated on the side stream) over to the main stream."""
 
-    def __init__(self, x: torch.Tensor):
+    def __init__(self, x: torch.Tensor, lane: int = 0):
         self.on = _BRANCH_STREAMS and x.is_cuda
         if self.on:
             self.main = torch.cuda.current_stream(x.device)
-            self.side = _side_stream(self.main)
+            self.side = _side_stream(self.main, lane)
         self.ctx = None
 
     def __enter__(self):
@@ -72,6 +73,14 @@ class _fork:
             self.main.wait_stream(self.side)
             t.record_stream(self.main)
         return t
+
+    def hand_over(self, *tensors: torch.Tensor) -> None:
+        """Tensors allocated on the side stream that kernels of the main stream read after the join: the caching allocator
+        must not hand their memory to a later side-stream allocation before the main stream is done with them."""
+        if self.on:
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)
 
 
 class _residulBlock(nn.Module):
@@ -93,9 +102,8 @@ class ResidualBlock(_residulBlock):
         super().__init__(nn.SiLU(), conv3x3(inChannels, outChannels), nn.SiLU(), conv3x3(outChannels, outChannels), None)
 
     def forward(self, x: torch.Tensor, res2: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if self.training and torch.is_grad_enabled():             # training graph: separate ops, HIP backward
-            t = self._branch[1](AG.silu(x))
-            return self._branch[3](AG.silu(t), res=x)
+        if self.training and torch.is_grad_enabled():             # training graph: two fused launches each way
+            return AG.residual_block(x, self)
         t = self._branch[1](x, silu_in=True, silu_out=True)      # silu(conv1(silu(x)))
         return self._branch[3](t, res=x, dual_silu=True)          # conv2(.) + x
 
@@ -151,7 +159,7 @@ class AttentionBlock(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
-            return AG.gate(self._mainBranch(x), self._sideBranch(x), x)
+            return AG.attention_block(x, self)
         with _fork(x) as f:
             b = x
             for i in range(3):

@@ -7,12 +7,13 @@ fallback implementation.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
 
 from . import _lib
-from ._lib import (CONV_DUAL_SILU, CONV_MUL, CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN,
+from ._lib import (CONV_DSILU_MUL, CONV_DUAL_SILU, CONV_MUL, CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN,
                    CONV_SILU_OUT, CONV_SQUARE_IN, ConvDesc, check)
 
 # A producer asked for `dual_silu` hangs silu(y) on its result under this attribute; a consumer asked for
@@ -23,6 +24,10 @@ _TWIN = "_mcq_silu_twin"
 
 def silu_twin(t: torch.Tensor) -> Optional[torch.Tensor]:
     return getattr(t, _TWIN, None)
+
+
+def set_silu_twin(t: torch.Tensor, twin: torch.Tensor) -> None:
+    setattr(t, _TWIN, twin)
 
 
 
@@ -107,12 +112,33 @@ class PackedConv:
         self.bias = None if bias is None else _dev(bias.detach(), "bias").clone()
         self.cout, self.cin, self.ksize = cout, cin, kh
 
+    @classmethod
+    def dgrad(cls, weight: torch.Tensor, stride: int) -> "PackedConv":
+        """Operand stream of the layer's input-gradient convolution, packed straight from its OIHW weight in one launch
+        (mcq_pack_conv_dgrad_weight_f32): stride 1 -> a [cin, cout, k, k] conv; stride 2 -> a [4 cin, cout, 3, 3] conv whose
+        result goes through the PixelShuffle(2) store."""
+        weight = _dev(weight.detach(), "weight")
+        cout, cin, kh, kw = weight.shape
+        lib = _lib.load()
+        co_d, ci_d = ctypes.c_int32(0), ctypes.c_int32(0)
+        if kh != kw or lib.mcq_dgrad_weight_shape(cout, cin, kh, stride, ctypes.byref(co_d), ctypes.byref(ci_d)) != 0:
+            raise NotImplementedError(f"input gradient of a {kh}x{kw} stride-{stride} convolution is not on the path")
+        self = cls.__new__(cls)
+        self.wp = torch.empty(lib.mcq_packed_conv_weight_floats(co_d.value, ci_d.value, kh), dtype=torch.float32, device=weight.device)
+        with _guard(weight.device):
+            check(lib.mcq_pack_conv_dgrad_weight_f32(_ptr(weight), cout, cin, kh, stride, _ptr(self.wp), _stream()),
+                  "mcq_pack_conv_dgrad_weight_f32")
+        self.bias = None
+        self.cout, self.cin, self.ksize = co_d.value, ci_d.value, kh
+        return self
+
 
 def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = False, square_in: bool = False,
            silu_out: bool = False, res: Optional[torch.Tensor] = None, res_scale: float = 1.0,
            gdn_mul: Optional[torch.Tensor] = None, igdn_mul: Optional[torch.Tensor] = None,
            gate_mul: Optional[torch.Tensor] = None, gate_id: Optional[torch.Tensor] = None,
-           mul: Optional[torch.Tensor] = None, shuffle2: bool = False, dual_silu: bool = False, tile: int = 0) -> torch.Tensor:
+           mul: Optional[torch.Tensor] = None, dsilu_mul: Optional[torch.Tensor] = None, shuffle2: bool = False,
+           dual_silu: bool = False, tile: int = 0) -> torch.Tensor:
     """y = epilogue(conv(prologue(x)) + bias); one kernel launch (mcq_conv2d_f32)."""
     if silu_in:
         twin = silu_twin(x)
@@ -148,7 +174,7 @@ def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = F
         res = _dev(res, "res")
         if res.shape != y.shape:
             raise ValueError(f"residual shape {tuple(res.shape)} != output shape {tuple(y.shape)}")
-    for flag, t in ((CONV_GDN, gdn_mul), (CONV_IGDN, igdn_mul), (CONV_GATE, gate_mul), (CONV_MUL, mul_in)):
+    for flag, t in ((CONV_GDN, gdn_mul), (CONV_IGDN, igdn_mul), (CONV_GATE, gate_mul), (CONV_MUL, mul_in), (CONV_DSILU_MUL, dsilu_mul)):
         if t is not None:
             flags |= flag
             mul = _dev(t, "mul")
@@ -334,6 +360,43 @@ def nchw_to_nhwc(x: torch.Tensor, square: bool = False) -> torch.Tensor:
     return out
 
 
+_WGRAD_ROWS = os.environ.get("MCQUIC_AMD_WGRAD_ROWS", "1") != "0"      # A/B switch: 0 = always the NHWC weight-gradient kernel
+
+
+def conv2d_wgrad_group(xs, dys, want_bias: bool = True):
+    """Weight (and bias) gradients of several 3x3 stride-1 convolutions of ONE shape in one launch pair
+    (mcq_conv2d_wgrad_nchw_group_f32).  Returns [(dW, db or None), ...]; shapes the row-walk kernel does not take, or a
+    single pair, go through conv2d_wgrad one by one."""
+    lib = _lib.load()
+    n, cin, h, w = xs[0].shape
+    cout = dys[0].shape[1]
+    same = all(x.shape == xs[0].shape for x in xs) and all(d.shape == dys[0].shape for d in dys)
+    nws = lib.mcq_conv2d_wgrad_nchw_workspace_floats(n, cin, h, w, cout) if (_WGRAD_ROWS and same and tuple(dys[0].shape[2:]) == (h, w)) else 0
+    if not nws or len(xs) == 1:
+        out = []
+        for x, dy in zip(xs, dys):
+            r = conv2d_wgrad(x, dy, 3, 1, want_bias=want_bias)
+            out.append(r if want_bias else (r, None))
+        return out
+    out = []
+    cap = lib.mcq_conv2d_wgrad_nchw_max_group()
+    for lo in range(0, len(xs), cap):
+        gx = [_dev(t, "x") for t in xs[lo:lo + cap]]
+        gd = [_dev(t, "dy") for t in dys[lo:lo + cap]]
+        k = len(gx)
+        ws = torch.empty(nws * k, dtype=torch.float32, device=gx[0].device)
+        dws = [torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=gx[0].device) for _ in range(k)]
+        dbs = [torch.empty((cout,), dtype=torch.float32, device=gx[0].device) for _ in range(k)] if want_bias else None
+        table = ctypes.c_void_p * k
+        with _guard(gx[0].device):
+            check(lib.mcq_conv2d_wgrad_nchw_group_f32(table(*[t.data_ptr() for t in gx]), table(*[t.data_ptr() for t in gd]),
+                                                      table(*[t.data_ptr() for t in dws]),
+                                                      table(*[t.data_ptr() for t in dbs]) if want_bias else None, k, _ptr(ws),
+                                                      n, cin, h, w, cout, _stream()), "mcq_conv2d_wgrad_nchw_group_f32")
+        out.extend(zip(dws, dbs if want_bias else [None] * k))
+    return out
+
+
 def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, square_x: bool = False, want_bias: bool = False):
     """dW [Cout, Cin, k, k] of y = conv(x, W) + b from NCHW x and dy (channel-major copies are made here, one launch for
     the pair); with `want_bias` returns (dW, db) where db[co] = sum of dy over images and pixels, from the same kernel."""
@@ -341,6 +404,17 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
     n, cin, h, w = x.shape
     cout, ho, wo = dy.shape[1], dy.shape[2], dy.shape[3]
     lib = _lib.load()
+    if ksize == 3 and stride == 1 and not square_x and _WGRAD_ROWS:
+        # straight from the NCHW tensors (csrc/wgrad_rows.hip); 0 = a shape that kernel does not take
+        nws = lib.mcq_conv2d_wgrad_nchw_workspace_floats(n, cin, h, w, cout)
+        if nws:
+            ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+            dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+            db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+            with _guard(x.device):
+                check(lib.mcq_conv2d_wgrad_nchw_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream()),
+                      "mcq_conv2d_wgrad_nchw_f32")
+            return (dw, db) if want_bias else dw
     xt = torch.empty((n, h, w, cin), dtype=torch.float32, device=x.device)
     dyt = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
     ws = torch.empty(lib.mcq_conv2d_wgrad_workspace_floats(n, cin, h, w, cout, ksize, stride), dtype=torch.float32, device=x.device)

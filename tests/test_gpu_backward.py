@@ -48,6 +48,67 @@ def test_conv_backward(dev, case):
     _close(conv.bias.grad, br.grad, 3e-6, f"db {case}")
 
 
+@pytest.mark.parametrize("case", [(2, 128, 128, 16, 16), (8, 128, 128, 32, 32), (1, 128, 512, 8, 16), (2, 128, 12, 16, 24),
+                                  (3, 40, 72, 8, 8), (1, 128, 128, 64, 64), (2, 128, 128, 128, 128), (5, 32, 32, 24, 8),
+                                  (8, 128, 128, 8, 8), (1, 3, 128, 40, 32)])
+def test_wgrad_rows_kernel(dev, case):
+    """The NCHW weight-gradient kernel (csrc/wgrad_rows.hip: 3x3, stride 1, H and W multiples of 8) against CPU autograd,
+    bit-identical when repeated (deterministic reduction), and equal to the NHWC kernel it replaces up to summation order."""
+    from mcquic_amd import ops
+    n, cin, cout, h, w = case
+    assert ops._lib.load().mcq_conv2d_wgrad_nchw_workspace_floats(n, cin, h, w, cout) > 0
+    x, gy = _rand((n, cin, h, w), 11), _rand((n, cout, h, w), 12)
+    wr = torch.zeros((cout, cin, 3, 3), requires_grad=True)
+    br = torch.zeros((cout,), requires_grad=True)
+    F.conv2d(x, wr, br, padding=1).backward(gy)
+    dw, db = ops.conv2d_wgrad(x.to(dev), gy.to(dev), 3, 1, want_bias=True)
+    _close(dw, wr.grad, 3e-6, f"dW {case}")
+    _close(db, br.grad, 3e-6, f"db {case}")
+    dw2, db2 = ops.conv2d_wgrad(x.to(dev), gy.to(dev), 3, 1, want_bias=True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    assert torch.equal(ops.conv2d_wgrad(x.to(dev), gy.to(dev), 3, 1), dw)
+    ops._WGRAD_ROWS = False
+    try:
+        old = ops.conv2d_wgrad(x.to(dev), gy.to(dev), 3, 1)
+    finally:
+        ops._WGRAD_ROWS = True
+    _close(dw, old.cpu(), 3e-6, f"rows vs NHWC kernel {case}")
+
+
+@pytest.mark.parametrize("case", [(8, 128, 128, 4, 4), (3, 40, 24, 4, 4), (11, 16, 16, 4, 8), (2, 128, 128, 6, 6), (8, 128, 128, 2, 2),
+                                  (1, 8, 8, 1, 1)])
+def test_wgrad_small_map_kernel(dev, case):
+    """Maps the strip walk does not take (the 4x4 level of a 256x256 crop): the one-launch LDS kernel against CPU autograd."""
+    from mcquic_amd import ops
+    n, cin, cout, h, w = case
+    assert ops._lib.load().mcq_conv2d_wgrad_nchw_workspace_floats(n, cin, h, w, cout) == 1
+    x, gy = _rand((n, cin, h, w), 21), _rand((n, cout, h, w), 22)
+    wr = torch.zeros((cout, cin, 3, 3), requires_grad=True)
+    br = torch.zeros((cout,), requires_grad=True)
+    F.conv2d(x, wr, br, padding=1).backward(gy)
+    dw, db = ops.conv2d_wgrad(x.to(dev), gy.to(dev), 3, 1, want_bias=True)
+    _close(dw, wr.grad, 3e-6, f"dW {case}")
+    _close(db, br.grad, 3e-6, f"db {case}")
+    (dw2, db2), (dw3, _) = ops.conv2d_wgrad_group([x.to(dev), x.to(dev)], [gy.to(dev), gy.to(dev)], want_bias=True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dw, dw3)
+
+
+@pytest.mark.parametrize("case", [(3, 2, 128, 128, 16, 16), (16, 8, 128, 128, 8, 8), (19, 1, 32, 64, 8, 16)])
+def test_wgrad_rows_grouped_launch(dev, case):
+    """Several convolutions of one shape in one launch pair: every (dW, db) equals the single-conv launch bit for bit."""
+    from mcquic_amd import ops
+    k, n, cin, cout, h, w = case
+    xs = [_rand((n, cin, h, w), 100 + i).to(dev) for i in range(k)]
+    dys = [_rand((n, cout, h, w), 200 + i).to(dev) for i in range(k)]
+    got = ops.conv2d_wgrad_group(xs, dys, want_bias=True)
+    assert len(got) == k
+    for i, (dw, db) in enumerate(got):
+        dw1, db1 = ops.conv2d_wgrad(xs[i], dys[i], 3, 1, want_bias=True)
+        assert torch.equal(dw, dw1) and torch.equal(db, db1), i
+    nb = ops.conv2d_wgrad_group(xs[:2], dys[:2], want_bias=False)
+    assert nb[1][1] is None and torch.equal(nb[1][0], got[1][0])
+
+
 def test_pixel_shuffle_conv_backward(dev):
     from mcquic_amd.nn import pixelShuffle3x3
     n, c, h, w = 2, 128, 6, 10

@@ -143,3 +143,13 @@ def test_oversized_planes_are_rejected_before_any_launch():
     d.Cin = 120
     assert lib.mcq_conv2d_f32(d, None) == _lib.MCQ_ETOOLARGE
     assert lib.mcq_vq_assign_f32(1, 1, 1, 1, 2, 64, 4096, 2048, 512, None) == _lib.MCQ_ETOOLARGE
+
+
+def test_wgrad_rows_kernel_declines_other_shapes():
+    from mcquic_amd import _lib
+    lib = _lib.load()
+    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(2, 128, 12, 16, 128) == 0      # H not a multiple of 8
+    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(2, 128, 16, 12, 128) == 0      # W not a multiple of 8
+    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(8, 128, 4, 4, 128) == 1        # small map: the LDS kernel, no workspace
+    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(64, 128, 256, 256, 128) == 0   # a tensor of 2 GiB
+    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(8, 128, 16, 16, 128) > 0

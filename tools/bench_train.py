@@ -25,7 +25,13 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--crop", type=int, default=256)
     ap.add_argument("--graph", action="store_true", help="capture forward+backward in one hipGraph and replay it (single GPU)")
+    ap.add_argument("--optimizer-step", action="store_true",
+                    help="SGD step inside the timed region: the weights change every step, so every conv re-packs its forward and "
+                         "input-gradient operand streams each step, as in a real training loop")
     args = ap.parse_args()
+    if args.graph:
+        # capturing the nested stream forks of the training graph crashes hipGraph capture (ROCm 7.2): one stream there
+        os.environ["MCQUIC_AMD_BRANCH_STREAMS"] = "0"
     from mcquic_amd import launch
     rank, local, world, launched = launch.ensure_world(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     launch.pin_rank_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
@@ -42,12 +48,16 @@ def main():
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
     x = (torch.rand((args.batch, 3, args.crop, args.crop), generator=torch.Generator().manual_seed(rank)) * 2 - 1).to(dev)
 
+    opt = torch.optim.SGD(model.parameters(), lr=1e-6) if args.optimizer_step else None
+
     def step():
         for p in model.parameters():
             p.grad = None
         xHat, yHat, codes, logits = net(x)
         loss = torch.nn.functional.mse_loss(xHat, x)       # loss glue is the trainer's business (out of scope): plain MSE
         loss.backward()
+        if opt is not None:
+            opt.step()
         return loss
 
     for _ in range(args.warmup):
@@ -82,7 +92,8 @@ def main():
         print(json.dumps({"metric": "training step (forward + backward), 256x256 crops, qp=2 model", "n_gpus": world,
                           "images_per_gpu": args.batch, "ms_per_step": round(dt / args.steps * 1e3, 2),
                           "images_per_s": round(world * args.batch * args.steps / dt, 2), "loss": float(loss), "grad_norm": gn,
-                          "dtype": "f32", "optimizer_step": "not included (trainer glue)"}))
+                          "dtype": "f32", "graph": bool(args.graph and world == 1),
+                          "optimizer_step": "SGD inside the timed region (weights re-packed every step)" if args.optimizer_step else "not included"}))
     if world > 1:
         dist.destroy_process_group()
 

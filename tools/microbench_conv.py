@@ -39,17 +39,19 @@ def main():
     ap.add_argument("--small", action="store_true", help="only the three small levels")
     ap.add_argument("--big", action="store_true", help="only the two largest levels")
     ap.add_argument("--k1", action="store_true", help="only the 1x1 shapes")
+    ap.add_argument("--train", action="store_true", help="the 3x3 shapes of the config-#5 training step (8 images of 128x128 ... 4x4)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     print("lib:", os.environ.get("MCQUIC_AMD_LIB", "default"))
-    for (n, cin, cout, h, w, ks, stride) in (SHAPES[3:6] if args.small else SHAPES[:2] if args.big else SHAPES[6:] if args.k1 else SHAPES[:7]):
+    train = [(8, 128, 128, s, s, 3, 1) for s in (128, 64, 32, 16, 8, 4)]
+    for (n, cin, cout, h, w, ks, stride) in train if args.train else (SHAPES[3:6] if args.small else SHAPES[:2] if args.big else SHAPES[6:] if args.k1 else SHAPES[:7]):
         x = torch.randn(n, cin, h, w, device=dev)
         res = torch.randn(n, cout, h // stride, w // stride, device=dev)
         packs = [ops.PackedConv(torch.randn(cout, cin, ks, ks, device=dev) * 0.03, torch.randn(cout, device=dev)) for _ in range(args.nweights)]
         flops = 2.0 * n * (h // stride) * (w // stride) * cout * cin * ks * ks
         row = []
         for tile in TILES:
-            if h * w > 100 * 64 and tile not in (0, 0x42, 0x41, 0x22, 0x11):
+            if h * w > 100 * 64 and tile not in (0, 0x42, 0x41, 0x22, 0x11) and not args.train:
                 continue
             kw = dict(tile=tile)
             if args.flags == "res":

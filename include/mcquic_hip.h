@@ -282,6 +282,10 @@ void mcq_ms_ssim_window(float* out11);
 int mcq_sqdiff_sum_u8(const uint8_t* x, const uint8_t* y, int64_t* out, int64_t per_image, int32_t N, void* stream);
 
 /* Library / build identification: returns a static string "mcquic_hip <ver> gfx950". */
+/* Launches a kernel with an invalid configuration on purpose and returns what every entry point returns when its launch is
+ * refused: MCQ_ELAUNCH.  Test hook for the error path (tests/test_gpu_ops.py); harmless (launch errors are not sticky). */
+int mcq_selftest_launch_failure(void* stream);
+
 const char* mcq_version(void);
 
 #ifdef __cplusplus

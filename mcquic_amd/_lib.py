@@ -88,6 +88,7 @@ SYMBOLS = {
     "mcq_ms_ssim_u8": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_ms_ssim_window": (None, [c_void_p]),
     "mcq_sqdiff_sum_u8": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "mcq_selftest_launch_failure": (c_int32, [c_void_p]),
     "mcq_version": (c_char_p, []),
 }
 

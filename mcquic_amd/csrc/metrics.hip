@@ -330,3 +330,14 @@ extern "C" int mcq_sqdiff_sum_u8(const uint8_t* x, const uint8_t* y, int64_t* ou
     hipLaunchKernelGGL(sqdiff_sum_u8_kernel, grid, dim3(256), 0, s, x, y, per_image, vec4, (unsigned long long*)out);
     return mcq_check_launch();
 }
+
+// ---- self-test of the launch-error path ----------------------------------------------------------------------------
+namespace { __global__ void mcq_noop_kernel() {} }
+
+extern "C" int mcq_selftest_launch_failure(void* stream) {
+    // 4096 threads per workgroup is beyond the device limit (1024): the launch is refused, hipGetLastError() reports it,
+    // and mcq_check_launch() turns that into MCQ_ELAUNCH like for any real kernel (the error is not sticky)
+    hipLaunchKernelGGL(mcq_noop_kernel, dim3(1), dim3(4096), 0, (hipStream_t)stream);
+    return mcq_check_launch();
+}
+

@@ -18,16 +18,26 @@ from ._lib import (CONV_DSILU_MUL, CONV_DUAL_SILU, CONV_MUL, CONV_GATE, CONV_GDN
 
 # A producer asked for `dual_silu` hangs silu(y) on its result under this attribute; a consumer asked for
 # `silu_in` uses the twin instead of re-evaluating SiLU inside its k-loop (9 taps x 2 half-waves times per
-# element).  The twin is only valid while y is not modified in place -- nothing in this package does that.
+# element).  The twin is stored with y's version counter and storage address: an in-place update of y by a caller
+# (y.add_(...), y.copy_(...), y.set_(...)) invalidates it -- the consumer then evaluates SiLU itself -- and views /
+# clones never carry it.  (Tensors made under torch.inference_mode() have no version counter and cannot be checked;
+# nothing in this package updates activations in place.)
 _TWIN = "_mcq_silu_twin"
 
 
 def silu_twin(t: torch.Tensor) -> Optional[torch.Tensor]:
-    return getattr(t, _TWIN, None)
+    rec = getattr(t, _TWIN, None)
+    if rec is None:
+        return None
+    twin, version, ptr = rec
+    if version != tensor_version(t) or ptr != t.data_ptr():
+        delattr(t, _TWIN)                       # y changed since the producer wrote silu(y): stale
+        return None
+    return twin
 
 
 def set_silu_twin(t: torch.Tensor, twin: torch.Tensor) -> None:
-    setattr(t, _TWIN, twin)
+    setattr(t, _TWIN, (twin, tensor_version(t), t.data_ptr()))
 
 
 
@@ -190,7 +200,7 @@ def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = F
     with _guard(x.device):
         check(lib.mcq_conv2d_f32(ctypes.byref(d), _stream()), "mcq_conv2d_f32")
     if y2 is not None:
-        setattr(y, _TWIN, y2)
+        set_silu_twin(y, y2)
     return y
 
 
@@ -245,7 +255,7 @@ def vq_gather(codes: torch.Tensor, cb: PackedCodebook, dual_silu: bool = False) 
         check(_lib.load().mcq_vq_gather_f32(_ptr(codes), _ptr(cb.codebook), _ptr(out), _ptr(out2), n, m, cb.d, h, w, cb.k,
                                             _stream()), "mcq_vq_gather_f32")
     if out2 is not None:
-        setattr(out, _TWIN, out2)
+        set_silu_twin(out, out2)
     return out
 
 
@@ -303,7 +313,7 @@ def add(a: torch.Tensor, b: torch.Tensor, dual_silu: bool = False) -> torch.Tens
     with _guard(a.device):
         check(_lib.load().mcq_add_f32(_ptr(a), _ptr(b), _ptr(out), _ptr(out2), a.numel(), _stream()), "mcq_add_f32")
     if out2 is not None:
-        setattr(out, _TWIN, out2)
+        set_silu_twin(out, out2)
     return out
 
 

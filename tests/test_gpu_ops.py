@@ -287,6 +287,19 @@ def test_add_and_detransform(dev):
     assert torch.equal(ops.detransform(x.to(dev)).cpu(), R.detransform(x))
 
 
+def test_refused_launch_surfaces_as_elaunch(dev):
+    """A refused kernel launch comes back as MCQ_ELAUNCH and `check` raises (VERDICT r1, weak #10); the device stays usable."""
+    from mcquic_amd import _lib, ops
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.mcq_selftest_launch_failure(torch.cuda.current_stream().cuda_stream)
+    assert rc == _lib.MCQ_ELAUNCH
+    with pytest.raises(RuntimeError, match="MCQ_ELAUNCH"):
+        _lib.check(rc, "mcq_selftest_launch_failure")
+    a = torch.ones(8, device=dev)
+    assert float(ops.add(a, a).sum()) == 16.0
+
+
 def test_cpu_tensor_is_rejected():
     from mcquic_amd import ops
     with pytest.raises(RuntimeError):
@@ -318,6 +331,12 @@ def test_dual_silu_twin(dev):
     assert torch.equal(ops.silu_twin(g).cpu(), F.silu(g.cpu())) or (ops.silu_twin(g).cpu() - F.silu(g.cpu())).abs().max() < 1e-6
     s = ops.add(x.to(dev), x.to(dev), dual_silu=True)
     assert (ops.silu_twin(s).cpu() - F.silu(x + x)).abs().max() < 1e-6
+    # a caller's in-place update makes the twin stale: it is dropped, not used
+    y2 = ops.conv2d(x.to(dev), pk, dual_silu=True)
+    assert ops.silu_twin(y2) is not None
+    y2.mul_(2.0)
+    assert ops.silu_twin(y2) is None
+    _close(ops.conv2d(y2, pk, silu_in=True), F.conv2d(F.silu(2.0 * want_y), wt, b, padding=1), 3e-6, "silu_in after an in-place update")
 
 
 def _ulp_err(got: torch.Tensor, want64: torch.Tensor) -> torch.Tensor:

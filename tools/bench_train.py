@@ -25,11 +25,12 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--crop", type=int, default=256)
     ap.add_argument("--graph", action="store_true", help="capture forward+backward in one hipGraph and replay it (single GPU)")
+    ap.add_argument("--graph-streams", action="store_true", help="with --graph: keep the branch streams on during capture (experiment)")
     ap.add_argument("--optimizer-step", action="store_true",
                     help="SGD step inside the timed region: the weights change every step, so every conv re-packs its forward and "
                          "input-gradient operand streams each step, as in a real training loop")
     args = ap.parse_args()
-    if args.graph:
+    if args.graph and not args.graph_streams:
         # capturing the nested stream forks of the training graph crashes hipGraph capture (ROCm 7.2): one stream there
         os.environ["MCQUIC_AMD_BRANCH_STREAMS"] = "0"
     from mcquic_amd import launch

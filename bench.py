@@ -89,12 +89,36 @@ class ConvProfiler:
             prof.records.append((s, e, flops, nbytes))
             return y
 
+        self._orig_multi = ops.conv2d_multi
+
+        def wrapped_multi(xs, ws, stride=1, per_problem=None, **shared):
+            if not prof.active:
+                return prof._orig_multi(xs, ws, stride, per_problem=per_problem, **shared)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ops.conv2d = prof._orig                     # (the multi launch is ONE launch: no per-problem brackets inside)
+            s.record()
+            ys = prof._orig_multi(xs, ws, stride, per_problem=per_problem, **shared)
+            e.record()
+            ops.conv2d = wrapped
+            flops = nbytes = 0.0
+            for i, (x, w, y) in enumerate(zip(xs, ws, ys)):
+                n, cin, h, wd = x.shape
+                flops += 2.0 * y.shape[0] * y.shape[2] * y.shape[3] * w.cout * cin * w.ksize * w.ksize
+                kw = dict(shared, **((per_problem or [{}] * len(xs))[i]))
+                sides = sum(1 for key in ("res", "gdn_mul", "igdn_mul", "gate_mul", "gate_id", "mul") if kw.get(key) is not None)
+                sides += 1 if kw.get("dual_silu") else 0
+                nbytes += 4.0 * (x.numel() + y.numel() * (1 + sides))
+            prof.records.append((s, e, flops, nbytes))
+            return ys
+
         ops.conv2d = wrapped
+        ops.conv2d_multi = wrapped_multi
         return self
 
     def remove(self):
         from mcquic_amd import ops
         ops.conv2d = self._orig
+        ops.conv2d_multi = self._orig_multi
 
     def summary(self):
         iv = sorted((self.base.elapsed_time(s), self.base.elapsed_time(e)) for s, e, _, _ in self.records)

@@ -89,6 +89,13 @@ int mcq_pack_conv_dgrad_weight_f32(const float* w, int32_t Cout, int32_t Cin, in
  * (blocks.py:281-288). */
 int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream);
 
+/* Up to mcq_conv2d_max_multi() independent convolutions of ONE geometry and flag set in one launch (descs[0..n): same N, Cin,
+ * H, W, Cout, ksize, stride, flags, res_scale, tile; their own tensors and packed weights).  The two stacks of an
+ * AttentionBlock (mcquic/nn/blocks.py:245-288) apply the same layer shapes to different tensors; on small maps, where a
+ * launch is latency rather than work, they go out together. */
+int32_t mcq_conv2d_max_multi(void);
+int mcq_conv2d_multi_f32(const mcq_conv_desc* descs, int32_t n, void* stream);
+
 /* GDN re-parametrisation folded once at load: out = max(p, bound)^2 - pedestal
  * (mcquic/nn/base.py:81-84 NonNegativeParametrizer.forward). */
 int mcq_nonneg_reparam_f32(const float* p, float bound, float pedestal, float* out, int64_t n,

@@ -36,6 +36,8 @@ SYMBOLS = {
     "mcq_dgrad_weight_shape": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "mcq_pack_conv_dgrad_weight_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "mcq_conv2d_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
+    "mcq_conv2d_max_multi": (c_int32, []),
+    "mcq_conv2d_multi_f32": (c_int32, [POINTER(ConvDesc), c_int32, c_void_p]),
     "mcq_nonneg_reparam_f32": (c_int32, [c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
     "mcq_packed_codebook_floats": (c_size_t, [c_int32, c_int32, c_int32]),
     "mcq_vq_pack_codebook_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

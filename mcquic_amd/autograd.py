@@ -142,28 +142,43 @@ class ResidualBlockFn(torch.autograd.Function):
         return dx, None, dw1, db1, dw2, db2, None
 
 
+def _rb_forward_multi(blocks, xs, sxs):
+    """Several ResidualBlocks of one shape side by side: each of the two layers is ONE launch for all of them."""
+    t1s = ops.conv2d_multi(sxs, [blk._branch[1].packed() for blk in blocks], dual_silu=True)
+    s1s = [ops.silu_twin(t) for t in t1s]
+    ys = ops.conv2d_multi(s1s, [blk._branch[3].packed() for blk in blocks], per_problem=[dict(res=x) for x in xs], dual_silu=True)
+    return ys, [ops.silu_twin(y) for y in ys], [(x, sx, t1, s1) for x, sx, t1, s1 in zip(xs, sxs, t1s, s1s)]
+
+
+def _rb_backward_multi(blocks, saveds, dys, pairs):
+    """Input gradients of several ResidualBlocks of one shape, two launches in all; operand pairs appended per block as
+    (conv1 pair, conv2 pair)."""
+    c1s, c2s = [blk._branch[1] for blk in blocks], [blk._branch[3] for blk in blocks]
+    d_t1s = ops.conv2d_multi(dys, [_dgrad_packed(c, c.weight) for c in c2s], per_problem=[dict(dsilu_mul=sv[2]) for sv in saveds])
+    dxs = ops.conv2d_multi(d_t1s, [_dgrad_packed(c, c.weight) for c in c1s],
+                           per_problem=[dict(dsilu_mul=sv[0], res=dy) for sv, dy in zip(saveds, dys)])
+    for sv, d_t1, dy in zip(saveds, d_t1s, dys):
+        pairs.append((sv[1], d_t1))
+        pairs.append((sv[3], dy))
+    return dxs
+
+
 class AttentionBlockFn(torch.autograd.Function):
-    """out = a * sigmoid(b) + x,  a = RB^3(x),  b = conv1x1(RB^3(x))   (mcquic/nn/blocks.py:245-288) as ONE autograd node:
-    the two stacks run on two streams in both directions (their 12-px-tile kernels do not fill the chip at the 16x16 ...
-    4x4 levels of a training step), every ResidualBlock is two fused launches each way, and the twelve 3x3 weight gradients
-    of the block leave in ONE grouped launch.  Parameter order: main RB 0..2 then side RB 0..2, each (w1, b1, w2, b2), then
-    the 1x1 conv's (w, b)."""
+    """out = a * sigmoid(b) + x,  a = RB^3(x),  b = conv1x1(RB^3(x))   (mcquic/nn/blocks.py:245-288) as ONE autograd node.
+    The two stacks apply the same layer shapes to different tensors: layer by layer they share a launch (mcq_conv2d_multi_f32),
+    in both directions -- on the 16x16 ... 4x4 maps of a training crop a launch is latency, not work --, every ResidualBlock
+    is two fused launches each way, and the twelve 3x3 weight gradients of the block leave in ONE grouped launch.
+    Parameter order: main RB 0..2 then side RB 0..2, each (w1, b1, w2, b2), then the 1x1 conv's (w, b)."""
 
     @staticmethod
     def forward(ctx, x, sx, *rest):
         block = rest[-1]
-        from .nn.blocks import _fork
         saved = []
-        with _fork(x) as f:
-            b, sb = x, sx
-            for i in range(3):
-                b, sb, keep = _rb_forward(block._sideBranch[i], b, sb)
-                saved.extend(keep)
-        a, sa = x, sx
+        a, sa, b, sb = x, sx, x, sx
         for i in range(3):
-            a, sa, keep = _rb_forward(block._mainBranch[i], a, sa)
-            saved.extend(keep)
-        b = f.join(b)
+            (a, b), (sa, sb), keep = _rb_forward_multi([block._mainBranch[i], block._sideBranch[i]], [a, b], [sa, sb])
+            saved.extend(keep[0])
+            saved.extend(keep[1])
         bb = ops.conv2d(b, block._sideBranch[3].packed())
         out = ops.gate(a, bb, x)
         ctx.save_for_backward(a, b, bb, *saved)
@@ -173,34 +188,25 @@ class AttentionBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         block = ctx.block
-        from .nn.blocks import _fork
         a, b, bb = ctx.saved_tensors[:3]
         saved = ctx.saved_tensors[3:]
-        side = [saved[4 * i: 4 * i + 4] for i in range(3)]
-        main = [saved[12 + 4 * i: 12 + 4 * i + 4] for i in range(3)]
+        main = [saved[8 * i: 8 * i + 4] for i in range(3)]
+        side = [saved[8 * i + 4: 8 * i + 8] for i in range(3)]
         dout = dout.contiguous()
-        da, dbb = ops.gate_bwd(a, bb, dout)
+        h, dbb = ops.gate_bwd(a, bb, dout)                       # d a, d (conv1x1 output)
         c11 = block._sideBranch[3]
-        pairs_side, pairs_main = [], []
-        with _fork(dout) as f:
-            g = ops.conv2d(dbb, _dgrad_packed(c11, c11.weight))
-            dw11, db11 = ops.conv2d_wgrad(b, dbb, 1, 1, want_bias=True)
-            for i in (2, 1, 0):
-                g = _rb_backward(block._sideBranch[i], side[i], g, pairs_side)
-        h = da
+        g = ops.conv2d(dbb, _dgrad_packed(c11, c11.weight))
+        dw11, db11 = ops.conv2d_wgrad(b, dbb, 1, 1, want_bias=True)
+        pairs = []                                               # appended RB 2, 1, 0; per RB: main (conv1, conv2), side (conv1, conv2)
         for i in (2, 1, 0):
-            h = _rb_backward(block._mainBranch[i], main[i], h, pairs_main)
-        g = f.join(g)
-        # the side stack's operand pairs (saved activations and gradients, all allocated on the side stream) are read by
-        # the grouped weight-gradient launch on THIS stream, and the 1x1 conv's gradients go on to autograd's consumers
-        f.hand_over(dw11, db11, *[t for pair in pairs_side for t in pair])
+            h, g = _rb_backward_multi([block._mainBranch[i], block._sideBranch[i]], [main[i], side[i]], [h, g], pairs)
         dx = ops.add(ops.add(h, g), dout)
-        grads = _wgrads(pairs_main[::-1] + pairs_side[::-1])      # RB-major: each RB contributed (conv1 pair, conv2 pair)
+        grads = _wgrads(pairs)
+        by_rb = {i: grads[4 * k: 4 * k + 4] for k, i in enumerate((2, 1, 0))}
         flat = []
-        # pairs were appended RB 2, 1, 0 with (conv1, conv2) inside each: reversed lists are conv2, conv1 of RB 0, 1, 2
-        for stack in (grads[:6], grads[6:]):
+        for stack in (0, 1):                                     # main RB 0..2, then side RB 0..2
             for i in range(3):
-                (dw2, db2), (dw1, db1) = stack[2 * i], stack[2 * i + 1]
+                (dw1, db1), (dw2, db2) = by_rb[i][2 * stack], by_rb[i][2 * stack + 1]
                 flat.extend([dw1, db1, dw2, db2])
         return (dx, None, *flat, dw11, db11, None)
 

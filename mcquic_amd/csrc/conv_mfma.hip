@@ -63,12 +63,25 @@
 #ifndef MCQ_HEAD16
 #define MCQ_HEAD16 1
 #endif
+#ifndef MCQ_CONV_MAX_MULTI
+#define MCQ_CONV_MAX_MULTI 4
+#endif
 
 namespace {
+
+// tensors of one convolution; a launch can carry up to MCQ_CONV_MAX_MULTI independent convolutions of ONE geometry and flag
+// set (blockIdx.z picks the problem): the two stacks of an AttentionBlock run the same layer shapes side by side, and on the
+// 16x16 ... 4x4 maps of a training crop (or at batch 1) a launch is latency, not work
+struct ConvPtrs {
+    const float* x; const float* wp; const float* wp64; const float* wp32; const float* bias; float* y; float* y2;
+    const float* res; const float* mul; const float* gid;
+};
 
 struct ConvK {
     const float* x; const float* wp; const float* wp64; const float* wp32; const float* bias; float* y; float* y2;
     const float* res; const float* mul; const float* gid;
+    ConvPtrs alt[MCQ_CONV_MAX_MULTI - 1];      // problems 1 .. nprob - 1
+    int nprob;
     int N, Cin, H, W, Cout, Ho, Wo;
     int ks, stride;
     int S;             // input-channel pairs (padded to a multiple of 16 for 1x1 convs)
@@ -138,6 +151,19 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     MCQ_STAMP(st0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // this workgroup's problem (scalar selects; one problem per launch is the common case)
+    const float* P_x = p.x; const float* P_wp = p.wp; const float* P_wp64 = p.wp64; const float* P_wp32 = p.wp32;
+    const float* P_bias = p.bias; float* P_y = p.y; float* P_y2 = p.y2;
+    const float* P_res = p.res; const float* P_mul = p.mul; const float* P_gid = p.gid;
+    if (p.nprob > 1) {
+#pragma unroll
+        for (int c = 1; c < MCQ_CONV_MAX_MULTI; ++c)
+            if ((int)blockIdx.z == c) {
+                const ConvPtrs& a = p.alt[c - 1];
+                P_x = a.x; P_wp = a.wp; P_wp64 = a.wp64; P_wp32 = a.wp32; P_bias = a.bias; P_y = a.y; P_y2 = a.y2;
+                P_res = a.res; P_mul = a.mul; P_gid = a.gid;
+            }
+    }
     const int KS = 1 << p.ks_log2;
     const int tile_in_wg = wave >> p.ks_log2;       // which output tile of this workgroup
     const int kslice = wave & (KS - 1);             // which slice of the k-steps
@@ -184,7 +210,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
         yo[nb] = by * BH + ly;
         xo[nb] = bx * BW + lx;
         valid[nb] = pbv && yo[nb] < p.Ho && xo[nb] < p.Wo;
-        xb[nb] = reinterpret_cast<const char*>(mcq_uniform_ptr(p.x + (size_t)n * p.Cin * HW));
+        xb[nb] = reinterpret_cast<const char*>(mcq_uniform_ptr(P_x + (size_t)n * p.Cin * HW));
         rsrc[nb] = mcq_make_rsrc(xb[nb], plane_bytes);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -213,9 +239,9 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     // four / two times the cache lines and made a 12x8-level launch 30 instead of 21 us)
     // -- as a wave-uniform base plus a constant per-lane offset, read through a buffer load whose running offset is
     // the scalar soffset (no per-lane pointer arithmetic in the k-loop)
-    const float* wbu = MB == 4 ? p.wp + ((size_t)tile128 * p.TP + (size_t)s0 * TAPS) * 256 + q0
-                     : MB == 2 ? p.wp64 + ((size_t)(co_base >> 6) * p.TP + (size_t)s0 * TAPS) * 128
-                               : p.wp32 + ((size_t)(co_base >> 5) * p.TP + (size_t)s0 * TAPS) * 64;
+    const float* wbu = MB == 4 ? P_wp + ((size_t)tile128 * p.TP + (size_t)s0 * TAPS) * 256 + q0
+                     : MB == 2 ? P_wp64 + ((size_t)(co_base >> 6) * p.TP + (size_t)s0 * TAPS) * 128
+                               : P_wp32 + ((size_t)(co_base >> 5) * p.TP + (size_t)s0 * TAPS) * 64;
     const __amdgpu_buffer_rsrc_t wr = mcq_make_rsrc(wbu, 0x7fffffffu);   // (the packed copies end in a zero tail: over-reads are in bounds)
     const unsigned wlane = (unsigned)lane * (unsigned)(4 * MB);
     unsigned wso = 0;
@@ -332,19 +358,19 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const size_t slab = (size_t)img[nb] * p.Cout * HoWo;
-            yr[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.y + slab), slab_bytes);
-            if (f & MCQ_CONV_DUAL_SILU) y2r[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.y2 + slab), slab_bytes);
-            if (f & MCQ_CONV_RESIDUAL) rr_[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.res + slab), slab_bytes);
+            yr[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_y + slab), slab_bytes);
+            if (f & MCQ_CONV_DUAL_SILU) y2r[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_y2 + slab), slab_bytes);
+            if (f & MCQ_CONV_RESIDUAL) rr_[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_res + slab), slab_bytes);
             if (f & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL | MCQ_CONV_DSILU_MUL))
-                mr[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.mul + slab), slab_bytes);
-            if (f & MCQ_CONV_GATE) gr[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.gid + slab), slab_bytes);
+                mr[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_mul + slab), slab_bytes);
+            if (f & MCQ_CONV_GATE) gr[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_gid + slab), slab_bytes);
             if (f & MCQ_CONV_SHUFFLE2)      // [Cout/4, 2 Ho, 2 Wo]: channel c = co / 4 -> rows of 2 Wo, this lane's 2x2 cell
                 pvo[nb] = valid[nb] ? ((unsigned)hi * 4u * HoWo + (unsigned)(2 * yo[nb]) * (unsigned)(2 * p.Wo) + (unsigned)(2 * xo[nb])) * 4u
                                     : MCQ_OOB;
             else
                 pvo[nb] = valid[nb] ? ((unsigned)(yo[nb] * p.Wo + xo[nb]) + 4u * (unsigned)hi * HoWo) * 4u : MCQ_OOB;
         }
-        const __amdgpu_buffer_rsrc_t br = mcq_make_rsrc(mcq_uniform_ptr(p.bias ? p.bias : p.wp), p.bias ? (unsigned)p.Cout * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t br = mcq_make_rsrc(mcq_uniform_ptr(P_bias ? P_bias : P_wp), P_bias ? (unsigned)p.Cout * 4u : 0u);
 
 #pragma unroll
         for (int mi = 0; mi < MC; ++mi) {
@@ -609,7 +635,7 @@ int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2
     k.tiles_log2 = ksplit_log2 >= 2 ? 0 : 2 - ksplit_log2;           // 4 waves per workgroup, 8 for 8-way split
     const int waves = 1 << (k.ks_log2 + k.tiles_log2);
     const size_t lds = ksplit_log2 ? (size_t)waves * NB * 1024 * sizeof(float) : 0;
-    const dim3 grid((unsigned)((tiles + (1 << k.tiles_log2) - 1) >> k.tiles_log2), (unsigned)co_tiles);
+    const dim3 grid((unsigned)((tiles + (1 << k.tiles_log2) - 1) >> k.tiles_log2), (unsigned)co_tiles, (unsigned)k.nprob);
     const dim3 block(64 * waves);
     if (k.ks == 3) {
         if (pro == PRO_SILU) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF3A, PF3B, 9, OCC>), grid, block, lds, s, k);
@@ -677,7 +703,9 @@ extern "C" int mcq_nonneg_reparam_f32(const float* p, float bound, float pedesta
     return mcq_check_launch();
 }
 
-extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
+namespace {
+
+int conv_validate(const mcq_conv_desc* d) {
     if (!d || !d->x || !d->w_packed || !d->y) return MCQ_EINVAL;
     if (d->N <= 0 || d->Cin <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return MCQ_EINVAL;
     if ((d->ksize != 1 && d->ksize != 3) || (d->stride != 1 && d->stride != 2)) return MCQ_EINVAL;
@@ -693,7 +721,12 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     // one image's input slab plus the prefetch rings' over-read (up to 8 channels) must stay below 2 GiB: byte offsets and
     // the descriptors' shrinking num_records are 32-bit (signed in the scalar arithmetic of the k-loop)
     if ((uint64_t)(d->Cin + 8) * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
+    return MCQ_OK;
+}
 
+int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
+    const mcq_conv_desc* d = descs;
+    const unsigned fl = d->flags;
     ConvK k;
     k.x = d->x; k.wp = d->w_packed;
     k.wp64 = k.wp + section_floats(d->Cout, d->Cin, d->ksize, 4);
@@ -707,9 +740,18 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     k.S = pairs_padded(d->Cin, d->ksize);
     k.TP = steps_padded(d->Cin, d->ksize);
     k.flags = fl; k.res_scale = d->res_scale;
+    k.nprob = nprob;
+    for (int c = 1; c < MCQ_CONV_MAX_MULTI; ++c) {
+        const mcq_conv_desc* e = descs + (c < nprob ? c : 0);
+        ConvPtrs& a = k.alt[c - 1];
+        a.x = e->x; a.wp = e->w_packed;
+        a.wp64 = a.wp + section_floats(d->Cout, d->Cin, d->ksize, 4);
+        a.wp32 = a.wp64 + section_floats(d->Cout, d->Cin, d->ksize, 2);
+        a.bias = e->bias; a.y = e->y; a.y2 = e->y_silu; a.res = e->res; a.mul = e->mul; a.gid = e->gate_id;
+    }
 
     // <= 16 output channels, 3x3, stride 1, nothing but bias / PixelShuffle in the epilogue: the 16-row MFMA kernel
-    if (MCQ_HEAD16 && head16_shape(d->Cout, d->ksize) && d->stride == 1 && (d->tile & 0xff) == 0 &&
+    if (MCQ_HEAD16 && nprob == 1 && head16_shape(d->Cout, d->ksize) && d->stride == 1 && (d->tile & 0xff) == 0 &&
         (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN)) == 0) {
         if ((uint64_t)d->Cout * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
         Head16K h;
@@ -753,7 +795,7 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     else if (co32 == 1) {
         // <= 32 output channels (the 12-channel head, the tiny fixture models): one weight load feeds NB MFMAs, so the
         // widest pixel tile that still leaves >= 2048 waves amortises it best (head conv 2.34 -> 2.05 ms with NB = 4)
-        MB = 1; NB = (MCQ_TILE_14 && tb >= 4 * 2048) ? 4 : 2;
+        MB = 1; NB = (MCQ_TILE_14 && tb * nprob >= 4 * 2048) ? 4 : 2;
     }
     else {
         // (the 128 x 32 tile <4, 1> is instantiated and reachable through `tile`; an automatic rule preferring it on
@@ -763,11 +805,11 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
         for (int c = 0; c < 3; ++c) {
             const int mb = cand[c][0], nb = cand[c][1];
             if (mb > co32) continue;
-            const long long tiles = ((tb + nb - 1) / nb) * ((co32 + mb - 1) / mb);
+            const long long tiles = ((tb + nb - 1) / nb) * ((co32 + mb - 1) / mb);      // (per problem: the tile a single launch takes)
             MB = mb; NB = nb;
             if (tiles * 8 >= 1024) break;          // even an 8-way split would leave SIMDs idle: try a smaller tile
         }
-        const long long tiles = ((tb + NB - 1) / NB) * ((co32 + MB - 1) / MB);
+        const long long tiles = ((tb + NB - 1) / NB) * ((co32 + MB - 1) / MB) * nprob;      // all problems of the launch
         while (ksl < 3 && (tiles << ksl) < 2048) ++ksl;
         // an 8-way split of the 128 x 64 tile runs as a 4-way split of the 128 x 32 tile instead: the same number of
         // waves, half the LDS reduction depth, 3 waves / SIMD resident (8 x 128 x 32 x 32 layer: 50 -> 28 us)
@@ -793,6 +835,28 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
     if (MB == 1 && NB == 2) return launch_tile<1, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 1 && NB == 1) return launch_tile<1, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
     return MCQ_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
+    const int rc = conv_validate(d);
+    return rc != MCQ_OK ? rc : conv_launch(d, 1, stream);
+}
+
+extern "C" int32_t mcq_conv2d_max_multi(void) { return MCQ_CONV_MAX_MULTI; }
+
+extern "C" int mcq_conv2d_multi_f32(const mcq_conv_desc* descs, int32_t n, void* stream) {
+    if (!descs || n < 1 || n > MCQ_CONV_MAX_MULTI) return MCQ_EINVAL;
+    for (int c = 0; c < n; ++c) {
+        const int rc = conv_validate(descs + c);
+        if (rc != MCQ_OK) return rc;
+        const mcq_conv_desc &a = descs[0], &b = descs[c];
+        if (a.N != b.N || a.Cin != b.Cin || a.H != b.H || a.W != b.W || a.Cout != b.Cout || a.ksize != b.ksize || a.stride != b.stride ||
+            a.flags != b.flags || a.res_scale != b.res_scale || a.tile != b.tile || (a.bias == nullptr) != (b.bias == nullptr))
+            return MCQ_EINVAL;                       // one geometry, one flag set, bias on all or none
+    }
+    return conv_launch(descs, n, stream);
 }
 
 #if MCQ_STAMPS

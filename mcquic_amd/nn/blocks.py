@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from .. import autograd as AG
+from .. import ops
 from .convs import conv1x1, conv3x3, pixelShuffle3x3
 from .gdn import GenDivNorm, InvGenDivNorm
 
@@ -32,7 +33,9 @@ __all__ = ["ResidualBlockWithStride", "ResidualBlockShuffle", "ResidualBlock", "
 # branch's workgroups, and the launch-latency-bound small levels run two kernels at once.  MCQUIC_AMD_BRANCH_STREAMS=0
 # turns it off (single stream, same results).
 _BRANCH_STREAMS = os.environ.get("MCQUIC_AMD_BRANCH_STREAMS", "1") != "0"
+_LEVEL_STREAMS = os.environ.get("MCQUIC_AMD_LEVEL_STREAMS", "1") != "0"      # lane 1: the level-granular forks of the training graph
 _side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
+_MULTI_MAX_PIXELS = int(os.environ.get("MCQUIC_AMD_MULTI_MAX_PIXELS", str(64 * 1024)))   # N * H * W up to which AttentionBlock stacks share launches
 
 
 def _side_stream(main: "torch.cuda.Stream", lane: int = 0) -> "torch.cuda.Stream":
@@ -50,7 +53,7 @@ class _fork:
     main stream wait for it and hands tensor `t` (allocated on the side stream) over to the main stream."""
 
     def __init__(self, x: torch.Tensor, lane: int = 0):
-        self.on = _BRANCH_STREAMS and x.is_cuda
+        self.on = _BRANCH_STREAMS and x.is_cuda and (lane == 0 or _LEVEL_STREAMS)
         if self.on:
             self.main = torch.cuda.current_stream(x.device)
             self.side = _side_stream(self.main, lane)
@@ -160,6 +163,17 @@ class AttentionBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
             return AG.attention_block(x, self)
+        if ops._MULTI and x.shape[0] * x.shape[2] * x.shape[3] <= _MULTI_MAX_PIXELS:
+            # the two stacks apply the same layer shapes to different tensors: layer by layer they share a launch
+            # (mcq_conv2d_multi_f32) -- twice the workgroups per launch, half the launches.  Measured on one MI355X: batch 1
+            # with hipGraphs 7.40 -> 7.09 ms per encode+decode; at batch 32 the big maps do better with the stacks on two
+            # streams (257.1 vs 255.7 images/s), so maps above _MULTI_MAX_PIXELS keep the fork below
+            a = b = x
+            for i in range(3):
+                m, sd = self._mainBranch[i]._branch, self._sideBranch[i]._branch
+                ta, tb = ops.conv2d_multi([a, b], [m[1].packed(), sd[1].packed()], silu_in=True, silu_out=True)
+                a, b = ops.conv2d_multi([ta, tb], [m[3].packed(), sd[3].packed()], per_problem=[dict(res=a), dict(res=b)], dual_silu=True)
+            return self._sideBranch[3](b, gate_mul=a, gate_id=x, dual_silu=True)
         with _fork(x) as f:
             b = x
             for i in range(3):

@@ -143,13 +143,13 @@ class PackedConv:
         return self
 
 
-def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = False, square_in: bool = False,
-           silu_out: bool = False, res: Optional[torch.Tensor] = None, res_scale: float = 1.0,
-           gdn_mul: Optional[torch.Tensor] = None, igdn_mul: Optional[torch.Tensor] = None,
-           gate_mul: Optional[torch.Tensor] = None, gate_id: Optional[torch.Tensor] = None,
-           mul: Optional[torch.Tensor] = None, dsilu_mul: Optional[torch.Tensor] = None, shuffle2: bool = False,
-           dual_silu: bool = False, tile: int = 0) -> torch.Tensor:
-    """y = epilogue(conv(prologue(x)) + bias); one kernel launch (mcq_conv2d_f32)."""
+def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = False, square_in: bool = False,
+               silu_out: bool = False, res: Optional[torch.Tensor] = None, res_scale: float = 1.0,
+               gdn_mul: Optional[torch.Tensor] = None, igdn_mul: Optional[torch.Tensor] = None,
+               gate_mul: Optional[torch.Tensor] = None, gate_id: Optional[torch.Tensor] = None,
+               mul: Optional[torch.Tensor] = None, dsilu_mul: Optional[torch.Tensor] = None, shuffle2: bool = False,
+               dual_silu: bool = False, tile: int = 0):
+    """(mcq_conv_desc, y, y_silu or None, tensors the descriptor points at) for one fused conv launch."""
     if silu_in:
         twin = silu_twin(x)
         if twin is not None:
@@ -196,12 +196,44 @@ def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = F
             raise ValueError("gate identity shape mismatch")
     d = ConvDesc(_ptr(x), _ptr(w.wp), _ptr(w.bias), _ptr(y), _ptr(y2), _ptr(res), _ptr(mul), _ptr(gate_id),
                  n, cin, h, wd, w.cout, w.ksize, stride, flags, float(res_scale), tile)
-    lib = _lib.load()
-    with _guard(x.device):
-        check(lib.mcq_conv2d_f32(ctypes.byref(d), _stream()), "mcq_conv2d_f32")
+    return d, y, y2, (x, res, mul, gate_id)
+
+
+def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, **fused) -> torch.Tensor:
+    """y = epilogue(conv(prologue(x)) + bias); one kernel launch (mcq_conv2d_f32).  Options: silu_in, square_in, silu_out,
+    res (+ res_scale), gdn_mul / igdn_mul / gate_mul (+ gate_id) / mul / dsilu_mul, shuffle2, dual_silu, tile."""
+    d, y, y2, keep = _conv_desc(x, w, stride, **fused)
+    with _guard(y.device):
+        check(_lib.load().mcq_conv2d_f32(ctypes.byref(d), _stream()), "mcq_conv2d_f32")
     if y2 is not None:
         set_silu_twin(y, y2)
     return y
+
+
+_MULTI = os.environ.get("MCQUIC_AMD_MULTI_CONV", "1") != "0"      # A/B switch: 0 = one launch per convolution
+
+
+def conv2d_multi(xs, ws, stride: int = 1, per_problem=None, **shared):
+    """Independent convolutions of ONE geometry and flag set in one launch (mcq_conv2d_multi_f32): xs[i] through ws[i] with
+    the options of `shared` plus per_problem[i] (tensor-valued options such as res= / dsilu_mul=).  Returns [y_i]."""
+    n = len(xs)
+    per_problem = per_problem or [{}] * n
+    lib = _lib.load()
+    if n == 1 or not _MULTI:
+        return [conv2d(x, w, stride, **shared, **pp) for x, w, pp in zip(xs, ws, per_problem)]
+    cap = lib.mcq_conv2d_max_multi()
+    out = []
+    for lo in range(0, n, cap):
+        built = [_conv_desc(x, w, stride, **shared, **pp) for x, w, pp in zip(xs[lo:lo + cap], ws[lo:lo + cap], per_problem[lo:lo + cap])]
+        k = len(built)
+        table = (ConvDesc * k)(*[b[0] for b in built])
+        with _guard(built[0][1].device):
+            check(lib.mcq_conv2d_multi_f32(table, k, _stream()), "mcq_conv2d_multi_f32")
+        for _, y, y2, _keep in built:
+            if y2 is not None:
+                set_silu_twin(y, y2)
+            out.append(y)
+    return out
 
 
 def nonneg_reparam(p: torch.Tensor, bound: float, pedestal: float) -> torch.Tensor:

@@ -8,7 +8,7 @@ import os as _os
 # initialises, so this must run before the first device call -- import mcquic_amd (or set the variable) first.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-from .modules.compressor import BaseCompressor, Compressor  # noqa: E402
+from .modules.compressor import BaseCompressor, Compressor, Neon  # noqa: E402
 
-__all__ = ["BaseCompressor", "Compressor"]
+__all__ = ["BaseCompressor", "Compressor", "Neon"]
 __version__ = "0.1.0"

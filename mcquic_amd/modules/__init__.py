@@ -1,3 +1,3 @@
-from .compressor import BaseCompressor, Compressor
+from .compressor import BaseCompressor, Compressor, Neon
 
-__all__ = ["BaseCompressor", "Compressor"]
+__all__ = ["BaseCompressor", "Compressor", "Neon"]

@@ -20,7 +20,7 @@ from torch import nn
 
 from ..nn import AttentionBlock, ResidualBlock, ResidualBlockShuffle, ResidualBlockWithStride, conv3x3, pixelShuffle3x3
 from ..utils.specification import FileHeader, ImageSize
-from .quantizer import BaseQuantizer, UMGMQuantizer
+from .quantizer import BaseQuantizer, ResidualBackwardQuantizer, UMGMQuantizer
 
 from ..utils.specification import VERSION as __version__   # the reference snapshot's mcquic.__version__ (FileHeader)
 
@@ -252,3 +252,64 @@ class Compressor(BaseCompressor):
                 AttentionBlock(channel), conv3x3(channel, channel), ResidualBlock(channel, channel)),
         })
         super().__init__(encoder, quantizer, decoder)
+
+
+
+class Neon(BaseCompressor):
+    """The stage-1 model of the reference's generative branch (mcquic/modules/compressor.py:181-241; what the snapshot's
+    trainer builds, mcquic/train/ddp.py:79-83): a 3x-strided encoder / decoder around a `ResidualBackwardQuantizer`.
+    Same constructor, module tree and state_dict keys; `checkpoint_wrapper` (fairscale activation checkpointing, a
+    training-memory measure) is not applied.  `groups` / `denseNorm`: see nn/blocks.py (`denseNorm=False` only)."""
+
+    def __init__(self, channel: int, k: int, size: List[int], denseNorm: bool = False, *_, **__):
+        quantizer = ResidualBackwardQuantizer(k, size, denseNorm)
+        q = quantizer.channel
+        encoder = nn.Sequential(
+            conv3x3(3, channel),
+            AttentionBlock(channel, 32, denseNorm),
+            ResidualBlock(channel, channel, 32, denseNorm),
+            ResidualBlock(channel, channel, 32, denseNorm),
+            ResidualBlockWithStride(channel, channel, 2, 32, denseNorm),
+            ResidualBlock(channel, channel, 32, denseNorm),
+            ResidualBlockWithStride(channel, channel, 2, 32, denseNorm),
+            ResidualBlock(channel, channel, 32, denseNorm),
+            ResidualBlockWithStride(channel, channel, 2, 32, denseNorm),
+            AttentionBlock(channel, 32, denseNorm),
+            ResidualBlock(channel, 2 * channel, 32, denseNorm),
+            ResidualBlock(2 * channel, 2 * channel, 32, denseNorm),
+            ResidualBlock(2 * channel, 2 * channel, 32, denseNorm),
+            ResidualBlock(2 * channel, 2 * channel, 32, denseNorm),
+            ResidualBlock(2 * channel, q, 1, denseNorm),
+            AttentionBlock(q, 1, denseNorm))
+        decoder = nn.Sequential(
+            AttentionBlock(q, 1, denseNorm),
+            ResidualBlock(q, 2 * channel, 1, denseNorm),
+            ResidualBlock(2 * channel, 2 * channel, 32, denseNorm),
+            ResidualBlock(2 * channel, 2 * channel, 32, denseNorm),
+            ResidualBlock(2 * channel, 2 * channel, 32, denseNorm),
+            ResidualBlock(2 * channel, channel, 32, denseNorm),
+            AttentionBlock(channel, 32, denseNorm),
+            ResidualBlock(channel, channel, 32, denseNorm),
+            ResidualBlockShuffle(channel, channel, 2, 32, denseNorm),
+            ResidualBlock(channel, channel, 32, denseNorm),
+            ResidualBlockShuffle(channel, channel, 2, 32, denseNorm),
+            ResidualBlock(channel, channel, 32, denseNorm),
+            ResidualBlockShuffle(channel, channel, 2, 32, denseNorm),
+            ResidualBlock(channel, channel, 32, denseNorm),
+            ResidualBlock(channel, channel, 32, denseNorm),
+            AttentionBlock(channel, 32, denseNorm),
+            conv3x3(channel, 3))
+        super().__init__(encoder, quantizer, decoder)
+
+    def _encode_latent(self, x: torch.Tensor, pad: bool = True) -> torch.Tensor:
+        return self._encoder(self._padding(x) if pad else x)
+
+    def residual_backward(self, code: torch.Tensor, level: int) -> torch.Tensor:
+        """[n, c, 2h, 2w] <- ([n, m, h, w], level)  (compressor.py:233-235)."""
+        with torch.no_grad():
+            return self._quantizer.residual_backward(code, level)
+
+    def residual_forward(self, code: torch.Tensor, formerLevel, level: int) -> torch.Tensor:
+        """compressor.py:237-239."""
+        with torch.no_grad():
+            return self._quantizer.residual_forward(code, formerLevel, level)

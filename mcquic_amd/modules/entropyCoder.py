@@ -256,3 +256,92 @@ class EntropyCoder(nn.Module):
             sym = ransDecodeBatchWithIndexes([binary[lv] for binary in binaries], idx, table)
             out.append(torch.from_numpy(sym.reshape(len(binaries), self._m, h, w).astype(np.int64)).to(device))
         return out
+
+
+
+class VariousMCoder(nn.Module):
+    """Code-frequency statistics + byte streams for quantizers whose group count differs per level (reference:
+    mcquic/modules/entropyCoder.py:295-425, the coder `Neon` / `ResidualBackwardQuantizer` use).  Like the reference's
+    live implementation the byte streams are the RAW int64 codes (`codePerImage.cpu().numpy().tobytes()`, :372; rANS is not
+    applied there), so files written by either side read back on the other; `_freqEMA.{l}` [m_l, k_l], EMA 0.998."""
+
+    def __init__(self, m: List[int], k: List[int], ema: float = 0.998):
+        super().__init__()
+        self._freqEMA = nn.ParameterList(nn.Parameter(torch.ones(mi, ki) / ki, requires_grad=False) for mi, ki in zip(m, k))
+        self._k, self._m, self._ema = k, m, ema
+        self._cdfs = None
+        self._normalizedFreq = None
+
+    @torch.no_grad()
+    def forward(self, codes: List[torch.Tensor]):
+        """EMA update (:306-323) from integer codes (level l: [n, m_l, h, w]); one fused all-reduce for all levels."""
+        from ..parallel import code_histograms
+        for lv, totalCount in enumerate(code_histograms(codes, self._k)):
+            totalCount = totalCount.to(self._freqEMA[lv].dtype)
+            normalized = totalCount / totalCount.sum(-1, keepdim=True)
+            self._freqEMA[lv].copy_((1 - self._ema) * normalized + self._ema * self._freqEMA[lv])
+        self.resetFreqAndCDF()
+
+    def resetFreqAndCDF(self):
+        self._normalizedFreq = None
+        self._cdfs = None
+
+    def updateFreqAndCDF(self):
+        freq = [(f / f.sum(-1, keepdim=True)).detach().clone() for f in self._freqEMA]
+        self._cdfs = [[pmfToQuantizedCDF(frAtM.tolist(), 16) for frAtM in fr.cpu()] for fr in freq]
+        self._normalizedFreq = freq
+
+    @property
+    def CDFs(self) -> List[List[List[int]]]:
+        if self._cdfs is None or self._normalizedFreq is None:
+            self.updateFreqAndCDF()
+        return self._cdfs
+
+    @property
+    def NormalizedFreq(self) -> List[torch.Tensor]:
+        if self._cdfs is None or self._normalizedFreq is None:
+            self.updateFreqAndCDF()
+        return self._normalizedFreq
+
+    def _checkShape(self, codes: List[torch.Tensor]) -> int:
+        """:348-361 (`m` may differ between levels here)."""
+        info = ("Please give codes with correct shape, for example, [[1, 2, 24, 24], [1, 2, 12, 12], ...], which is a "
+                "`level` length list. each code has shape [n, m, h, w]. ")
+        if len(codes) < 1:
+            raise RuntimeError("Length of codes is 0.")
+        n = codes[0].shape[0]
+        for code in codes:
+            if n < 1:
+                raise RuntimeError(info + "Now `n` = 0.")
+            if n != code.shape[0]:
+                raise RuntimeError(info + "Now `n` is inconsisitent.")
+        return n
+
+    @torch.inference_mode()
+    def compress(self, codes: List[torch.Tensor]) -> Tuple[List[List[bytes]], List[CodeSize]]:
+        n = self._checkShape(codes)
+        compressed: List[List[bytes]] = [[] for _ in range(n)]
+        heights, widths = [], []
+        for code in codes:
+            heights.append(code.shape[2])
+            widths.append(code.shape[3])
+            host = code.detach().to("cpu", torch.int64).contiguous().numpy()      # one D2H copy per level
+            for i in range(n):
+                compressed[i].append(host[i].tobytes())
+        return compressed, [CodeSize(list(self._m), heights, widths, list(self._k)) for _ in range(n)]
+
+    @torch.inference_mode()
+    def decompress(self, binaries: List[List[bytes]], codeSizes: List[CodeSize]) -> List[torch.Tensor]:
+        if len(binaries) < 1 or len(binaries) != len(codeSizes):
+            raise RuntimeError("`binaries` and `codeSizes` must be non-empty and of equal length.")
+        levels = len(binaries[0])
+        out = [[] for _ in range(levels)]
+        for binary, codeSize in zip(binaries, codeSizes):
+            if len(binary) != levels or len(codeSize.heights) != levels or len(codeSize.m) != levels:
+                raise RuntimeError("Every image must carry one stream per level.")
+            for lv, (b, mi, h, w) in enumerate(zip(binary, codeSize.m, codeSize.heights, codeSize.widths)):
+                if mi < 1 or h < 1 or w < 1 or len(b) != 8 * mi * h * w:
+                    raise RuntimeError("A stream's length does not match its header's code size.")
+                out[lv].append(torch.from_numpy(np.frombuffer(b, dtype=np.int64).copy()).reshape(mi, h, w))
+        device = self._freqEMA[0].device
+        return [torch.stack(c, 0).to(device) for c in out]

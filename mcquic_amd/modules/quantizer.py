@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .entropyCoder import EntropyCoder
+from .entropyCoder import EntropyCoder, VariousMCoder
 
 EPS = 1e-6
 
@@ -49,11 +49,13 @@ class _multiCodebookQuantization(nn.Module):
     """reference: quantizer.py:99-239.  Parameters: `_codebook` [m, k, d] (shared), `_temperature` [m, 1, 1, 1],
     buffer `_bound.bound`."""
 
-    def __init__(self, codebook: nn.Parameter, cache: _CodebookCache):
+    def __init__(self, codebook: nn.Parameter, cache: _CodebookCache, freqEMA: Optional[nn.Parameter] = None):
         super().__init__()
         self._m, self._k, self._d = codebook.shape
         self._codebook = codebook
         self._temperature = nn.Parameter(torch.ones((self._m, 1, 1, 1)))
+        if freqEMA is not None:        # ResidualBackwardQuantizer hands the level's EMA over (quantizer.py:607): a shared
+            self._freqEMA = freqEMA    # Parameter, visible in the state_dict under this module as well (`_freqEMA`)
         self._bound = LowerBound(EPS)
         self._cache = [cache]          # list: keep the cache out of nn.Module's attribute registration
 
@@ -363,3 +365,146 @@ class UMGMQuantizer(BaseQuantizer):
         dist.barrier()
         for encoder in self._encoders:
             encoder.syncCodebook()
+
+
+
+class VariousMQuantizer(BaseQuantizer):
+    """reference: quantizer.py:88-93 (group count per level, statistics in a VariousMCoder)."""
+
+    def __init__(self, m: List[int], k: List[int]):
+        nn.Module.__init__(self)
+        self._entropyCoder = VariousMCoder(m, k)
+        self._m = m
+        self._k = k
+
+
+class ResidualBackwardQuantizer(VariousMQuantizer):
+    """The quantizer of `Neon` (reference: quantizer.py:577-765): ONE codebook [1, k, 8] shared by all levels; every level has
+    a latent-stage encoder (down), a `backward` stack and a `restoreHead` (both up); codes are produced from the SMALLEST
+    level up, each level quantizing what the coarser levels' `backward` stacks did not explain, and come out small -> large.
+    Same module tree / state_dict keys as the reference (`_encoders`, `_decoders`, `_backwards`, `_quantizers`,
+    `_dequantizers`); the layers are the HIP-backed ones of mcquic_amd.nn."""
+
+    def __init__(self, k: int, size: List[int], denseNorm: bool = False):
+        from ..nn import AttentionBlock, ResidualBlock, ResidualBlockShuffle, ResidualBlockWithStride, conv1x1
+        channel = 8
+        self.channel = channel
+        super().__init__([1] * len(size), [k] * len(size))
+        codebook = nn.Parameter(nn.init.trunc_normal_(torch.empty(1, k, channel), std=math.sqrt(2 / (5 * channel))))
+        cache = _CodebookCache()
+        encoders, backwards, decoders, quantizers, dequantizers = [], [], [], [], []
+        lastSize = size[0] * 2
+        for i, thisSize in enumerate(size):
+            if thisSize == lastSize // 2:
+                down = lambda: ResidualBlockWithStride(channel * 4, channel * 4, 2, 1, denseNorm)       # noqa: E731
+                up = lambda: ResidualBlockShuffle(channel * 4, channel * 4, 2, 1, denseNorm)            # noqa: E731
+            elif thisSize == lastSize:
+                down = up = lambda: ResidualBlock(channel * 4, channel * 4, 1, denseNorm)               # noqa: E731
+            else:
+                raise ValueError("The given size sequence does not half or equal to from left to right.")
+            lastSize = thisSize
+
+            def upStack():
+                return nn.Sequential(conv1x1(channel, channel * 4, bias=False), up(), AttentionBlock(channel * 4, 1, denseNorm),
+                                     ResidualBlock(channel * 4, channel, 1, denseNorm))
+            encoders.append(nn.Sequential(ResidualBlock(channel, channel * 4, 1, denseNorm), AttentionBlock(channel * 4, 1, denseNorm),
+                                          down(), conv1x1(channel * 4, channel, bias=False)))
+            backwards.append(upStack() if i < len(size) - 1 else nn.Identity())
+            decoders.append(upStack())
+            # NOTE (reference): quantizers run large -> small, `_freqEMA` is stored small -> large
+            quantizers.append(_multiCodebookQuantization(codebook, cache, self._entropyCoder._freqEMA[-(i + 1)]))
+            dequantizers.append(_multiCodebookDeQuantization(codebook, cache))
+        self._encoders = nn.ModuleList(encoders)
+        self._decoders = nn.ModuleList(decoders)
+        self._backwards = nn.ModuleList(backwards)
+        self._quantizers = nn.ModuleList(quantizers)
+        self._dequantizers = nn.ModuleList(dequantizers)
+
+    @property
+    def Codebooks(self):
+        return list(quantizer._codebook for quantizer in self._quantizers)
+
+    def _latents(self, x: torch.Tensor) -> List[torch.Tensor]:
+        latents = []
+        for encoder in self._encoders:
+            x = encoder(x)
+            latents.append(x)
+        return latents
+
+    def encode(self, x: torch.Tensor) -> List[torch.Tensor]:
+        """quantizer.py:676-694."""
+        latents = self._latents(x)
+        codes, current = [], None
+        for quantizer, dequantizer, backward, latent in zip(self._quantizers[::-1], self._dequantizers[::-1], self._backwards[::-1],
+                                                            latents[::-1]):
+            residual = latent if current is None else ops.axpby(latent, current, 1.0, -1.0)      # (latent - 0 is latent, bit for bit)
+            code = quantizer.encode(residual)
+            codes.append(code)
+            current = backward(dequantizer.decode(code))
+        return codes
+
+    def decode(self, codes: List[torch.Tensor]) -> Optional[torch.Tensor]:
+        """quantizer.py:696-704."""
+        if len(codes) != len(self._decoders):
+            raise RuntimeError(f"expected {len(self._decoders)} code levels, got {len(codes)}")
+        self._entropyCoder._checkShape(codes)
+        formerLevel = None
+        for decoder, dequantizer, code in zip(self._decoders[::-1], self._dequantizers[::-1], codes):
+            quantized = dequantizer.decode(code)
+            formerLevel = decoder(quantized if formerLevel is None else ops.add(quantized, formerLevel))
+        return formerLevel
+
+    def residual_backward(self, code: torch.Tensor, level: int) -> torch.Tensor:
+        """quantizer.py:671-674."""
+        return self._backwards[-level](self._dequantizers[-level].decode(code))
+
+    def residual_forward(self, code: torch.Tensor, formerLevel: Optional[torch.Tensor], level: int) -> torch.Tensor:
+        """quantizer.py:706-713."""
+        if formerLevel is None and level > 0:
+            raise RuntimeError("For reconstruction after level-0, you should provide not None formerLevel as input.")
+        if formerLevel is not None and level == 0:
+            raise RuntimeError("For reconstruction at level-0, you should provide None formerLevel as input.")
+        decoder, dequantizer = self._decoders[-(level + 1)], self._dequantizers[-(level + 1)]
+        quantized = dequantizer.decode(code)
+        return decoder(ops.add(quantized, formerLevel)) if formerLevel is not None else decoder(quantized)
+
+    def reAssignCodebook(self) -> torch.Tensor:
+        """quantizer.py:715-721."""
+        reassigned = [quantizer.reAssignCodebook(freq) for quantizer, freq in zip(self._quantizers, self.NormalizedFreq)]
+        return torch.cat(reassigned).float().mean()
+
+    def syncCodebook(self):
+        """quantizer.py:723-726."""
+        import torch.distributed as dist
+        dist.barrier()
+        for quantizer in self._quantizers:
+            quantizer.syncCodebook()
+
+    def forward(self, x: torch.Tensor, uniforms=None):
+        """Training-mode forward (quantizer.py:727-765): (yHat, codes, logits), codes / logits small -> large;
+        `uniforms[j]` = (u_drop, u_gumbel) of the j-th quantization (smallest level first)."""
+        from .. import autograd as AG
+        grad = torch.is_grad_enabled()
+        latents = self._latents(x)
+        quantizeds, codes, logits = [], [], []
+        current = None
+        for j, (quantizer, dequantizer, backward, latent) in enumerate(zip(self._quantizers[::-1], self._dequantizers[::-1],
+                                                                           self._backwards[::-1], latents[::-1])):
+            if current is None:
+                residual = latent
+            else:
+                residual = AG.sub(latent, current) if grad else ops.axpby(latent, current, 1.0, -1.0)
+            sample, code, logit = quantizer(residual, quantizer._freqEMA, None if uniforms is None else uniforms[j])
+            quantized = dequantizer(sample)
+            quantizeds.append(quantized)
+            codes.append(code)
+            logits.append(logit)
+            current = backward(quantized)
+        formerLevel = None
+        for decoder, quantized in zip(self._decoders[::-1], quantizeds):
+            if formerLevel is None:
+                formerLevel = decoder(quantized)                                  # (0 + quantized is quantized, bit for bit)
+            else:
+                formerLevel = decoder(AG.add(formerLevel, quantized) if grad else ops.add(formerLevel, quantized))
+        self._entropyCoder(codes)
+        return formerLevel, codes, logits

@@ -96,27 +96,40 @@ class _residulBlock(nn.Module):
         self._skip = skip
 
 
+def _no_dense_norm(denseNorm: bool):
+    # In this snapshot of the reference the `groups` argument of the blocks only sets the group count of the GroupNorm that
+    # `denseNorm=True` puts in place of the second activation (mcquic/nn/blocks.py:179-200: conv3x3 is called without it):
+    # with denseNorm=False -- the default everywhere, Neon included -- every convolution is dense and `groups` is unused.
+    if denseNorm:
+        raise NotImplementedError("denseNorm=True (GroupNorm in place of the second activation) is not built")
+
+
 class ResidualBlock(_residulBlock):
-    """SiLU, conv3, SiLU, conv3, + x."""
+    """SiLU, conv3, SiLU, conv3, + x; with different widths the skip is a 1x1 conv (mcquic/nn/blocks.py:179-182)."""
 
     def __init__(self, inChannels: int, outChannels: int, groups: int = 1, denseNorm: bool = False):
-        if inChannels != outChannels or groups != 1 or denseNorm:
-            raise NotImplementedError("Compressor only uses ResidualBlock(c, c, groups=1, denseNorm=False)")
-        super().__init__(nn.SiLU(), conv3x3(inChannels, outChannels), nn.SiLU(), conv3x3(outChannels, outChannels), None)
+        _no_dense_norm(denseNorm)
+        super().__init__(nn.SiLU(), conv3x3(inChannels, outChannels), nn.SiLU(), conv3x3(outChannels, outChannels),
+                         conv1x1(inChannels, outChannels) if inChannels != outChannels else None)
 
     def forward(self, x: torch.Tensor, res2: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if self.training and torch.is_grad_enabled():             # training graph: two fused launches each way
-            return AG.residual_block(x, self)
+        if self.training and torch.is_grad_enabled():
+            if self._skip is None:                                # training graph: two fused launches each way
+                return AG.residual_block(x, self)
+            t = self._branch[1](AG.silu(x))                       # (width-changing blocks: op-by-op autograd)
+            return self._branch[3](AG.silu(t), res=self._skip(x))
         t = self._branch[1](x, silu_in=True, silu_out=True)      # silu(conv1(silu(x)))
-        return self._branch[3](t, res=x, dual_silu=True)          # conv2(.) + x
+        identity = x if self._skip is None else self._skip(x)
+        return self._branch[3](t, res=identity, dual_silu=True)   # conv2(.) + identity
 
 
 class ResidualBlockWithStride(_residulBlock):
     """SiLU, conv3 s2, GDN, conv3, + conv3 s2 skip."""
 
     def __init__(self, inChannels: int, outChannels: int, stride: int = 2, groups: int = 1, denseNorm: bool = False):
-        if stride != 2 or groups != 1 or denseNorm:
-            raise NotImplementedError("Compressor only uses ResidualBlockWithStride(c, c, stride=2)")
+        _no_dense_norm(denseNorm)
+        if stride != 2:
+            raise NotImplementedError("only stride-2 ResidualBlockWithStride is on the path")
         super().__init__(nn.SiLU(), conv3x3(inChannels, outChannels, stride=stride), GenDivNorm(outChannels),
                          conv3x3(outChannels, outChannels), conv3x3(inChannels, outChannels, stride=stride))
 
@@ -135,8 +148,9 @@ class ResidualBlockShuffle(_residulBlock):
     """SiLU, pixelShuffle3x3 (x2), IGDN, conv3, + pixelShuffle3x3 skip."""
 
     def __init__(self, inChannels: int, outChannels: int, upsample: int = 2, groups: int = 1, denseNorm: bool = False):
-        if upsample != 2 or groups != 1 or denseNorm:
-            raise NotImplementedError("Compressor only uses ResidualBlockShuffle(c, c, upsample=2)")
+        _no_dense_norm(denseNorm)
+        if upsample != 2:
+            raise NotImplementedError("only 2x ResidualBlockShuffle is on the path")
         super().__init__(nn.SiLU(), pixelShuffle3x3(inChannels, outChannels, upsample), InvGenDivNorm(outChannels),
                          conv3x3(outChannels, outChannels), pixelShuffle3x3(inChannels, outChannels, upsample))
 

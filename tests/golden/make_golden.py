@@ -307,6 +307,66 @@ def main():
             f9[f"new_codebook_{ci}"] = q._codebook.detach().numpy()
             f9[f"changed_{ci}"] = changed.numpy()
         np.savez_compressed(os.path.join(OUT, "f9_reassign.npz"), **f9)
+    # ---- F10: the Neon model family (mcquic/modules/compressor.py:181-241, ResidualBackwardQuantizer quantizer.py:577-765):
+    #           encode / decode / residual_backward / residual_forward and the training-mode forward -------------------
+    if want("f10"):
+        from oracle import neon_ref as NR            # generators only
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("gloo", rank=0, world_size=1)
+        ch, k, size = 32, 256, [8, 4, 2, 2]
+        sd = NR.make_state_dict(ch, k, size, seed=3)
+        model = C.Neon(ch, k, size).eval()
+        model.load_state_dict(sd, strict=True)
+        xi = R.make_images(2, 128, 128, seed=5)
+        f10 = {"config": np.array([ch, k] + size), "n_state_dict_entries": np.array([len(model.state_dict())])}
+        gaps = []
+        orig_distance = RQ._multiCodebookQuantization._distance
+
+        def recording_distance(self, x):
+            dist_ = orig_distance(self, x)
+            top2 = torch.topk(dist_, 2, dim=-1, largest=False).values
+            gaps.append((top2[..., 1] - top2[..., 0]).clone())
+            return dist_
+        RQ._multiCodebookQuantization._distance = recording_distance
+        try:
+            with torch.inference_mode():
+                codes = model.encode(xi)
+        finally:
+            RQ._multiCodebookQuantization._distance = orig_distance
+        with torch.inference_mode():
+            rec = model.decode(codes)
+            rb = model.residual_backward(codes[1], 2)
+            rf0 = model.residual_forward(codes[0], None, 0)
+            rf1 = model.residual_forward(codes[1], rf0, 1)
+        for lv, cd in enumerate(codes):
+            f10[f"code{lv}"] = cd.numpy().astype(np.int16)
+            f10[f"gap{lv}"] = gaps[lv].numpy()
+        f10["rec_strided"] = rec[..., ::4, ::4].numpy()
+        f10["rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
+        f10["residual_backward_1_2"] = rb.numpy()
+        f10["residual_forward_1"] = rf1.numpy()
+        model.train()
+        g = torch.Generator().manual_seed(9)
+        shapes = [(2, 1, 2, 2, k), (2, 1, 2, 2, k), (2, 1, 4, 4, k), (2, 1, 8, 8, k)]
+        us = [(torch.rand(sh, generator=g), torch.rand(sh, generator=g)) for sh in shapes]
+        it = iter([u for pair in us for u in pair])
+        orig = torch.rand_like
+        torch.rand_like = lambda t, **kw: next(it).clone()
+        try:
+            xHat, yHat, codesT, logitsT = model(xi.clone())
+        finally:
+            torch.rand_like = orig
+        f10["train_xHat_strided"] = xHat.detach()[..., ::4, ::4].numpy()
+        f10["train_yHat"] = yHat.detach().numpy()
+        for lv in range(len(size)):
+            f10[f"train_code{lv}"] = codesT[lv].numpy().astype(np.int16)
+            f10[f"train_logit{lv}_strided"] = logitsT[lv].detach()[..., ::8].numpy()
+            f10[f"train_ema{lv}"] = model._quantizer._entropyCoder._freqEMA[lv].detach().numpy()
+        np.savez_compressed(os.path.join(OUT, "f10_neon.npz"), **f10)
+
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -1,0 +1,153 @@
+"""The Neon model family (mcquic/modules/compressor.py:181-241, ResidualBackwardQuantizer
+quantizer.py:577-765): CPU -- the oracle against vectors captured from the reference (golden F10) and the raw-int64
+coder; GPU -- the HIP modules against the oracle, the golden vectors, and CPU autograd for every gradient."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mcquic_ref as R
+from oracle import neon_ref as N
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f10_neon.npz")
+CFG = (32, 256, [8, 4, 2, 2])
+
+
+def _uniforms(k, seed=9):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(2, 1, 2, 2, k), (2, 1, 2, 2, k), (2, 1, 4, 4, k), (2, 1, 8, 8, k)]
+    return [(torch.rand(s, generator=g), torch.rand(s, generator=g)) for s in shapes]
+
+
+def test_neon_oracle_matches_reference_vectors():
+    z = np.load(G)
+    ch, k, size = CFG
+    assert [int(v) for v in z["config"]] == [ch, k] + size
+    sd = N.make_state_dict(ch, k, size, seed=3)
+    assert len(sd) == int(z["n_state_dict_entries"][0])
+    x = R.make_images(2, 128, 128, seed=5)
+    codes = N.encode(sd, x)
+    for lv, c in enumerate(codes):
+        assert torch.equal(c, torch.from_numpy(z[f"code{lv}"].astype(np.int64))), lv
+    rec = N.decode(sd, codes)
+    np.testing.assert_allclose(rec[..., ::4, ::4].numpy(), z["rec_strided"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(N.residual_backward(sd, codes[1], 2).numpy(), z["residual_backward_1_2"], rtol=0, atol=2e-6)
+    rf = N.residual_forward(sd, codes[1], N.residual_forward(sd, codes[0], None, 0), 1)
+    np.testing.assert_allclose(rf.numpy(), z["residual_forward_1"], rtol=0, atol=2e-6)
+    xHat, yHat, codesT, logits, _ = N.forward_train(sd, x, _uniforms(k))
+    np.testing.assert_allclose(xHat[..., ::4, ::4].numpy(), z["train_xHat_strided"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(yHat.numpy(), z["train_yHat"], rtol=0, atol=5e-6)
+    for lv in range(4):
+        assert torch.equal(codesT[lv], torch.from_numpy(z[f"train_code{lv}"].astype(np.int64)))
+
+
+def test_various_m_coder_round_trip_and_errors():
+    from mcquic_amd.modules.entropyCoder import VariousMCoder
+    from mcquic_amd.utils.specification import CodeSize
+    coder = VariousMCoder([1, 2, 1], [16, 8, 4])
+    g = torch.Generator().manual_seed(0)
+    codes = [torch.randint(0, k, (3, m, s, s + 1), generator=g) for m, k, s in ((1, 16, 2), (2, 8, 4), (1, 4, 8))]
+    binaries, sizes = coder.compress(codes)
+    assert len(binaries) == 3 and [len(b) for b in binaries[0]] == [8 * 1 * 2 * 3, 8 * 2 * 4 * 5, 8 * 1 * 8 * 9]
+    assert binaries[1][1] == codes[1][1].numpy().tobytes()            # the reference's raw int64 bytes (entropyCoder.py:372)
+    assert sizes[0].m == [1, 2, 1] and sizes[0].heights == [2, 4, 8]
+    for a, b in zip(codes, coder.decompress(binaries, sizes)):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        coder.decompress([[b[:-8] for b in binaries[0]]], sizes[:1])
+    with pytest.raises(RuntimeError):
+        coder.decompress(binaries[:1], [CodeSize([1, 2, 1], [2, 4, -8], [3, 5, 9], [16, 8, 4])])
+    before = coder._freqEMA[1].clone()
+    coder(codes)                                                        # EMA 0.998 towards the batch histogram
+    counts = torch.stack([torch.bincount(codes[1][:, gi].reshape(-1), minlength=8) for gi in range(2)]).float()
+    assert torch.allclose(coder._freqEMA[1], R.freq_ema_update(before, counts, ema=0.998), atol=1e-7)
+
+
+def _model(dev):
+    from mcquic_amd import Neon
+    ch, k, size = CFG
+    sd = N.make_state_dict(ch, k, size, seed=3)
+    model = Neon(ch, k, size)
+    model.load_state_dict(sd, strict=True)
+    return model.to(dev), sd
+
+
+@pytest.mark.gpu
+def test_neon_hip_against_oracle_and_reference_vectors(dev):
+    z = np.load(G)
+    model, sd = _model(dev)
+    model.eval()
+    x = R.make_images(2, 128, 128, seed=5)
+    codes = [c.cpu() for c in model.encode(x.to(dev))]
+    alive = torch.ones(2, dtype=torch.bool)
+    for lv, c in enumerate(codes):                                     # near-tie protocol on the reference's gaps
+        want = torch.from_numpy(z[f"code{lv}"].astype(np.int64))
+        bad = (c != want) & alive[:, None, None, None]
+        if bad.any():
+            assert float(torch.from_numpy(z[f"gap{lv}"])[bad].max()) < 1e-5, f"level {lv}"
+            alive &= ~bad.flatten(1).any(1)
+    assert alive.all(), "a near-tie flipped on this small fixture (none observed when the test was written)"
+    want_codes = [torch.from_numpy(z[f"code{lv}"].astype(np.int64)).to(dev) for lv in range(4)]
+    rec = model.decode(want_codes).cpu()
+    np.testing.assert_allclose(rec[..., ::4, ::4].numpy(), z["rec_strided"], rtol=0, atol=1e-4)
+    assert float((rec - N.decode(sd, [c.cpu() for c in want_codes])).abs().max()) <= 1e-4
+    rb = model.residual_backward(want_codes[1], 2).cpu()
+    np.testing.assert_allclose(rb.numpy(), z["residual_backward_1_2"], rtol=0, atol=1e-4)
+    rf = model.residual_forward(want_codes[1], model.residual_forward(want_codes[0], None, 0), 1).cpu()
+    np.testing.assert_allclose(rf.numpy(), z["residual_forward_1"], rtol=0, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        model.residual_forward(want_codes[1], None, 1)
+    # byte streams (raw int64, like the reference's VariousMCoder) and the crop-back of decompress
+    xs = R.make_images(2, 100, 120, seed=6).to(dev)
+    cds, binaries, headers = model.compress(xs)
+    assert headers[0].CodeSize.m == [1, 1, 1, 1] and headers[0].ImageSize.height == 100
+    out = model.decompress(binaries, headers)
+    assert tuple(out.shape) == (2, 3, 100, 120)
+    assert torch.equal(out, R.aligned_crop_back(model.decode(cds), 100, 120))
+
+
+@pytest.mark.gpu
+def test_neon_training_forward_and_gradients(dev):
+    """Training-mode forward against the reference's vectors (F10) and every parameter gradient against CPU autograd
+    through the oracle (same weights, same uniform draws, loss = <xHat, G>)."""
+    z = np.load(G)
+    ch, k, size = CFG
+    model, sd = _model(dev)
+    model.train()
+    x = R.make_images(2, 128, 128, seed=5)
+    us = _uniforms(k)
+    leaf = {key: (v.clone().requires_grad_() if v.is_floating_point() and "reparam" not in key and "_bound" not in key and "_freqEMA" not in key else v)
+            for key, v in sd.items()}
+    cb = leaf["_quantizer._quantizers.0._codebook"]
+    for i in range(len(size)):                                         # one codebook under eight names
+        leaf[f"_quantizer._quantizers.{i}._codebook"] = cb
+        leaf[f"_quantizer._dequantizers.{i}._codebook"] = cb
+    xHat, yHat, codes, logits, _ = N.forward_train(leaf, x, us)
+    Gm = torch.rand(xHat.shape, generator=torch.Generator().manual_seed(5)) - 0.5
+    (xHat * Gm).sum().backward()
+    out = model(x.to(dev), uniforms=[(a.to(dev), b.to(dev)) for a, b in us])
+    for lv in range(len(size)):
+        assert torch.equal(out[2][lv].cpu(), codes[lv]), f"codes level {lv}"
+        assert torch.equal(out[2][lv].cpu(), torch.from_numpy(z[f"train_code{lv}"].astype(np.int64)))
+    np.testing.assert_allclose(out[0].detach().cpu()[..., ::4, ::4].numpy(), z["train_xHat_strided"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out[1].detach().cpu().numpy(), z["train_yHat"], rtol=0, atol=1e-4)
+    for lv in range(len(size)):
+        np.testing.assert_allclose(model._quantizer._entropyCoder._freqEMA[lv].detach().cpu().numpy(), z[f"train_ema{lv}"], rtol=0, atol=1e-7)
+    (out[0] * Gm.to(dev)).sum().backward()
+    worst = ("", 0.0)
+    seen = set()
+    for name, p in model.named_parameters():
+        if not p.requires_grad or id(p) in seen:
+            continue
+        seen.add(id(p))
+        want = leaf[name].grad
+        if want is None:            # `_backwards.0` runs after the LAST quantization: its output is never used (quantizer.py:746-757)
+            assert name.startswith("_quantizer._backwards.0."), f"oracle has no grad for {name}"
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+            continue
+        assert p.grad is not None, f"no grad for {name}"
+        rel = (p.grad.detach().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+        if rel > worst[1]:
+            worst = (name, rel)
+    assert worst[1] < 2e-3, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"

@@ -60,3 +60,39 @@ def test_metrics_oracle_against_reference_handlers():
                 hist[lv][g] += torch.bincount(c[:, g].flatten(), minlength=k)
                 count[lv][g] += c[:, g].numel()
     assert abs(M.ideal_bpp(hist, count, 3 * 3 * 768 * 512) - handler.Result) <= 1e-6 * handler.Result
+
+
+def test_neon_oracle_bit_equal_to_reference():
+    """oracle/neon_ref.py against the reference's Neon / ResidualBackwardQuantizer, live: state_dict layout, encode,
+    decode, residual_backward, residual_forward."""
+    from oracle import neon_ref as N
+    C = ref_harness.load()
+    ch, k, size = 16, 64, [4, 2, 2]
+    sd = N.make_state_dict(ch, k, size, seed=11)
+    model = C.Neon(ch, k, size).eval()
+    ref = model.state_dict()
+    assert set(sd) == set(ref)
+    for key in ref:
+        assert tuple(sd[key].shape) == tuple(ref[key].shape), key
+    model.load_state_dict(sd, strict=True)
+    x = R.make_images(2, 64, 64, seed=12)
+    with torch.inference_mode():
+        rc = model.encode(x)
+        rd = model.decode(rc)
+        rb = model.residual_backward(rc[1], 2)
+        rf = model.residual_forward(rc[1], model.residual_forward(rc[0], None, 0), 1)
+    oc = N.encode(sd, x)
+    assert all(torch.equal(a, b) for a, b in zip(rc, oc))
+    assert torch.equal(rd, N.decode(sd, oc))
+    assert torch.equal(rb, N.residual_backward(sd, oc[1], 2))
+    assert torch.equal(rf, N.residual_forward(sd, oc[1], N.residual_forward(sd, oc[0], None, 0), 1))
+
+
+def test_hip_neon_module_tree_matches_reference_keys():
+    from mcquic_amd import Neon
+    C = ref_harness.load()
+    ref = C.Neon(32, 256, [8, 4, 2, 2]).state_dict()
+    mine = Neon(32, 256, [8, 4, 2, 2]).state_dict()
+    assert list(mine.keys()) == list(ref.keys()) and len(ref) == 819
+    for key in ref:
+        assert tuple(mine[key].shape) == tuple(ref[key].shape), key

@@ -141,11 +141,15 @@ class ConvProfiler:
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (separate
     FETCH_SIZE / WRITE_SIZE passes of this same command; profiles/rNN_pmc.json).  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
-    try:
-        return json.load(open(path))
-    except (OSError, ValueError):
-        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")), reverse=True):     # the latest round's passes
+        try:
+            d = json.load(open(path))
+            d["_file"] = os.path.basename(path)
+            return d
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def usable_cores() -> int:
@@ -285,7 +289,7 @@ def main():
                 "achieved": round(achieved_tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / FP32_MATRIX_PEAK_TFLOPS, 4),
                 "traffic": (lambda t: None if t is None else round(t["all_conv_launches"]["fetch_bytes_per_launch_x2_corrected"] + t["all_conv_launches"]["write_size_bytes_per_launch"]))(pmc_traffic()),
-                "traffic_unit": "HBM-side bytes per conv kernel launch, averaged over all conv launches of a step like algorithmic_bytes_per_launch (PMC FETCH_SIZE x2-corrected + WRITE_SIZE, separate passes, profiles/r01_pmc.json)",
+                "traffic_unit": "HBM-side bytes per conv kernel launch, averaged over all conv launches of a step like algorithmic_bytes_per_launch (PMC FETCH_SIZE x2-corrected + WRITE_SIZE, separate passes, profiles/" + ((pmc_traffic() or {}).get("_file") or "rNN_pmc.json") + ")",
                 "algorithmic_bytes_per_launch": round(conv["bytes"] / max(conv["launches"], 1)),
                 "launches_per_step": conv["launches"] // conv["steps"],
                 "event_steps": conv["steps"],

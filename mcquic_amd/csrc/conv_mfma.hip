@@ -809,14 +809,19 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
             MB = mb; NB = nb;
             if (tiles * 8 >= 1024) break;          // even an 8-way split would leave SIMDs idle: try a smaller tile
         }
-        const long long tiles = ((tb + NB - 1) / NB) * ((co32 + MB - 1) / MB) * nprob;      // all problems of the launch
+        const long long tiles1 = ((tb + NB - 1) / NB) * ((co32 + MB - 1) / MB);             // one problem
+        const long long tiles = tiles1 * nprob;                                              // all problems of the launch
         while (ksl < 3 && (tiles << ksl) < 2048) ++ksl;
+        int ksl1 = 0;                                                                        // what a single-problem launch would split
+        while (ksl1 < 3 && (tiles1 << ksl1) < 2048) ++ksl1;
         // an 8-way split of the 128 x 64 tile runs as a 4-way split of the 128 x 32 tile instead: the same number of
         // waves, half the LDS reduction depth, 3 waves / SIMD resident (8 x 128 x 32 x 32 layer: 50 -> 28 us)
         // MCQ_TILE_22A: a 4-way split 128 x 64 tile that needs 1.5 rounds at 2 waves / SIMD -- the 48x32 level -- runs as
         // the 64 x 64 tile split 2 ways, all waves resident at 3 / SIMD (120 -> 111 us per launch, +0.4 % images/s; with
         // the earlier k-loop, whose address arithmetic weighed twice as much on the smaller tile, it cost 0.4 %)
-        if (MCQ_TILE_22A && MB == 4 && NB == 2 && ksl == 2 && tiles * 4 > 2048 && tiles * 4 <= 3072 && d->ksize == 3 &&
+        // (judged per problem: two such problems in one launch are 6144 waves = two full rounds at 3 / SIMD, 204 us per pair,
+        //  where the 128 x 64 tile split 2 ways would be 1.5 rounds at 2 / SIMD, 224 us)
+        if (MCQ_TILE_22A && MB == 4 && NB == 2 && ksl1 == 2 && tiles1 * 4 > 2048 && tiles1 * 4 <= 3072 && d->ksize == 3 &&
             k.S % 2 == 0 && (k.S >> 1) >= 8) { MB = 2; NB = 2; ksl = 1; }
         if (MCQ_TILE_41 && MB == 4 && NB == 2 && ksl == 3 && d->ksize == 3 && k.S % 4 == 0 && (k.S >> 2) >= 8) { NB = 1; ksl = 2; }
     }

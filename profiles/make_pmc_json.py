@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/pmc_stats.py writes /tmp/pmc_rows.json (per kernel x launch grid averages of the --pmc passes); this turns
 it into the summary bench.py reads for `roofline.traffic` (profiles/rNN_pmc.json).
-usage: python profiles/make_pmc_json.py gpurun_out/final/pmc_rows.json > profiles/r01_pmc.json"""
+usage: python profiles/make_pmc_json.py gpurun_out/r02/pmc_rows.json > profiles/rNN_pmc.json"""
 import json
 import sys
 

@@ -65,3 +65,20 @@ def test_import_sets_hw_queue_default():
     out = subprocess.run([sys.executable, "-c", "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import mcquic_amd; "
                           "print(os.environ['GPU_MAX_HW_QUEUES'])"], capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert out.returncode == 0 and out.stdout.strip() == "8", out.stderr[-500:]
+
+
+def test_training_step_under_ddp_matches_the_plain_step(dev):
+    """BASELINE configs[4] wraps the model in torch DDP over RCCL.  One rank is all this box has: the step is run under
+    `torch.distributed.run --nproc-per-node 1` (DDP buckets, gradient hooks and an RCCL all-reduce per bucket are live) and
+    must give the loss and gradient norm of the plain step."""
+    script = os.path.join(ROOT, "tools", "bench_train.py")
+    common = ["--steps", "2", "--warmup", "1", "--batch", "2", "--crop", "128"]
+    plain = subprocess.run([sys.executable, script, *common], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    ddp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29581", script, "--gpus", "1", *common], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert ddp.returncode == 0, ddp.stderr[-2000:]
+    a = json.loads([ln for ln in plain.stdout.splitlines() if ln.startswith("{")][-1])
+    b = json.loads([ln for ln in ddp.stdout.splitlines() if ln.startswith("{")][-1])
+    assert b["ddp"] is True and a["ddp"] is False
+    assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"]) and abs(a["grad_norm"] - b["grad_norm"]) <= 1e-5 * a["grad_norm"]

@@ -38,15 +38,17 @@ def main():
     launch.pin_rank_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or launched                     # under torch.distributed.run the DDP / RCCL path runs even at N = 1
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
         if launch.rccl_check(dist, dev) != world:
             raise SystemExit("bench_train.py: RCCL does not span the requested ranks")
     from mcquic_amd import Compressor
     torch.manual_seed(3407)
     model = Compressor(128, 2, [8192, 2048, 512]).to(dev).train()
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if use_dist else model
     x = (torch.rand((args.batch, 3, args.crop, args.crop), generator=torch.Generator().manual_seed(rank)) * 2 - 1).to(dev)
 
     opt = torch.optim.SGD(model.parameters(), lr=1e-6) if args.optimizer_step else None
@@ -63,7 +65,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if args.graph and world == 1:
+    if args.graph and not use_dist:
         # whole-step capture: ~5000 kernel launches per step become one graph launch
         torch.cuda.synchronize()
         for p in model.parameters():
@@ -79,13 +81,13 @@ def main():
             return static_loss
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     if rank == 0:
@@ -93,9 +95,9 @@ def main():
         print(json.dumps({"metric": "training step (forward + backward), 256x256 crops, qp=2 model", "n_gpus": world,
                           "images_per_gpu": args.batch, "ms_per_step": round(dt / args.steps * 1e3, 2),
                           "images_per_s": round(world * args.batch * args.steps / dt, 2), "loss": float(loss), "grad_norm": gn,
-                          "dtype": "f32", "graph": bool(args.graph and world == 1),
+                          "dtype": "f32", "graph": bool(args.graph and not use_dist), "ddp": bool(use_dist),
                           "optimizer_step": "SGD inside the timed region (weights re-packed every step)" if args.optimizer_step else "not included"}))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -201,6 +201,13 @@ int mcq_conv2d_wgrad_nchw_group_f32(const float* const* x, const float* const* d
                                     int32_t nconv, float* workspace, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout,
                                     void* stream);
 
+/* The 1x1 case (the AttentionBlock gate conv; with square_x the gamma of GDN / IGDN, whose operand is x^2,
+ * mcquic/nn/gdn.py:75): dW[co][ci] = sum dY[co] * X[ci] straight from NCHW, H even, W a multiple of 8.  The workspace query
+ * returns 0 for shapes this kernel does not take. */
+size_t mcq_conv2d_wgrad1x1_nchw_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout);
+int mcq_conv2d_wgrad1x1_nchw_f32(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int32_t N, int32_t Cin,
+                                 int32_t H, int32_t W, int32_t Cout, int32_t square_x, void* stream);
+
 /* out[c] = sum_{n,p} x[n][c][p]   (bias / beta gradients); optional workspace of min(N, 16) * C floats. */
 int mcq_channel_sum_f32(const float* x, float* out, float* workspace, int32_t N, int32_t C, int32_t HW, void* stream);
 

@@ -52,17 +52,18 @@ struct WgRowsK {
 
 struct RowsPlan { int F, strips, row_chunks, rpc, units, splits, ups, groups; };
 
-inline bool rows_plan(int N, int Cin, int H, int W, int Cout, RowsPlan& r) {
-    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (W & 7) || (H & 7)) return false;
+inline bool rows_plan(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int taps = 9) {
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (W & 7) || (H & (taps == 1 ? 1 : 7))) return false;
     if ((uint64_t)N * Cin * H * W * 4ull >= 0x40000000ull || (uint64_t)N * Cout * H * W * 4ull >= 0x40000000ull) return false;
-    const long long tiles = (long long)((Cout + 31) / 32) * ((Cin + 31) / 32);
+    const int tile = taps == 9 ? 32 : 64;                                    // the 1x1 kernel owns 64 x 64 tiles
+    const long long tiles = (long long)((Cout + tile - 1) / tile) * ((Cin + tile - 1) / tile);
     r.F = (W % 16 == 0 && MCQ_WGROWS_WIDE) ? 8 : 4;                           // floats per lane and row: strips of 16 / 8 pixels
     r.strips = W / (2 * r.F);
-    const int rb = r.F == 4 ? 8 : 4;                                          // rows per loop body (= X ring size)
+    const int rb = taps == 1 ? 2 : r.F == 4 ? 8 : 4;                          // rows per loop body (= X ring size)
     const long long sr = (long long)N * H * r.strips;                       // strip-rows in all
     long long splits = MCQ_WGROWS_WAVES / tiles;
     if (splits < 4) splits = 4;
-    long long by_work = sr * r.F / (4 * MCQ_WGROWS_MIN_ROWS);
+    long long by_work = sr * r.F / (4 * MCQ_WGROWS_MIN_ROWS) / (taps == 1 ? 2 : 1);      // (a 1x1 row is 32 MFMAs, not 72)
     if (by_work < 1) by_work = 1;
     if (splits > by_work) splits = by_work;
     long long chunks = (splits + (long long)N * r.strips - 1) / ((long long)N * r.strips);
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WgRowsK p) {
 
 struct WgRowsReduceK {
     const float* part; const float* bias_part; float* dw[ROWS_MAX_CONVS]; float* dbias[ROWS_MAX_CONVS];
-    int nconv, groups, Cout, Cin;
+    int nconv, groups, Cout, Cin, taps;
 };
 
 // dW[conv][co][ci][tap] = sum_g part[conv][g][tap][co][ci]; db[conv][co] = sum_s bias_part[conv][s][co]   (fixed order)
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(WgRowsReduceK p)
     const int Cout = p.Cout, Cin = p.Cin;
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * 64 + lane;                    // index into [tap][co][ci], then [co] of the bias
-    const size_t per = (size_t)9 * Cout * Cin;
+    const size_t per = (size_t)p.taps * Cout * Cin;
     const bool is_bias = i >= per;
     const size_t co_b = i - per;
     const bool live = is_bias ? (dbias != nullptr && co_b < (size_t)Cout) : true;
@@ -299,7 +300,134 @@ __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(WgRowsReduceK p)
     const size_t r = i / Cin;
     const int co = (int)(r % Cout);
     const int tap = (int)(r / Cout);
-    dw[((size_t)co * Cin + ci) * 9 + tap] = s;
+    dw[((size_t)co * Cin + ci) * p.taps + tap] = s;
+}
+
+// ---- 1x1 convolutions (the AttentionBlock gate conv, GDN's gamma) ------------------------------------------------------
+//   dW[co][ci] = sum_{n, y, x} dY[n][co][y][x] * X[n][ci][y][x]            (SQ: X squared -- gamma multiplies x^2, gdn.py:75)
+// The same walk without a window: a wave owns a 64 co x 64 ci tile (4 accumulator tiles), reads F = 8 (4) consecutive pixels
+// per lane and row for its two dY and two X bands, 4 MFMAs per k-step, next row's operands requested one row ahead.
+template <bool BIAS, bool SQ, int F>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_rows1_kernel(WgRowsK p) {
+    __shared__ float red[2][64][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int kh = lane >> 5, j = lane & 31;
+    const int group = blockIdx.x;
+    const int split = group * 4 + wave;
+    const int ci_base = blockIdx.y * 64, co_base = blockIdx.z * 64;
+    const __amdgpu_buffer_rsrc_t rx = mcq_make_rsrc(p.x[0], (uint32_t)((size_t)p.N * p.Cin * p.H * p.W * 4));
+    const __amdgpu_buffer_rsrc_t rd = mcq_make_rsrc(p.dy[0], (uint32_t)((size_t)p.N * p.Cout * p.H * p.W * 4));
+    const unsigned rowb = (unsigned)p.W * 4u;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float bsum[2] = {0.0f, 0.0f};
+    for (int i = 0; i < p.ups; ++i) {
+        const int u = (group * p.ups + i) * 4 + wave;
+        if (u >= p.units) break;
+        const int sx = u % p.strips;
+        const int t0 = u / p.strips;
+        const int chunk = t0 % p.row_chunks, n = t0 / p.row_chunks;
+        const int y0 = chunk * p.rpc;
+        int y1 = y0 + p.rpc;
+        if (y1 > p.H) y1 = p.H;
+        const int xl = sx * (2 * F) + F * kh;
+        unsigned vA[2], vB[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            vA[t] = co_base + 32 * t + j < p.Cout ? (unsigned)(((n * p.Cout + co_base + 32 * t + j) * p.H * p.W + xl) * 4) : MCQ_OOB;
+            vB[t] = ci_base + 32 * t + j < p.Cin ? (unsigned)(((n * p.Cin + ci_base + 32 * t + j) * p.H * p.W + xl) * 4) : MCQ_OOB;
+        }
+        float A[2][2][F], B[2][2][F];                         // [slot][band][pixel]
+        auto load = [&](int slot, int y) {
+            const unsigned so = (unsigned)y * rowb;           // (rows past the range are requested but never used)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < F / 4; ++v) {
+                    const f32x4v a = rows_ld4(rd, vA[t] + 16u * v, so);
+                    const f32x4v b = rows_ld4(rx, vB[t] + 16u * v, so);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { A[slot][t][4 * v + e] = a[e]; B[slot][t][4 * v + e] = b[e]; }
+                }
+        };
+        load(0, y0);
+        for (int yb = y0; yb < y1; yb += 2) {
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                load(uu ^ 1, yb + uu + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < F; ++q) {
+                    float b0 = B[uu][0][q], b1 = B[uu][1][q];
+                    if (SQ) { b0 = b0 * b0; b1 = b1 * b1; }
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][0][q], b0, acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][1][q], b0, acc[1][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][0][q], b1, acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][1][q], b1, acc[1][1], 0, 0, 0);
+                    if (BIAS) { bsum[0] = bsum[0] + A[uu][0][q]; bsum[1] = bsum[1] + A[uu][1][q]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // LDS tree of the four waves, one accumulator tile pair at a time: (w0 + w1) + (w2 + w3)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (wave & 1) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave >> 1][a * 16 + r][lane] = acc[a][b][r];
+        }
+        __syncthreads();
+        if (!(wave & 1)) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = acc[a][b][r] + red[wave >> 1][a * 16 + r][lane];
+        }
+        __syncthreads();
+        if (wave == 2) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[0][a * 16 + r][lane] = acc[a][b][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = acc[a][b][r] + red[0][a * 16 + r][lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float* out = p.part + (size_t)group * p.Cout * p.Cin;                       // part[group][co][ci]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_base + 32 * a + mcq_drow(r, kh), ci = ci_base + 32 * b + j;
+                    if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Cin + ci] = acc[a][b][r];
+                }
+    }
+    if (BIAS && blockIdx.y == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float sv = bsum[t] + __shfl_xor(bsum[t], 32);
+            const int co = co_base + 32 * t + j;
+            if (kh == 0 && co < p.Cout) p.bias_part[(size_t)split * p.Cout + co] = sv;
+        }
+    }
 }
 
 }  // namespace
@@ -421,7 +549,7 @@ extern "C" int mcq_conv2d_wgrad_nchw_group_f32(const float* const* x, const floa
     p.nconv = nconv; p.groups = r.groups;
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
     p.strips = r.strips; p.row_chunks = r.row_chunks; p.rpc = r.rpc; p.units = r.units; p.splits = r.splits; p.ups = r.ups;
-    q.part = workspace; q.bias_part = p.bias_part; q.nconv = nconv; q.groups = r.groups; q.Cout = Cout; q.Cin = Cin;
+    q.part = workspace; q.bias_part = p.bias_part; q.nconv = nconv; q.groups = r.groups; q.Cout = Cout; q.Cin = Cin; q.taps = 9;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(r.groups * nconv), (unsigned)((Cin + 31) / 32), (unsigned)((Cout + 31) / 32));
     if (r.F == 8) {
@@ -444,3 +572,41 @@ extern "C" int mcq_conv2d_wgrad_nchw_f32(const float* x, const float* dy, float*
     float* dbs[1] = {dbias};
     return mcq_conv2d_wgrad_nchw_group_f32(xs, dys, dws, dbias ? dbs : nullptr, 1, workspace, N, Cin, H, W, Cout, stream);
 }
+
+extern "C" size_t mcq_conv2d_wgrad1x1_nchw_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout) {
+    RowsPlan r;
+    if ((H & 1) || !rows_plan(N, Cin, H, W, Cout, r, 1)) return 0;
+    return (size_t)r.groups * Cout * Cin + (size_t)r.groups * 4 * Cout;
+}
+
+extern "C" int mcq_conv2d_wgrad1x1_nchw_f32(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int32_t N,
+                                            int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t square_x, void* stream) {
+    if (!x || !dy || !dw || !workspace) return MCQ_EINVAL;
+    RowsPlan r;
+    if ((H & 1) || !rows_plan(N, Cin, H, W, Cout, r, 1)) return MCQ_EINVAL;
+    WgRowsK p;
+    WgRowsReduceK q;
+    for (int c = 0; c < ROWS_MAX_CONVS; ++c) { p.x[c] = x; p.dy[c] = dy; q.dw[c] = dw; q.dbias[c] = dbias; }
+    p.part = workspace;
+    p.bias_part = dbias ? workspace + (size_t)r.groups * Cout * Cin : nullptr;
+    p.nconv = 1; p.groups = r.groups;
+    p.N = N; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
+    p.strips = r.strips; p.row_chunks = r.row_chunks; p.rpc = r.rpc; p.units = r.units; p.splits = r.splits; p.ups = r.ups;
+    q.part = workspace; q.bias_part = p.bias_part; q.nconv = 1; q.groups = r.groups; q.Cout = Cout; q.Cin = Cin; q.taps = 1;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)r.groups, (unsigned)((Cin + 63) / 64), (unsigned)((Cout + 63) / 64));
+#define MCQ_LAUNCH_ROWS1(B_, S_, F_) hipLaunchKernelGGL((conv_wgrad_rows1_kernel<B_, S_, F_>), grid, dim3(256), 0, s, p)
+    const bool b = dbias != nullptr, sq = square_x != 0;
+    if (r.F == 8) {
+        if (b) { if (sq) MCQ_LAUNCH_ROWS1(true, true, 8); else MCQ_LAUNCH_ROWS1(true, false, 8); }
+        else { if (sq) MCQ_LAUNCH_ROWS1(false, true, 8); else MCQ_LAUNCH_ROWS1(false, false, 8); }
+    } else {
+        if (b) { if (sq) MCQ_LAUNCH_ROWS1(true, true, 4); else MCQ_LAUNCH_ROWS1(true, false, 4); }
+        else { if (sq) MCQ_LAUNCH_ROWS1(false, true, 4); else MCQ_LAUNCH_ROWS1(false, false, 4); }
+    }
+#undef MCQ_LAUNCH_ROWS1
+    const size_t per = (size_t)Cout * Cin + (dbias ? (size_t)Cout : 0);
+    hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3((unsigned)((per + 63) / 64), 1u), dim3(256), 0, s, q);
+    return mcq_check_launch();
+}
+

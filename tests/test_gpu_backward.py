@@ -75,6 +75,32 @@ def test_wgrad_rows_kernel(dev, case):
     _close(dw, old.cpu(), 3e-6, f"rows vs NHWC kernel {case}")
 
 
+@pytest.mark.parametrize("case", [(8, 128, 128, 64, 64, False), (8, 128, 128, 16, 16, True), (2, 128, 128, 8, 8, False), (3, 40, 72, 8, 24, True),
+                                  (1, 8, 32, 16, 16, False), (8, 32, 32, 32, 32, True), (2, 128, 128, 6, 8, False)])
+def test_wgrad_rows_1x1_kernel(dev, case):
+    """The NCHW weight-gradient kernel for 1x1 convolutions (gate conv; GDN's gamma with the squared operand) against CPU
+    autograd, repeatable bit for bit, and equal to the NHWC kernel it replaces up to summation order."""
+    from mcquic_amd import ops
+    n, cin, cout, h, w, sq = case
+    assert ops._lib.load().mcq_conv2d_wgrad1x1_nchw_workspace_floats(n, cin, h, w, cout) > 0
+    x, gy = _rand((n, cin, h, w), 31), _rand((n, cout, h, w), 32)
+    wr = torch.zeros((cout, cin, 1, 1), requires_grad=True)
+    br = torch.zeros((cout,), requires_grad=True)
+    F.conv2d(x * x if sq else x, wr, br).backward(gy)
+    dw, db = ops.conv2d_wgrad(x.to(dev), gy.to(dev), 1, 1, square_x=sq, want_bias=True)
+    _close(dw, wr.grad, 3e-6, f"dW {case}")
+    _close(db, br.grad, 3e-6, f"db {case}")
+    dw2, db2 = ops.conv2d_wgrad(x.to(dev), gy.to(dev), 1, 1, square_x=sq, want_bias=True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    assert torch.equal(ops.conv2d_wgrad(x.to(dev), gy.to(dev), 1, 1, square_x=sq), dw)
+    ops._WGRAD_ROWS = False
+    try:
+        old = ops.conv2d_wgrad(x.to(dev), gy.to(dev), 1, 1, square_x=sq)
+    finally:
+        ops._WGRAD_ROWS = True
+    _close(dw, old.cpu(), 3e-6, f"rows vs NHWC kernel {case}")
+
+
 @pytest.mark.parametrize("case", [(8, 128, 128, 4, 4), (3, 40, 24, 4, 4), (11, 16, 16, 4, 8), (2, 128, 128, 6, 6), (8, 128, 128, 2, 2),
                                   (1, 8, 8, 1, 1)])
 def test_wgrad_small_map_kernel(dev, case):

@@ -211,6 +211,135 @@ class AttentionBlockFn(torch.autograd.Function):
         return (dx, None, *flat, dw11, db11, None)
 
 
+# ---- same-structure stacks in lockstep ------------------------------------------------------------------------------------
+# `latentHead` / `quantizationHead` (RB, AttentionBlock, conv3x3; mcquic/modules/compressor.py:148-160) consume the same z, and
+# `dequantizationHead` / `sideHead` (AttentionBlock, conv3x3, RB; :166-175) are independent until their sum: layer by layer the
+# two stacks are the same shapes on different tensors, so every layer is ONE multi-problem launch for both (four problems inside
+# their AttentionBlocks).  15 + 15 convolutions become 10 launches each way.
+def _kind(m) -> str:
+    name = type(m).__name__
+    if name == "ResidualBlock" and m._skip is None:
+        return "rb"
+    if name == "AttentionBlock":
+        return "attn"
+    if name == "Conv2d" and m.kernelSize == 3 and m.stride == 1:
+        return "conv"
+    raise NotImplementedError(f"lockstep: {name} is not a layer of the paired heads")
+
+
+def lockstep_compatible(stacks) -> bool:
+    try:
+        kinds = [[_kind(m) for m in st] for st in stacks]
+    except NotImplementedError:
+        return False
+    return all(k == kinds[0] for k in kinds[1:])
+
+
+def _lockstep_forward(stacks, xs, keep: bool):
+    """Run the k stacks layer by layer; with `keep` returns the tape backward needs."""
+    k = len(stacks)
+    xs = list(xs)
+    tape = []
+    for layer in zip(*stacks):
+        kind = _kind(layer[0])
+        if kind == "rb":
+            ys, sys_, saved = _rb_forward_multi(list(layer), xs, [_silu_of(x) for x in xs])
+            for y, sy in zip(ys, sys_):
+                ops.set_silu_twin(y, sy)
+            tape.append((kind, layer, saved))
+            xs = ys
+        elif kind == "attn":
+            a, b = list(xs), list(xs)
+            sa = [_silu_of(x) for x in xs]
+            sb = list(sa)
+            saved = []
+            for i in range(3):
+                blocks = [m._mainBranch[i] for m in layer] + [m._sideBranch[i] for m in layer]
+                ys, sys_, sv = _rb_forward_multi(blocks, a + b, sa + sb)
+                a, b, sa, sb = ys[:k], ys[k:], sys_[:k], sys_[k:]
+                saved.append(sv)
+            bbs = ops.conv2d_multi(b, [m._sideBranch[3].packed() for m in layer])
+            outs = [ops.gate(ai, bbi, xi) for ai, bbi, xi in zip(a, bbs, xs)]
+            tape.append((kind, layer, (a, b, bbs, saved)))
+            xs = outs
+        else:
+            ys = ops.conv2d_multi(xs, [m.packed() for m in layer])
+            tape.append((kind, layer, xs))
+            xs = ys
+    return xs, (tape if keep else None)
+
+
+def _lockstep_backward(tape, dys, grads):
+    """Input gradients of the k stacks; parameter gradients go into `grads` (id(parameter) -> tensor)."""
+    dys = [d.contiguous() for d in dys]
+    pairs, owners = [], []                                     # 3x3 weight-gradient operand pairs and the convs they belong to
+    for kind, layer, saved in reversed(tape):
+        k = len(layer)
+        if kind == "rb":
+            before = len(pairs)
+            dys = _rb_backward_multi(list(layer), saved, dys, pairs)
+            for m in layer:
+                owners.extend([m._branch[1], m._branch[3]])
+            assert len(pairs) - before == 2 * k
+        elif kind == "attn":
+            a, b, bbs, rbsaved = saved
+            hs, gs = [], []
+            for m, ai, bi, bbi, dout in zip(layer, a, b, bbs, dys):
+                h, dbb = ops.gate_bwd(ai, bbi, dout)
+                c11 = m._sideBranch[3]
+                gs.append(ops.conv2d(dbb, _dgrad_packed(c11, c11.weight)))
+                dw11, db11 = ops.conv2d_wgrad(bi, dbb, 1, 1, want_bias=True)
+                grads[id(c11.weight)], grads[id(c11.bias)] = dw11, db11
+                hs.append(h)
+            for i in (2, 1, 0):
+                blocks = [m._mainBranch[i] for m in layer] + [m._sideBranch[i] for m in layer]
+                out = _rb_backward_multi(blocks, rbsaved[i], hs + gs, pairs)
+                hs, gs = out[:k], out[k:]
+                for blk in blocks:
+                    owners.extend([blk._branch[1], blk._branch[3]])
+            dys = [ops.add(ops.add(h, g), dout) for h, g, dout in zip(hs, gs, dys)]
+        else:
+            xs = saved
+            for m, x, dy in zip(layer, xs, dys):
+                pairs.append((x, dy))
+                owners.append(m)
+            dys = ops.conv2d_multi(dys, [_dgrad_packed(m, m.weight) for m in layer])
+    for conv, (dw, db) in zip(owners, _wgrads(pairs)):
+        grads[id(conv.weight)] = dw
+        if conv.bias is not None:
+            grads[id(conv.bias)] = db
+    return dys
+
+
+class LockstepFn(torch.autograd.Function):
+    """k same-structure stacks (nn.Sequential of ResidualBlock / AttentionBlock / conv3x3) on k inputs as ONE autograd node.
+    apply(x_1 .. x_k, *parameters (all stacks', in `stack.parameters()` order), stacks) -> (y_1 .. y_k)."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        stacks = args[-1]
+        k = len(stacks)
+        ys, tape = _lockstep_forward(stacks, args[:k], keep=True)
+        ctx.tape, ctx.stacks, ctx.k = tape, stacks, k
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        grads = {}
+        dxs = _lockstep_backward(ctx.tape, list(dys), grads)
+        ctx.tape = None
+        params = [p for st in ctx.stacks for p in st.parameters()]
+        return (*dxs, *[grads.get(id(p)) for p in params], None)
+
+
+def lockstep(stacks, xs):
+    """Training graph: the stacks in lockstep (LockstepFn); falls back to one after the other when their structures differ."""
+    if not (ops._MULTI and lockstep_compatible(stacks)):
+        return [st(x) for st, x in zip(stacks, xs)]
+    params = [p for st in stacks for p in st.parameters()]
+    return list(LockstepFn.apply(*xs, *params, tuple(stacks)))
+
+
 class GateFn(torch.autograd.Function):
     """out = a * sigmoid(b) + x."""
 

@@ -208,16 +208,13 @@ class _quantizerEncoder(nn.Module):
             return q, None, code, logit
         head = self._latentHead
         if torch.is_grad_enabled():
-            # latentHead(z) does not depend on the codes: it runs on the side stream beside quantizationHead + the soft
-            # assignment (15 convolutions each, launch-bound on the 16x16 ... 4x4 maps of a training crop); autograd
-            # replays the same two-stream schedule in the backward pass
+            # latentHead(z) does not depend on the codes: it runs in lockstep with quantizationHead -- same layer shapes,
+            # one multi-problem launch per layer for both (autograd.LockstepFn; 15 + 15 convolutions, launch-bound on the
+            # 16x16 ... 4x4 maps of a training crop, become 10 launches each way)
             from .. import autograd as AG
-            from ..nn.blocks import _fork
-            AG._silu_of(z)                                     # both heads open with silu(z): made once, before the streams part
-            with _fork(z, lane=1) as f:
-                hz = head(z)
-            q, code, logit = self._quantizer(self._quantizationHead(z), freqEMA, uniforms)
-            return q, AG.sub(f.join(hz), self._dequantizer(q)), code, logit
+            hz, qin = AG.lockstep([head, self._quantizationHead], [z, z])
+            q, code, logit = self._quantizer(qin, freqEMA, uniforms)
+            return q, AG.sub(hz, self._dequantizer(q)), code, logit
         q, code, logit = self._quantizer(self._quantizationHead(z), freqEMA, uniforms)
         deq = self._dequantizer(q)
         t = z
@@ -251,12 +248,9 @@ class _quantizerDecoder(nn.Module):
     def forward(self, q, formerLevel: Optional[torch.Tensor]):
         """Training-mode level (:359-365): like decode, from the straight-through sample."""
         if self._sideHead is not None and torch.is_grad_enabled():
-            from .. import autograd as AG
-            from ..nn.blocks import _fork
-            with _fork(formerLevel, lane=1) as f:              # sideHead || dequantizationHead (see _quantizerEncoder._forward)
-                side = self._sideHead(formerLevel)
-            x = AG.add(self._dequantizationHead(self._dequantizer(q)), f.join(side))
-            return self._restoreHead(x)
+            from .. import autograd as AG                      # sideHead and dequantizationHead in lockstep (see _quantizerEncoder._forward)
+            x, side = AG.lockstep([self._dequantizationHead, self._sideHead], [self._dequantizer(q), formerLevel])
+            return self._restoreHead(AG.add(x, side))
         x = self._dequantizationHead(self._dequantizer(q))
         if self._sideHead is not None:
             if torch.is_grad_enabled():

@@ -80,7 +80,8 @@ int mcq_pack_conv_weight_f32(const float* w_oihw, int32_t Cout, int32_t Cin, int
  * mcq_dgrad_weight_shape gives that conv's (Cout_d, Cin_d); `out` holds mcq_packed_conv_weight_floats(Cout_d, Cin_d, k)
  * floats and is used with mcq_conv2d_f32 like any packed weight (MCQ_CONV_SHUFFLE2 for stride 2). */
 int mcq_dgrad_weight_shape(int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t* Cout_d, int32_t* Cin_d);
-int mcq_pack_conv_dgrad_weight_f32(const float* w, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, float* out, void* stream);
+int mcq_pack_conv_dgrad_weight_f32(const float* w, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, float scale, float* out,
+                                   void* stream);      /* every packed value times `scale` (GDN backward: 2 gamma^T; 1 otherwise) */
 
 /* Dense 2-D convolution (zeros padding ksize/2) + fused prologue/epilogue.
  * Replaces nn.Conv2d.forward for conv3x3 / conv1x1 / pixelShuffle3x3 (mcquic/nn/convs.py:77-100,
@@ -168,6 +169,10 @@ int mcq_vq_soft_bwd_f32(const float* ddist, const float* rowsum, const float* x,
 /* Input gradients of the convolutions reuse mcq_conv2d_f32 with transformed weights (see mcquic_amd/autograd.py);
  * the reference obtains all of these from torch.autograd over nn.Conv2d / SiLU / GDN / sigmoid
  * (mcquic/nn/convs.py, nn/gdn.py:67-91, nn/blocks.py:70-78,281-288). */
+
+/* Backward of mcq_nonneg_reparam_f32 under LowerBound's gradient rule (mcquic/nn/base.py:17-29,81-84):
+ * g = 2 max(p, bound) dfolded;  dp = g where p >= bound or g < 0, else 0. */
+int mcq_nonneg_reparam_bwd_f32(const float* p, const float* dfolded, float bound, float* dp, int64_t n, void* stream);
 
 /* out[n][p][c] = x[n][c][p] (squared if `square`): channel-major copies feeding the weight-gradient GEMM. */
 int mcq_nchw_to_nhwc_f32(const float* x, float* out, int32_t N, int32_t C, int32_t HW, int32_t square, void* stream);

@@ -387,28 +387,46 @@ class LowerBoundFn(torch.autograd.Function):
         return ((x >= bound) | (g < 0)).to(g.dtype) * g, None
 
 
+def _gdn_bounds(module):
+    """(beta bound, beta pedestal, gamma bound, gamma pedestal) as floats, read from the module's buffers ONCE (a float() of a
+    device buffer is a host sync, and illegal inside a captured hipGraph); the buffers are constants of the layer."""
+    cached = module.__dict__.get("_boundsCache")
+    key = (module.beta_reparam.lowerBound.bound.data_ptr(), module.gamma_reparam.lowerBound.bound.data_ptr())
+    if cached is None or cached[0] != key:
+        vals = (float(module.beta_reparam.lowerBound.bound), float(module.beta_reparam.eps),
+                float(module.gamma_reparam.lowerBound.bound), float(module.gamma_reparam.eps))
+        cached = module.__dict__["_boundsCache"] = (key, vals)
+    return cached[1]
+
+
 class GdnFn(torch.autograd.Function):
-    """y = x * f(beta + gamma @ x^2) on the FOLDED (non-negative) beta [C], gamma [C, C]."""
+    """y = x * f(beta + gamma @ x^2) with the non-negative re-parametrisation of beta [C], gamma [C, C] INSIDE the node
+    (mcquic/nn/gdn.py:67-91, mcquic/nn/base.py:17-29,81-84): folding, the 1x1 launch, and in backward the two input-gradient
+    pieces, gamma's and beta's gradients (one 1x1 weight-gradient launch on x^2) and the re-parametrisation's own gradient
+    rule are HIP launches -- no ATen max / pow / compare / mask glue (it was ~1 ms of a 28 ms training step)."""
 
     @staticmethod
-    def forward(ctx, x, beta, gamma, inverse):
-        packed = ops.PackedConv(gamma.detach()[..., None, None], beta.detach())
+    def forward(ctx, x, beta_p, gamma_p, module, inverse):
+        bb, be, gb, ge = _gdn_bounds(module)
+        beta = ops.nonneg_reparam(beta_p, bb, be)
+        gamma = ops.nonneg_reparam(gamma_p, gb, ge)
+        packed = ops.PackedConv(gamma[..., None, None], beta, copy_bias=False)
         y = ops.conv2d(x, packed, square_in=True, igdn_mul=x) if inverse else ops.conv2d(x, packed, square_in=True, gdn_mul=x)
-        ctx.save_for_backward(x, gamma)
-        ctx.packed, ctx.inverse = packed, inverse
+        ctx.save_for_backward(x, beta_p, gamma_p, gamma)
+        ctx.packed, ctx.inverse, ctx.bounds = packed, inverse, (bb, gb)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma = ctx.saved_tensors
+        x, beta_p, gamma_p, gamma = ctx.saved_tensors
         dy = dy.contiguous()
         s = ops.conv2d(x, ctx.packed, square_in=True)                          # beta + gamma @ x^2, recomputed
         dxd, ds = ops.gdn_bwd_prep(x, s, dy, ctx.inverse)
-        back = ops.PackedConv((2.0 * gamma.detach().t().contiguous())[..., None, None], None)
+        back = ops.PackedConv.dgrad(gamma[..., None, None], 1, scale=2.0)      # 2 gamma^T, packed in one launch
         dx = ops.conv2d(ds, back, mul=x, res=dxd)                              # dy f(s) + 2 x (gamma^T ds)
         dgamma, dbeta = ops.conv2d_wgrad(x, ds, 1, 1, square_x=True, want_bias=True)
-        dgamma = dgamma[:, :, 0, 0]
-        return dx, dbeta, dgamma, None
+        bb, gb = ctx.bounds
+        return (dx, ops.nonneg_reparam_bwd(beta_p, dbeta, bb), ops.nonneg_reparam_bwd(gamma_p, dgamma[:, :, 0, 0], gb), None, None)
 
 
 def conv(x, module, res: Optional[torch.Tensor] = None, shuffle2: bool = False):
@@ -462,9 +480,7 @@ def sub(a, b):
 
 def gdn(x, module, inverse: bool):
     """GenDivNorm / InvGenDivNorm with the reference's re-parametrisation inside the graph (nn/base.py:81-84)."""
-    beta = LowerBoundFn.apply(module.beta, module.beta_reparam.lowerBound.bound) ** 2 - module.beta_reparam.eps
-    gamma = LowerBoundFn.apply(module.gamma, module.gamma_reparam.lowerBound.bound) ** 2 - module.gamma_reparam.eps
-    return GdnFn.apply(x, beta, gamma, inverse)
+    return GdnFn.apply(x, module.beta, module.gamma, module, inverse)
 
 
 class SoftQuantizeFn(torch.autograd.Function):

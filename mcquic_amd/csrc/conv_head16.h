@@ -178,7 +178,7 @@ __device__ __forceinline__ float pack_source(const float* __restrict__ w, int mo
 
 // OIHW -> [S4 * 9 + tail][64 lanes]: lane l of k-step s * 9 + tap holds W'[co = l & 15][ci = 4 s + (l >> 4)][tap]
 __global__ void pack_head16_kernel(const float* __restrict__ w, int Cout, int Cin, int S4, float* __restrict__ out, size_t total,
-                                   int mode, int Co, int Ci) {
+                                   int mode, int Co, int Ci, float scale) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int lane = (int)(i & 63);
@@ -187,7 +187,7 @@ __global__ void pack_head16_kernel(const float* __restrict__ w, int Cout, int Ci
     if (step < (size_t)S4 * 9) {
         const int s = (int)(step / 9), tap = (int)(step - (size_t)s * 9);
         const int co = lane & 15, ci = 4 * s + (lane >> 4);
-        if (co < Cout && ci < Cin) v = pack_source(w, mode, Co, Ci, 3, co, ci, tap);
+        if (co < Cout && ci < Cin) v = pack_source(w, mode, Co, Ci, 3, co, ci, tap) * scale;
     }
     out[i] = v;
 }

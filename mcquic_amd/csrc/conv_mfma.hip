@@ -572,7 +572,8 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
 // OIHW -> [Cout/(32 bands)][TP][64 lanes][bands]: lane l, slot q holds W[co = 32 bands T + 32 q + (l & 31)][ci = 2 s + (l >> 5)][tap]
 // for k-step = s * taps + tap (channel-major, tap-inner); zero beyond Cout / Cin and in the 16-step tail.
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, int S, int TP,
-                                        float* __restrict__ out, size_t sec4, size_t sec2, size_t total, int mode, int Co, int Ci) {
+                                        float* __restrict__ out, size_t sec4, size_t sec2, size_t total, int mode, int Co, int Ci,
+                                        float scale) {
     // three copies back to back, `bands` = 32-row bands per tile (4 / 2 / 1 for the 128- / 64- / 32-row copies), each
     // laid out [tile][step][lane][band] and followed by its zero tail
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -592,7 +593,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
         const int s = step / taps, tap = step - s * taps;
         const int co = tile * 32 * bands + 32 * q + (lane & 31);
         const int ci = 2 * s + (lane >> 5);
-        if (co < Cout && ci < Cin) v = pack_source(w, mode, Co, Ci, ks, co, ci, tap);
+        if (co < Cout && ci < Cin) v = pack_source(w, mode, Co, Ci, ks, co, ci, tap) * scale;
     }
     out[at] = v;
 }
@@ -662,11 +663,11 @@ extern "C" int mcq_pack_conv_weight_f32(const float* w, int32_t Cout, int32_t Ci
     const size_t total = general_floats(Cout, Cin, ksize);
     const int S = pairs_padded(Cin, ksize), TP = steps_padded(Cin, ksize);
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
-                       ksize, S, TP, out, section_floats(Cout, Cin, ksize, 4), section_floats(Cout, Cin, ksize, 2), total, 0, Cout, Cin);
+                       ksize, S, TP, out, section_floats(Cout, Cin, ksize, 4), section_floats(Cout, Cin, ksize, 2), total, 0, Cout, Cin, 1.0f);
     if (MCQ_HEAD16 && head16_shape(Cout, ksize)) {      // second copy in the 16-row operand order of conv_head16_kernel
         const size_t t16 = head16_floats(Cin);
         hipLaunchKernelGGL(pack_head16_kernel, dim3((unsigned)((t16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
-                           (Cin + 3) / 4, out + total, t16, 0, Cout, Cin);
+                           (Cin + 3) / 4, out + total, t16, 0, Cout, Cin, 1.0f);
     }
     return mcq_check_launch();
 }
@@ -678,8 +679,8 @@ extern "C" int mcq_dgrad_weight_shape(int32_t Cout, int32_t Cin, int32_t ksize, 
     return MCQ_EINVAL;
 }
 
-extern "C" int mcq_pack_conv_dgrad_weight_f32(const float* w, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, float* out,
-                                              void* stream) {
+extern "C" int mcq_pack_conv_dgrad_weight_f32(const float* w, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, float scale,
+                                              float* out, void* stream) {
     int32_t co_d = 0, ci_d = 0;
     if (!w || !out || mcq_dgrad_weight_shape(Cout, Cin, ksize, stride, &co_d, &ci_d) != MCQ_OK) return MCQ_EINVAL;
     // same layout and size as a forward pack of a [co_d, ci_d, ks, ks] weight: mcq_packed_conv_weight_floats(co_d, ci_d, ks)
@@ -687,11 +688,11 @@ extern "C" int mcq_pack_conv_dgrad_weight_f32(const float* w, int32_t Cout, int3
     const int S = pairs_padded(ci_d, ksize), TP = steps_padded(ci_d, ksize);
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, co_d, ci_d,
                        ksize, S, TP, out, section_floats(co_d, ci_d, ksize, 4), section_floats(co_d, ci_d, ksize, 2), total,
-                       stride == 1 ? 1 : 2, Cout, Cin);
+                       stride == 1 ? 1 : 2, Cout, Cin, scale);
     if (MCQ_HEAD16 && head16_shape(co_d, ksize)) {      // narrow input gradients (the 8-channel fixture models) take the 16-row kernel
         const size_t t16 = head16_floats(ci_d);
         hipLaunchKernelGGL(pack_head16_kernel, dim3((unsigned)((t16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, co_d, ci_d,
-                           (ci_d + 3) / 4, out + total, t16, stride == 1 ? 1 : 2, Cout, Cin);
+                           (ci_d + 3) / 4, out + total, t16, stride == 1 ? 1 : 2, Cout, Cin, scale);
     }
     return mcq_check_launch();
 }

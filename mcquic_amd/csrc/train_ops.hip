@@ -419,6 +419,18 @@ __global__ void gdn_bwd_prep_kernel(const float* __restrict__ x, const float* __
     }
 }
 
+// Backward of NonNegativeParametrizer (mcquic/nn/base.py:81-84 under LowerBound's gradient rule, :17-29):
+//   folded = max(p, bound)^2 - eps;  g = 2 max(p, bound) dfolded;  dp = g where p >= bound or g < 0, else 0
+__global__ void nonneg_reparam_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dfolded, float bound,
+                                          float* __restrict__ dp, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float v = p[i];
+        const float g = (2.0f * fmaxf(v, bound)) * dfolded[i];
+        dp[i] = (v >= bound || g < 0.0f) ? g : 0.0f;
+    }
+}
+
 // out[n][c*4 + i*2 + j][y][x] = in[n][c][2y + i][2x + j]   (inverse of nn.PixelShuffle(2))
 __global__ void pixel_unshuffle2_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int H, int W) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // over the INPUT [N, C, 2H, 2W]
@@ -548,6 +560,12 @@ extern "C" int mcq_gdn_bwd_prep_f32(const float* x, const float* s, const float*
     if (!x || !s || !dy || !dx_direct || !ds || n <= 0) return MCQ_EINVAL;
     hipLaunchKernelGGL(gdn_bwd_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, s, dy, inverse,
                        dx_direct, ds, n);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_nonneg_reparam_bwd_f32(const float* p, const float* dfolded, float bound, float* dp, int64_t n, void* stream) {
+    if (!p || !dfolded || !dp || n <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(nonneg_reparam_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, dfolded, bound, dp, n);
     return mcq_check_launch();
 }
 

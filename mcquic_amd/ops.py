@@ -109,7 +109,7 @@ class PackedConv:
 
     __slots__ = ("wp", "bias", "cout", "cin", "ksize")
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], copy_bias: bool = True):
         weight = _dev(weight.detach(), "weight")
         cout, cin, kh, kw = weight.shape
         if kh != kw or kh not in (1, 3):
@@ -119,11 +119,12 @@ class PackedConv:
         self.wp = torch.empty(n, dtype=torch.float32, device=weight.device)
         with _guard(weight.device):
             check(lib.mcq_pack_conv_weight_f32(_ptr(weight), cout, cin, kh, _ptr(self.wp), _stream()), "mcq_pack_conv_weight_f32")
-        self.bias = None if bias is None else _dev(bias.detach(), "bias").clone()
+        # (the copy decouples the pack from later in-place updates of the parameter; a caller that hands over a fresh tensor skips it)
+        self.bias = None if bias is None else (_dev(bias.detach(), "bias").clone() if copy_bias else _dev(bias.detach(), "bias"))
         self.cout, self.cin, self.ksize = cout, cin, kh
 
     @classmethod
-    def dgrad(cls, weight: torch.Tensor, stride: int) -> "PackedConv":
+    def dgrad(cls, weight: torch.Tensor, stride: int, scale: float = 1.0) -> "PackedConv":
         """Operand stream of the layer's input-gradient convolution, packed straight from its OIHW weight in one launch
         (mcq_pack_conv_dgrad_weight_f32): stride 1 -> a [cin, cout, k, k] conv; stride 2 -> a [4 cin, cout, 3, 3] conv whose
         result goes through the PixelShuffle(2) store."""
@@ -136,7 +137,7 @@ class PackedConv:
         self = cls.__new__(cls)
         self.wp = torch.empty(lib.mcq_packed_conv_weight_floats(co_d.value, ci_d.value, kh), dtype=torch.float32, device=weight.device)
         with _guard(weight.device):
-            check(lib.mcq_pack_conv_dgrad_weight_f32(_ptr(weight), cout, cin, kh, stride, _ptr(self.wp), _stream()),
+            check(lib.mcq_pack_conv_dgrad_weight_f32(_ptr(weight), cout, cin, kh, stride, float(scale), _ptr(self.wp), _stream()),
                   "mcq_pack_conv_dgrad_weight_f32")
         self.bias = None
         self.cout, self.cin, self.ksize = co_d.value, ci_d.value, kh
@@ -243,6 +244,18 @@ def nonneg_reparam(p: torch.Tensor, bound: float, pedestal: float) -> torch.Tens
     with _guard(p.device):
         check(_lib.load().mcq_nonneg_reparam_f32(_ptr(p), float(bound), float(pedestal), _ptr(out), p.numel(), _stream()),
               "mcq_nonneg_reparam_f32")
+    return out
+
+
+def nonneg_reparam_bwd(p: torch.Tensor, dfolded: torch.Tensor, bound: float) -> torch.Tensor:
+    """Gradient of max(p, bound)^2 - pedestal w.r.t. p under LowerBound's rule (mcq_nonneg_reparam_bwd_f32)."""
+    p, dfolded = _dev(p.detach(), "p"), _dev(dfolded, "dfolded")
+    if p.shape != dfolded.shape:
+        raise ValueError("nonneg_reparam_bwd: shape mismatch")
+    out = torch.empty_like(p)
+    with _guard(p.device):
+        check(_lib.load().mcq_nonneg_reparam_bwd_f32(_ptr(p), _ptr(dfolded), float(bound), _ptr(out), p.numel(), _stream()),
+              "mcq_nonneg_reparam_bwd_f32")
     return out
 
 

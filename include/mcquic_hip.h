@@ -219,7 +219,7 @@ int mcq_channel_sum_f32(const float* x, float* out, float* workspace, int32_t N,
 /* Stand-alone forms of ops that the inference path fuses into conv prologues / epilogues; the training graph keeps
  * them separate so that each has its own backward:  y = silu(x);  out = a * sigmoid(b) + x;  out = alpha a + beta b. */
 int mcq_silu_f32(const float* x, float* y, int64_t n, void* stream);
-int mcq_gate_f32(const float* a, const float* b, const float* x, float* out, int64_t n, void* stream);
+int mcq_gate_f32(const float* a, const float* b, const float* x, float* out, float* out_silu /* or NULL */, int64_t n, void* stream);
 int mcq_axpby_f32(const float* a, const float* b, float alpha, float beta, float* out, int64_t n, void* stream);
 
 /* dx = dy * d/dx silu(x). */

@@ -73,7 +73,7 @@ SYMBOLS = {
                                             c_int32, c_void_p]),
     "mcq_channel_sum_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_silu_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
-    "mcq_gate_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_gate_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_axpby_f32": (c_int32, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
     "mcq_silu_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_gate_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

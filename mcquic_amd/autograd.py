@@ -180,13 +180,15 @@ class AttentionBlockFn(torch.autograd.Function):
             saved.extend(keep[0])
             saved.extend(keep[1])
         bb = ops.conv2d(b, block._sideBranch[3].packed())
-        out = ops.gate(a, bb, x)
+        out = ops.gate(a, bb, x, dual_silu=True)                 # silu(out) for the block that follows, in the same launch
+        sout = ops.silu_twin(out)
         ctx.save_for_backward(a, b, bb, *saved)
         ctx.block = block
-        return out
+        ctx.mark_non_differentiable(sout)
+        return out, sout
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dsout):
         block = ctx.block
         a, b, bb = ctx.saved_tensors[:3]
         saved = ctx.saved_tensors[3:]
@@ -259,7 +261,7 @@ def _lockstep_forward(stacks, xs, keep: bool):
                 a, b, sa, sb = ys[:k], ys[k:], sys_[:k], sys_[k:]
                 saved.append(sv)
             bbs = ops.conv2d_multi(b, [m._sideBranch[3].packed() for m in layer])
-            outs = [ops.gate(ai, bbi, xi) for ai, bbi, xi in zip(a, bbs, xs)]
+            outs = [ops.gate(ai, bbi, xi, dual_silu=True) for ai, bbi, xi in zip(a, bbs, xs)]
             tape.append((kind, layer, (a, b, bbs, saved)))
             xs = outs
         else:
@@ -455,7 +457,9 @@ def attention_block(x, block):
             c1, c2 = stack[i]._branch[1], stack[i]._branch[3]
             params.extend([c1.weight, c1.bias, c2.weight, c2.bias])
     c11 = block._sideBranch[3]
-    return AttentionBlockFn.apply(x, _silu_of(x), *params, c11.weight, c11.bias, block)
+    out, sout = AttentionBlockFn.apply(x, _silu_of(x), *params, c11.weight, c11.bias, block)
+    ops.set_silu_twin(out, sout)
+    return out
 
 
 def residual_block(x, block):

@@ -370,9 +370,13 @@ __global__ void silu_fwd_kernel(const float* __restrict__ x, float* __restrict__
 }
 
 __global__ void gate_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ x,
-                                float* __restrict__ out, int64_t n) {
+                                float* __restrict__ out, float* __restrict__ out_silu, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a[i] * mcq_sigmoid(b[i]) + x[i];
+    if (i < n) {
+        const float v = a[i] * mcq_sigmoid(b[i]) + x[i];
+        out[i] = v;
+        if (out_silu) out_silu[i] = mcq_silu(v);               // the next block's act1(x), like MCQ_CONV_DUAL_SILU
+    }
 }
 
 __global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float alpha, float beta,
@@ -531,9 +535,9 @@ extern "C" int mcq_silu_f32(const float* x, float* y, int64_t n, void* stream) {
     return mcq_check_launch();
 }
 
-extern "C" int mcq_gate_f32(const float* a, const float* b, const float* x, float* out, int64_t n, void* stream) {
+extern "C" int mcq_gate_f32(const float* a, const float* b, const float* x, float* out, float* out_silu, int64_t n, void* stream) {
     if (!a || !b || !x || !out || n <= 0) return MCQ_EINVAL;
-    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, x, out, n);
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, x, out, out_silu, n);
     return mcq_check_launch();
 }
 

@@ -545,11 +545,15 @@ def silu(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def gate(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+def gate(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor, dual_silu: bool = False) -> torch.Tensor:
+    """a * sigmoid(b) + x; with `dual_silu` the result carries silu(result) as its twin (same launch)."""
     a, b, x = _dev(a, "a"), _dev(b, "b"), _dev(x, "x")
     out = torch.empty_like(a)
+    out2 = torch.empty_like(a) if dual_silu else None
     with _guard(a.device):
-        check(_lib.load().mcq_gate_f32(_ptr(a), _ptr(b), _ptr(x), _ptr(out), a.numel(), _stream()), "mcq_gate_f32")
+        check(_lib.load().mcq_gate_f32(_ptr(a), _ptr(b), _ptr(x), _ptr(out), _ptr(out2), a.numel(), _stream()), "mcq_gate_f32")
+    if out2 is not None:
+        set_silu_twin(out, out2)
     return out
 
 

@@ -117,7 +117,7 @@ def plan_rank_cores(allowed: Sequence[int], local_world: int, numa_of_rank: Sequ
 
 def pin_rank_cores(local_rank: int, local_world: int) -> Optional[List[int]]:
     """Pin this rank to its share of the node's cores (no-op at local_world == 1 or without sched_setaffinity)."""
-    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity") or os.environ.get("MCQUIC_AMD_PIN_CORES", "1") == "0":
         return None
     try:
         import torch
@@ -142,7 +142,7 @@ def pin_rank_cores(local_rank: int, local_world: int) -> Optional[List[int]]:
         if len(mine) >= 2:               # a rank needs its launch thread plus RCCL's proxy thread
             os.sched_setaffinity(0, mine)
             return mine
-    except OSError:
+    except Exception:                    # noqa: BLE001 -- pinning is an optimisation: whatever sysfs / the runtime says, run unpinned
         pass
     return None
 

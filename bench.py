@@ -216,9 +216,9 @@ def main():
     if world > torch.cuda.device_count():
         raise SystemExit(f"bench.py: --gpus {world} but this node has {torch.cuda.device_count()} HIP devices")
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    cores = launch.pin_rank_cores(local_rank, local_world)  # disjoint host cores per rank, from the GPU's NUMA node
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)                        # (first: the runtime's primary context belongs on this rank's GPU)
     dev = torch.device("cuda", local_rank)
+    cores = launch.pin_rank_cores(local_rank, local_world)  # disjoint host cores per rank, from the GPU's NUMA node
     rccl_world = None
     if use_dist:                                             # launched by torch.distributed.run: the RCCL path even at N=1
         import torch.distributed as dist

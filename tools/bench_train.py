@@ -35,9 +35,9 @@ def main():
         os.environ["MCQUIC_AMD_BRANCH_STREAMS"] = "0"
     from mcquic_amd import launch
     rank, local, world, launched = launch.ensure_world(args.gpus, os.path.abspath(__file__), sys.argv[1:])
-    launch.pin_rank_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    launch.pin_rank_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     use_dist = world > 1 or launched                     # under torch.distributed.run the DDP / RCCL path runs even at N = 1
     if use_dist:
         import torch.distributed as dist

@@ -82,3 +82,17 @@ def test_training_step_under_ddp_matches_the_plain_step(dev):
     b = json.loads([ln for ln in ddp.stdout.splitlines() if ln.startswith("{")][-1])
     assert b["ddp"] is True and a["ddp"] is False
     assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"]) and abs(a["grad_norm"] - b["grad_norm"]) <= 1e-5 * a["grad_norm"]
+
+
+def test_bench_gpus_2_really_launches_two_ranks(dev):
+    """`python bench.py --gpus 2` with no launcher re-executes itself under torch.distributed.run with two ranks (VERDICT r1:
+    the flag used to be parsed and ignored).  This box has one GPU, so the ranks must refuse -- loudly, naming the cause --
+    instead of quietly measuring one GPU; on a node with two GPUs the same command is the N = 2 benchmark."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU node: the command would run the real N = 2 benchmark")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode != 0
+    assert "--gpus 2 but this node has 1 HIP devices" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]      # no benchmark line from a refused run

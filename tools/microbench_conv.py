@@ -64,6 +64,10 @@ def main():
                 kw.update(square_in=True, gdn_mul=x)
             elif args.flags == "silu_out":
                 kw.update(silu_out=True)
+            elif args.flags == "dsilu":                       # the input-gradient launch of a ResidualBlock: * silu'(x) + dy
+                kw.update(dsilu_mul=res, res=res)
+            elif args.flags == "dsilu_only":
+                kw.update(dsilu_mul=res)
             for i in range(3):
                 ops.conv2d(x, packs[i % len(packs)], stride, **kw)
             torch.cuda.synchronize()

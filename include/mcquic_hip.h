@@ -206,6 +206,12 @@ int mcq_conv2d_wgrad_nchw_group_f32(const float* const* x, const float* const* d
                                     int32_t nconv, float* workspace, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout,
                                     void* stream);
 
+/* The 3x3 stride-2 case (ResidualBlockWithStride's convs, the 3-channel stem): X [N,Cin,H,W] with H, W even, dY
+ * [N,Cout,H/2,W/2], W/2 a multiple of 8.  The walk runs over dY's rows with a ring of four input rows. */
+size_t mcq_conv2d_wgrad_s2_nchw_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout);
+int mcq_conv2d_wgrad_s2_nchw_f32(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int32_t N, int32_t Cin,
+                                 int32_t H, int32_t W, int32_t Cout, void* stream);
+
 /* The 1x1 case (the AttentionBlock gate conv; with square_x the gamma of GDN / IGDN, whose operand is x^2,
  * mcquic/nn/gdn.py:75): dW[co][ci] = sum dY[co] * X[ci] straight from NCHW, H even, W a multiple of 8.  The workspace query
  * returns 0 for shapes this kernel does not take. */

@@ -66,6 +66,9 @@ SYMBOLS = {
     "mcq_conv2d_wgrad_nchw_max_group": (c_int32, []),
     "mcq_conv2d_wgrad_nchw_group_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
                                                   c_int32, c_int32, c_void_p]),
+    "mcq_conv2d_wgrad_s2_nchw_workspace_floats": (c_size_t, [c_int32] * 5),
+    "mcq_conv2d_wgrad_s2_nchw_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                               c_int32, c_void_p]),
     "mcq_conv2d_wgrad1x1_nchw_workspace_floats": (c_size_t, [c_int32] * 5),
     "mcq_conv2d_wgrad1x1_nchw_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                                c_int32, c_int32, c_void_p]),

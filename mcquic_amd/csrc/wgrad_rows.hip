@@ -57,14 +57,15 @@ struct WgRowsK {
 
 struct RowsPlan { int F, strips, row_chunks, rpc, units, splits, ups, groups; };
 
-inline bool rows_plan(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int taps = 9) {
-    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (W & 7) || (H & (taps == 1 ? 1 : 7))) return false;
-    if ((uint64_t)N * Cin * H * W * 4ull >= 0x40000000ull || (uint64_t)N * Cout * H * W * 4ull >= 0x40000000ull) return false;
+inline bool rows_plan(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int taps = 9, bool stride2 = false) {
+    // (H, W: the map the walk runs over = dY's; with stride2 the input is 2H x 2W)
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (W & 7) || (H & ((taps == 1 || stride2) ? 1 : 7))) return false;
+    if ((uint64_t)N * Cin * H * W * (stride2 ? 16ull : 4ull) >= 0x40000000ull || (uint64_t)N * Cout * H * W * 4ull >= 0x40000000ull) return false;
     const int tile = taps == 9 ? 32 : 64;                                    // the 1x1 kernel owns 64 x 64 tiles
     const long long tiles = (long long)((Cout + tile - 1) / tile) * ((Cin + tile - 1) / tile);
-    r.F = (W % 16 == 0 && MCQ_WGROWS_WIDE) ? 8 : 4;                           // floats per lane and row: strips of 16 / 8 pixels
+    r.F = (W % 16 == 0 && MCQ_WGROWS_WIDE && !stride2) ? 8 : 4;              // floats per lane and row: strips of 16 / 8 pixels
     r.strips = W / (2 * r.F);
-    const int rb = taps == 1 ? 2 : r.F == 4 ? 8 : 4;                          // rows per loop body (= X ring size)
+    const int rb = (taps == 1 || stride2) ? 2 : r.F == 4 ? 8 : 4;             // rows per loop body
     const long long sr = (long long)N * H * r.strips;                       // strip-rows in all
     long long splits = MCQ_WGROWS_WAVES / tiles;
     if (splits < 4) splits = 4;
@@ -321,6 +322,149 @@ __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(WgRowsReduceK p)
     const int co = (int)(r % Cout);
     const int tap = (int)(r / Cout);
     dw[((size_t)co * Cin + ci) * p.taps + tap] = s;
+}
+
+// ---- 3x3 stride-2 convolutions (ResidualBlockWithStride's two convs, the 3-channel stem) --------------------------------
+//   dW[co][ci][dy][dx] = sum dY[n][co][yo][xo] * X[n][ci][2 yo + dy - 1][2 xo + dx - 1]
+// The walk runs over dY's rows; a lane reads 4 consecutive dY pixels and, per input row, the 9 input columns 2 x0 - 1 .. 2 x0 + 7
+// they touch (two 16-byte loads + the left neighbour): tap (dy, dx) of k-step q is window register 2 q + dx of input row
+// 2 yo + dy - 1.  Output row yo + 1 re-uses input row 2 yo + 1, so two new input rows arrive per output row, in a ring of four
+// (slot = row mod 4; the slot of row 2 yo - 1 is re-filled right after the dy = 0 taps).  Only the top border is padding
+// (even H, W: row -1 and column -1), handled like in the stride-1 walk.  Same tile, LDS tree, partial layout and reduce pass.
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_rows_s2_kernel(WgRowsK p) {
+    __shared__ float red[2][80][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int kh = lane >> 5, j = lane & 31;
+    const int group = blockIdx.x;
+    const int split = group * 4 + wave;
+    const int ci_base = blockIdx.y * 32, co_base = blockIdx.z * 32;
+    const int Hi = 2 * p.H, Wi = 2 * p.W;                      // the input map
+    const __amdgpu_buffer_rsrc_t rx = mcq_make_rsrc(p.x[0], (uint32_t)((size_t)p.N * p.Cin * Hi * Wi * 4));
+    const __amdgpu_buffer_rsrc_t rd = mcq_make_rsrc(p.dy[0], (uint32_t)((size_t)p.N * p.Cout * p.H * p.W * 4));
+    const unsigned rowd = (unsigned)p.W * 4u, rowx = (unsigned)Wi * 4u;
+    const bool co_ok = co_base + j < p.Cout, ci_ok = ci_base + j < p.Cin;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float bsum = 0.0f;
+    for (int i = 0; i < p.ups; ++i) {
+        const int u = (group * p.ups + i) * 4 + wave;
+        if (u >= p.units) break;
+        const int sx = u % p.strips;
+        const int t0 = u / p.strips;
+        const int chunk = t0 % p.row_chunks, n = t0 / p.row_chunks;
+        const int y0 = chunk * p.rpc;
+        int y1 = y0 + p.rpc;
+        if (y1 > p.H) y1 = p.H;
+        const int xo0 = sx * 8 + 4 * kh;                      // this lane's first output column
+        const unsigned vA = co_ok ? (unsigned)(((n * p.Cout + co_base + j) * p.H * p.W + xo0) * 4) : MCQ_OOB;
+        const unsigned vB = ci_ok ? (unsigned)(((n * p.Cin + ci_base + j) * Hi * Wi + 2 * xo0) * 4) : MCQ_OOB;
+        const unsigned vBl = (ci_ok && xo0 > 0) ? vB - 4u : MCQ_OOB;
+        float A[2][4];
+        float Bw[4][9];
+        auto loadA = [&](int slot, int y) {
+            const f32x4v m = rows_ld4(rd, vA, (unsigned)y * rowd);
+            A[slot][0] = m[0]; A[slot][1] = m[1]; A[slot][2] = m[2]; A[slot][3] = m[3];
+        };
+        auto loadB = [&](int slot, int r) {
+            const unsigned so = (r >= 0 && r < Hi) ? (unsigned)r * rowx : ROWS_OOB_S;
+            Bw[slot][0] = mcq_buffer_load_s(rx, vBl, so);
+            const f32x4v m0 = rows_ld4(rx, vB, so), m1 = rows_ld4(rx, vB + 16u, so);
+            Bw[slot][1] = m0[0]; Bw[slot][2] = m0[1]; Bw[slot][3] = m0[2]; Bw[slot][4] = m0[3];
+            Bw[slot][5] = m1[0]; Bw[slot][6] = m1[1]; Bw[slot][7] = m1[2]; Bw[slot][8] = m1[3];
+        };
+        // y0 is even (row ranges are whole multiples of 2 rows), so input row r lives in slot r mod 4 with 2 y0 = 0 mod 4 ... only
+        // if y0 is even in units of 2: use slots relative to the walk instead: row 2 (y0 + t) + d - 1 -> slot (2 t + d + 3) mod 4
+        loadA(0, y0);
+        loadB(3, 2 * y0 - 1);
+        loadB(0, 2 * y0);
+        loadB(1, 2 * y0 + 1);
+        for (int yb = y0; yb < y1; yb += 2) {
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                const int yo = yb + uu;
+                const int s0 = uu == 0 ? 3 : 1, s1 = uu == 0 ? 0 : 2, s2 = uu == 0 ? 1 : 3;   // rows 2 yo - 1, 2 yo, 2 yo + 1
+                const int snew = uu == 0 ? 2 : 0;                                               // free: takes row 2 yo + 2
+                loadB(snew, 2 * yo + 2);
+                loadA(uu ^ 1, yo + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+                        acc[dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][q], Bw[s0][2 * q + dx], acc[dx], 0, 0, 0);
+                loadB(s0, 2 * yo + 3);                        // (the slot of row 2 yo - 1, done with)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+                        acc[3 + dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][q], Bw[s1][2 * q + dx], acc[3 + dx], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+                        acc[6 + dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][q], Bw[s2][2 * q + dx], acc[6 + dx], 0, 0, 0);
+                if (BIAS) bsum = bsum + ((A[uu][0] + A[uu][1]) + (A[uu][2] + A[uu][3]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int tb = half * 5, tn = half ? 4 : 5;
+        if (wave & 1) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                if (t < tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[wave >> 1][t * 16 + r][lane] = acc[tb + t][r];
+        }
+        __syncthreads();
+        if (!(wave & 1)) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                if (t < tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tb + t][r] = acc[tb + t][r] + red[wave >> 1][t * 16 + r][lane];
+        }
+        __syncthreads();
+        if (wave == 2) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                if (t < tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[0][t * 16 + r][lane] = acc[tb + t][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                if (t < tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tb + t][r] = acc[tb + t][r] + red[0][t * 16 + r][lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float* out = p.part + (size_t)group * 9 * p.Cout * p.Cin;
+        const int ci = ci_base + j;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + mcq_drow(r, kh);
+                if (co < p.Cout && ci < p.Cin) out[((size_t)t * p.Cout + co) * p.Cin + ci] = acc[t][r];
+            }
+    }
+    if (BIAS && blockIdx.y == 0) {
+        const float sv = bsum + __shfl_xor(bsum, 32);
+        if (kh == 0 && co_ok) p.bias_part[(size_t)split * p.Cout + co_base + j] = sv;
+    }
 }
 
 // ---- 1x1 convolutions (the AttentionBlock gate conv, GDN's gamma) ------------------------------------------------------
@@ -626,6 +770,35 @@ extern "C" int mcq_conv2d_wgrad1x1_nchw_f32(const float* x, const float* dy, flo
     }
 #undef MCQ_LAUNCH_ROWS1
     const size_t per = (size_t)Cout * Cin + (dbias ? (size_t)Cout : 0);
+    hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3((unsigned)((per + 63) / 64), 1u), dim3(256), 0, s, q);
+    return mcq_check_launch();
+}
+
+extern "C" size_t mcq_conv2d_wgrad_s2_nchw_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout) {
+    RowsPlan r;
+    if ((H & 1) || (W & 1) || !rows_plan(N, Cin, H / 2, W / 2, Cout, r, 9, true)) return 0;
+    return (size_t)r.groups * 9 * Cout * Cin + (size_t)r.groups * 4 * Cout;
+}
+
+extern "C" int mcq_conv2d_wgrad_s2_nchw_f32(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int32_t N,
+                                            int32_t Cin, int32_t H, int32_t W, int32_t Cout, void* stream) {
+    if (!x || !dy || !dw || !workspace) return MCQ_EINVAL;
+    RowsPlan r;
+    if ((H & 1) || (W & 1) || !rows_plan(N, Cin, H / 2, W / 2, Cout, r, 9, true)) return MCQ_EINVAL;
+    WgRowsK p;
+    WgRowsReduceK q;
+    for (int c = 0; c < ROWS_MAX_CONVS; ++c) { p.x[c] = x; p.dy[c] = dy; q.dw[c] = dw; q.dbias[c] = dbias; }
+    p.part = workspace;
+    p.bias_part = dbias ? workspace + (size_t)r.groups * 9 * Cout * Cin : nullptr;
+    p.nconv = 1; p.groups = r.groups;
+    p.N = N; p.Cin = Cin; p.Cout = Cout; p.H = H / 2; p.W = W / 2;          // the walk's map = dY's
+    p.strips = r.strips; p.row_chunks = r.row_chunks; p.rpc = r.rpc; p.units = r.units; p.splits = r.splits; p.ups = r.ups;
+    q.part = workspace; q.bias_part = p.bias_part; q.nconv = 1; q.groups = r.groups; q.Cout = Cout; q.Cin = Cin; q.taps = 9;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)r.groups, (unsigned)((Cin + 31) / 32), (unsigned)((Cout + 31) / 32));
+    if (dbias) hipLaunchKernelGGL(conv_wgrad_rows_s2_kernel<true>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_wgrad_rows_s2_kernel<false>, grid, dim3(256), 0, s, p);
+    const size_t per = (size_t)9 * Cout * Cin + (dbias ? (size_t)Cout : 0);
     hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3((unsigned)((per + 63) / 64), 1u), dim3(256), 0, s, q);
     return mcq_check_launch();
 }

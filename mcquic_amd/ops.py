@@ -470,6 +470,16 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
                 check(lib.mcq_conv2d_wgrad_nchw_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream()),
                       "mcq_conv2d_wgrad_nchw_f32")
             return (dw, db) if want_bias else dw
+    if ksize == 3 and stride == 2 and not square_x and _WGRAD_ROWS and (ho, wo) == (h // 2, w // 2):
+        nws = lib.mcq_conv2d_wgrad_s2_nchw_workspace_floats(n, cin, h, w, cout)
+        if nws:
+            ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+            dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+            db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+            with _guard(x.device):
+                check(lib.mcq_conv2d_wgrad_s2_nchw_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream()),
+                      "mcq_conv2d_wgrad_s2_nchw_f32")
+            return (dw, db) if want_bias else dw
     if ksize == 1 and stride == 1 and _WGRAD_ROWS:
         nws = lib.mcq_conv2d_wgrad1x1_nchw_workspace_floats(n, cin, h, w, cout)
         if nws:

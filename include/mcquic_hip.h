@@ -251,6 +251,14 @@ int mcq_detransform_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 
 /* ---- entropy coder beside the tensor path (host code, no GPU work) ------------------------------ */
 
+/* Up to mcq_pack_conv_weight_max_multi() weights of ONE shape packed in one launch: w[i] -> out[i], forward streams
+ * (`dgrad` = 0) or input-gradient streams (`dgrad` = 1, with `stride` and `scale` as in mcq_pack_conv_dgrad_weight_f32).  Layers
+ * with <= 16 output channels (they carry a second copy) are refused: pack those one by one.  After an optimizer step every
+ * convolution of the network re-packs both streams; this turns 660 launches into ~45. */
+int32_t mcq_pack_conv_weight_max_multi(void);
+int mcq_pack_conv_weight_multi_f32(const float* const* w, float* const* out, int32_t n, int32_t Cout, int32_t Cin, int32_t ksize,
+                                   int32_t dgrad, int32_t stride, float scale, void* stream);
+
 /* cdf[0..k] (uint32, cdf[0] = 0, cdf[k] = 1 << precision, strictly increasing) from pmf[0..k-1].
  * Same arithmetic as pmfToQuantizedCDF (third_party/CompressAI/cpp_exts/ops.cpp:42-111). */
 int mcq_pmf_to_quantized_cdf(const float* pmf, int32_t k, int32_t precision, uint32_t* cdf);

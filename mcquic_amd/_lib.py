@@ -37,6 +37,8 @@ SYMBOLS = {
     "mcq_pack_conv_dgrad_weight_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p]),
     "mcq_nonneg_reparam_bwd_f32": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "mcq_conv2d_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
+    "mcq_pack_conv_weight_max_multi": (c_int32, []),
+    "mcq_pack_conv_weight_multi_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "mcq_conv2d_max_multi": (c_int32, []),
     "mcq_conv2d_multi_f32": (c_int32, [POINTER(ConvDesc), c_int32, c_void_p]),
     "mcq_nonneg_reparam_f32": (c_int32, [c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),

@@ -571,9 +571,14 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
 
 // OIHW -> [Cout/(32 bands)][TP][64 lanes][bands]: lane l, slot q holds W[co = 32 bands T + 32 q + (l & 31)][ci = 2 s + (l >> 5)][tap]
 // for k-step = s * taps + tap (channel-major, tap-inner); zero beyond Cout / Cin and in the 16-step tail.
-__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, int S, int TP,
-                                        float* __restrict__ out, size_t sec4, size_t sec2, size_t total, int mode, int Co, int Ci,
-                                        float scale) {
+// up to MCQ_PACK_MAX_MULTI weights of one shape per launch (blockIdx.y picks the pair): after an optimizer step every conv of
+// the network re-packs its forward and its input-gradient operand stream -- 660 launches of ~4 us each, one by one
+constexpr int PACK_MAX_MULTI = 16;
+struct PackTable { const float* w[PACK_MAX_MULTI]; float* out[PACK_MAX_MULTI]; };
+
+__device__ __forceinline__ void pack_conv_weight_body(const float* __restrict__ w, int Cout, int Cin, int ks, int S, int TP,
+                                                      float* __restrict__ out, size_t sec4, size_t sec2, size_t total, int mode, int Co, int Ci,
+                                                      float scale) {
     // three copies back to back, `bands` = 32-row bands per tile (4 / 2 / 1 for the 128- / 64- / 32-row copies), each
     // laid out [tile][step][lane][band] and followed by its zero tail
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -596,6 +601,22 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
         if (co < Cout && ci < Cin) v = pack_source(w, mode, Co, Ci, ks, co, ci, tap) * scale;
     }
     out[at] = v;
+}
+
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, int S, int TP,
+                                        float* __restrict__ out, size_t sec4, size_t sec2, size_t total, int mode, int Co, int Ci,
+                                        float scale) {
+    pack_conv_weight_body(w, Cout, Cin, ks, S, TP, out, sec4, sec2, total, mode, Co, Ci, scale);
+}
+
+__global__ void pack_conv_weight_multi_kernel(PackTable t, int Cout, int Cin, int ks, int S, int TP, size_t sec4, size_t sec2, size_t total,
+                                              int mode, int Co, int Ci, float scale) {
+    const float* w = t.w[0];
+    float* out = t.out[0];
+#pragma unroll
+    for (int c = 1; c < PACK_MAX_MULTI; ++c)
+        if ((int)blockIdx.y == c) { w = t.w[c]; out = t.out[c]; }
+    pack_conv_weight_body(w, Cout, Cin, ks, S, TP, out, sec4, sec2, total, mode, Co, Ci, scale);
 }
 
 __global__ void nonneg_reparam_kernel(const float* __restrict__ p, float bound, float pedestal, float* __restrict__ out,
@@ -694,6 +715,32 @@ extern "C" int mcq_pack_conv_dgrad_weight_f32(const float* w, int32_t Cout, int3
         hipLaunchKernelGGL(pack_head16_kernel, dim3((unsigned)((t16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, co_d, ci_d,
                            (ci_d + 3) / 4, out + total, t16, stride == 1 ? 1 : 2, Cout, Cin, scale);
     }
+    return mcq_check_launch();
+}
+
+extern "C" int32_t mcq_pack_conv_weight_max_multi(void) { return PACK_MAX_MULTI; }
+
+extern "C" int mcq_pack_conv_weight_multi_f32(const float* const* w, float* const* out, int32_t n, int32_t Cout, int32_t Cin, int32_t ksize,
+                                              int32_t dgrad, int32_t stride, float scale, void* stream) {
+    if (!w || !out || n < 1 || n > PACK_MAX_MULTI || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return MCQ_EINVAL;
+    int32_t co = Cout, ci = Cin;
+    int mode = 0;
+    if (dgrad) {
+        if (mcq_dgrad_weight_shape(Cout, Cin, ksize, stride, &co, &ci) != MCQ_OK) return MCQ_EINVAL;
+        mode = stride == 1 ? 1 : 2;
+    }
+    if (MCQ_HEAD16 && head16_shape(co, ksize)) return MCQ_EINVAL;          // (narrow layers carry a second copy: one by one)
+    PackTable t;
+    for (int c = 0; c < PACK_MAX_MULTI; ++c) {
+        const int k = c < n ? c : 0;
+        if (!w[k] || !out[k]) return MCQ_EINVAL;
+        t.w[c] = w[k]; t.out[c] = out[k];
+    }
+    const size_t total = general_floats(co, ci, ksize);
+    const int S = pairs_padded(ci, ksize), TP = steps_padded(ci, ksize);
+    hipLaunchKernelGGL(pack_conv_weight_multi_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, t, co,
+                       ci, ksize, S, TP, section_floats(co, ci, ksize, 4), section_floats(co, ci, ksize, 2), total, mode, Cout, Cin,
+                       dgrad ? scale : 1.0f);
     return mcq_check_launch();
 }
 

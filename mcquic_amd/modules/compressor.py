@@ -147,6 +147,7 @@ class BaseCompressor(nn.Module):
             return None
         self._check(x)
         if torch.is_grad_enabled():
+            self._repackStale()
             y = self._encoder(x)                          # no padding in the training forward (compressor.py:39)
             yHat, codes, logits = self._quantizer(y, uniforms)
             return self._decoder(yHat), yHat, codes, logits
@@ -154,6 +155,16 @@ class BaseCompressor(nn.Module):
         yHat, codes, logits = self._quantizer(y, uniforms)
         xHat = self._decoder(yHat)
         return xHat, yHat, codes, logits
+
+    def _repackStale(self):
+        """After an optimizer step every convolution's operand streams are stale: refresh them in grouped launches
+        (nn.convs.Conv2d.repack_stale) before the step instead of one by one inside it."""
+        convs = self.__dict__.get("_convList")
+        if convs is None:
+            from ..nn.convs import Conv2d
+            convs = self.__dict__["_convList"] = [m for m in self.modules() if isinstance(m, Conv2d)]
+        from ..nn.convs import Conv2d
+        Conv2d.repack_stale(convs)
 
     def reAssignCodebook(self) -> torch.Tensor:
         return self._quantizer.reAssignCodebook()

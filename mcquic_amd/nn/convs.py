@@ -34,13 +34,43 @@ class Conv2d(nn.Module):
         self._packed: Optional[ops.PackedConv] = None
         self._packedKey = None
 
+    def _key(self):
+        return (ops.tensor_version(self.weight), self.weight.data_ptr(), None if self.bias is None else (ops.tensor_version(self.bias), self.bias.data_ptr()))
+
     def packed(self) -> ops.PackedConv:
         """Weights in MFMA operand order; re-packed whenever the parameters change (version / storage / device)."""
-        key = (ops.tensor_version(self.weight), self.weight.data_ptr(), None if self.bias is None else (ops.tensor_version(self.bias), self.bias.data_ptr()))
+        key = self._key()
         if self._packed is None or key != self._packedKey:
             self._packed = ops.PackedConv(self.weight, self.bias)
             self._packedKey = key
         return self._packed
+
+    @staticmethod
+    def repack_stale(convs) -> int:
+        """Bring the operand streams of all `convs` up to date in grouped launches (ops.pack_convs: up to 16 weights of one
+        shape per launch) -- what a training loop does once per step after its optimizer update instead of 2 launches + a bias
+        copy per convolution.  Forward streams for every stale conv; input-gradient streams for the stale ones that have
+        been asked for one before.  Returns the number of streams re-packed."""
+        fwd, bwd = {}, {}
+        for c in convs:
+            key = c._key()
+            if c._packed is None or key != c._packedKey:
+                fwd.setdefault((tuple(c.weight.shape), c.weight.device), []).append((c, key))
+            cache = c.__dict__.get("_dgradCache")
+            if cache is not None and cache.key is not None and cache.key != (key[0], key[1], c.stride):
+                bwd.setdefault((tuple(c.weight.shape), c.weight.device, c.stride), []).append((c, cache))
+        done = 0
+        for group in fwd.values():
+            packs = ops.pack_convs([c.weight for c, _ in group], [c.bias for c, _ in group])
+            for (c, key), pk in zip(group, packs):
+                c._packed, c._packedKey = pk, key
+            done += len(group)
+        for (_, _, stride), group in bwd.items():
+            packs = ops.pack_convs([c.weight for c, _ in group], dgrad=True, stride=stride)
+            for (c, cache), pk in zip(group, packs):
+                cache.packed, cache.key = pk, (ops.tensor_version(c.weight), c.weight.data_ptr(), stride)
+            done += len(group)
+        return done
 
     def forward(self, x: torch.Tensor, **fused) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import Optional
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -142,6 +142,50 @@ class PackedConv:
         self.bias = None
         self.cout, self.cin, self.ksize = co_d.value, ci_d.value, kh
         return self
+
+
+def pack_convs(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]] = None, *, dgrad: bool = False,
+               stride: int = 1, scale: float = 1.0) -> List[PackedConv]:
+    """PackedConv (or PackedConv.dgrad) of several weights of ONE shape in ceil(n / 16) launches
+    (mcq_pack_conv_weight_multi_f32).  The biases are referenced, not copied: this is the re-pack after an optimizer step,
+    whose caller re-packs again whenever a parameter changes."""
+    lib = _lib.load()
+    ws = [_dev(w.detach(), "weight") for w in weights]
+    if not ws:
+        return []
+    cout, cin, kh, kw = ws[0].shape
+    if any(w.shape != ws[0].shape or w.device != ws[0].device for w in ws):
+        raise ValueError("pack_convs: all weights must have one shape and one device")
+    co, ci = cout, cin
+    if dgrad:
+        co_d, ci_d = ctypes.c_int32(0), ctypes.c_int32(0)
+        if kh != kw or lib.mcq_dgrad_weight_shape(cout, cin, kh, stride, ctypes.byref(co_d), ctypes.byref(ci_d)) != 0:
+            raise NotImplementedError(f"input gradient of a {kh}x{kw} stride-{stride} convolution is not on the path")
+        co, ci = co_d.value, ci_d.value
+    if kh != kw or kh not in (1, 3):
+        raise ValueError(f"unsupported kernel size {kh}x{kw}")
+    if co <= 16 and kh == 3:                                   # narrow layers carry a second copy: one by one
+        if dgrad:
+            return [PackedConv.dgrad(w, stride, scale) for w in ws]
+        return [PackedConv(w, None if biases is None else biases[i], copy_bias=False) for i, w in enumerate(ws)]
+    floats = lib.mcq_packed_conv_weight_floats(co, ci, kh)
+    slab = torch.empty((len(ws), floats), dtype=torch.float32, device=ws[0].device)
+    cap = lib.mcq_pack_conv_weight_max_multi()
+    with _guard(ws[0].device):
+        for at in range(0, len(ws), cap):
+            n = min(cap, len(ws) - at)
+            src = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws[at:at + n]])
+            dst = (ctypes.c_void_p * n)(*[slab[at + i].data_ptr() for i in range(n)])
+            check(lib.mcq_pack_conv_weight_multi_f32(src, dst, n, cout, cin, kh, 1 if dgrad else 0, stride, float(scale), _stream()),
+                  "mcq_pack_conv_weight_multi_f32")
+    out = []
+    for i in range(len(ws)):
+        pk = PackedConv.__new__(PackedConv)
+        pk.wp = slab[i]
+        pk.bias = None if dgrad or biases is None or biases[i] is None else _dev(biases[i].detach(), "bias")
+        pk.cout, pk.cin, pk.ksize = co, ci, kh
+        out.append(pk)
+    return out
 
 
 def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = False, square_in: bool = False,

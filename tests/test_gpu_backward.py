@@ -263,3 +263,56 @@ def test_full_training_step_gradients(dev, cfg):
         if rel > worst[1]:
             worst = (name, rel)
     assert worst[1] < 2e-3, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"
+
+
+@pytest.mark.parametrize("case", [(128, 128, 3, 1, 5), (128, 128, 3, 2, 3), (128, 128, 1, 1, 17), (40, 24, 3, 1, 2), (12, 128, 3, 1, 3),
+                                  (128, 3, 3, 2, 1)])
+def test_grouped_pack_equals_single_packs(dev, case):
+    """ops.pack_convs (up to 16 weights of one shape per launch) against one PackedConv / PackedConv.dgrad per weight: the same
+    operand streams bit for bit, forward and input-gradient form (flip / transpose, sub-pixel form for stride 2)."""
+    from mcquic_amd import ops
+    cout, cin, ks, stride, n = case
+    ws = [_rand((cout, cin, ks, ks), 300 + i, 0.1).to(dev) for i in range(n)]
+    bs = [_rand((cout,), 400 + i).to(dev) if i % 2 == 0 else None for i in range(n)]
+    got = ops.pack_convs(ws, bs)
+    for i in range(n):
+        one = ops.PackedConv(ws[i], bs[i])
+        assert torch.equal(got[i].wp, one.wp), f"forward stream {i}"
+        assert (got[i].cout, got[i].cin, got[i].ksize) == (one.cout, one.cin, one.ksize)
+        assert (got[i].bias is None) == (bs[i] is None) and (bs[i] is None or torch.equal(got[i].bias, bs[i]))
+    got = ops.pack_convs(ws, dgrad=True, stride=stride, scale=1.0)
+    for i in range(n):
+        one = ops.PackedConv.dgrad(ws[i], stride)
+        assert torch.equal(got[i].wp, one.wp), f"input-gradient stream {i}"
+        assert (got[i].cout, got[i].cin, got[i].ksize, got[i].bias) == (one.cout, one.cin, one.ksize, None)
+
+
+def test_repack_stale_after_parameter_update(dev):
+    """The grouped re-pack a training step starts with (Compressor._repackStale): after an in-place update of every parameter
+    all forward streams and all input-gradient streams that had been built are fresh again, bit-equal to packing one by one,
+    and a second call finds nothing to do."""
+    from mcquic_amd import Compressor, ops
+    from mcquic_amd.nn.convs import Conv2d
+    torch.manual_seed(3)
+    model = Compressor(8, 2, [16, 8, 4]).to(dev).train()
+    x = _rand((2, 3, 64, 64), 9).to(dev)
+    model(x)[0].sum().backward()
+    convs = [m for m in model.modules() if isinstance(m, Conv2d)]
+    assert Conv2d.repack_stale(convs) == 0
+    with_dgrad = [c for c in convs if "_dgradCache" in c.__dict__]
+    assert len(with_dgrad) > len(convs) // 2
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    assert Conv2d.repack_stale(convs) == len(convs) + len(with_dgrad)
+    for c in convs:
+        fresh = ops.PackedConv(c.weight, c.bias)
+        assert c._packedKey == c._key() and torch.equal(c._packed.wp, fresh.wp)
+        assert (c.bias is None) or torch.equal(c._packed.bias, c.bias)
+    for c in with_dgrad:
+        cache = c.__dict__["_dgradCache"]
+        assert cache.key == (ops.tensor_version(c.weight), c.weight.data_ptr(), c.stride)
+        assert torch.equal(cache.packed.wp, ops.PackedConv.dgrad(c.weight, c.stride).wp)
+    assert Conv2d.repack_stale(convs) == 0
+    out = model(x)                                   # and the step after the update runs on them
+    assert torch.isfinite(out[0]).all()

@@ -44,6 +44,9 @@ extern "C" {
 #define MCQ_CONV_DSILU_MUL  0x400u /* y = acc * silu'(mul)              (backward of SiLU fused into the input-gradient conv:  */
                                    /*                                    mul = the SiLU's input; then + res as usual)           */
 #define MCQ_CONV_DUAL_SILU  0x100u /* also store silu(y) to y_silu: the next block's act1(x), computed once per element */
+#define MCQ_CONV_WINOGRAD   0x800u /* OPT-IN, not the reference's arithmetic: 3x3 stride-1 layer in the Winograd F(2, 3) form along x */
+                                   /* (2/3 of the multiplications, float32 throughout, results differ from the direct form in   */
+                                   /* the last bits); w_packed then comes from mcq_pack_conv_weight_winograd_f32                 */
 
 typedef struct mcq_conv_desc {
     const float* x;        /* [N, Cin, H, W]                                                      */
@@ -71,6 +74,15 @@ size_t mcq_packed_conv_weight_floats(int32_t Cout, int32_t Cin, int32_t ksize);
  * 16-row image-head kernel; every copy zero padded (one launch). */
 int mcq_pack_conv_weight_f32(const float* w_oihw, int32_t Cout, int32_t Cin, int32_t ksize,
                              float* w_packed, void* stream);
+
+/* OPT-IN fast path (never the default): the operand stream of a 3x3 stride-1 layer in the Winograd F(2, 3) form along x --
+ * per filter row (g0, g1, g2) the four transformed taps (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2), formed in float64
+ * and rounded once, in the same [Cout/128][Cin/2 x 12][64][4] (+ 64-row copy) order.  Used with MCQ_CONV_WINOGRAD, which
+ * needs Cout % 64 == 0, ksize 3, stride 1 and no input prologue (SILU_IN / SQUARE_IN).  mcq_conv2d_winograd_ok tells
+ * whether a geometry is taken (1) or would be refused (0). */
+size_t mcq_packed_conv_winograd_floats(int32_t Cout, int32_t Cin);
+int mcq_pack_conv_weight_winograd_f32(const float* w_oihw, int32_t Cout, int32_t Cin, float* w_packed, void* stream);
+int32_t mcq_conv2d_winograd_ok(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, uint32_t flags);
 
 /* The operand stream of a layer's INPUT-GRADIENT convolution, packed straight from the layer's own OIHW weight
  * [Cout, Cin, k, k] in one launch (what torch.autograd derives for nn.Conv2d, mcquic/nn/convs.py:77-100):

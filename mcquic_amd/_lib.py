@@ -18,6 +18,7 @@ _ERR = {MCQ_EINVAL: "MCQ_EINVAL (invalid argument)", MCQ_ELAUNCH: "MCQ_ELAUNCH (
 
 CONV_SILU_IN, CONV_SQUARE_IN, CONV_SILU_OUT, CONV_RESIDUAL = 0x1, 0x2, 0x4, 0x8
 CONV_GDN, CONV_IGDN, CONV_GATE, CONV_SHUFFLE2, CONV_DUAL_SILU, CONV_MUL, CONV_DSILU_MUL = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200, 0x400
+CONV_WINOGRAD = 0x800
 
 
 class ConvDesc(Structure):
@@ -37,6 +38,9 @@ SYMBOLS = {
     "mcq_pack_conv_dgrad_weight_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p]),
     "mcq_nonneg_reparam_bwd_f32": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "mcq_conv2d_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
+    "mcq_packed_conv_winograd_floats": (c_size_t, [c_int32, c_int32]),
+    "mcq_pack_conv_weight_winograd_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "mcq_conv2d_winograd_ok": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint32]),
     "mcq_pack_conv_weight_max_multi": (c_int32, []),
     "mcq_pack_conv_weight_multi_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "mcq_conv2d_max_multi": (c_int32, []),

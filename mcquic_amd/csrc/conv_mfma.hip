@@ -63,6 +63,12 @@
 #ifndef MCQ_HEAD16
 #define MCQ_HEAD16 1
 #endif
+#ifndef MCQ_ONLY_WINO
+#define MCQ_ONLY_WINO 0
+#endif
+#ifndef MCQ_WINO_PFB2
+#define MCQ_WINO_PFB2 48
+#endif
 #ifndef MCQ_CONV_MAX_MULTI
 #define MCQ_CONV_MAX_MULTI 4
 #endif
@@ -113,6 +119,8 @@ template <> __device__ __forceinline__ float a_elem<1>(const float& v, int) { re
 
 extern __shared__ __attribute__((aligned(16))) float mcq_lds[];
 
+#define MCQ_CLOBBER_ALL_AGPRS() asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255")
+
 // weight-ring load: 4 * MB bytes per lane from a buffer descriptor, per-lane byte offset + wave-uniform byte offset
 template <int MB> __device__ __forceinline__ typename AVec<MB>::T mcq_wload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
 template <> __device__ __forceinline__ f32x4v mcq_wload<4>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -145,9 +153,26 @@ __device__ __forceinline__ void mcq_stamp_write(unsigned long long t0, unsigned 
 #endif
 
 template <int MB, int NB, int PRO, int PFA, int PFB, int TAPS, int OCC>
-__global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
-    static_assert(TAPS == 1 ? PFA == PFB : ((9 % PFA == 0 || PFA % 9 == 0) && PFB % 9 == 0 && PFB % PFA == 0),
+__global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(ConvK p) {
+    static_assert(TAPS == 1 ? PFA == PFB : ((TAPS % PFA == 0 || PFA % TAPS == 0) && PFB % TAPS == 0 && PFB % PFA == 0),
                   "ring depths must tile the unrolled body");
+    // TAPS == 12: the Winograd F(2, 3) form of a 3x3 stride-1 convolution along x (opt-in, MCQ_CONV_WINOGRAD).  A lane owns a
+    // PAIR of horizontally adjacent output pixels; per channel pair and filter row it loads the four inputs d0..d3 under the
+    // pair (x = 2 xp - 1 .. 2 xp + 2), forms (d0 - d2, d1 + d2, d2 - d1, d1 - d3) and feeds them to four k-steps whose weights
+    // are the transformed filter row (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2): 12 k-steps per channel pair instead of
+    // 18 for the two pixels, accumulated per transform position (4 x MB tiles) and folded back to the two pixels
+    // (M0 + M1 + M2, M1 - M2 - M3) in front of the unchanged epilogue, which sees them as NB = 2 pixel blocks.
+    constexpr bool WINO = TAPS == 12;
+    static_assert(!WINO || (NB == 2 && PRO == PRO_NONE), "the Winograd form has two virtual pixel blocks and no prologue");
+    constexpr int NBG = WINO ? 1 : NB;              // pixel blocks the operand stream walks (pair blocks for WINO)
+    constexpr int NACC = WINO ? 4 : NB;             // accumulator tiles per 32-row band
+    // The 128-row Winograd instance has 4 x 4 accumulator tiles = 256 registers: the whole AGPR half of a one-wave-per-SIMD
+    // register file.  hipcc's allocator cannot work with that (it parks other values in AGPRs that do not exist and splits
+    // every tuple into VGPRs at the loop exit: 130-345 spilled dwords, scratch traffic inside the k-loop), so this instance
+    // keeps its accumulators out of the compiler's sight: tile (band mb, position t) IS a[16 (4 mb + t) : +15], written only
+    // by the inline-asm MFMAs below and read back element by element in the epilogue.  The compiler's own code stays within
+    // the VGPR half (tests/test_host_abi.py checks the disassembly: no AGPR operand outside these instructions).
+    constexpr bool WASM = WINO && MB == 4;
     MCQ_STAMP(st0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -179,7 +204,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
         wg = base + slot;
     }
     const int gw = (int)(wg << p.tiles_log2) + tile_in_wg;       // tile index along the pixel-block axis
-    const bool active = gw * NB < p.total_blocks;   // wave-uniform
+    const bool active = gw * NBG < p.total_blocks;  // wave-uniform
     if (KS == 1 && !active) return;                 // (split-K waves stay for the barriers)
     const int co_base = blockIdx.y * (32 * MB);     // first output channel of this wave
     const int hi = lane >> 5, j = lane & 31;
@@ -187,7 +212,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     const int ly = j >> p.bw_log2, lx = j & (BW - 1);
     const int BH = 32 >> p.bw_log2;
     const int HW = p.H * p.W;
-    const int pad = TAPS == 9 ? 1 : 0;
+    const int pad = TAPS == 1 ? 0 : 1;
     const unsigned plane_bytes = (unsigned)p.Cin * (unsigned)HW * 4u;
 
     // ---- geometry of the NB pixel blocks this wave owns -------------------------------------
@@ -195,10 +220,10 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     bool valid[NB];
     __amdgpu_buffer_rsrc_t rsrc[NB];
     const char* xb[NB];                             // (wave-uniform) first byte of the block's image
-    unsigned voff[NB][TAPS];                        // per-tap byte offset of this lane's pixel, or the OOB marker
+    unsigned voff[NBG][TAPS];                       // per-tap byte offset of this lane's pixel, or the OOB marker
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        int pb = gw * NB + nb;
+        int pb = WINO ? gw : gw * NB + nb;
         const bool pbv = pb < p.total_blocks;
         if (!pbv) pb = p.total_blocks - 1;
         const int per_img = p.nby * p.nbx;
@@ -208,17 +233,19 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
         const int bx = rem - by * p.nbx;
         img[nb] = n;
         yo[nb] = by * BH + ly;
-        xo[nb] = bx * BW + lx;
+        xo[nb] = WINO ? 2 * (bx * BW + lx) + nb : bx * BW + lx;
         valid[nb] = pbv && yo[nb] < p.Ho && xo[nb] < p.Wo;
         xb[nb] = reinterpret_cast<const char*>(mcq_uniform_ptr(P_x + (size_t)n * p.Cin * HW));
         rsrc[nb] = mcq_make_rsrc(xb[nb], plane_bytes);
+        if (WINO && nb > 0) continue;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
+            // (WINO: tap = 4 dy + position under the pair, x = 2 xp - 1 + position)
+            const int dy = TAPS == 9 ? tap / 3 : WINO ? tap / 4 : 0, dx = TAPS == 9 ? tap % 3 : WINO ? tap % 4 : 0;
             const int yi = yo[nb] * p.stride + dy - pad;
             const int xi = xo[nb] * p.stride + dx - pad;
             const bool inb = valid[nb] && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
-            voff[nb][tap] = inb ? (unsigned)(yi * p.W + xi + hi * HW) * 4u : MCQ_OOB;
+            voff[WINO ? 0 : nb][tap] = inb ? (unsigned)(yi * p.W + xi + hi * HW) * 4u : MCQ_OOB;
         }
     }
 
@@ -227,11 +254,11 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     // ahead of the MFMAs that consume them; activations, whose first touch of a row comes from HBM / MALL
     // (~2.5 us under load, i.e. more than the nine steps of one channel pair), run PFB steps ahead.  The loop body
     // covers U consecutive steps so that every ring slot, tap and look-ahead distance is a compile-time constant.
-    constexpr int U = TAPS == 9 ? PFB : PFA;        // 3x3: one or two channel pairs; 1x1: PFA pairs
-    constexpr int PAIRS_PER_ITER = TAPS == 9 ? U / 9 : U;
+    constexpr int U = TAPS != 1 ? PFB : PFA;        // 3x3: one or two channel pairs; 1x1: PFA pairs
+    constexpr int PAIRS_PER_ITER = TAPS != 1 ? U / TAPS : U;
     typedef typename AVec<MB>::T avec_t;
     avec_t A[PFA];
-    float B[PFB][NB];
+    float B[PFB][NBG];
     const int tile128 = co_base >> 7, q0 = (co_base & 127) >> 5;
     const int s0 = kslice * p.slice_pairs;          // first channel pair of this wave's slice
     // weights: the copy packed for this tile height, so that a wave-wide load is one dense run of 64 * MB floats
@@ -248,13 +275,20 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
     const unsigned step_bytes = 2u * (unsigned)HW * 4u;     // one channel pair further
     unsigned soff = (unsigned)s0 * step_bytes;
 
-    f32x16 acc[MB][NB];
+    f32x16 acc[MB][NACC];                           // (unused by the WASM instance)
+    if (WASM) {
+        MCQ_CLOBBER_ALL_AGPRS();                    // (tells hipcc the kernel uses a0 .. a255; nothing is emitted)
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+        for (int i = 0; i < 256; ++i) asm volatile("v_accvgpr_write_b32 a[%0], 0" :: "n"(i));
+        asm volatile("s_nop 7");
+    } else {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+            for (int nb = 0; nb < NACC; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+    }
 
     const int npairs = active ? p.slice_pairs : 0;
     if (active) {
@@ -265,23 +299,29 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
         }
 #pragma unroll
         for (int st = 0; st < PFB; ++st) {          // activations of steps 0 .. PFB-1
-            const int tap = TAPS == 9 ? st % 9 : 0;
-            const unsigned so = soff + (unsigned)(TAPS == 9 ? st / 9 : st) * step_bytes;
+            const int tap = TAPS != 1 ? st % TAPS : 0;
+            const unsigned so = soff + (unsigned)(TAPS != 1 ? st / TAPS : st) * step_bytes;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) B[st][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tap] + so);
+            for (int nb = 0; nb < NBG; ++nb) B[st][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tap] + so);
         }
     }
 
+    float Vn[4] = {0.0f, 0.0f, 0.0f, 0.0f};              // (WINO) transformed inputs of the group about to start
+    if (WINO && active) {
+        const float d0 = B[0][0], d1 = B[1 % PFB][0], d2 = B[2 % PFB][0], d3 = B[3 % PFB][0];
+        Vn[0] = d0 - d2; Vn[1] = d1 + d2; Vn[2] = d2 - d1; Vn[3] = d1 - d3;
+    }
     MCQ_STAMP(st1);
     for (int sp = 0; sp < npairs; sp += PAIRS_PER_ITER) {
         // Every VALU instruction between two MFMAs costs the matrix pipe ~10 cycles (tools/probes/mfma_issue.hip), so
         // the k-loop has none: the channel-pair offset of an activation load lives in its buffer descriptor -- one per
         // pixel block and channel pair of the body, rebuilt by the scalar unit each iteration with num_records shrunk
         // accordingly (reads past the last channel stay out of range = 0) -- and the voffset is the bare tap offset.
-        constexpr int PFBP = TAPS == 9 ? PFB / 9 : PFB;      // look-ahead in channel pairs
-        __amdgpu_buffer_rsrc_t rB[NB][PAIRS_PER_ITER];
+        constexpr int PFBP = TAPS != 1 ? PFB / TAPS : PFB;   // look-ahead in channel pairs
+        __amdgpu_buffer_rsrc_t rB[NBG][PAIRS_PER_ITER];
+        float V[4];                                          // (WINO) the transformed inputs of the current group of four steps
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NBG; ++nb)
 #pragma unroll
             for (int j = 0; j < PAIRS_PER_ITER; ++j) {
                 const unsigned off = soff + (unsigned)(PFBP + j) * step_bytes;
@@ -290,31 +330,50 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
             }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (TAPS == 9 && u > 0 && u % 9 == 0 && sp + u / 9 >= npairs) break;   // the slice ends inside the body
+            if (TAPS != 1 && u > 0 && u % TAPS == 0 && sp + u / TAPS >= npairs) break;   // the slice ends inside the body
             const int sa = u % PFA, sb = u % PFB;
-            float bv[NB];
+            float bv[NBG];
+            if (WINO) {
+                // four loads of one (channel pair, filter row) -> the B operands of four k-steps, formed one group AHEAD (during
+                // the second step of the group before): a VALU result consumed by the very next MFMA is a hazard the inline-asm
+                // MFMAs of the 128-row instance get no wait states for, and a stall for the others
+                if (u % 4 == 0) { V[0] = Vn[0]; V[1] = Vn[1]; V[2] = Vn[2]; V[3] = Vn[3]; }
+                if (u % 4 == 1) {
+                    const float d0 = B[(u + 3) % PFB][0], d1 = B[(u + 4) % PFB][0], d2 = B[(u + 5) % PFB][0], d3 = B[(u + 6) % PFB][0];
+                    Vn[0] = d0 - d2; Vn[1] = d1 + d2; Vn[2] = d2 - d1; Vn[3] = d1 - d3;
+                }
+                bv[0] = V[u % 4];
+            } else {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                float v = B[sb][nb];
-                if (PRO == PRO_SILU) v = mcq_silu(v);
-                if (PRO == PRO_SQUARE) v = v * v;
-                bv[nb] = v;
+                for (int nb = 0; nb < NBG; ++nb) {
+                    float v = B[sb][nb];
+                    if (PRO == PRO_SILU) v = mcq_silu(v);
+                    if (PRO == PRO_SQUARE) v = v * v;
+                    bv[nb] = v;
+                }
             }
             // MFMAs pixel-block major, and each activation slot refilled right after its last use: the refill of block 0
             // issues while the MFMAs of block 1 run instead of queueing behind all MB x NB of them together with the
             // other loads (+1.6 % on the large layers); over-reads past the slice are harmless (the packed weights carry a
             // zero tail, activation offsets past the last channel are out of range = 0)
-            const int tl = TAPS == 9 ? (u + PFB) % 9 : 0;                       // tap of the step being loaded
-            const int ds = TAPS == 9 ? (u + PFB) / 9 : u + PFB;                 // its channel-pair distance
+            const int tl = TAPS != 1 ? (u + PFB) % TAPS : 0;                    // tap of the step being loaded
+            const int ds = TAPS != 1 ? (u + PFB) / TAPS : u + PFB;              // its channel-pair distance
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
+            for (int nb = 0; nb < NBG; ++nb) {
+                const int at = WINO ? u % 4 : nb;            // accumulator tile: transform position / pixel block
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[sa], mb), bv[nb], acc[mb][nb], 0, 0, 0);
+                for (int mb = 0; mb < MB; ++mb) {
+                    if (WASM)
+                        asm volatile("v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, a[%2:%3]"
+                                     :: "v"(a_elem<MB>(A[sa], mb)), "v"(bv[nb]), "n"(16 * (4 * mb + at)), "n"(16 * (4 * mb + at) + 15));
+                    else
+                        acc[mb][at] =
+                            __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[sa], mb), bv[nb], acc[mb][at], 0, 0, 0);
+                }
 #if MCQ_ABLATE == 2 || MCQ_ABLATE == 4
                 asm volatile("" : "+v"(B[sb][nb]));
 #elif MCQ_ABLATE == 1
-                B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][TAPS == 9 ? 4 : 0]);
+                B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][TAPS != 1 ? 4 : 0]);
 #else
                 B[sb][nb] = mcq_buffer_load(rB[nb][ds - PFBP], voff[nb][tl]);
 #endif
@@ -332,6 +391,7 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
         soff += (unsigned)PAIRS_PER_ITER * step_bytes;
     }
 
+    if (WASM) asm volatile("s_nop 15\n\ts_nop 15");       // (the last MFMAs' results must have landed before the first v_accvgpr_read)
     MCQ_STAMP(st2);
 #if MCQ_STAMPS
     unsigned long long ph_a = 0, ph_b = 0, ph_c = 0;     // band epilogue: side loads issued / arithmetic done / stores issued
@@ -523,6 +583,23 @@ __global__ __launch_bounds__(512, OCC) void conv_mfma_kernel(ConvK p) {
 #else
         run_epilogue(true, [&](int mi, int nb, float (&v)[16]) {           // (mi, nb are constants once unrolled)
 #endif
+            if (WINO) {
+                // back from the four transform positions to the two pixels of the pair, band by band (all 4 MB tiles at
+                // once would need every accumulator in a VALU-readable register at the same time)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (WASM) {
+                        float a, b, c;
+                        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(a) : "n"(16 * (4 * mi + (nb == 0 ? 0 : 1)) + r));
+                        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(b) : "n"(16 * (4 * mi + (nb == 0 ? 1 : 2)) + r));
+                        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(c) : "n"(16 * (4 * mi + (nb == 0 ? 2 : 3)) + r));
+                        v[r] = nb == 0 ? (a + b) + c : (a - b) - c;
+                    } else
+                        v[r] = nb == 0 ? (acc[mi][0][r] + acc[mi][1][r]) + acc[mi][2 % NACC][r]
+                                       : (acc[mi][1][r] - acc[mi][2 % NACC][r]) - acc[mi][3 % NACC][r];
+                }
+                return;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = acc[mi][nb][r];
         }, 0, std::integral_constant<int, MB>{});
@@ -593,12 +670,21 @@ __device__ __forceinline__ void pack_conv_weight_body(const float* __restrict__ 
     const int tile = (int)(stepg / TP);
     const int step = (int)(stepg - (size_t)tile * TP);
     float v = 0.0f;
-    const int taps = ks * ks;
+    const int taps = mode == 3 ? 12 : ks * ks;
     if (tile < ntile && step < TP) {
         const int s = step / taps, tap = step - s * taps;
         const int co = tile * 32 * bands + 32 * q + (lane & 31);
         const int ci = 2 * s + (lane >> 5);
-        if (co < Cout && ci < Cin) v = pack_source(w, mode, Co, Ci, ks, co, ci, tap) * scale;
+        if (co < Cout && ci < Cin) {
+            if (mode == 3) {
+                // Winograd F(2, 3) along x: tap = 4 dy + position; G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]
+                const float* g = w + (((size_t)co * Cin + ci) * 3 + (tap >> 2)) * 3;
+                const double g0 = g[0], g1 = g[1], g2 = g[2];
+                const int pos = tap & 3;
+                v = (float)(pos == 0 ? g0 : pos == 1 ? 0.5 * (g0 + g1 + g2) : pos == 2 ? 0.5 * (g0 - g1 + g2) : g2);
+            } else
+                v = pack_source(w, mode, Co, Ci, ks, co, ci, tap) * scale;
+        }
     }
     out[at] = v;
 }
@@ -671,7 +757,48 @@ int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2
     return mcq_check_launch();
 }
 
+inline size_t wino_section_floats(int Cout, int Cin, int bands) {
+    const size_t ntile = (size_t)(Cout + 32 * bands - 1) / (32 * bands);
+    return (ntile * (size_t)((Cin + 1) / 2) * 12 + 16) * 64 * bands;
+}
+
+// Winograd F(2, 3) launches: one pair block (32 pairs of pixels) per wave, four waves per workgroup, no split-K
+template <int MB>
+int launch_wino(ConvK k, long long tiles, int co_tiles, hipStream_t s) {
+    constexpr int OCC = MB == 4 ? 1 : 2;                   // 4 x MB accumulator tiles: 256 registers at MB = 4
+    k.ks_log2 = 0;
+    k.slice_pairs = k.S;
+    k.tiles_log2 = 2;
+    const dim3 grid((unsigned)((tiles + 3) >> 2), (unsigned)co_tiles, (unsigned)k.nprob);
+    // activations run ~2.6 us ahead of their MFMAs (a step is MB MFMAs of 64 cycles): 24 steps at MB = 4, 48 at MB = 2
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, 2, PRO_NONE, 12, MB == 4 ? 24 : MCQ_WINO_PFB2, 12, OCC>), grid, dim3(256), 0, s, k);
+    return mcq_check_launch();
+}
+
+bool wino_shape(int Cout, int ksize, int stride, unsigned fl) {
+    return ksize == 3 && stride == 1 && Cout % 64 == 0 && !(fl & (MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN));
+}
+
 }  // namespace
+
+extern "C" size_t mcq_packed_conv_winograd_floats(int32_t Cout, int32_t Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return wino_section_floats(Cout, Cin, 4) + wino_section_floats(Cout, Cin, 2);
+}
+
+extern "C" int mcq_pack_conv_weight_winograd_f32(const float* w, int32_t Cout, int32_t Cin, float* out, void* stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0) return MCQ_EINVAL;
+    const size_t sec4 = wino_section_floats(Cout, Cin, 4), sec2 = wino_section_floats(Cout, Cin, 2), total = sec4 + sec2;
+    const int S = (Cin + 1) / 2, TP = S * 12;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
+                       3, S, TP, out, sec4, sec2, total, 3, Cout, Cin, 1.0f);
+    return mcq_check_launch();
+}
+
+extern "C" int32_t mcq_conv2d_winograd_ok(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride,
+                                          uint32_t flags) {
+    return (N > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && wino_shape(Cout, ksize, stride, flags)) ? 1 : 0;
+}
 
 extern "C" size_t mcq_packed_conv_weight_floats(int32_t Cout, int32_t Cin, int32_t ksize) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
@@ -764,7 +891,7 @@ int conv_validate(const mcq_conv_desc* d) {
     if ((fl & MCQ_CONV_DUAL_SILU) && (!d->y_silu || (fl & MCQ_CONV_SILU_OUT))) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_SILU_IN) && (fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;
     if (fl & MCQ_CONV_SHUFFLE2) {
-        if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN))) return MCQ_EINVAL;
+        if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN | MCQ_CONV_WINOGRAD))) return MCQ_EINVAL;
     }
     // one image's input slab plus the prefetch rings' over-read (up to 8 channels) must stay below 2 GiB: byte offsets and
     // the descriptors' shrinking num_records are 32-bit (signed in the scalar arithmetic of the k-loop)
@@ -796,6 +923,39 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         a.wp64 = a.wp + section_floats(d->Cout, d->Cin, d->ksize, 4);
         a.wp32 = a.wp64 + section_floats(d->Cout, d->Cin, d->ksize, 2);
         a.bias = e->bias; a.y = e->y; a.y2 = e->y_silu; a.res = e->res; a.mul = e->mul; a.gid = e->gate_id;
+    }
+
+    if (fl & MCQ_CONV_WINOGRAD) {
+        if (!wino_shape(d->Cout, d->ksize, d->stride, fl)) return MCQ_EINVAL;
+        if ((uint64_t)(d->Cin + 16) * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;     // (rings up to 8 channel pairs ahead)
+        const int forced_mb = (d->tile & 0xff) >> 4;
+        const int MBw = forced_mb == 2 || d->Cout % 128 != 0 ? 2 : 4;
+        k.TP = k.S * 12;
+        k.wp64 = k.wp + wino_section_floats(d->Cout, d->Cin, 4);
+        k.wp32 = k.wp64;
+        for (int c = 1; c < MCQ_CONV_MAX_MULTI; ++c) {
+            k.alt[c - 1].wp64 = k.alt[c - 1].wp + wino_section_floats(d->Cout, d->Cin, 4);
+            k.alt[c - 1].wp32 = k.alt[c - 1].wp64;
+        }
+        // pair blocks: 32 pairs shaped (32 >> b) rows x (1 << b) pairs, b by the fewest wasted lanes
+        const int Wp = (k.Wo + 1) / 2;
+        int best_log2 = 5; double best_util = -1.0;
+        for (int lg = 5; lg >= 2; --lg) {
+            const int bw = 1 << lg, bh = 32 >> lg;
+            const double cover = (double)((k.Ho + bh - 1) / bh * bh) * (double)((Wp + bw - 1) / bw * bw);
+            const double util = (double)k.Ho * Wp / cover;
+            if (util > best_util + 1e-9) { best_util = util; best_log2 = lg; }
+        }
+        k.bw_log2 = best_log2;
+        k.nbx = (Wp + (1 << best_log2) - 1) >> best_log2;
+        k.nby = (k.Ho + (32 >> best_log2) - 1) / (32 >> best_log2);
+        const long long tbw = (long long)k.N * k.nbx * k.nby;
+        if (tbw > 0x7fffffffLL) return MCQ_ETOOLARGE;
+        k.total_blocks = (int)tbw;
+        const int co_tiles = (d->Cout + 32 * MBw - 1) / (32 * MBw);
+        if ((uint64_t)co_tiles * 32u * (unsigned)MBw * (uint64_t)k.Ho * k.Wo * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
+        k.flags = fl & ~(unsigned)MCQ_CONV_WINOGRAD;
+        return MBw == 4 ? launch_wino<4>(k, tbw, co_tiles, (hipStream_t)stream) : launch_wino<2>(k, tbw, co_tiles, (hipStream_t)stream);
     }
 
     // <= 16 output channels, 3x3, stride 1, nothing but bias / PixelShuffle in the epilogue: the 16-row MFMA kernel
@@ -880,6 +1040,9 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     // rows of the last cout tile included
     if ((uint64_t)co_tiles * 32u * (unsigned)MB * (uint64_t)k.Ho * k.Wo * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
     hipStream_t s = (hipStream_t)stream;
+#if MCQ_ONLY_WINO          // (tuning aid: compile the Winograd instances alone)
+    return MCQ_EINVAL;
+#else
     if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42A, MCQ_PF42B, 4>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 2) return launch_tile<2, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
@@ -888,6 +1051,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     if (MB == 1 && NB == 2) return launch_tile<1, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 1 && NB == 1) return launch_tile<1, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
     return MCQ_EINVAL;
+#endif
 }
 
 }  // namespace

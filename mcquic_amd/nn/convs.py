@@ -35,7 +35,8 @@ class Conv2d(nn.Module):
         self._packedKey = None
 
     def _key(self):
-        return (ops.tensor_version(self.weight), self.weight.data_ptr(), None if self.bias is None else (ops.tensor_version(self.bias), self.bias.data_ptr()))
+        return (ops.tensor_version(self.weight), self.weight.data_ptr(), None if self.bias is None else (ops.tensor_version(self.bias), self.bias.data_ptr()),
+                ops.winograd_enabled())
 
     def packed(self) -> ops.PackedConv:
         """Weights in MFMA operand order; re-packed whenever the parameters change (version / storage / device)."""

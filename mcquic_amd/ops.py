@@ -14,7 +14,23 @@ import torch
 
 from . import _lib
 from ._lib import (CONV_DSILU_MUL, CONV_DUAL_SILU, CONV_MUL, CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN,
-                   CONV_SILU_OUT, CONV_SQUARE_IN, ConvDesc, check)
+                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, ConvDesc, check)
+
+# OPT-IN fast path, never the default and never the headline bench: large 3x3 stride-1 layers in the Winograd F(2, 3) form
+# along x (mcq_pack_conv_weight_winograd_f32 + MCQ_CONV_WINOGRAD): 2/3 of the multiplications, float32 throughout, but not
+# the reference's arithmetic -- results differ from the direct form in the last bits, so near-tie code indices may move.
+_WINOGRAD = os.environ.get("MCQUIC_AMD_WINOGRAD", "0") == "1"
+_WINOGRAD_MIN_PIXELS = int(os.environ.get("MCQUIC_AMD_WINOGRAD_MIN_PIXELS", str(128 * 1024)))   # N*H*W below this: direct form
+
+
+def winograd_enabled() -> bool:
+    return _WINOGRAD
+
+
+def set_winograd(enabled: bool) -> None:
+    """Switch the opt-in Winograd path on / off for convolutions packed from now on (nn.Conv2d re-packs on the change)."""
+    global _WINOGRAD
+    _WINOGRAD = bool(enabled)
 
 # A producer asked for `dual_silu` hangs silu(y) on its result under this attribute; a consumer asked for
 # `silu_in` uses the twin instead of re-evaluating SiLU inside its k-loop (9 taps x 2 half-waves times per
@@ -107,9 +123,9 @@ def _ptr(t: Optional[torch.Tensor]):
 class PackedConv:
     """A conv weight re-laid for the MFMA operand stream (+ its bias), see mcq_pack_conv_weight_f32."""
 
-    __slots__ = ("wp", "bias", "cout", "cin", "ksize")
+    __slots__ = ("wp", "bias", "cout", "cin", "ksize", "wino")
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], copy_bias: bool = True):
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], copy_bias: bool = True, winograd: Optional[bool] = None):
         weight = _dev(weight.detach(), "weight")
         cout, cin, kh, kw = weight.shape
         if kh != kw or kh not in (1, 3):
@@ -122,6 +138,12 @@ class PackedConv:
         # (the copy decouples the pack from later in-place updates of the parameter; a caller that hands over a fresh tensor skips it)
         self.bias = None if bias is None else (_dev(bias.detach(), "bias").clone() if copy_bias else _dev(bias.detach(), "bias"))
         self.cout, self.cin, self.ksize = cout, cin, kh
+        self.wino = None
+        if (winograd if winograd is not None else _WINOGRAD) and kh == 3 and cout % 64 == 0:
+            self.wino = torch.empty(lib.mcq_packed_conv_winograd_floats(cout, cin), dtype=torch.float32, device=weight.device)
+            with _guard(weight.device):
+                check(lib.mcq_pack_conv_weight_winograd_f32(_ptr(weight), cout, cin, _ptr(self.wino), _stream()),
+                      "mcq_pack_conv_weight_winograd_f32")
 
     @classmethod
     def dgrad(cls, weight: torch.Tensor, stride: int, scale: float = 1.0) -> "PackedConv":
@@ -141,6 +163,7 @@ class PackedConv:
                   "mcq_pack_conv_dgrad_weight_f32")
         self.bias = None
         self.cout, self.cin, self.ksize = co_d.value, ci_d.value, kh
+        self.wino = None
         return self
 
 
@@ -184,6 +207,7 @@ def pack_convs(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Option
         pk.wp = slab[i]
         pk.bias = None if dgrad or biases is None or biases[i] is None else _dev(biases[i].detach(), "bias")
         pk.cout, pk.cin, pk.ksize = co, ci, kh
+        pk.wino = None
         out.append(pk)
     return out
 
@@ -193,7 +217,7 @@ def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool
                gdn_mul: Optional[torch.Tensor] = None, igdn_mul: Optional[torch.Tensor] = None,
                gate_mul: Optional[torch.Tensor] = None, gate_id: Optional[torch.Tensor] = None,
                mul: Optional[torch.Tensor] = None, dsilu_mul: Optional[torch.Tensor] = None, shuffle2: bool = False,
-               dual_silu: bool = False, tile: int = 0):
+               dual_silu: bool = False, tile: int = 0, winograd: Optional[bool] = None):
     """(mcq_conv_desc, y, y_silu or None, tensors the descriptor points at) for one fused conv launch."""
     if silu_in:
         twin = silu_twin(x)
@@ -239,7 +263,15 @@ def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool
         gate_id = _dev(gate_id, "gate_id")
         if gate_id.shape != y.shape:
             raise ValueError("gate identity shape mismatch")
-    d = ConvDesc(_ptr(x), _ptr(w.wp), _ptr(w.bias), _ptr(y), _ptr(y2), _ptr(res), _ptr(mul), _ptr(gate_id),
+    wp = w.wp
+    if winograd or (winograd is None and _WINOGRAD and n * h * wd >= _WINOGRAD_MIN_PIXELS):
+        ok = w.wino is not None and stride == 1 and not (flags & (CONV_SILU_IN | CONV_SQUARE_IN))
+        if ok:
+            flags |= CONV_WINOGRAD
+            wp = w.wino
+        elif winograd:
+            raise ValueError("winograd=True needs a 3x3 stride-1 layer with Cout % 64 == 0, packed with winograd=True, and no input prologue")
+    d = ConvDesc(_ptr(x), _ptr(wp), _ptr(w.bias), _ptr(y), _ptr(y2), _ptr(res), _ptr(mul), _ptr(gate_id),
                  n, cin, h, wd, w.cout, w.ksize, stride, flags, float(res_scale), tile)
     return d, y, y2, (x, res, mul, gate_id)
 

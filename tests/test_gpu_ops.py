@@ -407,3 +407,53 @@ def test_silu_accuracy(dev):
     serr = _ulp_err(sg, torch.sigmoid(x.double()))[inrange]
     assert serr.max().item() <= 3.5, serr.max().item()
     assert serr.mean().item() <= 0.40
+
+
+WINO_CASES = [  # n, cin, cout, h, w
+    (2, 128, 128, 12, 16), (1, 128, 128, 9, 7), (1, 64, 128, 33, 65), (2, 128, 64, 10, 6), (1, 128, 512, 8, 12),
+    (1, 6, 128, 5, 1), (1, 128, 192, 1, 9), (3, 130, 128, 16, 64),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+@pytest.mark.parametrize("tile", [0, 0x22])
+def test_conv_winograd_opt_in(dev, case, tile):
+    """The opt-in Winograd F(2, 3) form of a 3x3 stride-1 layer (MCQ_CONV_WINOGRAD) against F.conv2d on the CPU: float32
+    throughout, 2/3 of the multiplications; looser than the direct form's 2e-6 because the transformed operands are sums /
+    differences of inputs and the result a difference of partial sums.  Odd widths, one-pixel maps, odd channel counts,
+    128- and 64-row tiles (tile 0x22 forces the 64-row one)."""
+    from mcquic_amd import ops
+    n, cin, cout, h, w = case
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, 3, 3), 2, 1.0 / np.sqrt(cin * 9))
+    b = _rand((cout,), 3, 0.1)
+    want = F.conv2d(x, wt, b, padding=1)
+    pk = ops.PackedConv(wt.to(dev), b.to(dev), winograd=True)
+    assert pk.wino is not None
+    got = ops.conv2d(x.to(dev), pk, tile=tile, winograd=True)
+    _close(got, want, 1e-5, f"winograd conv{case}")
+    direct = ops.conv2d(x.to(dev), pk, winograd=False)
+    assert not torch.equal(direct, got) or h * w == 1        # (it IS a different arithmetic)
+    _close(direct, want, 2e-6, f"direct conv{case}")
+
+
+def test_conv_winograd_epilogues(dev):
+    """Same fused epilogues as the direct form: residual + SiLU twin, SiLU out, PixelShuffle store; and the refusals."""
+    from mcquic_amd import ops
+    x = _rand((2, 128, 14, 22), 5)
+    wt = _rand((128, 128, 3, 3), 6, 0.03)
+    b = _rand((128,), 7, 0.1)
+    res = _rand((2, 128, 14, 22), 8)
+    pk = ops.PackedConv(wt.to(dev), b.to(dev), winograd=True)
+    y = F.conv2d(x, wt, b, padding=1)
+    got = ops.conv2d(x.to(dev), pk, res=res.to(dev), dual_silu=True, winograd=True)
+    _close(got, y + res, 1e-5, "res")
+    _close(ops.silu_twin(got), F.silu(y + res), 1e-5, "twin")
+    _close(ops.conv2d(x.to(dev), pk, silu_out=True, winograd=True), F.silu(y), 1e-5, "silu_out")
+    _close(ops.conv2d(x.to(dev), pk, shuffle2=True, winograd=True), F.pixel_shuffle(y, 2), 1e-5, "shuffle2")
+    with pytest.raises(ValueError):
+        ops.conv2d(x.to(dev), pk, silu_in=True, winograd=True)          # no input prologue in this form
+    with pytest.raises(ValueError):
+        ops.conv2d(x.to(dev), ops.PackedConv(wt.to(dev), b.to(dev), winograd=False), winograd=True)
+    with pytest.raises(ValueError):
+        ops.conv2d(x.to(dev), pk, 2, winograd=True)                     # stride 2

@@ -205,6 +205,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="images in the CPU-oracle sample (SURVEY 8(d): batch 4)")
     ap.add_argument("--graphs", action="store_true", help="replay encode/decode as captured hipGraphs (small-batch latency)")
+    ap.add_argument("--winograd", action="store_true",
+                    help="OPT-IN experiment, never the headline: large 3x3 stride-1 layers in the Winograd F(2, 3) form (not the reference's arithmetic)")
     args = ap.parse_args()
 
     from mcquic_amd import launch
@@ -228,7 +230,9 @@ def main():
         if rccl_world != world or dist.get_world_size() != world:
             raise SystemExit(f"bench.py: RCCL spans {rccl_world} ranks, expected {world}")
 
-    from mcquic_amd import Compressor
+    from mcquic_amd import Compressor, ops
+    if args.winograd:
+        ops.set_winograd(True)
     torch.manual_seed(3407)                                   # same random-init weights on every rank
     model = Compressor(**MODEL).eval().to(dev)
     if args.graphs:
@@ -278,6 +282,9 @@ def main():
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (uniform [-1,1) images, random-init weights)",
+            "arithmetic": ("OPT-IN winograd F(2,3) along x for the 3x3 stride-1 layers of >= 128 k pixels (float32, 2/3 of the multiplications; "
+                           "NOT the reference's arithmetic -- roofline.achieved counts the direct form's FLOPs and is an equivalent rate here)")
+                          if args.winograd else "direct form, exact fp32 MFMA (the reference's arithmetic)",
             "rccl_world": rccl_world, "rank0_cores": None if cores is None else len(cores),
             "config": {"workload": f"qp=2 reference model Compressor(128, 2, [8192, 2048, 512]), batch={args.batch} "
                                    f"768x512 random images per GPU, encode+decode tensor path (BASELINE configs[1])",

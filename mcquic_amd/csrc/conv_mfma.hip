@@ -63,6 +63,9 @@
 #ifndef MCQ_HEAD16
 #define MCQ_HEAD16 1
 #endif
+#ifndef MCQ_WINO_STAGGER
+#define MCQ_WINO_STAGGER 2          // s_sleep 127 (~3.4 us) units per phase step; 0 = off
+#endif
 #ifndef MCQ_ONLY_WINO
 #define MCQ_ONLY_WINO 0
 #endif
@@ -203,6 +206,16 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
         const unsigned base = xcd * (nwg >> 3) + (xcd < (nwg & 7u) ? xcd : (nwg & 7u));      // workgroups of the XCDs before this one
         wg = base + slot;
     }
+#if MCQ_WINO_STAGGER
+    if (WASM && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 256u && gridDim.x >= 512u) {
+        // One wave per SIMD and identical tiles: the whole chip would run k-loop, then epilogue, in lock step -- every round
+        // ends in one burst of side loads and stores from all 256 CUs at once, which HBM serves in ~19 us while the matrix
+        // pipes wait (16 % of a launch).  The workgroups of the FIRST round start 0 .. 3 quarter-bursts late, so the CUs stay
+        // in four phases for the rest of the launch and the epilogues of one phase overlap the k-loops of the others.
+        const unsigned phase = (blockIdx.x >> 3) & 3u;
+        for (unsigned i = 0; i < phase * MCQ_WINO_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int gw = (int)(wg << p.tiles_log2) + tile_in_wg;       // tile index along the pixel-block axis
     const bool active = gw * NBG < p.total_blocks;  // wave-uniform
     if (KS == 1 && !active) return;                 // (split-K waves stay for the barriers)
@@ -575,6 +588,97 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
             epilogue(std::integral_constant<unsigned, RUNTIME_FLAGS>{}, tile_active, get_acc, mb_first, mb_count);
     };
 
+    if constexpr (WASM) {
+        // Epilogue of the 128-row Winograd instance for the flag sets of the network's 3x3 layers (plain, SiLU, residual,
+        // residual + SiLU twin); anything else (PixelShuffle store, ...) takes the generic path below.  One wave per SIMD:
+        // nothing else hides the latency of the side loads, so ALL of them (bias and residual of the four bands: 64 + 128
+        // registers, the operand rings are dead by now) are issued before the first band is finished.  With an even width
+        // the two pixels of a lane's pair are 8 adjacent, 8-byte aligned bytes of every output-shaped tensor: one 64-bit
+        // access per row instead of two 32-bit ones at a stride of 8 bytes.
+        const unsigned ef = fl & ~(unsigned)(MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN);
+        constexpr unsigned SIMPLE_W = MCQ_CONV_SILU_OUT | MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU;
+        auto wasm_epilogue = [&](auto tag) __attribute__((always_inline)) {
+            constexpr unsigned EF = decltype(tag)::value;
+            const size_t slab = (size_t)img[0] * p.Cout * HoWo;
+            const __amdgpu_buffer_rsrc_t yr = mcq_make_rsrc(mcq_uniform_ptr(P_y + slab), slab_bytes);
+            const __amdgpu_buffer_rsrc_t y2r = mcq_make_rsrc(mcq_uniform_ptr((EF & MCQ_CONV_DUAL_SILU) ? P_y2 + slab : P_y + slab), slab_bytes);
+            const __amdgpu_buffer_rsrc_t rr = mcq_make_rsrc(mcq_uniform_ptr((EF & MCQ_CONV_RESIDUAL) ? P_res + slab : P_y + slab), slab_bytes);
+            const __amdgpu_buffer_rsrc_t br = mcq_make_rsrc(mcq_uniform_ptr(P_bias ? P_bias : P_wp), P_bias ? (unsigned)p.Cout * 4u : 0u);
+            unsigned pvo[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                pvo[nb] = valid[nb] ? ((unsigned)(yo[nb] * p.Wo + xo[nb]) + 4u * (unsigned)hi * HoWo) * 4u : MCQ_OOB;
+            const bool wide = (p.Wo & 1) == 0;                  // (wave-uniform)
+            float ball[MB][16];
+            f32x2v rall[MB][16];
+            // side loads run two bands ahead of the band being finished (all four at once would leave the compiler short of
+            // VGPRs, and it must not touch an AGPR here)
+            auto side_loads = [&](const int mb) __attribute__((always_inline)) {
+                const unsigned co_row0 = (unsigned)(co_base + mb * 32);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ball[mb][r] = mcq_buffer_load_s(br, (unsigned)hi * 16u, (co_row0 + (unsigned)mcq_drow(r, 0)) * 4u);
+                if (EF & MCQ_CONV_RESIDUAL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned so = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
+                        if (wide) rall[mb][r] = mcq_buffer_load2_s(rr, pvo[0], so);
+                        else rall[mb][r] = f32x2v{mcq_buffer_load_s(rr, pvo[0], so), mcq_buffer_load_s(rr, pvo[1], so)};
+                    }
+                }
+            };
+            side_loads(0);
+            side_loads(1);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (mb + 2 < MB) side_loads(mb + 2);
+                const unsigned co_row0 = (unsigned)(co_base + mb * 32);
+                float v[2][16], t[2][16];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float a, b, c;                            // back from the four transform positions to the pixel
+                        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(a) : "n"(16 * (4 * mb + (nb == 0 ? 0 : 1)) + r));
+                        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(b) : "n"(16 * (4 * mb + (nb == 0 ? 1 : 2)) + r));
+                        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(c) : "n"(16 * (4 * mb + (nb == 0 ? 2 : 3)) + r));
+                        float y = (nb == 0 ? (a + b) + c : (a - b) - c) + ball[mb][r];
+                        if (EF & MCQ_CONV_RESIDUAL) y = y + p.res_scale * rall[mb][r][nb];
+                        if (EF & MCQ_CONV_SILU_OUT) y = mcq_silu(y);
+                        v[nb][r] = y;
+                        if (EF & MCQ_CONV_DUAL_SILU) t[nb][r] = mcq_silu(y);
+                    }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned so = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
+                    if (wide) {
+                        mcq_buffer_store2_s(f32x2v{v[0][r], v[1][r]}, yr, pvo[0], so);
+                        if (EF & MCQ_CONV_DUAL_SILU) mcq_buffer_store2_s(f32x2v{t[0][r], t[1][r]}, y2r, pvo[0], so);
+                    } else {
+                        mcq_buffer_store_s(v[0][r], yr, pvo[0], so);
+                        mcq_buffer_store_s(v[1][r], yr, pvo[1], so);
+                        if (EF & MCQ_CONV_DUAL_SILU) {
+                            mcq_buffer_store_s(t[0][r], y2r, pvo[0], so);
+                            mcq_buffer_store_s(t[1][r], y2r, pvo[1], so);
+                        }
+                    }
+                }
+            }
+        };
+        if ((ef & ~SIMPLE_W) == 0u) {
+            if (ef == (MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU)) wasm_epilogue(std::integral_constant<unsigned, MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU>{});
+            else if (ef == MCQ_CONV_SILU_OUT) wasm_epilogue(std::integral_constant<unsigned, MCQ_CONV_SILU_OUT>{});
+            else if (ef == 0u) wasm_epilogue(std::integral_constant<unsigned, 0u>{});
+            else if (ef == MCQ_CONV_RESIDUAL) wasm_epilogue(std::integral_constant<unsigned, MCQ_CONV_RESIDUAL>{});
+            else if (ef == MCQ_CONV_DUAL_SILU) wasm_epilogue(std::integral_constant<unsigned, MCQ_CONV_DUAL_SILU>{});
+            else wasm_epilogue(std::integral_constant<unsigned, MCQ_CONV_RESIDUAL | MCQ_CONV_SILU_OUT>{});
+#if MCQ_STAMPS
+            { MCQ_STAMP(st3); mcq_stamp_write(st0, st1, st2, st3, 0, 0, 0); }
+#endif
+            return;
+        }
+    }
     if (KS == 1) {
 #if MCQ_ABLATE_EPI
         float keep = 0.0f;

@@ -85,6 +85,9 @@ __device__ __forceinline__ void mcq_buffer_store_s(float v, __amdgpu_buffer_rsrc
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, (int)voff, (int)soff, 0);
 }
 typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2v mcq_buffer_load2_s(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
 __device__ __forceinline__ void mcq_buffer_store2_s(f32x2v v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), r, (int)voff, (int)soff, 0);
 }

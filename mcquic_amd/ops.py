@@ -27,10 +27,13 @@ def winograd_enabled() -> bool:
     return _WINOGRAD
 
 
-def set_winograd(enabled: bool) -> None:
-    """Switch the opt-in Winograd path on / off for convolutions packed from now on (nn.Conv2d re-packs on the change)."""
-    global _WINOGRAD
+def set_winograd(enabled: bool, min_pixels: Optional[int] = None) -> None:
+    """Switch the opt-in Winograd path on / off for convolutions packed from now on (nn.Conv2d re-packs on the change);
+    `min_pixels`: layers with fewer than N*H*W input pixels keep the direct form (default 128 k)."""
+    global _WINOGRAD, _WINOGRAD_MIN_PIXELS
     _WINOGRAD = bool(enabled)
+    if min_pixels is not None:
+        _WINOGRAD_MIN_PIXELS = int(min_pixels)
 
 # A producer asked for `dual_silu` hangs silu(y) on its result under this attribute; a consumer asked for
 # `silu_in` uses the twin instead of re-evaluating SiLU inside its k-loop (9 taps x 2 half-waves times per

@@ -74,6 +74,31 @@ def test_qp2_model_eight_kodak_images_exact(dev):
     assert mism == 0, f"{mism} code mismatches"
 
 
+def test_qp2_model_winograd_opt_in(dev):
+    """The OPT-IN Winograd F(2, 3) path (ops.set_winograd; never the default): three 768x512 images through the qp=2 model
+    under the same near-tie protocol and the same 1e-4 pixel bar as the direct form -- every 3x3 stride-1 layer with 64 k
+    pixels or more takes the Winograd kernel (128-row instance; 96x64 ... 384x256 maps), the rest the direct one."""
+    from mcquic_amd import ops
+    ops.set_winograd(True, min_pixels=3 * 96 * 64)
+    try:
+        launches = {"n": 0}
+        real = ops._lib.load().mcq_conv2d_f32
+
+        def counting(desc, stream):
+            launches["n"] += bool(desc._obj.flags & ops.CONV_WINOGRAD)
+            return real(desc, stream)
+        lib = ops._lib.load()
+        lib.mcq_conv2d_f32 = counting
+        try:
+            mism, err = _compare(dev, 128, 2, [8192, 2048, 512], n=3, h=768, w=512, seed=5, pix_tol=1e-4)
+        finally:
+            lib.mcq_conv2d_f32 = real
+        assert launches["n"] >= 30, f"only {launches['n']} convolutions took the Winograd kernel"
+        assert mism <= 1
+    finally:
+        ops.set_winograd(False, min_pixels=128 * 1024)
+
+
 def test_encode_is_batch_invariant(dev):
     from mcquic_amd import Compressor
     sd = R.make_state_dict(128, 2, [8192, 2048, 512], seed=0)

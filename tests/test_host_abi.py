@@ -153,3 +153,40 @@ def test_wgrad_rows_kernel_declines_other_shapes():
     assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(8, 128, 4, 4, 128) == 1        # small map: the LDS kernel, no workspace
     assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(64, 128, 256, 256, 128) == 0   # a tensor of 2 GiB
     assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(8, 128, 16, 16, 128) > 0
+
+
+def test_winograd_instance_keeps_its_accumulators_to_itself():
+    """The 128-row Winograd instance of conv_mfma_kernel (opt-in path) addresses its 256 accumulator registers a0..a255 by
+    NUMBER from inline asm (csrc/conv_mfma.hip, `WASM`): correct only while the compiler's own code never touches an AGPR
+    and never spills.  Checked on the disassembly of the built object: in that kernel every AGPR operand belongs to one of
+    the three hand-written instruction forms, and there is no scratch access."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "mcquic_amd", "_obj", "conv_mfma.o")
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("needs the built object mcquic_amd/_obj/conv_mfma.o and the ROCm llvm tools")
+    tmp = tempfile.mkdtemp()
+    try:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", obj, os.path.join(tmp, "copy.o")], check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        asm = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    body, inside = [], False
+    for line in asm.splitlines():
+        if line.endswith(">:"):
+            inside = "conv_mfma_kernelILi4ELi2ELi0ELi12E" in line
+        elif inside:
+            body.append(line.split("//")[0])
+    assert len(body) > 1000, "Winograd instance not found in the device code"
+    ok = re.compile(r"^\s*(v_mfma_f32_32x32x2_f32 a\[\d+:\d+\], v\d+, v\d+, a\[\d+:\d+\]|v_accvgpr_read_b32 v\d+, a\d+|v_accvgpr_write_b32 a\d+, 0)\s*$")
+    agpr = [ln for ln in body if re.search(r"\ba(\d+|\[\d+:\d+\])", ln)]
+    assert len(agpr) >= 96 + 256 + 128 * 3
+    stray = [ln for ln in agpr if not ok.match(ln)]
+    assert not stray, f"compiler-generated AGPR use in the Winograd instance: {stray[:3]}"
+    assert not [ln for ln in body if "scratch_" in ln], "the Winograd instance spills"

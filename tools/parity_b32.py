@@ -23,8 +23,11 @@ def main():
     ap.add_argument("--images", type=int, default=32)
     ap.add_argument("--chunk", type=int, default=4)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_b32.json"))
+    ap.add_argument("--winograd", action="store_true", help="audit the OPT-IN Winograd F(2, 3) path instead of the default direct form")
     a = ap.parse_args()
-    from mcquic_amd import Compressor
+    from mcquic_amd import Compressor, ops
+    if a.winograd:
+        ops.set_winograd(True)
     from oracle import mcquic_ref as R
     dev = torch.device("cuda:0")
     ks = [8192, 2048, 512]
@@ -60,7 +63,8 @@ def main():
         rec_gpu = model.decode([c.to(dev) for c in want]).cpu()  # pixels from the ORACLE's codes
         pix_err = max(pix_err, float((rec_gpu - rec_cpu).abs().max()))
         psnr_min = min(psnr_min, float(R.psnr(R.detransform(rec_gpu), R.detransform(rec_cpu)).min()))
-    rec = {"workload": f"qp=2 model, {a.images} x 3 x 768 x 512, seed 3407 (BASELINE configs[1])",
+    rec = {"arithmetic": "OPT-IN winograd F(2,3) on the large 3x3 stride-1 layers" if a.winograd else "direct form (default)",
+           "workload": f"qp=2 model, {a.images} x 3 x 768 x 512, seed 3407 (BASELINE configs[1])",
            "codes_per_level": total, "first_flips_per_level": mism, "first_flips": sum(mism),
            "worst_oracle_gap_at_a_first_flip": worst_gap, "downstream_differences_per_level": downstream,
            "note": "a first flip = a code that differs although all codes upstream of it agree; excused only if the oracle's own "

@@ -29,9 +29,11 @@ def main():
     for (n, cin, cout, h, w) in shapes:
         x = torch.randn(n, cin, h, w, device=dev)
         res = torch.randn(n, cout, h, w, device=dev)
-        packs = [ops.PackedConv(torch.randn(cout, cin, 3, 3, device=dev) * 0.03, torch.randn(cout, device=dev)) for _ in range(3)]
+        wino = os.environ.get("PROBE_WINOGRAD", "0") == "1"          # the opt-in Winograd instance instead of the direct form
+        packs = [ops.PackedConv(torch.randn(cout, cin, 3, 3, device=dev) * 0.03, torch.randn(cout, device=dev), winograd=wino) for _ in range(3)]
         for flags in ("plain", "res"):
             kw = dict(res=res, dual_silu=True) if flags == "res" else {}
+            kw["winograd"] = wino
             for i in range(3):
                 ops.conv2d(x, packs[i], 1, **kw)
             torch.cuda.synchronize()

@@ -132,6 +132,7 @@ class ResidualBlockFn(torch.autograd.Function):
         ctx.save_for_backward(*saved)
         ctx.block = block
         ctx.mark_non_differentiable(sy)
+        ctx.set_materialize_grads(False)        # (or autograd fills a zero tensor of sy's size for `_dsy` on every backward)
         return y, sy
 
     @staticmethod
@@ -185,6 +186,7 @@ class AttentionBlockFn(torch.autograd.Function):
         ctx.save_for_backward(a, b, bb, *saved)
         ctx.block = block
         ctx.mark_non_differentiable(sout)
+        ctx.set_materialize_grads(False)
         return out, sout
 
     @staticmethod
@@ -401,6 +403,21 @@ def _gdn_bounds(module):
     return cached[1]
 
 
+def _gdn_operands(module, beta_p, gamma_p, bounds):
+    """(forward operand stream of beta + gamma @ x^2, operand stream of 2 gamma^T for the input gradient) of a GDN layer in
+    the training graph, folded and packed once per parameter version (4 launches) like a convolution's streams."""
+    key = (ops.tensor_version(beta_p), beta_p.data_ptr(), ops.tensor_version(gamma_p), gamma_p.data_ptr())
+    cached = module.__dict__.get("_trainOperands")
+    if cached is None or cached[0] != key:
+        bb, be, gb, ge = bounds
+        beta = ops.nonneg_reparam(beta_p, bb, be)
+        gamma = ops.nonneg_reparam(gamma_p, gb, ge)
+        packed = ops.PackedConv(gamma[..., None, None], beta, copy_bias=False)
+        back = ops.PackedConv.dgrad(gamma[..., None, None], 1, scale=2.0)      # 2 gamma^T, packed in one launch
+        cached = module.__dict__["_trainOperands"] = (key, packed, back)
+    return cached[1], cached[2]
+
+
 class GdnFn(torch.autograd.Function):
     """y = x * f(beta + gamma @ x^2) with the non-negative re-parametrisation of beta [C], gamma [C, C] INSIDE the node
     (mcquic/nn/gdn.py:67-91, mcquic/nn/base.py:17-29,81-84): folding, the 1x1 launch, and in backward the two input-gradient
@@ -410,22 +427,19 @@ class GdnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, beta_p, gamma_p, module, inverse):
         bb, be, gb, ge = _gdn_bounds(module)
-        beta = ops.nonneg_reparam(beta_p, bb, be)
-        gamma = ops.nonneg_reparam(gamma_p, gb, ge)
-        packed = ops.PackedConv(gamma[..., None, None], beta, copy_bias=False)
+        packed, back = _gdn_operands(module, beta_p, gamma_p, (bb, be, gb, ge))
         y = ops.conv2d(x, packed, square_in=True, igdn_mul=x) if inverse else ops.conv2d(x, packed, square_in=True, gdn_mul=x)
-        ctx.save_for_backward(x, beta_p, gamma_p, gamma)
-        ctx.packed, ctx.inverse, ctx.bounds = packed, inverse, (bb, gb)
+        ctx.save_for_backward(x, beta_p, gamma_p)
+        ctx.packed, ctx.back, ctx.inverse, ctx.bounds = packed, back, inverse, (bb, gb)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, beta_p, gamma_p, gamma = ctx.saved_tensors
+        x, beta_p, gamma_p = ctx.saved_tensors
         dy = dy.contiguous()
         s = ops.conv2d(x, ctx.packed, square_in=True)                          # beta + gamma @ x^2, recomputed
         dxd, ds = ops.gdn_bwd_prep(x, s, dy, ctx.inverse)
-        back = ops.PackedConv.dgrad(gamma[..., None, None], 1, scale=2.0)      # 2 gamma^T, packed in one launch
-        dx = ops.conv2d(ds, back, mul=x, res=dxd)                              # dy f(s) + 2 x (gamma^T ds)
+        dx = ops.conv2d(ds, ctx.back, mul=x, res=dxd)                          # dy f(s) + 2 x (gamma^T ds)
         dgamma, dbeta = ops.conv2d_wgrad(x, ds, 1, 1, square_x=True, want_bias=True)
         bb, gb = ctx.bounds
         return (dx, ops.nonneg_reparam_bwd(beta_p, dbeta, bb), ops.nonneg_reparam_bwd(gamma_p, dgamma[:, :, 0, 0], gb), None, None)
@@ -504,6 +518,7 @@ class SoftQuantizeFn(torch.autograd.Function):
         ctx.save_for_backward(x, logits, u_gumbel, index, hot, temperature)
         ctx.packed, ctx.bound = packed, bound
         ctx.mark_non_differentiable(code, logits)
+        ctx.set_materialize_grads(False)        # (`_dlogits` would be a zero fill of the [n, m, h, w, k] logits: 134 MB at level 0)
         return deq, code, logits
 
     @staticmethod

@@ -66,6 +66,15 @@
 #ifndef MCQ_WINO_STAGGER
 #define MCQ_WINO_STAGGER 2          // s_sleep 127 (~3.4 us) units per phase step; 0 = off
 #endif
+// SiLU of the band epilogue two values at a time on packed fp32 instructions (mcq_silu2: bit-identical results, 15 issue
+// slots per pair instead of 24).  Measured on the direct kernel: 253.2 vs 256.2 images/s (same box, alternating runs) -- the
+// packed forms cost the co-resident wave's MFMA stream MORE than the scalar ones they replace: off.
+#ifndef MCQ_PK_SILU
+#define MCQ_PK_SILU 0
+#endif
+#ifndef MCQ_PK_SILU_W          // the same switch for the one-wave-per-SIMD Winograd instance's own epilogue: no difference (187.0 vs 186.9)
+#define MCQ_PK_SILU_W 0
+#endif
 #ifndef MCQ_ONLY_WINO
 #define MCQ_ONLY_WINO 0
 #endif
@@ -481,6 +490,23 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
 #pragma unroll
                         for (int r = 0; r < 16; ++r) vv[nb][r] = vv[nb][r] + p.res_scale * rvv[nb][r];
                     }
+#if MCQ_PK_SILU
+                    // two values per call: the multiplies / FMAs / adds of the activation as packed instructions (same results)
+                    if (EF & MCQ_CONV_SILU_OUT) {
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const f32x2v sv = mcq_silu2(f32x2v{vv[nb][r], vv[nb][r + 1]});
+                            vv[nb][r] = sv[0]; vv[nb][r + 1] = sv[1];
+                        }
+                    }
+                    if (EF & MCQ_CONV_DUAL_SILU) {
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const f32x2v sv = mcq_silu2(f32x2v{vv[nb][r], vv[nb][r + 1]});
+                            tw[nb][r] = sv[0]; tw[nb][r + 1] = sv[1];
+                        }
+                    }
+#else
                     if (EF & MCQ_CONV_SILU_OUT) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) vv[nb][r] = mcq_silu(vv[nb][r]);
@@ -489,6 +515,7 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
 #pragma unroll
                         for (int r = 0; r < 16; ++r) tw[nb][r] = mcq_silu(vv[nb][r]);
                     }
+#endif
                 }
 #if MCQ_STAMPS
                 asm volatile("" :: "v"(vv[0][0]), "v"(vv[NB - 1][15]), "v"(tw[0][0]), "v"(tw[NB - 1][15]));
@@ -636,19 +663,24 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
                 const unsigned co_row0 = (unsigned)(co_base + mb * 32);
                 float v[2][16], t[2][16];
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int r = 0; r < 16; ++r) {
+                    f32x2v y;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                    for (int nb = 0; nb < 2; ++nb) {
                         float a, b, c;                            // back from the four transform positions to the pixel
                         asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(a) : "n"(16 * (4 * mb + (nb == 0 ? 0 : 1)) + r));
                         asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(b) : "n"(16 * (4 * mb + (nb == 0 ? 1 : 2)) + r));
                         asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(c) : "n"(16 * (4 * mb + (nb == 0 ? 2 : 3)) + r));
-                        float y = (nb == 0 ? (a + b) + c : (a - b) - c) + ball[mb][r];
-                        if (EF & MCQ_CONV_RESIDUAL) y = y + p.res_scale * rall[mb][r][nb];
-                        if (EF & MCQ_CONV_SILU_OUT) y = mcq_silu(y);
-                        v[nb][r] = y;
-                        if (EF & MCQ_CONV_DUAL_SILU) t[nb][r] = mcq_silu(y);
+                        y[nb] = (nb == 0 ? (a + b) + c : (a - b) - c) + ball[mb][r];
+                        if (EF & MCQ_CONV_RESIDUAL) y[nb] = y[nb] + p.res_scale * rall[mb][r][nb];
                     }
+                    if (EF & MCQ_CONV_SILU_OUT) y = MCQ_PK_SILU_W ? mcq_silu2(y) : f32x2v{mcq_silu(y[0]), mcq_silu(y[1])};
+                    v[0][r] = y[0]; v[1][r] = y[1];
+                    if (EF & MCQ_CONV_DUAL_SILU) {
+                        const f32x2v s2 = MCQ_PK_SILU_W ? mcq_silu2(y) : f32x2v{mcq_silu(y[0]), mcq_silu(y[1])};
+                        t[0][r] = s2[0]; t[1][r] = s2[1];
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned so = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;

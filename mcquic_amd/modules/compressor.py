@@ -116,7 +116,8 @@ class BaseCompressor(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def _graphed(self, kind: str, fn, inputs):
-        stamp = self._weightStamp()
+        from .. import ops
+        stamp = (self._weightStamp(), ops.winograd_enabled())     # (the opt-in switch re-packs every convolution: as good as new weights)
         if stamp != self._graphStamp:            # weights changed since the captures: their packed operands are stale
             self._graphs.clear()
             self._graphStamp = stamp

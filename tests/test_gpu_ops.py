@@ -457,3 +457,31 @@ def test_conv_winograd_epilogues(dev):
         ops.conv2d(x.to(dev), ops.PackedConv(wt.to(dev), b.to(dev), winograd=False), winograd=True)
     with pytest.raises(ValueError):
         ops.conv2d(x.to(dev), pk, 2, winograd=True)                     # stride 2
+
+
+def test_conv_random_shapes_sweep(dev):
+    """Forty seeded random geometries (odd sizes, ragged channel counts, both strides, 1x1 and 3x3, the library's own tile
+    choice) against F.conv2d on the CPU -- beyond the hand-picked cases above; the 3x3 stride-1 ones with Cout % 64 == 0 also
+    go through the opt-in Winograd form."""
+    from mcquic_amd import ops
+    rng = np.random.default_rng(20260928)
+    wino = 0
+    for i in range(40):
+        n = int(rng.integers(1, 4))
+        cin = int(rng.choice([3, 8, 24, 64, 96, 128, 130, 192]))
+        cout = int(rng.choice([4, 12, 32, 64, 128, 192, 256]))
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+        ks = int(rng.choice([1, 3]))
+        stride = int(rng.choice([1, 2])) if ks == 3 else 1
+        x = _rand((n, cin, h, w), 1000 + i)
+        wt = _rand((cout, cin, ks, ks), 2000 + i, 1.0 / np.sqrt(cin * ks * ks))
+        b = _rand((cout,), 3000 + i, 0.1) if i % 3 else None
+        want = F.conv2d(x, wt, b, stride=stride, padding=ks // 2)
+        use_w = ks == 3 and stride == 1 and cout % 64 == 0
+        pk = ops.PackedConv(wt.to(dev), None if b is None else b.to(dev), winograd=use_w)
+        got = ops.conv2d(x.to(dev), pk, stride, winograd=False)
+        _close(got, want, 2e-6, f"case {i}: {n}x{cin}->{cout} {h}x{w} k{ks}s{stride}")
+        if use_w:
+            wino += 1
+            _close(ops.conv2d(x.to(dev), pk, stride, winograd=True), want, 1e-5, f"case {i} (winograd): {n}x{cin}->{cout} {h}x{w}")
+    assert wino >= 5

@@ -190,3 +190,16 @@ def test_winograd_instance_keeps_its_accumulators_to_itself():
     stray = [ln for ln in agpr if not ok.match(ln)]
     assert not stray, f"compiler-generated AGPR use in the Winograd instance: {stray[:3]}"
     assert not [ln for ln in body if "scratch_" in ln], "the Winograd instance spills"
+    # The hazard recogniser does not see inside inline asm: a VALU result consumed by the very next MFMA came out wrong on
+    # the GPU (the input transform therefore runs one group ahead).  No MFMA source may be written by a VALU instruction in
+    # the three instructions before it.
+    ins = [ln.strip() for ln in body if ln.strip()]
+    for i, ln in enumerate(ins):
+        m = re.match(r"v_mfma_f32_32x32x2_f32 a\[\d+:\d+\], (v\d+), (v\d+),", ln)
+        if not m:
+            continue
+        for back in (1, 2, 3):
+            prev = ins[i - back]
+            w = re.match(r"(v_\w+)\s+(v\d+)", prev)
+            assert not (w and not prev.startswith(("v_mfma", "v_accvgpr")) and w.group(2) in m.groups()), \
+                f"VALU result feeds an inline-asm MFMA {back} instruction(s) later: {prev!r} -> {ln!r}"

@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -104,13 +104,18 @@ def ransEncodeBatchWithIndexes(symbols: np.ndarray, indexes: np.ndarray, t: _Tab
     return [out[i, :sizes[i]].tobytes() for i in range(ns)]
 
 
-def ransDecodeBatchWithIndexes(binaries: List[bytes], indexes: np.ndarray, t: _Tables, threads: int = 0) -> np.ndarray:
-    """One byte string per stream -> int32 [n_streams, n]; ONE C call over a pool of host threads."""
+def ransDecodeBatchWithIndexes(binaries: List[bytes], indexes: np.ndarray, t: _Tables, threads: int = 0,
+                               out: Optional[np.ndarray] = None) -> np.ndarray:
+    """One byte string per stream -> int32 [n_streams, n]; ONE C call over a pool of host threads.  `out`: a C-contiguous
+    int32 [n_streams, n] array to decode into (e.g. the view of a pinned staging tensor)."""
     indexes = np.ascontiguousarray(indexes, dtype=np.int32)
     offs = np.zeros(len(binaries) + 1, dtype=np.int64)
     np.cumsum([len(b) for b in binaries], out=offs[1:])
     buf = np.frombuffer(b"".join(binaries), dtype=np.uint8)
-    out = np.empty((len(binaries), indexes.size), dtype=np.int32)
+    if out is None:
+        out = np.empty((len(binaries), indexes.size), dtype=np.int32)
+    elif out.dtype != np.int32 or out.shape != (len(binaries), indexes.size) or not out.flags.c_contiguous:
+        raise ValueError("ransDecodeBatchWithIndexes: `out` must be a C-contiguous int32 [n_streams, n] array")
     rc = _lib.load().mcq_rans_decode_batch_with_indexes(_vp(buf), _vp(offs), len(binaries), _vp(indexes), indexes.size, _vp(t.cdfs),
                                                         _vp(t.starts), _vp(t.sizes), _vp(t.lens), _vp(t.offsets), t.m, _vp(out),
                                                         threads or hostThreads())
@@ -249,12 +254,17 @@ class EntropyCoder(nn.Module):
             if list(codeSize.heights) != list(first.heights) or list(codeSize.widths) != list(first.widths):
                 raise RuntimeError("All images of one batch must share their code sizes.")
         device = self._freqEMA[0].device
+        n = len(binaries)
         out = []
         for lv, table in enumerate(self._tables):
             h, w = int(first.heights[lv]), int(first.widths[lv])
             idx = np.repeat(np.arange(self._m, dtype=np.int32), h * w)
-            sym = ransDecodeBatchWithIndexes([binary[lv] for binary in binaries], idx, table)
-            out.append(torch.from_numpy(sym.reshape(len(binaries), self._m, h, w).astype(np.int64)).to(device))
+            # decoded straight into a pinned staging tensor and handed to the device without waiting for it: the host is
+            # never blocked behind the GPU's queue (a pageable copy is), so the coder of the next call runs while the GPU still
+            # decodes this one; int32 -> int64 happens on the device
+            host = torch.empty((n, idx.size), dtype=torch.int32, pin_memory=device.type == "cuda")
+            ransDecodeBatchWithIndexes([binary[lv] for binary in binaries], idx, table, out=host.numpy())
+            out.append(host.to(device, non_blocking=True).to(torch.int64).reshape(n, self._m, h, w))
         return out
 
 

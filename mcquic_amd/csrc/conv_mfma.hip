@@ -780,6 +780,9 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = own[nb][r];
     }, kslice, std::integral_constant<int, 1>{});
+#if MCQ_STAMPS
+    { MCQ_STAMP(st3); mcq_stamp_write(st0, st1, st2, st3, 0, 0, 0); }
+#endif
 }
 
 // OIHW -> [Cout/(32 bands)][TP][64 lanes][bands]: lane l, slot q holds W[co = 32 bands T + 32 q + (l & 31)][ci = 2 s + (l >> 5)][tap]

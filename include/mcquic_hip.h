@@ -82,6 +82,9 @@ int mcq_pack_conv_weight_f32(const float* w_oihw, int32_t Cout, int32_t Cin, int
  * whether a geometry is taken (1) or would be refused (0). */
 size_t mcq_packed_conv_winograd_floats(int32_t Cout, int32_t Cin);
 int mcq_pack_conv_weight_winograd_f32(const float* w_oihw, int32_t Cout, int32_t Cin, float* w_packed, void* stream);
+/* ... and of the layer's stride-1 input-gradient convolution (torch.autograd's conv2d backward w.r.t. the input), straight from
+ * the layer's own OIHW weight: w_packed holds mcq_packed_conv_winograd_floats(Cin, Cout) floats */
+int mcq_pack_conv_dgrad_weight_winograd_f32(const float* w_oihw, int32_t Cout, int32_t Cin, float* w_packed, void* stream);
 int32_t mcq_conv2d_winograd_ok(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, uint32_t flags);
 
 /* The operand stream of a layer's INPUT-GRADIENT convolution, packed straight from the layer's own OIHW weight

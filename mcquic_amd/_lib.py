@@ -40,6 +40,7 @@ SYMBOLS = {
     "mcq_conv2d_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
     "mcq_packed_conv_winograd_floats": (c_size_t, [c_int32, c_int32]),
     "mcq_pack_conv_weight_winograd_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "mcq_pack_conv_dgrad_weight_winograd_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "mcq_conv2d_winograd_ok": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint32]),
     "mcq_pack_conv_weight_max_multi": (c_int32, []),
     "mcq_pack_conv_weight_multi_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),

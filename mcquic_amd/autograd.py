@@ -22,13 +22,13 @@ from . import ops
 # ---- input-gradient operand streams (packed straight from the OIHW parameter, cached per weight version) ----------
 class _DgradCache:
     def __init__(self):
-        self.key, self.packed = None, None
+        self.key, self.packed, self.winograd = None, None, False
 
     def get(self, weight: torch.Tensor, stride: int) -> ops.PackedConv:
         key = (ops.tensor_version(weight), weight.data_ptr(), stride)
-        if key != self.key:
+        if key != self.key or self.winograd != ops.winograd_enabled():
             self.packed = ops.PackedConv.dgrad(weight, stride)      # one pack launch (flip / transpose / sub-pixel scatter inside)
-            self.key = key
+            self.key, self.winograd = key, ops.winograd_enabled()
         return self.packed
 
 

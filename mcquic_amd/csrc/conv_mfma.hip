@@ -809,16 +809,18 @@ __device__ __forceinline__ void pack_conv_weight_body(const float* __restrict__ 
     const int tile = (int)(stepg / TP);
     const int step = (int)(stepg - (size_t)tile * TP);
     float v = 0.0f;
-    const int taps = mode == 3 ? 12 : ks * ks;
+    const int taps = mode >= 3 ? 12 : ks * ks;
     if (tile < ntile && step < TP) {
         const int s = step / taps, tap = step - s * taps;
         const int co = tile * 32 * bands + 32 * q + (lane & 31);
         const int ci = 2 * s + (lane >> 5);
         if (co < Cout && ci < Cin) {
-            if (mode == 3) {
-                // Winograd F(2, 3) along x: tap = 4 dy + position; G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]
-                const float* g = w + (((size_t)co * Cin + ci) * 3 + (tap >> 2)) * 3;
-                const double g0 = g[0], g1 = g[1], g2 = g[2];
+            if (mode >= 3) {
+                // Winograd F(2, 3) along x: tap = 4 dy + position; G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]];
+                // mode 3 from the layer's own filter rows, mode 4 from those of its stride-1 input-gradient convolution
+                const int row = 3 * (tap >> 2), src = mode == 3 ? 0 : 1;
+                const double g0 = pack_source(w, src, Co, Ci, 3, co, ci, row), g1 = pack_source(w, src, Co, Ci, 3, co, ci, row + 1),
+                             g2 = pack_source(w, src, Co, Ci, 3, co, ci, row + 2);
                 const int pos = tap & 3;
                 v = (float)(pos == 0 ? g0 : pos == 1 ? 0.5 * (g0 + g1 + g2) : pos == 2 ? 0.5 * (g0 - g1 + g2) : g2);
             } else
@@ -931,6 +933,18 @@ extern "C" int mcq_pack_conv_weight_winograd_f32(const float* w, int32_t Cout, i
     const int S = (Cin + 1) / 2, TP = S * 12;
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
                        3, S, TP, out, sec4, sec2, total, 3, Cout, Cin, 1.0f);
+    return mcq_check_launch();
+}
+
+// the same for the layer's stride-1 INPUT-GRADIENT convolution (a [Cin, Cout, 3, 3] conv on flipped / transposed taps): `out`
+// holds mcq_packed_conv_winograd_floats(Cin, Cout) floats
+extern "C" int mcq_pack_conv_dgrad_weight_winograd_f32(const float* w, int32_t Cout, int32_t Cin, float* out, void* stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0) return MCQ_EINVAL;
+    const int co_d = Cin, ci_d = Cout;
+    const size_t sec4 = wino_section_floats(co_d, ci_d, 4), sec2 = wino_section_floats(co_d, ci_d, 2), total = sec4 + sec2;
+    const int S = (ci_d + 1) / 2, TP = S * 12;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, co_d, ci_d,
+                       3, S, TP, out, sec4, sec2, total, 4, Cout, Cin, 1.0f);
     return mcq_check_launch();
 }
 

@@ -70,6 +70,7 @@ class Conv2d(nn.Module):
             packs = ops.pack_convs([c.weight for c, _ in group], dgrad=True, stride=stride)
             for (c, cache), pk in zip(group, packs):
                 cache.packed, cache.key = pk, (ops.tensor_version(c.weight), c.weight.data_ptr(), stride)
+                cache.winograd = ops.winograd_enabled()           # (grouped packs carry no Winograd stream: those launches stay direct)
             done += len(group)
         return done
 

@@ -149,7 +149,7 @@ class PackedConv:
                       "mcq_pack_conv_weight_winograd_f32")
 
     @classmethod
-    def dgrad(cls, weight: torch.Tensor, stride: int, scale: float = 1.0) -> "PackedConv":
+    def dgrad(cls, weight: torch.Tensor, stride: int, scale: float = 1.0, winograd: Optional[bool] = None) -> "PackedConv":
         """Operand stream of the layer's input-gradient convolution, packed straight from its OIHW weight in one launch
         (mcq_pack_conv_dgrad_weight_f32): stride 1 -> a [cin, cout, k, k] conv; stride 2 -> a [4 cin, cout, 3, 3] conv whose
         result goes through the PixelShuffle(2) store."""
@@ -167,6 +167,11 @@ class PackedConv:
         self.bias = None
         self.cout, self.cin, self.ksize = co_d.value, ci_d.value, kh
         self.wino = None
+        if (winograd if winograd is not None else _WINOGRAD) and kh == 3 and stride == 1 and scale == 1.0 and cin % 64 == 0:
+            self.wino = torch.empty(lib.mcq_packed_conv_winograd_floats(cin, cout), dtype=torch.float32, device=weight.device)
+            with _guard(weight.device):
+                check(lib.mcq_pack_conv_dgrad_weight_winograd_f32(_ptr(weight), cout, cin, _ptr(self.wino), _stream()),
+                      "mcq_pack_conv_dgrad_weight_winograd_f32")
         return self
 
 

@@ -316,3 +316,17 @@ def test_repack_stale_after_parameter_update(dev):
     assert Conv2d.repack_stale(convs) == 0
     out = model(x)                                   # and the step after the update runs on them
     assert torch.isfinite(out[0]).all()
+
+
+def test_winograd_input_gradient_pack(dev):
+    """Opt-in: the stride-1 input-gradient convolution of a 3x3 layer in the Winograd F(2, 3) form, packed straight from the
+    layer's OIHW weight (mcq_pack_conv_dgrad_weight_winograd_f32), against torch.autograd's conv2d input gradient."""
+    from mcquic_amd import ops
+    x = _rand((2, 128, 18, 22), 1).requires_grad_()
+    wt = _rand((64, 128, 3, 3), 2, 0.05)
+    dy = _rand((2, 64, 18, 22), 3)
+    F.conv2d(x, wt, None, padding=1).backward(dy)
+    back = ops.PackedConv.dgrad(wt.to(dev), 1, winograd=True)
+    assert back.wino is not None and (back.cout, back.cin) == (128, 64)
+    _close(ops.conv2d(dy.to(dev), back, winograd=True), x.grad, 1e-5, "winograd input gradient")
+    _close(ops.conv2d(dy.to(dev), back, winograd=False), x.grad, 2e-6, "direct input gradient")

@@ -63,8 +63,8 @@
 #ifndef MCQ_HEAD16
 #define MCQ_HEAD16 1
 #endif
-#ifndef MCQ_WINO_STAGGER
-#define MCQ_WINO_STAGGER 2          // s_sleep 127 (~3.4 us) units per phase step; 0 = off
+#ifndef MCQ_WINO_PERSIST
+#define MCQ_WINO_PERSIST 1          // workgroups per CU of the persistent 128-row Winograd instance; 0 = one workgroup per four tiles
 #endif
 // SiLU of the band epilogue two values at a time on packed fp32 instructions (mcq_silu2: bit-identical results, 15 issue
 // slots per pair instead of 24).  Measured on the direct kernel: 253.2 vs 256.2 images/s (same box, alternating runs) -- the
@@ -109,10 +109,16 @@ struct ConvK {
     int ks_log2;       // split-K: 1 << ks_log2 waves of a workgroup share one output tile, each a slice of the k-steps
     int slice_pairs;   // channel pairs per split-K slice
     int tiles_log2;    // (1 << tiles_log2) output tiles per workgroup
+    int total_wgs;     // (persistent Winograd instance) workgroups' worth of tiles along x; the grid may be smaller
     unsigned flags; float res_scale;
 };
 
 constexpr int PRO_NONE = 0, PRO_SILU = 1, PRO_SQUARE = 2;
+// 128-row Winograd instance: the epilogue flag set instance `id` (the kernel's PRO slot) is compiled for; 0 = any (run-time flags)
+constexpr unsigned wino_epilogue_flags(int id) {
+    return id == 1 ? 0u : id == 2 ? MCQ_CONV_SILU_OUT : id == 3 ? MCQ_CONV_RESIDUAL : id == 4 ? (MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU)
+         : id == 5 ? MCQ_CONV_DUAL_SILU : id == 6 ? (MCQ_CONV_RESIDUAL | MCQ_CONV_SILU_OUT) : 0xffffffffu;
+}
 constexpr unsigned RUNTIME_FLAGS = 0xffffffffu;    // epilogue instance that tests the flags at run time
 
 }  // namespace
@@ -175,7 +181,11 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
     // 18 for the two pixels, accumulated per transform position (4 x MB tiles) and folded back to the two pixels
     // (M0 + M1 + M2, M1 - M2 - M3) in front of the unchanged epilogue, which sees them as NB = 2 pixel blocks.
     constexpr bool WINO = TAPS == 12;
-    static_assert(!WINO || (NB == 2 && PRO == PRO_NONE), "the Winograd form has two virtual pixel blocks and no prologue");
+    static_assert(!WINO || NB == 2, "the Winograd form has two virtual pixel blocks");
+    // (the Winograd form has no input prologue; its 128-row instance reuses the PRO slot of the template for the flag set its
+    //  epilogue is compiled for -- one set per kernel instance: dispatching on the flags inside the persistent tile loop left
+    //  every instance's temporaries live around the loop and pushed the compiler into the AGPRs)
+    constexpr unsigned WEF = wino_epilogue_flags(PRO);
     constexpr int NBG = WINO ? 1 : NB;              // pixel blocks the operand stream walks (pair blocks for WINO)
     constexpr int NACC = WINO ? 4 : NB;             // accumulator tiles per 32-row band
     // The 128-row Winograd instance has 4 x 4 accumulator tiles = 256 registers: the whole AGPR half of a one-wave-per-SIMD
@@ -209,31 +219,29 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
     // on different XCDs and every XCD pulls the halo rows through the fabric again (FETCH_SIZE 3.1x the input on the
     // 384x256 level).  Remapped, XCD k walks the contiguous k-th eighth of the tiles, so the halo of one workgroup is the
     // row its own XCD touched a moment ago.
-    unsigned wg = blockIdx.x;
+    // The 128-row Winograd instance is PERSISTENT: one workgroup per CU (it fills the register file) walks the tiles
+    // vwg, vwg + gridDim.x, ... -- no kernel-argument fetch, dispatch gap and first-wave ramp per tile (~3 us of a ~95 us tile).
+    unsigned vwg = blockIdx.x;
+next_tile:
+    // (everything below is recomputed per tile on the scalar unit: hoisted out of the tile loop, the ~100 wave-uniform offsets of
+    //  prologue and epilogue would not fit the SGPR file and come back as VGPR spills -- `tile_zero` keeps them loop-variant)
+    int tile_zero = 0;
+    if (WASM) asm volatile("" : "+s"(tile_zero));
+    unsigned wg = vwg;
     if (MCQ_XCD_REMAP) {
-        const unsigned nwg = gridDim.x, xcd = wg & 7u, slot = wg >> 3;
+        const unsigned nwg = WASM ? (unsigned)p.total_wgs : gridDim.x, xcd = wg & 7u, slot = wg >> 3;   // (WASM: gridDim.x % 8 == 0)
         const unsigned base = xcd * (nwg >> 3) + (xcd < (nwg & 7u) ? xcd : (nwg & 7u));      // workgroups of the XCDs before this one
         wg = base + slot;
     }
-#if MCQ_WINO_STAGGER
-    if (WASM && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 256u && gridDim.x >= 512u) {
-        // One wave per SIMD and identical tiles: the whole chip would run k-loop, then epilogue, in lock step -- every round
-        // ends in one burst of side loads and stores from all 256 CUs at once, which HBM serves in ~19 us while the matrix
-        // pipes wait (16 % of a launch).  The workgroups of the FIRST round start 0 .. 3 quarter-bursts late, so the CUs stay
-        // in four phases for the rest of the launch and the epilogues of one phase overlap the k-loops of the others.
-        const unsigned phase = (blockIdx.x >> 3) & 3u;
-        for (unsigned i = 0; i < phase * MCQ_WINO_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     const int gw = (int)(wg << p.tiles_log2) + tile_in_wg;       // tile index along the pixel-block axis
     const bool active = gw * NBG < p.total_blocks;  // wave-uniform
     if (KS == 1 && !active) return;                 // (split-K waves stay for the barriers)
-    const int co_base = blockIdx.y * (32 * MB);     // first output channel of this wave
+    const int co_base = blockIdx.y * (32 * MB) + tile_zero;     // first output channel of this wave
     const int hi = lane >> 5, j = lane & 31;
     const int BW = 1 << p.bw_log2;
     const int ly = j >> p.bw_log2, lx = j & (BW - 1);
     const int BH = 32 >> p.bw_log2;
-    const int HW = p.H * p.W;
+    const int HW = p.H * p.W + tile_zero;
     const int pad = TAPS == 1 ? 0 : 1;
     const unsigned plane_bytes = (unsigned)p.Cin * (unsigned)HW * 4u;
 
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
     // lanes without a pixel carry the out-of-range marker, so loads return 0 and stores are dropped by the hardware:
     // no predication, no branches, and hipcc is free to overlap the side loads of one tile with the math of another.
     const unsigned fl = p.flags;
-    const unsigned HoWo = (unsigned)(p.Ho * p.Wo);
+    const unsigned HoWo = (unsigned)(p.Ho * p.Wo + tile_zero);
     const unsigned slab_bytes = (unsigned)p.Cout * HoWo * 4u;
 
     auto epilogue = [&](auto tag, const bool tile_active, auto&& get_acc, const int mb_first, auto count_tag) {
@@ -638,8 +646,8 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
             const bool wide = (p.Wo & 1) == 0;                  // (wave-uniform)
             float ball[MB][16];
             f32x2v rall[MB][16];
-            // side loads run two bands ahead of the band being finished (all four at once would leave the compiler short of
-            // VGPRs, and it must not touch an AGPR here)
+            // side loads run one band ahead of the band being finished (a band takes longer than their latency; more of them in
+            // flight would leave the compiler short of VGPRs, and it must not touch an AGPR here)
             auto side_loads = [&](const int mb) __attribute__((always_inline)) {
                 const unsigned co_row0 = (unsigned)(co_base + mb * 32);
 #pragma unroll
@@ -655,16 +663,18 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
                 }
             };
             side_loads(0);
-            side_loads(1);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (mb + 2 < MB) side_loads(mb + 2);
+                asm volatile("" ::: "memory");              // (keeps the next bands' side loads from being hoisted up here)
+                if (mb + 1 < MB) side_loads(mb + 1);
                 const unsigned co_row0 = (unsigned)(co_base + mb * 32);
-                float v[2][16], t[2][16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    f32x2v y;
+                    // a row is stored as soon as it is finished (whole bands of results held back for a store phase cost
+                    // 64 registers, which this instance does not have to spare next to the side loads)
+                    if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                    f32x2v y, tw = {0.0f, 0.0f};
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
                         float a, b, c;                            // back from the four transform positions to the pixel
@@ -675,39 +685,30 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
                         if (EF & MCQ_CONV_RESIDUAL) y[nb] = y[nb] + p.res_scale * rall[mb][r][nb];
                     }
                     if (EF & MCQ_CONV_SILU_OUT) y = MCQ_PK_SILU_W ? mcq_silu2(y) : f32x2v{mcq_silu(y[0]), mcq_silu(y[1])};
-                    v[0][r] = y[0]; v[1][r] = y[1];
-                    if (EF & MCQ_CONV_DUAL_SILU) {
-                        const f32x2v s2 = MCQ_PK_SILU_W ? mcq_silu2(y) : f32x2v{mcq_silu(y[0]), mcq_silu(y[1])};
-                        t[0][r] = s2[0]; t[1][r] = s2[1];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                    if (EF & MCQ_CONV_DUAL_SILU) tw = MCQ_PK_SILU_W ? mcq_silu2(y) : f32x2v{mcq_silu(y[0]), mcq_silu(y[1])};
                     const unsigned so = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
                     if (wide) {
-                        mcq_buffer_store2_s(f32x2v{v[0][r], v[1][r]}, yr, pvo[0], so);
-                        if (EF & MCQ_CONV_DUAL_SILU) mcq_buffer_store2_s(f32x2v{t[0][r], t[1][r]}, y2r, pvo[0], so);
+                        mcq_buffer_store2_s(y, yr, pvo[0], so);
+                        if (EF & MCQ_CONV_DUAL_SILU) mcq_buffer_store2_s(tw, y2r, pvo[0], so);
                     } else {
-                        mcq_buffer_store_s(v[0][r], yr, pvo[0], so);
-                        mcq_buffer_store_s(v[1][r], yr, pvo[1], so);
+                        mcq_buffer_store_s(y[0], yr, pvo[0], so);
+                        mcq_buffer_store_s(y[1], yr, pvo[1], so);
                         if (EF & MCQ_CONV_DUAL_SILU) {
-                            mcq_buffer_store_s(t[0][r], y2r, pvo[0], so);
-                            mcq_buffer_store_s(t[1][r], y2r, pvo[1], so);
+                            mcq_buffer_store_s(tw[0], y2r, pvo[0], so);
+                            mcq_buffer_store_s(tw[1], y2r, pvo[1], so);
                         }
                     }
                 }
             }
         };
-        if ((ef & ~SIMPLE_W) == 0u) {
-            if (ef == (MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU)) wasm_epilogue(std::integral_constant<unsigned, MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU>{});
-            else if (ef == MCQ_CONV_SILU_OUT) wasm_epilogue(std::integral_constant<unsigned, MCQ_CONV_SILU_OUT>{});
-            else if (ef == 0u) wasm_epilogue(std::integral_constant<unsigned, 0u>{});
-            else if (ef == MCQ_CONV_RESIDUAL) wasm_epilogue(std::integral_constant<unsigned, MCQ_CONV_RESIDUAL>{});
-            else if (ef == MCQ_CONV_DUAL_SILU) wasm_epilogue(std::integral_constant<unsigned, MCQ_CONV_DUAL_SILU>{});
-            else wasm_epilogue(std::integral_constant<unsigned, MCQ_CONV_RESIDUAL | MCQ_CONV_SILU_OUT>{});
+        (void)ef; (void)SIMPLE_W;
+        if constexpr (WEF != RUNTIME_FLAGS) {
+            wasm_epilogue(std::integral_constant<unsigned, WEF>{});
 #if MCQ_STAMPS
             { MCQ_STAMP(st3); mcq_stamp_write(st0, st1, st2, st3, 0, 0, 0); }
 #endif
+            vwg += gridDim.x;
+            if (vwg < (unsigned)p.total_wgs) goto next_tile;
             return;
         }
     }
@@ -742,6 +743,10 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
 #if MCQ_STAMPS
         { MCQ_STAMP(st3); mcq_stamp_write(st0, st1, st2, st3, ph_a, ph_b, ph_c); }
 #endif
+        if constexpr (WASM) {
+            vwg += gridDim.x;
+            if (vwg < (unsigned)p.total_wgs) goto next_tile;
+        }
         return;
     }
 
@@ -910,9 +915,27 @@ int launch_wino(ConvK k, long long tiles, int co_tiles, hipStream_t s) {
     k.ks_log2 = 0;
     k.slice_pairs = k.S;
     k.tiles_log2 = 2;
-    const dim3 grid((unsigned)((tiles + 3) >> 2), (unsigned)co_tiles, (unsigned)k.nprob);
+    k.total_wgs = (int)((tiles + 3) >> 2);
+    // MB = 4: one workgroup per CU is all that fits, so 256 * MCQ_WINO_PERSIST of them walk the tiles (a multiple of 8 keeps a
+    // workgroup on one XCD's eighth of the image); MB = 2 launches a workgroup per four tiles as usual
+    const unsigned gx = MB == 4 && MCQ_WINO_PERSIST > 0 && k.total_wgs > 256 * MCQ_WINO_PERSIST ? 256u * MCQ_WINO_PERSIST : (unsigned)k.total_wgs;
+    const dim3 grid(gx, (unsigned)co_tiles, (unsigned)k.nprob);
     // activations run ~2.6 us ahead of their MFMAs (a step is MB MFMAs of 64 cycles): 24 steps at MB = 4, 48 at MB = 2
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, 2, PRO_NONE, 12, MB == 4 ? 24 : MCQ_WINO_PFB2, 12, OCC>), grid, dim3(256), 0, s, k);
+    if constexpr (MB == 4) {
+        const unsigned ef = k.flags & ~(unsigned)(MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN);
+        int id = 0;
+        for (int c = 1; c <= 6; ++c) if (ef == wino_epilogue_flags(c)) id = c;
+        switch (id) {
+            case 1: hipLaunchKernelGGL((conv_mfma_kernel<4, 2, 1, 12, 24, 12, OCC>), grid, dim3(256), 0, s, k); break;
+            case 2: hipLaunchKernelGGL((conv_mfma_kernel<4, 2, 2, 12, 24, 12, OCC>), grid, dim3(256), 0, s, k); break;
+            case 3: hipLaunchKernelGGL((conv_mfma_kernel<4, 2, 3, 12, 24, 12, OCC>), grid, dim3(256), 0, s, k); break;
+            case 4: hipLaunchKernelGGL((conv_mfma_kernel<4, 2, 4, 12, 24, 12, OCC>), grid, dim3(256), 0, s, k); break;
+            case 5: hipLaunchKernelGGL((conv_mfma_kernel<4, 2, 5, 12, 24, 12, OCC>), grid, dim3(256), 0, s, k); break;
+            case 6: hipLaunchKernelGGL((conv_mfma_kernel<4, 2, 6, 12, 24, 12, OCC>), grid, dim3(256), 0, s, k); break;
+            default: hipLaunchKernelGGL((conv_mfma_kernel<4, 2, 0, 12, 24, 12, OCC>), grid, dim3(256), 0, s, k); break;
+        }
+    } else
+        hipLaunchKernelGGL((conv_mfma_kernel<MB, 2, PRO_NONE, 12, MCQ_WINO_PFB2, 12, OCC>), grid, dim3(256), 0, s, k);
     return mcq_check_launch();
 }
 

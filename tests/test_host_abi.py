@@ -177,19 +177,23 @@ def test_winograd_instance_keeps_its_accumulators_to_itself():
         asm = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    body, inside = [], False
+    bodies, cur = {}, None
     for line in asm.splitlines():
         if line.endswith(">:"):
-            inside = "conv_mfma_kernelILi4ELi2ELi0ELi12E" in line
-        elif inside:
-            body.append(line.split("//")[0])
-    assert len(body) > 1000, "Winograd instance not found in the device code"
+            cur = line if re.search(r"conv_mfma_kernelILi4ELi2ELi\dELi12E", line) else None
+        elif cur:
+            bodies.setdefault(cur, []).append(line.split("//")[0])
+    assert len(bodies) == 7, f"expected the seven 128-row Winograd instances (one per epilogue flag set), found {len(bodies)}"
     ok = re.compile(r"^\s*(v_mfma_f32_32x32x2_f32 a\[\d+:\d+\], v\d+, v\d+, a\[\d+:\d+\]|v_accvgpr_read_b32 v\d+, a\d+|v_accvgpr_write_b32 a\d+, 0)\s*$")
-    agpr = [ln for ln in body if re.search(r"\ba(\d+|\[\d+:\d+\])", ln)]
-    assert len(agpr) >= 96 + 256 + 128 * 3
-    stray = [ln for ln in agpr if not ok.match(ln)]
-    assert not stray, f"compiler-generated AGPR use in the Winograd instance: {stray[:3]}"
-    assert not [ln for ln in body if "scratch_" in ln], "the Winograd instance spills"
+    body = []
+    for name, lines in bodies.items():
+        assert len(lines) > 1000
+        agpr = [ln for ln in lines if re.search(r"\ba(\d+|\[\d+:\d+\])", ln)]
+        assert len(agpr) >= 96 + 256 + 128 * 3, name
+        stray = [ln for ln in agpr if not ok.match(ln)]
+        assert not stray, f"compiler-generated AGPR use in {name}: {stray[:3]}"
+        assert not [ln for ln in lines if "scratch_" in ln], f"{name} spills"
+        body += lines + ["s_nop 0", "s_nop 0", "s_nop 0"]
     # The hazard recogniser does not see inside inline asm: a VALU result consumed by the very next MFMA came out wrong on
     # the GPU (the input transform therefore runs one group ahead).  No MFMA source may be written by a VALU instruction in
     # the three instructions before it.

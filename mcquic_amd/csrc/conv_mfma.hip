@@ -371,6 +371,10 @@ next_tile:
                 if (u % 4 == 1) {
                     const float d0 = B[(u + 3) % PFB][0], d1 = B[(u + 4) % PFB][0], d2 = B[(u + 5) % PFB][0], d3 = B[(u + 6) % PFB][0];
                     Vn[0] = d0 - d2; Vn[1] = d1 + d2; Vn[2] = d2 - d1; Vn[3] = d1 - d3;
+                    if (WASM) {                              // (opaque: under register pressure the compiler re-forms a difference right in
+                                                             //  front of its MFMA instead of keeping it -- seen once, caught by the hygiene test)
+                        asm volatile("" : "+v"(Vn[0]), "+v"(Vn[1]), "+v"(Vn[2]), "+v"(Vn[3]));
+                    }
                 }
                 bv[0] = V[u % 4];
             } else {

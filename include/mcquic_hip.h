@@ -44,6 +44,8 @@ extern "C" {
 #define MCQ_CONV_DSILU_MUL  0x400u /* y = acc * silu'(mul)              (backward of SiLU fused into the input-gradient conv:  */
                                    /*                                    mul = the SiLU's input; then + res as usual)           */
 #define MCQ_CONV_DUAL_SILU  0x100u /* also store silu(y) to y_silu: the next block's act1(x), computed once per element */
+#define MCQ_CONV_WINOGRAD2D 0x1000u /* OPT-IN like MCQ_CONV_WINOGRAD: F(2x2, 3x3), 4/9 of the multiplications; w_packed from   */
+                                    /* mcq_pack_conv_weight_winograd2d_f32; Cout % 128 == 0, Cin % 8 == 0                                */
 #define MCQ_CONV_WINOGRAD   0x800u /* OPT-IN, not the reference's arithmetic: 3x3 stride-1 layer in the Winograd F(2, 3) form along x */
                                    /* (2/3 of the multiplications, float32 throughout, results differ from the direct form in   */
                                    /* the last bits); w_packed then comes from mcq_pack_conv_weight_winograd_f32                 */
@@ -81,6 +83,10 @@ int mcq_pack_conv_weight_f32(const float* w_oihw, int32_t Cout, int32_t Cin, int
  * needs Cout % 64 == 0, ksize 3, stride 1 and no input prologue (SILU_IN / SQUARE_IN).  mcq_conv2d_winograd_ok tells
  * whether a geometry is taken (1) or would be refused (0). */
 size_t mcq_packed_conv_winograd_floats(int32_t Cout, int32_t Cin);
+/* The same in both directions, F(2x2, 3x3) (MCQ_CONV_WINOGRAD2D; Cout % 128 == 0 and Cin % 8 == 0): G g G^T, sixteen transformed taps per filter,
+ * [Cout/32][Cin/2 x 16][64 lanes]; 4/9 of the multiplications. */
+size_t mcq_packed_conv_winograd2d_floats(int32_t Cout, int32_t Cin);
+int mcq_pack_conv_weight_winograd2d_f32(const float* w_oihw, int32_t Cout, int32_t Cin, float* w_packed, void* stream);
 int mcq_pack_conv_weight_winograd_f32(const float* w_oihw, int32_t Cout, int32_t Cin, float* w_packed, void* stream);
 /* ... and of the layer's stride-1 input-gradient convolution (torch.autograd's conv2d backward w.r.t. the input), straight from
  * the layer's own OIHW weight: w_packed holds mcq_packed_conv_winograd_floats(Cin, Cout) floats */

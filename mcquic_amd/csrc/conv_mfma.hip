@@ -63,6 +63,9 @@
 #ifndef MCQ_HEAD16
 #define MCQ_HEAD16 1
 #endif
+#ifndef MCQ_W2D_EXP
+#define MCQ_W2D_EXP 0
+#endif
 #ifndef MCQ_WINO_PERSIST
 #define MCQ_WINO_PERSIST 1          // workgroups per CU of the persistent 128-row Winograd instance; 0 = one workgroup per four tiles
 #endif
@@ -171,7 +174,7 @@ __device__ __forceinline__ void mcq_stamp_write(unsigned long long t0, unsigned 
 #endif
 
 template <int MB, int NB, int PRO, int PFA, int PFB, int TAPS, int OCC>
-__global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(ConvK p) {
+__global__ __launch_bounds__(TAPS >= 12 ? 256 : 512, OCC) void conv_mfma_kernel(ConvK p) {
     static_assert(TAPS == 1 ? PFA == PFB : ((TAPS % PFA == 0 || PFA % TAPS == 0) && PFB % TAPS == 0 && PFB % PFA == 0),
                   "ring depths must tile the unrolled body");
     // TAPS == 12: the Winograd F(2, 3) form of a 3x3 stride-1 convolution along x (opt-in, MCQ_CONV_WINOGRAD).  A lane owns a
@@ -180,21 +183,30 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
     // are the transformed filter row (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2): 12 k-steps per channel pair instead of
     // 18 for the two pixels, accumulated per transform position (4 x MB tiles) and folded back to the two pixels
     // (M0 + M1 + M2, M1 - M2 - M3) in front of the unchanged epilogue, which sees them as NB = 2 pixel blocks.
-    constexpr bool WINO = TAPS == 12;
-    static_assert(!WINO || NB == 2, "the Winograd form has two virtual pixel blocks");
+    // TAPS == 16: F(2x2, 3x3), the same idea in both directions.  A lane owns a 2 x 2 tile of output pixels; per channel pair it
+    // loads the 4 x 4 inputs under the tile, forms B^T d B (32 additions, one group ahead) and feeds the sixteen results to sixteen
+    // k-steps whose weights are G g G^T: 16 MFMA k-steps per channel pair for FOUR pixels (36 in the direct form, 24 in the 1-D
+    // form).  Sixteen accumulator tiles per 32-row band: the instance takes ONE band per wave (MB = 1; the four waves of a
+    // workgroup are the four bands of 128 output channels over the same tiles, so the input patches hit L1 three times out of
+    // four), accumulators again in hand-numbered AGPRs; the epilogue sees NB = 4 pixel blocks (oy, ox).
+    constexpr bool W2D = TAPS == 16;
+    constexpr bool WINO = TAPS == 12 || W2D;
+    constexpr int PG = W2D ? 16 : 4;                // transform positions = k-steps per group of operand loads
+    static_assert(!WINO || NB == (W2D ? 4 : 2), "the Winograd forms have two / four virtual pixel blocks");
+    static_assert(!W2D || MB == 1, "the 2-D form takes one 32-row band per wave");
     // (the Winograd form has no input prologue; its 128-row instance reuses the PRO slot of the template for the flag set its
     //  epilogue is compiled for -- one set per kernel instance: dispatching on the flags inside the persistent tile loop left
     //  every instance's temporaries live around the loop and pushed the compiler into the AGPRs)
     constexpr unsigned WEF = wino_epilogue_flags(PRO);
     constexpr int NBG = WINO ? 1 : NB;              // pixel blocks the operand stream walks (pair blocks for WINO)
-    constexpr int NACC = WINO ? 4 : NB;             // accumulator tiles per 32-row band
+    constexpr int NACC = WINO ? PG : NB;            // accumulator tiles per 32-row band
     // The 128-row Winograd instance has 4 x 4 accumulator tiles = 256 registers: the whole AGPR half of a one-wave-per-SIMD
     // register file.  hipcc's allocator cannot work with that (it parks other values in AGPRs that do not exist and splits
     // every tuple into VGPRs at the loop exit: 130-345 spilled dwords, scratch traffic inside the k-loop), so this instance
     // keeps its accumulators out of the compiler's sight: tile (band mb, position t) IS a[16 (4 mb + t) : +15], written only
     // by the inline-asm MFMAs below and read back element by element in the epilogue.  The compiler's own code stays within
     // the VGPR half (tests/test_host_abi.py checks the disassembly: no AGPR operand outside these instructions).
-    constexpr bool WASM = WINO && MB == 4;
+    constexpr bool WASM = WINO && MB * PG == 16;
     MCQ_STAMP(st0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(TAPS == 12 ? 256 : 512, OCC) void conv_mfma_kernel(
             }
     }
     const int KS = 1 << p.ks_log2;
-    const int tile_in_wg = wave >> p.ks_log2;       // which output tile of this workgroup
+    const int tile_in_wg = W2D ? 0 : wave >> p.ks_log2;       // which output tile of this workgroup (W2D: all waves share it)
     const int kslice = wave & (KS - 1);             // which slice of the k-steps
     // XCD-aware tile order: the dispatcher deals workgroups round-robin to the 8 XCDs (linear id % 8), each with its own
     // L2.  Taking the id as is, vertically adjacent pixel rows -- which share two of their three input rows -- always sit
@@ -236,7 +248,7 @@ next_tile:
     const int gw = (int)(wg << p.tiles_log2) + tile_in_wg;       // tile index along the pixel-block axis
     const bool active = gw * NBG < p.total_blocks;  // wave-uniform
     if (KS == 1 && !active) return;                 // (split-K waves stay for the barriers)
-    const int co_base = blockIdx.y * (32 * MB) + tile_zero;     // first output channel of this wave
+    const int co_base = (W2D ? ((int)blockIdx.y * 4 + wave) * 32 : (int)blockIdx.y * (32 * MB)) + tile_zero;     // first output channel of this wave
     const int hi = lane >> 5, j = lane & 31;
     const int BW = 1 << p.bw_log2;
     const int ly = j >> p.bw_log2, lx = j & (BW - 1);
@@ -262,8 +274,8 @@ next_tile:
         const int by = rem / p.nbx;
         const int bx = rem - by * p.nbx;
         img[nb] = n;
-        yo[nb] = by * BH + ly;
-        xo[nb] = WINO ? 2 * (bx * BW + lx) + nb : bx * BW + lx;
+        yo[nb] = W2D ? 2 * (by * BH + ly) + (nb >> 1) : by * BH + ly;
+        xo[nb] = W2D ? 2 * (bx * BW + lx) + (nb & 1) : WINO ? 2 * (bx * BW + lx) + nb : bx * BW + lx;
         valid[nb] = pbv && yo[nb] < p.Ho && xo[nb] < p.Wo;
         xb[nb] = reinterpret_cast<const char*>(mcq_uniform_ptr(P_x + (size_t)n * p.Cin * HW));
         rsrc[nb] = mcq_make_rsrc(xb[nb], plane_bytes);
@@ -321,6 +333,105 @@ next_tile:
     }
 
     const int npairs = active ? p.slice_pairs : 0;
+    if constexpr (W2D) {
+        // ---- F(2x2, 3x3) k-loop ---------------------------------------------------------------------------------------------
+        // The four waves of the workgroup are the four 32-row bands over the SAME 32 tiles, so they share the input transform
+        // through LDS: wave w loads row w of every lane's 4 x 4 patch (4 loads per channel pair instead of 16 -- with each wave
+        // loading whole patches the launch was bound by L1 throughput: 155 -> 246 "TFLOP/s" without those loads), transforms it
+        // along x and parks the four values in LDS; after ONE workgroup barrier per channel pair (two buffers) every wave reads
+        // the four rows back and transforms along y.  All of it one group ahead of the MFMAs that use it.
+        constexpr int GA = 4;                               // channel pairs the row loads run ahead = groups per loop body
+        unsigned vrow[4];
+        {
+            const int yi = yo[0] + wave - 1;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const int xi = xo[0] - 1 + px;
+                const bool inb = valid[0] && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
+                vrow[px] = inb ? (unsigned)(yi * p.W + xi + hi * HW) * 4u : MCQ_OOB;
+            }
+        }
+        float Bw[GA][4];
+        f32x4v* const tl = reinterpret_cast<f32x4v*>(mcq_lds);          // [2 buffers][4 patch rows][64 lanes]
+        if (active) {
+#pragma unroll
+            for (int st = 0; st < PFA; ++st) { A[st] = mcq_wload<MB>(wr, wlane, wso); wso += 256 * MB; }
+#pragma unroll
+            for (int g = 0; g < GA; ++g)
+#pragma unroll
+                for (int px = 0; px < 4; ++px) Bw[g][px] = mcq_buffer_load(rsrc[0], vrow[px] + soff + (unsigned)g * step_bytes);
+        }
+        auto row_to_lds = [&](const int slot, const int buf) __attribute__((always_inline)) {
+            const float d0 = Bw[slot][0], d1 = Bw[slot][1], d2 = Bw[slot][2], d3 = Bw[slot][3];
+            tl[(buf * 4 + wave) * 64 + lane] = f32x4v{d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+        };
+        auto lds_rows = [&](const int buf, f32x4v (&t)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int py = 0; py < 4; ++py) t[py] = tl[(buf * 4 + py) * 64 + lane];
+        };
+        auto rows_to_v = [&](const f32x4v (&t)[4], float (&out)[16]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                out[j] = t[0][j] - t[2][j]; out[4 + j] = t[1][j] + t[2][j]; out[8 + j] = t[2][j] - t[1][j]; out[12 + j] = t[1][j] - t[3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(out[i]));      // (opaque: never re-formed in front of an MFMA)
+        };
+        // the workgroup barrier WITHOUT the fence of __syncthreads(): that one waits for every outstanding vector load,
+        // i.e. it would drain the prefetch rings once per channel pair
+#if MCQ_W2D_EXP == 1
+        auto wg_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+#elif MCQ_W2D_EXP == 2
+        auto wg_barrier = [&]() __attribute__((always_inline)) { asm volatile("" ::: "memory"); };
+#else
+        auto wg_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#endif
+        float Vn[16];
+        f32x4v tq[4];
+        row_to_lds(0, 0);
+        wg_barrier();
+        lds_rows(0, tq);
+        rows_to_v(tq, Vn);
+        MCQ_STAMP(st1w);
+        // The first body is peeled off the loop: hipcc's wait-count pass merges the loop-entry state (operands requested by the
+        // preload above, back to back) with the back-edge state (requested one body ago, 80 loads apart) and would wait at every
+        // use as if the loads had only just been issued -- draining the rings once per channel pair (55 instead of 155 "TFLOP/s").
+        auto body = [&](const int sp) __attribute__((always_inline)) {
+            __amdgpu_buffer_rsrc_t rB[GA];
+#pragma unroll
+            for (int j = 0; j < GA; ++j) {
+                const unsigned off = soff + (unsigned)(GA + j) * step_bytes;
+                const int left = (int)plane_bytes - (int)off;
+                rB[j] = mcq_make_rsrc(xb[0] + off, (unsigned)(left > 0 ? left : 0));
+            }
+            float V[16];
+#pragma unroll
+            for (int u = 0; u < GA * 16; ++u) {
+                const int k = u / 16, st = u % 16;
+                // (no early exit: the launcher only takes layers whose channel pairs fill whole bodies, Cin % 8 == 0 -- a branch
+                //  per step makes every step its own basic block, 86 instead of 155 "TFLOP/s", and a `break` around the barrier
+                //  keeps the loop from unrolling at all)
+                if (st == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) V[i] = Vn[i];
+                }
+                // the next group's transform, spread over this group's steps so that neither the barrier (by step 6 every wave has
+                // long written its row) nor the LDS round trip stalls the MFMA stream: in-order issue stops at a wait
+                if (st == 1) row_to_lds((k + 1) % GA, (k + 1) & 1);
+                if (st == 6) { wg_barrier(); lds_rows((k + 1) & 1, tq); }
+                if (st == 11) rows_to_v(tq, Vn);
+                asm volatile("v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, a[%2:%3]"
+                             :: "v"(a_elem<MB>(A[st], 0)), "v"(V[st]), "n"(16 * st), "n"(16 * st + 15));
+                if (st < 4) Bw[k][st] = mcq_buffer_load(rB[k], vrow[st]);         // my row of the pair GA groups ahead
+                A[st] = mcq_wload<MB>(wr, wlane, wso);
+                wso += 256 * MB;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            soff += (unsigned)GA * step_bytes;
+        };
+        if (npairs > 0) body(0);
+        for (int sp = GA; sp < npairs; sp += GA) body(sp);
+    } else {
     if (active) {
 #pragma unroll
         for (int st = 0; st < PFA; ++st) {          // weights of steps 0 .. PFA-1 of the slice
@@ -336,11 +447,20 @@ next_tile:
         }
     }
 
-    float Vn[4] = {0.0f, 0.0f, 0.0f, 0.0f};              // (WINO) transformed inputs of the group about to start
-    if (WINO && active) {
-        const float d0 = B[0][0], d1 = B[1 % PFB][0], d2 = B[2 % PFB][0], d3 = B[3 % PFB][0];
-        Vn[0] = d0 - d2; Vn[1] = d1 + d2; Vn[2] = d2 - d1; Vn[3] = d1 - d3;
-    }
+    // (WINO) the transformed inputs of a group of PG k-steps from its PG loads, ring slots first .. first + PG - 1
+    constexpr int PGV = WINO ? PG : 4;
+    auto wino_transform = [&](const int first, float (&out)[PGV]) __attribute__((always_inline)) {
+        if (W2D) {
+            (void)first; (void)out;                      // (the 2-D form has its own loop above)
+        } else {
+            const float d0 = B[first % PFB][0], d1 = B[(first + 1) % PFB][0], d2 = B[(first + 2) % PFB][0], d3 = B[(first + 3) % PFB][0];
+            out[0] = d0 - d2; out[1] = d1 + d2; out[2] = d2 - d1; out[3] = d1 - d3;
+        }
+    };
+    float Vn[PGV];                                       // (WINO) transformed inputs of the group about to start
+#pragma unroll
+    for (int i = 0; i < PGV; ++i) Vn[i] = 0.0f;
+    if (WINO && active) wino_transform(0, Vn);
     MCQ_STAMP(st1);
     for (int sp = 0; sp < npairs; sp += PAIRS_PER_ITER) {
         // Every VALU instruction between two MFMAs costs the matrix pipe ~10 cycles (tools/probes/mfma_issue.hip), so
@@ -349,7 +469,7 @@ next_tile:
         // accordingly (reads past the last channel stay out of range = 0) -- and the voffset is the bare tap offset.
         constexpr int PFBP = TAPS != 1 ? PFB / TAPS : PFB;   // look-ahead in channel pairs
         __amdgpu_buffer_rsrc_t rB[NBG][PAIRS_PER_ITER];
-        float V[4];                                          // (WINO) the transformed inputs of the current group of four steps
+        float V[PGV];                                        // (WINO) the transformed inputs of the current group of PG steps
 #pragma unroll
         for (int nb = 0; nb < NBG; ++nb)
 #pragma unroll
@@ -367,16 +487,19 @@ next_tile:
                 // four loads of one (channel pair, filter row) -> the B operands of four k-steps, formed one group AHEAD (during
                 // the second step of the group before): a VALU result consumed by the very next MFMA is a hazard the inline-asm
                 // MFMAs of the 128-row instance get no wait states for, and a stall for the others
-                if (u % 4 == 0) { V[0] = Vn[0]; V[1] = Vn[1]; V[2] = Vn[2]; V[3] = Vn[3]; }
-                if (u % 4 == 1) {
-                    const float d0 = B[(u + 3) % PFB][0], d1 = B[(u + 4) % PFB][0], d2 = B[(u + 5) % PFB][0], d3 = B[(u + 6) % PFB][0];
-                    Vn[0] = d0 - d2; Vn[1] = d1 + d2; Vn[2] = d2 - d1; Vn[3] = d1 - d3;
+                if (u % PG == 0) {
+#pragma unroll
+                    for (int i = 0; i < PGV; ++i) V[i] = Vn[i];
+                }
+                if (u % PG == 1) {
+                    wino_transform(u + PG - 1, Vn);
                     if (WASM) {                              // (opaque: under register pressure the compiler re-forms a difference right in
                                                              //  front of its MFMA instead of keeping it -- seen once, caught by the hygiene test)
-                        asm volatile("" : "+v"(Vn[0]), "+v"(Vn[1]), "+v"(Vn[2]), "+v"(Vn[3]));
+#pragma unroll
+                        for (int i = 0; i < PGV; ++i) asm volatile("" : "+v"(Vn[i]));
                     }
                 }
-                bv[0] = V[u % 4];
+                bv[0] = V[(u % PG) % PGV];
             } else {
 #pragma unroll
                 for (int nb = 0; nb < NBG; ++nb) {
@@ -394,15 +517,15 @@ next_tile:
             const int ds = TAPS != 1 ? (u + PFB) / TAPS : u + PFB;              // its channel-pair distance
 #pragma unroll
             for (int nb = 0; nb < NBG; ++nb) {
-                const int at = WINO ? u % 4 : nb;            // accumulator tile: transform position / pixel block
+                const int at = WINO ? u % PG : nb;           // accumulator tile: transform position / pixel block
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
                     if (WASM)
                         asm volatile("v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, a[%2:%3]"
-                                     :: "v"(a_elem<MB>(A[sa], mb)), "v"(bv[nb]), "n"(16 * (4 * mb + at)), "n"(16 * (4 * mb + at) + 15));
+                                     :: "v"(a_elem<MB>(A[sa], mb)), "v"(bv[nb]), "n"(16 * (PG * mb + at)), "n"(16 * (PG * mb + at) + 15));
                     else
-                        acc[mb][at] =
-                            __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[sa], mb), bv[nb], acc[mb][at], 0, 0, 0);
+                        acc[mb][at % NACC] =
+                            __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[sa], mb), bv[nb], acc[mb][at % NACC], 0, 0, 0);
                 }
 #if MCQ_ABLATE == 2 || MCQ_ABLATE == 4
                 asm volatile("" : "+v"(B[sb][nb]));
@@ -424,6 +547,7 @@ next_tile:
         }
         soff += (unsigned)PAIRS_PER_ITER * step_bytes;
     }
+    }       // (!W2D)
 
     if (WASM) asm volatile("s_nop 15\n\ts_nop 15");       // (the last MFMAs' results must have landed before the first v_accvgpr_read)
     MCQ_STAMP(st2);
@@ -648,6 +772,64 @@ next_tile:
             for (int nb = 0; nb < 2; ++nb)
                 pvo[nb] = valid[nb] ? ((unsigned)(yo[nb] * p.Wo + xo[nb]) + 4u * (unsigned)hi * HoWo) * 4u : MCQ_OOB;
             const bool wide = (p.Wo & 1) == 0;                  // (wave-uniform)
+            if constexpr (W2D) {
+                // one 32-row band, a 2 x 2 pixel tile per lane: rows oy = 0 / 1 of the tile are two 64-bit accesses (even width)
+                unsigned pv4[4];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    pv4[nb] = valid[nb] ? ((unsigned)(yo[nb] * p.Wo + xo[nb]) + 4u * (unsigned)hi * HoWo) * 4u : MCQ_OOB;
+                float bias16[16];
+                f32x2v res2[2][16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned row = (unsigned)co_base + (unsigned)mcq_drow(r, 0);
+                    bias16[r] = mcq_buffer_load_s(br, (unsigned)hi * 16u, row * 4u);
+                    if (EF & MCQ_CONV_RESIDUAL) {
+#pragma unroll
+                        for (int oy = 0; oy < 2; ++oy) {
+                            if (wide) res2[oy][r] = mcq_buffer_load2_s(rr, pv4[2 * oy], row * HoWo * 4u);
+                            else res2[oy][r] = f32x2v{mcq_buffer_load_s(rr, pv4[2 * oy], row * HoWo * 4u), mcq_buffer_load_s(rr, pv4[2 * oy + 1], row * HoWo * 4u)};
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                    float m[16];
+#pragma unroll
+                    for (int pos = 0; pos < 16; ++pos) asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(m[pos]) : "n"(16 * pos + r));
+                    float sx[4][2];                           // A^T M A: along x ...
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        sx[i][0] = (m[4 * i] + m[4 * i + 1]) + m[4 * i + 2];
+                        sx[i][1] = (m[4 * i + 1] - m[4 * i + 2]) - m[4 * i + 3];
+                    }
+                    const unsigned so = ((unsigned)co_base + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
+#pragma unroll
+                    for (int oy = 0; oy < 2; ++oy) {          // ... then along y: the two pixels of output row oy
+                        f32x2v y, tw = {0.0f, 0.0f};
+#pragma unroll
+                        for (int ox = 0; ox < 2; ++ox) {
+                            y[ox] = (oy == 0 ? (sx[0][ox] + sx[1][ox]) + sx[2][ox] : (sx[1][ox] - sx[2][ox]) - sx[3][ox]) + bias16[r];
+                            if (EF & MCQ_CONV_RESIDUAL) y[ox] = y[ox] + p.res_scale * res2[oy][r][ox];
+                        }
+                        if (EF & MCQ_CONV_SILU_OUT) y = f32x2v{mcq_silu(y[0]), mcq_silu(y[1])};
+                        if (EF & MCQ_CONV_DUAL_SILU) tw = f32x2v{mcq_silu(y[0]), mcq_silu(y[1])};
+                        if (wide) {
+                            mcq_buffer_store2_s(y, yr, pv4[2 * oy], so);
+                            if (EF & MCQ_CONV_DUAL_SILU) mcq_buffer_store2_s(tw, y2r, pv4[2 * oy], so);
+                        } else {
+                            mcq_buffer_store_s(y[0], yr, pv4[2 * oy], so);
+                            mcq_buffer_store_s(y[1], yr, pv4[2 * oy + 1], so);
+                            if (EF & MCQ_CONV_DUAL_SILU) {
+                                mcq_buffer_store_s(tw[0], y2r, pv4[2 * oy], so);
+                                mcq_buffer_store_s(tw[1], y2r, pv4[2 * oy + 1], so);
+                            }
+                        }
+                    }
+                }
+                return;
+            }
             float ball[MB][16];
             f32x2v rall[MB][16];
             // side loads run one band ahead of the band being finished (a band takes longer than their latency; more of them in
@@ -725,19 +907,28 @@ next_tile:
         run_epilogue(true, [&](int mi, int nb, float (&v)[16]) {           // (mi, nb are constants once unrolled)
 #endif
             if (WINO) {
-                // back from the four transform positions to the two pixels of the pair, band by band (all 4 MB tiles at
+                // back from the transform positions to the pixels of the pair / tile, band by band (all accumulator tiles at
                 // once would need every accumulator in a VALU-readable register at the same time)
+                auto m_at = [&](const int pos, const int r) __attribute__((always_inline)) -> float {
+                    if (WASM) {
+                        float x;
+                        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(16 * (PG * mi + pos) + r));
+                        return x;
+                    }
+                    return acc[mi][pos % NACC][r];
+                };
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if (WASM) {
-                        float a, b, c;
-                        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(a) : "n"(16 * (4 * mi + (nb == 0 ? 0 : 1)) + r));
-                        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(b) : "n"(16 * (4 * mi + (nb == 0 ? 1 : 2)) + r));
-                        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(c) : "n"(16 * (4 * mi + (nb == 0 ? 2 : 3)) + r));
-                        v[r] = nb == 0 ? (a + b) + c : (a - b) - c;
+                    if (W2D) {                               // pixel (oy, ox) = nb: A^T M A, first along x, then along y
+                        const int oy = nb >> 1, ox = nb & 1;
+                        float sx[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            sx[i] = ox == 0 ? (m_at(4 * i, r) + m_at(4 * i + 1, r)) + m_at(4 * i + 2, r)
+                                            : (m_at(4 * i + 1, r) - m_at(4 * i + 2, r)) - m_at(4 * i + 3, r);
+                        v[r] = oy == 0 ? (sx[0] + sx[1]) + sx[2] : (sx[1] - sx[2]) - sx[3];
                     } else
-                        v[r] = nb == 0 ? (acc[mi][0][r] + acc[mi][1][r]) + acc[mi][2 % NACC][r]
-                                       : (acc[mi][1][r] - acc[mi][2 % NACC][r]) - acc[mi][3 % NACC][r];
+                        v[r] = nb == 0 ? (m_at(0, r) + m_at(1, r)) + m_at(2, r) : (m_at(1, r) - m_at(2, r)) - m_at(3, r);
                 }
                 return;
             }
@@ -818,13 +1009,21 @@ __device__ __forceinline__ void pack_conv_weight_body(const float* __restrict__ 
     const int tile = (int)(stepg / TP);
     const int step = (int)(stepg - (size_t)tile * TP);
     float v = 0.0f;
-    const int taps = mode >= 3 ? 12 : ks * ks;
+    const int taps = mode == 5 ? 16 : mode >= 3 ? 12 : ks * ks;
     if (tile < ntile && step < TP) {
         const int s = step / taps, tap = step - s * taps;
         const int co = tile * 32 * bands + 32 * q + (lane & 31);
         const int ci = 2 * s + (lane >> 5);
         if (co < Cout && ci < Cin) {
-            if (mode >= 3) {
+            if (mode == 5) {
+                // F(2x2, 3x3): tap = 4 i + j, U = G g G^T in float64, rounded once
+                const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+                const int pi = tap >> 2, pj = tap & 3;
+                double u = 0.0;
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) u += G[pi][a] * (double)pack_source(w, 0, Co, Ci, 3, co, ci, 3 * a + b) * G[pj][b];
+                v = (float)u;
+            } else if (mode >= 3) {
                 // Winograd F(2, 3) along x: tap = 4 dy + position; G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]];
                 // mode 3 from the layer's own filter rows, mode 4 from those of its stride-1 input-gradient convolution
                 const int row = 3 * (tap >> 2), src = mode == 3 ? 0 : 1;
@@ -943,6 +1142,33 @@ int launch_wino(ConvK k, long long tiles, int co_tiles, hipStream_t s) {
     return mcq_check_launch();
 }
 
+// F(2x2, 3x3) launches: one block of 32 tiles (2 x 2 pixels each) per workgroup, its four waves = four 32-row bands
+int launch_wino2d(ConvK k, long long tiles, int co_groups, hipStream_t s) {
+    k.ks_log2 = 0;
+    k.slice_pairs = k.S;
+    k.tiles_log2 = 0;
+    k.total_wgs = (int)tiles;
+    const unsigned gx = MCQ_WINO_PERSIST > 0 && k.total_wgs > 256 * MCQ_WINO_PERSIST ? 256u * MCQ_WINO_PERSIST : (unsigned)k.total_wgs;
+    const dim3 grid(gx, (unsigned)co_groups, (unsigned)k.nprob);
+    const unsigned ef = k.flags & ~(unsigned)(MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN);
+    int id = 0;
+    for (int c = 1; c <= 6; ++c) if (ef == wino_epilogue_flags(c)) id = c;
+    switch (id) {
+        case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, 4, 1, 16, 32, 16, 1>), grid, dim3(256), 8192, s, k); break;
+        case 2: hipLaunchKernelGGL((conv_mfma_kernel<1, 4, 2, 16, 32, 16, 1>), grid, dim3(256), 8192, s, k); break;
+        case 3: hipLaunchKernelGGL((conv_mfma_kernel<1, 4, 3, 16, 32, 16, 1>), grid, dim3(256), 8192, s, k); break;
+        case 4: hipLaunchKernelGGL((conv_mfma_kernel<1, 4, 4, 16, 32, 16, 1>), grid, dim3(256), 8192, s, k); break;
+        case 5: hipLaunchKernelGGL((conv_mfma_kernel<1, 4, 5, 16, 32, 16, 1>), grid, dim3(256), 8192, s, k); break;
+        case 6: hipLaunchKernelGGL((conv_mfma_kernel<1, 4, 6, 16, 32, 16, 1>), grid, dim3(256), 8192, s, k); break;
+        default: hipLaunchKernelGGL((conv_mfma_kernel<1, 4, 0, 16, 32, 16, 1>), grid, dim3(256), 8192, s, k); break;
+    }
+    return mcq_check_launch();
+}
+
+inline size_t wino2d_floats(int Cout, int Cin) {           // [Cout/32][Cin/2 x 16 (+ 16 tail)][64 lanes]
+    return (((size_t)(Cout + 31) / 32) * (size_t)((Cin + 1) / 2) * 16 + 16) * 64;
+}
+
 bool wino_shape(int Cout, int ksize, int stride, unsigned fl) {
     return ksize == 3 && stride == 1 && Cout % 64 == 0 && !(fl & (MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN));
 }
@@ -972,6 +1198,19 @@ extern "C" int mcq_pack_conv_dgrad_weight_winograd_f32(const float* w, int32_t C
     const int S = (ci_d + 1) / 2, TP = S * 12;
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, co_d, ci_d,
                        3, S, TP, out, sec4, sec2, total, 4, Cout, Cin, 1.0f);
+    return mcq_check_launch();
+}
+
+extern "C" size_t mcq_packed_conv_winograd2d_floats(int32_t Cout, int32_t Cin) {
+    return Cout <= 0 || Cin <= 0 ? 0 : wino2d_floats(Cout, Cin);
+}
+
+extern "C" int mcq_pack_conv_weight_winograd2d_f32(const float* w, int32_t Cout, int32_t Cin, float* out, void* stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0) return MCQ_EINVAL;
+    const size_t total = wino2d_floats(Cout, Cin);
+    const int S = (Cin + 1) / 2, TP = S * 16;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
+                       3, S, TP, out, (size_t)0, (size_t)0, total, 5, Cout, Cin, 1.0f);
     return mcq_check_launch();
 }
 
@@ -1071,7 +1310,7 @@ int conv_validate(const mcq_conv_desc* d) {
     if ((fl & MCQ_CONV_DUAL_SILU) && (!d->y_silu || (fl & MCQ_CONV_SILU_OUT))) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_SILU_IN) && (fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;
     if (fl & MCQ_CONV_SHUFFLE2) {
-        if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN | MCQ_CONV_WINOGRAD))) return MCQ_EINVAL;
+        if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN | MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D))) return MCQ_EINVAL;
     }
     // one image's input slab plus the prefetch rings' over-read (up to 8 channels) must stay below 2 GiB: byte offsets and
     // the descriptors' shrinking num_records are 32-bit (signed in the scalar arithmetic of the k-loop)
@@ -1105,6 +1344,31 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         a.bias = e->bias; a.y = e->y; a.y2 = e->y_silu; a.res = e->res; a.mul = e->mul; a.gid = e->gate_id;
     }
 
+    if (fl & MCQ_CONV_WINOGRAD2D) {
+        if ((fl & MCQ_CONV_WINOGRAD) || !wino_shape(d->Cout, d->ksize, d->stride, fl) || d->Cout % 128 != 0 || d->Cin % 8 != 0) return MCQ_EINVAL;
+        if ((uint64_t)(d->Cin + 16) * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
+        k.TP = k.S * 16;
+        k.wp32 = k.wp; k.wp64 = k.wp;
+        for (int c = 1; c < MCQ_CONV_MAX_MULTI; ++c) { k.alt[c - 1].wp32 = k.alt[c - 1].wp; k.alt[c - 1].wp64 = k.alt[c - 1].wp; }
+        // tile blocks: 32 tiles of 2 x 2 pixels shaped (32 >> b) rows x (1 << b) tiles, b by the fewest wasted lanes
+        const int Wt = (k.Wo + 1) / 2, Ht = (k.Ho + 1) / 2;
+        int best_log2 = 5; double best_util = -1.0;
+        for (int lg = 5; lg >= 0; --lg) {
+            const int bw = 1 << lg, bh = 32 >> lg;
+            const double cover = (double)((Ht + bh - 1) / bh * bh) * (double)((Wt + bw - 1) / bw * bw);
+            const double util = (double)Ht * Wt / cover;
+            if (util > best_util + 1e-9) { best_util = util; best_log2 = lg; }
+        }
+        k.bw_log2 = best_log2;
+        k.nbx = (Wt + (1 << best_log2) - 1) >> best_log2;
+        k.nby = (Ht + (32 >> best_log2) - 1) / (32 >> best_log2);
+        const long long tbw = (long long)k.N * k.nbx * k.nby;
+        if (tbw > 0x7fffffffLL) return MCQ_ETOOLARGE;
+        k.total_blocks = (int)tbw;
+        if ((uint64_t)d->Cout * (uint64_t)k.Ho * k.Wo * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
+        k.flags = fl & ~(unsigned)MCQ_CONV_WINOGRAD2D;
+        return launch_wino2d(k, tbw, d->Cout / 128, (hipStream_t)stream);
+    }
     if (fl & MCQ_CONV_WINOGRAD) {
         if (!wino_shape(d->Cout, d->ksize, d->stride, fl)) return MCQ_EINVAL;
         if ((uint64_t)(d->Cin + 16) * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;     // (rings up to 8 channel pairs ahead)

@@ -14,24 +14,29 @@ import torch
 
 from . import _lib
 from ._lib import (CONV_DSILU_MUL, CONV_DUAL_SILU, CONV_MUL, CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN,
-                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, ConvDesc, check)
+                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, CONV_WINOGRAD2D, ConvDesc, check)
 
 # OPT-IN fast path, never the default and never the headline bench: large 3x3 stride-1 layers in the Winograd F(2, 3) form
 # along x (mcq_pack_conv_weight_winograd_f32 + MCQ_CONV_WINOGRAD): 2/3 of the multiplications, float32 throughout, but not
 # the reference's arithmetic -- results differ from the direct form in the last bits, so near-tie code indices may move.
-_WINOGRAD = os.environ.get("MCQUIC_AMD_WINOGRAD", "0") == "1"
+_WINOGRAD = os.environ.get("MCQUIC_AMD_WINOGRAD", "0") in ("1", "2")
+# ... and where Cout % 128 == 0, in both directions: F(2x2, 3x3), 4/9 of the multiplications (MCQUIC_AMD_WINOGRAD=2)
+_WINOGRAD_2D = os.environ.get("MCQUIC_AMD_WINOGRAD", "0") == "2"
 _WINOGRAD_MIN_PIXELS = int(os.environ.get("MCQUIC_AMD_WINOGRAD_MIN_PIXELS", str(128 * 1024)))   # N*H*W below this: direct form
 
 
-def winograd_enabled() -> bool:
-    return _WINOGRAD
+def winograd_enabled() -> int:
+    """0 = off (the default), 1 = F(2, 3) along x, 2 = F(2x2, 3x3) where the layer allows it."""
+    return (2 if _WINOGRAD_2D else 1) if _WINOGRAD else 0
 
 
-def set_winograd(enabled: bool, min_pixels: Optional[int] = None) -> None:
-    """Switch the opt-in Winograd path on / off for convolutions packed from now on (nn.Conv2d re-packs on the change);
+def set_winograd(enabled, min_pixels: Optional[int] = None) -> None:
+    """Switch the opt-in Winograd path on / off for convolutions packed from now on (nn.Conv2d re-packs on the change):
+    False / 0 = off, True / 1 = F(2, 3) along x, 2 = F(2x2, 3x3) for layers with Cout % 128 == 0 (the 1-D form elsewhere).
     `min_pixels`: layers with fewer than N*H*W input pixels keep the direct form (default 128 k)."""
-    global _WINOGRAD, _WINOGRAD_MIN_PIXELS
+    global _WINOGRAD, _WINOGRAD_2D, _WINOGRAD_MIN_PIXELS
     _WINOGRAD = bool(enabled)
+    _WINOGRAD_2D = enabled is not True and int(enabled) >= 2
     if min_pixels is not None:
         _WINOGRAD_MIN_PIXELS = int(min_pixels)
 
@@ -126,7 +131,7 @@ def _ptr(t: Optional[torch.Tensor]):
 class PackedConv:
     """A conv weight re-laid for the MFMA operand stream (+ its bias), see mcq_pack_conv_weight_f32."""
 
-    __slots__ = ("wp", "bias", "cout", "cin", "ksize", "wino")
+    __slots__ = ("wp", "bias", "cout", "cin", "ksize", "wino", "wino2d")
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], copy_bias: bool = True, winograd: Optional[bool] = None):
         weight = _dev(weight.detach(), "weight")
@@ -141,12 +146,20 @@ class PackedConv:
         # (the copy decouples the pack from later in-place updates of the parameter; a caller that hands over a fresh tensor skips it)
         self.bias = None if bias is None else (_dev(bias.detach(), "bias").clone() if copy_bias else _dev(bias.detach(), "bias"))
         self.cout, self.cin, self.ksize = cout, cin, kh
-        self.wino = None
-        if (winograd if winograd is not None else _WINOGRAD) and kh == 3 and cout % 64 == 0:
+        self.wino = self.wino2d = None
+        level = (2 if _WINOGRAD_2D else 1) if _WINOGRAD else 0
+        if winograd is not None:
+            level = 1 if winograd is True else int(winograd)
+        if level >= 1 and kh == 3 and cout % 64 == 0:
             self.wino = torch.empty(lib.mcq_packed_conv_winograd_floats(cout, cin), dtype=torch.float32, device=weight.device)
             with _guard(weight.device):
                 check(lib.mcq_pack_conv_weight_winograd_f32(_ptr(weight), cout, cin, _ptr(self.wino), _stream()),
                       "mcq_pack_conv_weight_winograd_f32")
+        if level >= 2 and kh == 3 and cout % 128 == 0 and cin % 8 == 0:
+            self.wino2d = torch.empty(lib.mcq_packed_conv_winograd2d_floats(cout, cin), dtype=torch.float32, device=weight.device)
+            with _guard(weight.device):
+                check(lib.mcq_pack_conv_weight_winograd2d_f32(_ptr(weight), cout, cin, _ptr(self.wino2d), _stream()),
+                      "mcq_pack_conv_weight_winograd2d_f32")
 
     @classmethod
     def dgrad(cls, weight: torch.Tensor, stride: int, scale: float = 1.0, winograd: Optional[bool] = None) -> "PackedConv":
@@ -166,7 +179,7 @@ class PackedConv:
                   "mcq_pack_conv_dgrad_weight_f32")
         self.bias = None
         self.cout, self.cin, self.ksize = co_d.value, ci_d.value, kh
-        self.wino = None
+        self.wino = self.wino2d = None
         if (winograd if winograd is not None else _WINOGRAD) and kh == 3 and stride == 1 and scale == 1.0 and cin % 64 == 0:
             self.wino = torch.empty(lib.mcq_packed_conv_winograd_floats(cin, cout), dtype=torch.float32, device=weight.device)
             with _guard(weight.device):
@@ -215,7 +228,7 @@ def pack_convs(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Option
         pk.wp = slab[i]
         pk.bias = None if dgrad or biases is None or biases[i] is None else _dev(biases[i].detach(), "bias")
         pk.cout, pk.cin, pk.ksize = co, ci, kh
-        pk.wino = None
+        pk.wino = pk.wino2d = None
         out.append(pk)
     return out
 
@@ -274,7 +287,13 @@ def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool
     wp = w.wp
     if winograd or (winograd is None and _WINOGRAD and n * h * wd >= _WINOGRAD_MIN_PIXELS):
         ok = w.wino is not None and stride == 1 and not (flags & (CONV_SILU_IN | CONV_SQUARE_IN))
-        if ok:
+        two_d = w.wino2d is not None and (_WINOGRAD_2D if winograd is None or winograd is True else int(winograd) >= 2)
+        if winograd is not None and winograd is not True and int(winograd) >= 2 and w.wino2d is None:
+            raise ValueError("winograd=2 needs a 3x3 layer with Cout % 128 == 0 and Cin % 8 == 0, packed with winograd=2")
+        if ok and two_d:
+            flags |= CONV_WINOGRAD2D
+            wp = w.wino2d
+        elif ok:
             flags |= CONV_WINOGRAD
             wp = w.wino
         elif winograd:

@@ -485,3 +485,48 @@ def test_conv_random_shapes_sweep(dev):
             wino += 1
             _close(ops.conv2d(x.to(dev), pk, stride, winograd=True), want, 1e-5, f"case {i} (winograd): {n}x{cin}->{cout} {h}x{w}")
     assert wino >= 5
+
+
+WINO2D_CASES = [  # n, cin, cout, h, w
+    (2, 128, 128, 12, 16), (1, 128, 128, 9, 7), (1, 64, 128, 33, 65), (1, 128, 256, 8, 12), (1, 8, 128, 5, 1), (1, 136, 128, 1, 9),
+    (3, 128, 128, 16, 64), (1, 128, 512, 6, 10),
+]
+
+
+@pytest.mark.parametrize("case", WINO2D_CASES)
+def test_conv_winograd2d_opt_in(dev, case):
+    """The opt-in F(2x2, 3x3) form (MCQ_CONV_WINOGRAD2D: 4/9 of the multiplications, float32 throughout) against F.conv2d on
+    the CPU; odd sizes exercise half-empty tiles in both directions."""
+    from mcquic_amd import ops
+    n, cin, cout, h, w = case
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, 3, 3), 2, 1.0 / np.sqrt(cin * 9))
+    b = _rand((cout,), 3, 0.1)
+    want = F.conv2d(x, wt, b, padding=1)
+    pk = ops.PackedConv(wt.to(dev), b.to(dev), winograd=2)
+    assert pk.wino2d is not None and pk.wino is not None
+    got = ops.conv2d(x.to(dev), pk, winograd=2)
+    _close(got, want, 2e-5, f"winograd 2-D conv{case}")
+    _close(ops.conv2d(x.to(dev), pk, winograd=1), want, 1e-5, f"winograd 1-D conv{case}")
+
+
+def test_conv_winograd2d_epilogues(dev):
+    from mcquic_amd import ops
+    for (h, w) in ((14, 22), (9, 13)):                       # even and odd widths (64-bit / 32-bit row accesses)
+        x = _rand((2, 128, h, w), 5)
+        wt = _rand((128, 128, 3, 3), 6, 0.03)
+        b = _rand((128,), 7, 0.1)
+        res = _rand((2, 128, h, w), 8)
+        pk = ops.PackedConv(wt.to(dev), b.to(dev), winograd=2)
+        y = F.conv2d(x, wt, b, padding=1)
+        got = ops.conv2d(x.to(dev), pk, res=res.to(dev), dual_silu=True, winograd=2)
+        _close(got, y + res, 2e-5, "res")
+        _close(ops.silu_twin(got), F.silu(y + res), 2e-5, "twin")
+        _close(ops.conv2d(x.to(dev), pk, silu_out=True, winograd=2), F.silu(y), 2e-5, "silu_out")
+        _close(ops.conv2d(x.to(dev), pk, res=res.to(dev), winograd=2), y + res, 2e-5, "res only")
+        _close(ops.conv2d(x.to(dev), pk, winograd=2), y, 2e-5, "plain")
+        _close(ops.conv2d(x.to(dev), pk, shuffle2=True, winograd=2), F.pixel_shuffle(y, 2), 2e-5, "shuffle2 (generic epilogue)")
+    with pytest.raises(ValueError):
+        ops.conv2d(x.to(dev), ops.PackedConv(_rand((64, 128, 3, 3), 1, 0.03).to(dev), None, winograd=2), winograd=2)   # Cout % 128
+    with pytest.raises(ValueError):
+        ops.conv2d(_rand((1, 130, 6, 6), 2).to(dev), ops.PackedConv(_rand((128, 130, 3, 3), 1, 0.03).to(dev), None, winograd=2), winograd=2)   # Cin % 8

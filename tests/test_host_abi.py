@@ -180,16 +180,16 @@ def test_winograd_instance_keeps_its_accumulators_to_itself():
     bodies, cur = {}, None
     for line in asm.splitlines():
         if line.endswith(">:"):
-            cur = line if re.search(r"conv_mfma_kernelILi4ELi2ELi\dELi12E", line) else None
+            cur = line if re.search(r"conv_mfma_kernelILi(4ELi2ELi\dELi12E|1ELi4ELi\dELi16E)", line) else None
         elif cur:
             bodies.setdefault(cur, []).append(line.split("//")[0])
-    assert len(bodies) == 7, f"expected the seven 128-row Winograd instances (one per epilogue flag set), found {len(bodies)}"
+    assert len(bodies) == 14, f"expected the 7 + 7 hand-numbered Winograd instances (F(2,3) 128-row and F(2x2,3x3); one per epilogue flag set), found {len(bodies)}"
     ok = re.compile(r"^\s*(v_mfma_f32_32x32x2_f32 a\[\d+:\d+\], v\d+, v\d+, a\[\d+:\d+\]|v_accvgpr_read_b32 v\d+, a\d+|v_accvgpr_write_b32 a\d+, 0)\s*$")
     body = []
     for name, lines in bodies.items():
         assert len(lines) > 1000
         agpr = [ln for ln in lines if re.search(r"\ba(\d+|\[\d+:\d+\])", ln)]
-        assert len(agpr) >= 96 + 256 + 128 * 3, name
+        assert len(agpr) >= 32 + 256 + 256, name
         stray = [ln for ln in agpr if not ok.match(ln)]
         assert not stray, f"compiler-generated AGPR use in {name}: {stray[:3]}"
         assert not [ln for ln in lines if "scratch_" in ln], f"{name} spills"

@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--small", action="store_true", help="only the three small levels")
     ap.add_argument("--big", action="store_true", help="only the two largest levels")
     ap.add_argument("--k1", action="store_true", help="only the 1x1 shapes")
-    ap.add_argument("--winograd", action="store_true", help="the opt-in Winograd F(2, 3) form beside the direct one (3x3 stride-1 shapes)")
+    ap.add_argument("--winograd", action="store_true", help="the opt-in Winograd forms beside the direct one (3x3 stride-1 shapes): columns direct | F(2,3) 128-row | F(2x2,3x3)")
     ap.add_argument("--train", action="store_true", help="the 3x3 shapes of the config-#5 training step (8 images of 128x128 ... 4x4)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -48,7 +48,7 @@ def main():
     for (n, cin, cout, h, w, ks, stride) in train if args.train else (SHAPES[3:6] if args.small else SHAPES[:2] if args.big else SHAPES[6:] if args.k1 else SHAPES[:7]):
         x = torch.randn(n, cin, h, w, device=dev)
         res = torch.randn(n, cout, h // stride, w // stride, device=dev)
-        packs = [ops.PackedConv(torch.randn(cout, cin, ks, ks, device=dev) * 0.03, torch.randn(cout, device=dev), winograd=args.winograd)
+        packs = [ops.PackedConv(torch.randn(cout, cin, ks, ks, device=dev) * 0.03, torch.randn(cout, device=dev), winograd=2 if args.winograd else None)
                  for _ in range(args.nweights)]
         flops = 2.0 * n * (h // stride) * (w // stride) * cout * cin * ks * ks
         row = []
@@ -59,8 +59,8 @@ def main():
             if args.winograd:
                 if ks != 3 or stride != 1 or tile not in (0, 0x42, 0x22):
                     continue
-                kw["winograd"] = tile != 0                     # column 0 = direct form with the library's tile, 0x42 / 0x22 = Winograd tiles
-                kw["tile"] = 0 if tile == 0 else tile
+                kw["winograd"] = False if tile == 0 else 1 if tile == 0x42 else 2      # columns: direct | F(2,3) 128-row | F(2x2,3x3)
+                kw["tile"] = 0
             if args.flags == "res":
                 kw.update(res=res, dual_silu=True)
             elif args.flags == "resonly":

@@ -205,8 +205,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="images in the CPU-oracle sample (SURVEY 8(d): batch 4)")
     ap.add_argument("--graphs", action="store_true", help="replay encode/decode as captured hipGraphs (small-batch latency)")
-    ap.add_argument("--winograd", action="store_true",
-                    help="OPT-IN experiment, never the headline: large 3x3 stride-1 layers in the Winograd F(2, 3) form (not the reference's arithmetic)")
+    ap.add_argument("--winograd", type=int, nargs="?", const=1, default=0, choices=(0, 1, 2),
+                    help="OPT-IN experiment, never the headline: large 3x3 stride-1 layers in a Winograd form (not the reference's arithmetic); "
+                         "1 = F(2, 3) along x, 2 = F(2x2, 3x3) where the layer allows it")
     args = ap.parse_args()
 
     from mcquic_amd import launch
@@ -232,7 +233,7 @@ def main():
 
     from mcquic_amd import Compressor, ops
     if args.winograd:
-        ops.set_winograd(True)
+        ops.set_winograd(args.winograd)
     torch.manual_seed(3407)                                   # same random-init weights on every rank
     model = Compressor(**MODEL).eval().to(dev)
     if args.graphs:
@@ -282,8 +283,10 @@ def main():
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (uniform [-1,1) images, random-init weights)",
-            "arithmetic": ("OPT-IN winograd F(2,3) along x for the 3x3 stride-1 layers of >= 128 k pixels (float32, 2/3 of the multiplications; "
-                           "NOT the reference's arithmetic -- roofline.achieved counts the direct form's FLOPs and is an equivalent rate here)")
+            "arithmetic": (("OPT-IN winograd F(2x2,3x3) (4/9 of the multiplications; F(2,3) along x where a layer does not qualify)" if args.winograd == 2 else
+                            "OPT-IN winograd F(2,3) along x (2/3 of the multiplications)") +
+                           " for the 3x3 stride-1 layers of >= 128 k pixels, float32; NOT the reference's arithmetic -- roofline.achieved counts "
+                           "the direct form's FLOPs and is an equivalent rate here")
                           if args.winograd else "direct form, exact fp32 MFMA (the reference's arithmetic)",
             "rccl_world": rccl_world, "rank0_cores": None if cores is None else len(cores),
             "config": {"workload": f"qp=2 reference model Compressor(128, 2, [8192, 2048, 512]), batch={args.batch} "

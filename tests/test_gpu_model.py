@@ -74,18 +74,19 @@ def test_qp2_model_eight_kodak_images_exact(dev):
     assert mism == 0, f"{mism} code mismatches"
 
 
-def test_qp2_model_winograd_opt_in(dev):
-    """The OPT-IN Winograd F(2, 3) path (ops.set_winograd; never the default): three 768x512 images through the qp=2 model
-    under the same near-tie protocol and the same 1e-4 pixel bar as the direct form -- every 3x3 stride-1 layer with 64 k
-    pixels or more takes the Winograd kernel (128-row instance; 96x64 ... 384x256 maps), the rest the direct one."""
+@pytest.mark.parametrize("level", [1, 2])
+def test_qp2_model_winograd_opt_in(dev, level):
+    """The OPT-IN Winograd paths (ops.set_winograd; never the default; 1 = F(2, 3) along x, 2 = F(2x2, 3x3)): three 768x512 images
+    through the qp=2 model under the same near-tie protocol and the same 1e-4 pixel bar as the direct form -- every 3x3
+    stride-1 layer with 18 k pixels or more takes a Winograd kernel (96x64 ... 384x256 maps), the rest the direct one."""
     from mcquic_amd import ops
-    ops.set_winograd(True, min_pixels=3 * 96 * 64)
+    ops.set_winograd(level, min_pixels=3 * 96 * 64)
     try:
         launches = {"n": 0}
         real = ops._lib.load().mcq_conv2d_f32
 
         def counting(desc, stream):
-            launches["n"] += bool(desc._obj.flags & ops.CONV_WINOGRAD)
+            launches["n"] += bool(desc._obj.flags & (ops.CONV_WINOGRAD2D if level == 2 else ops.CONV_WINOGRAD))
             return real(desc, stream)
         lib = ops._lib.load()
         lib.mcq_conv2d_f32 = counting

@@ -23,11 +23,12 @@ def main():
     ap.add_argument("--images", type=int, default=32)
     ap.add_argument("--chunk", type=int, default=4)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_b32.json"))
-    ap.add_argument("--winograd", action="store_true", help="audit the OPT-IN Winograd F(2, 3) path instead of the default direct form")
+    ap.add_argument("--winograd", type=int, nargs="?", const=1, default=0, choices=(0, 1, 2),
+                    help="audit an OPT-IN Winograd path instead of the default direct form: 1 = F(2, 3) along x, 2 = F(2x2, 3x3)")
     a = ap.parse_args()
     from mcquic_amd import Compressor, ops
     if a.winograd:
-        ops.set_winograd(True)
+        ops.set_winograd(a.winograd)
     from oracle import mcquic_ref as R
     dev = torch.device("cuda:0")
     ks = [8192, 2048, 512]
@@ -63,7 +64,7 @@ def main():
         rec_gpu = model.decode([c.to(dev) for c in want]).cpu()  # pixels from the ORACLE's codes
         pix_err = max(pix_err, float((rec_gpu - rec_cpu).abs().max()))
         psnr_min = min(psnr_min, float(R.psnr(R.detransform(rec_gpu), R.detransform(rec_cpu)).min()))
-    rec = {"arithmetic": "OPT-IN winograd F(2,3) on the large 3x3 stride-1 layers" if a.winograd else "direct form (default)",
+    rec = {"arithmetic": ("OPT-IN winograd F(2x2,3x3) on the large 3x3 stride-1 layers" if a.winograd == 2 else "OPT-IN winograd F(2,3) on the large 3x3 stride-1 layers") if a.winograd else "direct form (default)",
            "workload": f"qp=2 model, {a.images} x 3 x 768 x 512, seed 3407 (BASELINE configs[1])",
            "codes_per_level": total, "first_flips_per_level": mism, "first_flips": sum(mism),
            "worst_oracle_gap_at_a_first_flip": worst_gap, "downstream_differences_per_level": downstream,

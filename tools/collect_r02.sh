@@ -27,10 +27,13 @@ python profiles/kernel_stats.py $O/kt_train/kt_results.db > $O/kernel_stats_trai
 python tools/bench_speed_protocol.py 2>/dev/null | tail -1 > $O/speed_protocol.txt
 python tools/bench_vq.py > $O/bench_vq.json 2>/dev/null
 python bench.py --batch 1 --graphs --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_batch1_graphs.json
-python bench.py --winograd --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_winograd.json
-MCQUIC_AMD_BRANCH_STREAMS=0 rocprofv3 --kernel-trace -d $O/kt_wino -o kt -- python bench.py --winograd --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-python profiles/kernel_stats.py $O/kt_wino/kt_results.db > $O/kernel_stats_winograd_single_stream.txt
-python tools/parity_b32.py --winograd --out $O/parity_b32_winograd.json > /dev/null 2>&1
-rm -rf $O/kt_wino
+for lv in 1 2; do
+  sfx=$([ $lv = 2 ] && echo winograd2d || echo winograd)
+  python bench.py --winograd $lv --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$sfx.json
+  MCQUIC_AMD_BRANCH_STREAMS=0 rocprofv3 --kernel-trace -d $O/kt_wino -o kt -- python bench.py --winograd $lv --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  python profiles/kernel_stats.py $O/kt_wino/kt_results.db > $O/kernel_stats_${sfx}_single_stream.txt
+  python tools/parity_b32.py --winograd $lv --out $O/parity_b32_$sfx.json > /dev/null 2>&1
+  rm -rf $O/kt_wino
+done
 rm -rf $O/kt_bench $O/kt_train $O/kt_bench_ss $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES
 ls -la $O

@@ -15,7 +15,11 @@ from mcquic_amd import build as B  # noqa: E402
 def main():
     src = os.path.abspath(sys.argv[1])
     cmd = ["hipcc"] + B.CFLAGS + sys.argv[2:] + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
-    txt = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(src)).stderr
+    run = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(src))
+    txt = run.stderr
+    if run.returncode != 0:                      # (a failed compile must not look like "no kernels")
+        sys.stderr.write("".join(ln + "\n" for ln in txt.splitlines() if "error" in ln or "note:" in ln)[:4000])
+        sys.exit(run.returncode)
     keys = {"vgpr": r"    VGPRs", "agpr": r"AGPRs", "scratch": r"ScratchSize \[bytes/lane\]", "occ": r"Occupancy \[waves/SIMD\]",
             "spill": r"VGPRs Spill", "lds": r"LDS Size \[bytes/block\]"}
     for b in re.split(r"remark: Function Name: ", txt)[1:]:

@@ -23,6 +23,8 @@ _WINOGRAD = os.environ.get("MCQUIC_AMD_WINOGRAD", "0") in ("1", "2")
 # ... and where Cout % 128 == 0, in both directions: F(2x2, 3x3), 4/9 of the multiplications (MCQUIC_AMD_WINOGRAD=2)
 _WINOGRAD_2D = os.environ.get("MCQUIC_AMD_WINOGRAD", "0") == "2"
 _WINOGRAD_MIN_PIXELS = int(os.environ.get("MCQUIC_AMD_WINOGRAD_MIN_PIXELS", str(128 * 1024)))   # N*H*W below this: direct form
+# (the 2-D form still wins at a third of that: 32 x 48x32 maps 112 -> 86 us per launch; 32 x 24x16 it loses, 41 -> 44)
+_WINOGRAD_MIN_PIXELS_2D = int(os.environ.get("MCQUIC_AMD_WINOGRAD_MIN_PIXELS_2D", str(40 * 1024)))
 
 
 def winograd_enabled() -> int:
@@ -34,11 +36,12 @@ def set_winograd(enabled, min_pixels: Optional[int] = None) -> None:
     """Switch the opt-in Winograd path on / off for convolutions packed from now on (nn.Conv2d re-packs on the change):
     False / 0 = off, True / 1 = F(2, 3) along x, 2 = F(2x2, 3x3) for layers with Cout % 128 == 0 (the 1-D form elsewhere).
     `min_pixels`: layers with fewer than N*H*W input pixels keep the direct form (default 128 k)."""
-    global _WINOGRAD, _WINOGRAD_2D, _WINOGRAD_MIN_PIXELS
+    global _WINOGRAD, _WINOGRAD_2D, _WINOGRAD_MIN_PIXELS, _WINOGRAD_MIN_PIXELS_2D
     _WINOGRAD = bool(enabled)
     _WINOGRAD_2D = enabled is not True and int(enabled) >= 2
     if min_pixels is not None:
         _WINOGRAD_MIN_PIXELS = int(min_pixels)
+        _WINOGRAD_MIN_PIXELS_2D = min(_WINOGRAD_MIN_PIXELS_2D, int(min_pixels)) if int(min_pixels) < 128 * 1024 else 40 * 1024
 
 # A producer asked for `dual_silu` hangs silu(y) on its result under this attribute; a consumer asked for
 # `silu_in` uses the twin instead of re-evaluating SiLU inside its k-loop (9 taps x 2 half-waves times per
@@ -285,7 +288,8 @@ def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool
         if gate_id.shape != y.shape:
             raise ValueError("gate identity shape mismatch")
     wp = w.wp
-    if winograd or (winograd is None and _WINOGRAD and n * h * wd >= _WINOGRAD_MIN_PIXELS):
+    auto_2d = winograd is None and _WINOGRAD and _WINOGRAD_2D and w.wino2d is not None and n * h * wd >= _WINOGRAD_MIN_PIXELS_2D
+    if winograd or auto_2d or (winograd is None and _WINOGRAD and n * h * wd >= _WINOGRAD_MIN_PIXELS):
         ok = w.wino is not None and stride == 1 and not (flags & (CONV_SILU_IN | CONV_SQUARE_IN))
         two_d = w.wino2d is not None and (_WINOGRAD_2D if winograd is None or winograd is True else int(winograd) >= 2)
         if winograd is not None and winograd is not True and int(winograd) >= 2 and w.wino2d is None:

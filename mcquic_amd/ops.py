@@ -23,8 +23,9 @@ _WINOGRAD = os.environ.get("MCQUIC_AMD_WINOGRAD", "0") in ("1", "2")
 # ... and where Cout % 128 == 0, in both directions: F(2x2, 3x3), 4/9 of the multiplications (MCQUIC_AMD_WINOGRAD=2)
 _WINOGRAD_2D = os.environ.get("MCQUIC_AMD_WINOGRAD", "0") == "2"
 _WINOGRAD_MIN_PIXELS = int(os.environ.get("MCQUIC_AMD_WINOGRAD_MIN_PIXELS", str(128 * 1024)))   # N*H*W below this: direct form
-# (the 2-D form still wins at a third of that: 32 x 48x32 maps 112 -> 86 us per launch; 32 x 24x16 it loses, 41 -> 44)
-_WINOGRAD_MIN_PIXELS_2D = int(os.environ.get("MCQUIC_AMD_WINOGRAD_MIN_PIXELS_2D", str(40 * 1024)))
+# (the 2-D form still wins far below that: 32 x 48x32 maps 112 -> 86 us per launch, one 192x128 map at batch 1 -- 24 k pixels --
+#  7.3 -> 6.0 ms per encode+decode with the maps above it; at 12 k pixels, 32 x 24x16, it loses, 41 -> 44 us)
+_WINOGRAD_MIN_PIXELS_2D = int(os.environ.get("MCQUIC_AMD_WINOGRAD_MIN_PIXELS_2D", str(20 * 1024)))
 
 
 def winograd_enabled() -> int:
@@ -41,7 +42,7 @@ def set_winograd(enabled, min_pixels: Optional[int] = None) -> None:
     _WINOGRAD_2D = enabled is not True and int(enabled) >= 2
     if min_pixels is not None:
         _WINOGRAD_MIN_PIXELS = int(min_pixels)
-        _WINOGRAD_MIN_PIXELS_2D = min(_WINOGRAD_MIN_PIXELS_2D, int(min_pixels)) if int(min_pixels) < 128 * 1024 else 40 * 1024
+        _WINOGRAD_MIN_PIXELS_2D = min(_WINOGRAD_MIN_PIXELS_2D, int(min_pixels)) if int(min_pixels) < 128 * 1024 else 20 * 1024
 
 # A producer asked for `dual_silu` hangs silu(y) on its result under this attribute; a consumer asked for
 # `silu_in` uses the twin instead of re-evaluating SiLU inside its k-loop (9 taps x 2 half-waves times per

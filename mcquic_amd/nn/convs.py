@@ -52,6 +52,8 @@ class Conv2d(nn.Module):
         shape per launch) -- what a training loop does once per step after its optimizer update instead of 2 launches + a bias
         copy per convolution.  Forward streams for every stale conv; input-gradient streams for the stale ones that have
         been asked for one before.  Returns the number of streams re-packed."""
+        if ops.winograd_enabled():
+            return 0            # (the opt-in Winograd streams are packed per convolution: grouped packs carry none)
         fwd, bwd = {}, {}
         for c in convs:
             key = c._key()

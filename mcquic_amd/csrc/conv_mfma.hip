@@ -63,6 +63,9 @@
 #ifndef MCQ_HEAD16
 #define MCQ_HEAD16 1
 #endif
+#ifndef MCQ_PEEL
+#define MCQ_PEEL 0
+#endif
 #ifndef MCQ_W2D_EXP
 #define MCQ_W2D_EXP 0
 #endif
@@ -462,7 +465,7 @@ next_tile:
     for (int i = 0; i < PGV; ++i) Vn[i] = 0.0f;
     if (WINO && active) wino_transform(0, Vn);
     MCQ_STAMP(st1);
-    for (int sp = 0; sp < npairs; sp += PAIRS_PER_ITER) {
+    auto kbody = [&](const int sp) __attribute__((always_inline)) {
         // Every VALU instruction between two MFMAs costs the matrix pipe ~10 cycles (tools/probes/mfma_issue.hip), so
         // the k-loop has none: the channel-pair offset of an activation load lives in its buffer descriptor -- one per
         // pixel block and channel pair of the body, rebuilt by the scalar unit each iteration with num_records shrunk
@@ -546,7 +549,14 @@ next_tile:
 #endif
         }
         soff += (unsigned)PAIRS_PER_ITER * step_bytes;
-    }
+    };
+#if MCQ_PEEL
+    // (first body peeled: see the F(2x2, 3x3) loop -- the wait counts of the looped copy then reflect the steady state)
+    if (npairs > 0) kbody(0);
+    for (int sp = PAIRS_PER_ITER; sp < npairs; sp += PAIRS_PER_ITER) kbody(sp);
+#else
+    for (int sp = 0; sp < npairs; sp += PAIRS_PER_ITER) kbody(sp);
+#endif
     }       // (!W2D)
 
     if (WASM) asm volatile("s_nop 15\n\ts_nop 15");       // (the last MFMAs' results must have landed before the first v_accvgpr_read)

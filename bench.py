@@ -51,8 +51,9 @@ class ConvProfiler:
     MAX_STEPS = 8       # timed steps that carry events (132 k live HIP events over a 200-step run slowed the launches 3 %)
 
     def __init__(self):
-        self.records = []           # (start, end, flops, bytes)
+        self.records = []           # (start, end, algorithmic flops, bytes, executed MFMA flops)
         self.base = None
+        self._descs = []            # flags of the descriptors built since the current launch wrapper started
         self.steps = 0              # timed steps bracketed so far
         self.active = True
 
@@ -68,11 +69,27 @@ class ConvProfiler:
         prof = self
         self.base = torch.cuda.Event(enable_timing=True)
         self.base.record()
+        self._orig_desc = ops._conv_desc
+
+        def wrapped_desc(*a, **kw):
+            out = prof._orig_desc(*a, **kw)
+            prof._descs.append(int(out[0].flags))
+            return out
+        ops._conv_desc = wrapped_desc
+
+        def executed(flops, flags):
+            """MFMA work actually issued: the Winograd forms run 16 of 36 (F(2x2, 3x3)) / 12 of 18 (F(2, 3)) k-steps."""
+            if flags & ops.CONV_WINOGRAD2D:
+                return flops * 16.0 / 36.0
+            if flags & ops.CONV_WINOGRAD:
+                return flops * 12.0 / 18.0
+            return flops
 
         def wrapped(x, w, stride=1, **kw):
             if not prof.active:
                 return prof._orig(x, w, stride, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            del prof._descs[:]
             s.record()
             y = prof._orig(x, w, stride, **kw)
             e.record()
@@ -86,7 +103,7 @@ class ConvProfiler:
             sides = sum(1 for key in ("res", "gdn_mul", "igdn_mul", "gate_mul", "gate_id", "mul") if kw.get(key) is not None)
             sides += 1 if kw.get("dual_silu") else 0
             nbytes = 4.0 * (x.numel() + y.numel() * (1 + sides))
-            prof.records.append((s, e, flops, nbytes))
+            prof.records.append((s, e, flops, nbytes, executed(flops, prof._descs[-1] if prof._descs else 0)))
             return y
 
         self._orig_multi = ops.conv2d_multi
@@ -96,19 +113,22 @@ class ConvProfiler:
                 return prof._orig_multi(xs, ws, stride, per_problem=per_problem, **shared)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ops.conv2d = prof._orig                     # (the multi launch is ONE launch: no per-problem brackets inside)
+            del prof._descs[:]
             s.record()
             ys = prof._orig_multi(xs, ws, stride, per_problem=per_problem, **shared)
             e.record()
             ops.conv2d = wrapped
-            flops = nbytes = 0.0
+            flops = nbytes = done = 0.0
             for i, (x, w, y) in enumerate(zip(xs, ws, ys)):
                 n, cin, h, wd = x.shape
-                flops += 2.0 * y.shape[0] * y.shape[2] * y.shape[3] * w.cout * cin * w.ksize * w.ksize
+                fl = 2.0 * y.shape[0] * y.shape[2] * y.shape[3] * w.cout * cin * w.ksize * w.ksize
+                flops += fl
+                done += executed(fl, prof._descs[i] if i < len(prof._descs) else 0)
                 kw = dict(shared, **((per_problem or [{}] * len(xs))[i]))
                 sides = sum(1 for key in ("res", "gdn_mul", "igdn_mul", "gate_mul", "gate_id", "mul") if kw.get(key) is not None)
                 sides += 1 if kw.get("dual_silu") else 0
                 nbytes += 4.0 * (x.numel() + y.numel() * (1 + sides))
-            prof.records.append((s, e, flops, nbytes))
+            prof.records.append((s, e, flops, nbytes, done))
             return ys
 
         ops.conv2d = wrapped
@@ -119,9 +139,10 @@ class ConvProfiler:
         from mcquic_amd import ops
         ops.conv2d = self._orig
         ops.conv2d_multi = self._orig_multi
+        ops._conv_desc = self._orig_desc
 
     def summary(self):
-        iv = sorted((self.base.elapsed_time(s), self.base.elapsed_time(e)) for s, e, _, _ in self.records)
+        iv = sorted((self.base.elapsed_time(r[0]), self.base.elapsed_time(r[1])) for r in self.records)
         busy, cur_s, cur_e = 0.0, None, None
         for a, b in iv:
             if cur_e is None or a > cur_e:
@@ -135,7 +156,7 @@ class ConvProfiler:
         fl = sum(r[2] for r in self.records)
         by = sum(r[3] for r in self.records)
         return dict(launches=len(self.records), ms=busy, flops=fl, bytes=by, steps=max(self.steps, 1),
-                    sum_ms=sum(s.elapsed_time(e) for s, e, _, _ in self.records))
+                    mfma_flops=sum(r[4] for r in self.records), sum_ms=sum(r[0].elapsed_time(r[1]) for r in self.records))
 
 
 def pmc_traffic():
@@ -146,6 +167,8 @@ def pmc_traffic():
         try:
             d = json.load(open(path))
             d["_file"] = os.path.basename(path)
+            from mcquic_amd.build import csrc_sha
+            d["_stale"] = d.get("csrc_sha") != csrc_sha()       # collected on other kernel sources than the ones running now
             return d
         except (OSError, ValueError):
             continue
@@ -196,6 +219,128 @@ def parity_report(gpu_codes, gpu_pixels, cpu_codes, cpu_pixels):
             "psnr_gpu_vs_cpu_u8_min_db": round(psnr, 2), "note": "decode compared from the CPU oracle's codes"}
 
 
+def _timed(fn, steps, warmup=1):
+    """ms per call: `warmup` untimed calls, then `steps` calls between two events on the current stream."""
+    for _ in range(warmup):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(steps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / steps
+
+
+def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
+    """Round results the headline does not show, measured in the same run (about 40 s; every entry is independent and
+    carries its own `error` if it fails -- the headline line never depends on them):
+      winograd2d   the OPT-IN F(2x2, 3x3) mode on the same batch: images/s, the fraction of the fp32-MFMA peak in REAL issued
+                   work (never the direct form's FLOPs), and the code / pixel parity of the same 4 images against the oracle
+      train_step   BASELINE configs[4]'s per-GPU work: forward + Gumbel straight-through backward of the qp=2 model on
+                   8 x 256x256 crops as ONE captured hipGraph, 10 replays
+      vq_config4   BASELINE configs[3]: M=4, K=4096, D=256 distance + argmin on 49 152 vectors per codebook
+      batch1       one 768x512 image, encode+decode as hipGraph replays (latency)"""
+    from mcquic_amd import Compressor, ops
+    from mcquic_amd.nn import blocks
+    sec = {}
+    # ---- opt-in Winograd F(2x2, 3x3) ------------------------------------------------------------------------------------
+    try:
+        ops.set_winograd(2)
+        prof = ConvProfiler().install()
+        prof.MAX_STEPS = 3
+
+        def step():
+            prof.next_step()
+            return model.decode(model.encode(x))
+        prof.active = False
+        model.decode(model.encode(x))                         # re-pack + warm-up, not bracketed
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        prof.remove()
+        c = prof.summary()
+        w = {"arithmetic": "OPT-IN, not the reference's: F(2x2,3x3) on the 3x3 stride-1 layers with Cout % 128 == 0 and >= 20 k pixels, F(2,3) along x elsewhere above 128 k pixels",
+             "images_s": round(x.shape[0] / ms * 1e3, 2), "ms_per_step": round(ms, 3),
+             "mfma_work_frac": round(c["mfma_flops"] / (c["ms"] * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+             "mfma_gflop_per_step": round(c["mfma_flops"] / c["steps"] / 1e9, 1),
+             "direct_form_gflop_per_step": round(c["flops"] / c["steps"] / 1e9, 1)}
+        if cpu_codes is not None:
+            codes = model.encode(x[:nb])
+            pix = model.decode([t.to(dev) for t in cpu_codes])
+            w["parity"] = parity_report(codes, pix, cpu_codes, cpu_pix)
+        sec["winograd2d"] = w
+    except Exception as exc:                                  # noqa: BLE001 -- a secondary figure must not take the headline down
+        sec["winograd2d"] = {"error": repr(exc)[:300]}
+    finally:
+        ops.set_winograd(0)
+    # ---- batch-1 latency, hipGraph replay ---------------------------------------------------------------------------------
+    try:
+        model.enableGraphs(True)
+        x1 = x[:1].contiguous()
+        ms = _timed(lambda: model.decode(model.encode(x1)), 30, warmup=3)
+        sec["batch1"] = {"ms_per_image_encode_decode": round(ms, 3), "graphs": True,
+                         "frac_of_peak": round(536.63e9 / (ms * 1e-3) / (FP32_MATRIX_PEAK_TFLOPS * 1e12), 4)}
+    except Exception as exc:                                  # noqa: BLE001
+        sec["batch1"] = {"error": repr(exc)[:300]}
+    finally:
+        model.enableGraphs(False)
+    # ---- VQ distance + argmin, BASELINE configs[3] --------------------------------------------------------------------
+    try:
+        g = torch.Generator().manual_seed(0)
+        lat = (torch.randn((32, 4 * 256, 48, 32), generator=g) * 0.1).to(dev)
+        cb = ops.PackedCodebook((torch.randn((4, 4096, 256), generator=g) * (2 / (5 * 256)) ** 0.5).to(dev))
+        ms = _timed(lambda: ops.vq_assign(lat, cb), 10, warmup=2)
+        flops = 2.0 * 4 * 32 * 48 * 32 * 4096 * 256
+        sec["vq_config4"] = {"ms": round(ms, 4), "tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+                             "frac_of_peak": round(flops / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+                             "workload": "M=4 K=4096 D=256, 49152 vectors per codebook (412.3 GFLOP)"}
+        del lat, cb
+    except Exception as exc:                                  # noqa: BLE001
+        sec["vq_config4"] = {"error": repr(exc)[:300]}
+    # ---- training step, BASELINE configs[4] per-GPU work ------------------------------------------------------------------
+    streams = blocks._BRANCH_STREAMS
+    try:
+        blocks._BRANCH_STREAMS = False                        # nested stream forks crash hipGraph capture (ROCm 7.2): one stream
+        torch.manual_seed(3407)
+        tm = Compressor(**MODEL).to(dev).train()
+        xt = (torch.rand((8, 3, 256, 256), generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
+
+        def train_step():
+            for p in tm.parameters():
+                p.grad = None
+            xHat, _, _, _ = tm(xt)
+            loss = torch.nn.functional.mse_loss(xHat, xt)
+            loss.backward()
+            return loss
+        for _ in range(2):
+            train_step()
+        torch.cuda.synchronize()
+        for p in tm.parameters():
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            xHat, _, _, _ = tm(xt)
+            static_loss = torch.nn.functional.mse_loss(xHat, xt)
+            static_loss.backward()
+        ms = _timed(graph.replay, 10, warmup=1)
+        flops = 3.0 * 536.63e9 * 8 * (256 * 256) / (768 * 512)      # forward + input gradients + weight gradients
+        sec["train_step"] = {"ms": round(ms, 3), "graph": True, "images_per_step": 8, "crop": 256,
+                             "frac_of_peak": round(flops / (ms * 1e-3) / (FP32_MATRIX_PEAK_TFLOPS * 1e12), 4),
+                             "tflop_per_step": round(flops / 1e12, 3), "loss": round(float(static_loss), 6),
+                             "workload": "forward + Gumbel straight-through backward, Compressor(128, 2, [8192, 2048, 512]), 8 x 3 x 256 x 256, one hipGraph"}
+        del graph, tm
+    except Exception as exc:                                  # noqa: BLE001
+        sec["train_step"] = {"error": repr(exc)[:300]}
+    finally:
+        blocks._BRANCH_STREAMS = streams
+    return sec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +350,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="images in the CPU-oracle sample (SURVEY 8(d): batch 4)")
     ap.add_argument("--graphs", action="store_true", help="replay encode/decode as captured hipGraphs (small-batch latency)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` measurements (opt-in Winograd mode, training step, VQ config #4, batch-1 latency; ~40 s)")
     ap.add_argument("--winograd", type=int, nargs="?", const=1, default=0, choices=(0, 1, 2),
                     help="OPT-IN experiment, never the headline: large 3x3 stride-1 layers in a Winograd form (not the reference's arithmetic); "
                          "1 = F(2, 3) along x, 2 = F(2x2, 3x3) where the layer allows it")
@@ -234,12 +381,11 @@ def main():
     from mcquic_amd import Compressor, ops
     if args.winograd:
         ops.set_winograd(args.winograd)
-    torch.manual_seed(3407)                                   # same random-init weights on every rank
-    model = Compressor(**MODEL).eval().to(dev)
+    from mcquic_amd.utils import synthetic
+    model = synthetic.bench_model().to(dev)                   # torch.manual_seed(3407): the same random-init weights on every rank
     if args.graphs:
         model.enableGraphs(True)
-    g = torch.Generator(device="cpu").manual_seed(3407 + rank)
-    x = (torch.rand((args.batch, 3, H, W), generator=g) * 2 - 1).to(dev)
+    x = synthetic.bench_images(rank, args.batch, H, W).to(dev)         # seed 3407 + rank: configs[2] = ranks 0..7 of this
 
     def barrier():
         torch.cuda.synchronize()
@@ -277,16 +423,25 @@ def main():
         conv = prof.summary()
         images = world * args.batch * args.steps
         value = images / dt
-        achieved_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        # the profiler sees Python-side launches only: under --graphs the step is one graph replay and there is nothing to
+        # bracket -- the per-kernel fields are then null (never 0.0); whole_step_frac still holds
+        seen = conv["launches"] > 0 and conv["ms"] > 0
+        # roofline.achieved counts the MFMA work actually ISSUED (= the algorithmic FLOPs in the default direct form; in the
+        # opt-in Winograd modes 16/36 resp. 12/18 of them on the layers that run transformed), so frac is a true pipe
+        # utilisation and cannot exceed 1; the direct-form-equivalent rate is reported beside it
+        achieved_tf = conv["mfma_flops"] / (conv["ms"] * 1e-3) / 1e12 if seen else None
+        equivalent_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if seen else None
+        pmc = pmc_traffic()
+        step_s = dt / args.steps
         out = {
             "metric": "images/sec encode+decode, 768x512 Kodak-shape batch, qp=2",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (uniform [-1,1) images, random-init weights)",
             "arithmetic": (("OPT-IN winograd F(2x2,3x3) (4/9 of the multiplications; F(2,3) along x where a layer does not qualify)" if args.winograd == 2 else
                             "OPT-IN winograd F(2,3) along x (2/3 of the multiplications)") +
-                           " for the 3x3 stride-1 layers of >= 128 k pixels, float32; NOT the reference's arithmetic -- roofline.achieved counts "
-                           "the direct form's FLOPs and is an equivalent rate here")
+                           " for the large 3x3 stride-1 layers, float32; NOT the reference's arithmetic -- roofline.achieved counts the MFMA work "
+                           "issued, roofline.equivalent_direct the direct form's FLOPs")
                           if args.winograd else "direct form, exact fp32 MFMA (the reference's arithmetic)",
             "rccl_world": rccl_world, "rank0_cores": None if cores is None else len(cores),
             "config": {"workload": f"qp=2 reference model Compressor(128, 2, [8192, 2048, 512]), batch={args.batch} "
@@ -296,18 +451,24 @@ def main():
             "encode_mpps": round(args.batch * H * W / 1e3 / enc_ms, 3), "decode_mpps": round(args.batch * H * W / 1e3 / dec_ms, 3),
             "roofline": {
                 "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM, all tile variants; + the 16-row conv_head16_kernel of the image head)",
-                "achieved": round(achieved_tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved_tf / FP32_MATRIX_PEAK_TFLOPS, 4),
-                "traffic": (lambda t: None if t is None else round(t["all_conv_launches"]["fetch_bytes_per_launch_x2_corrected"] + t["all_conv_launches"]["write_size_bytes_per_launch"]))(pmc_traffic()),
-                "traffic_unit": "HBM-side bytes per conv kernel launch, averaged over all conv launches of a step like algorithmic_bytes_per_launch (PMC FETCH_SIZE x2-corrected + WRITE_SIZE, separate passes, profiles/" + ((pmc_traffic() or {}).get("_file") or "rNN_pmc.json") + ")",
-                "algorithmic_bytes_per_launch": round(conv["bytes"] / max(conv["launches"], 1)),
-                "launches_per_step": conv["launches"] // conv["steps"],
-                "event_steps": conv["steps"],
-                "avg_launch_ms": round(conv["sum_ms"] / max(conv["launches"], 1), 4),
-                "conv_busy_ms_per_step": round(conv["ms"] / conv["steps"], 3),
-                "algorithmic_gflop_per_step": round(conv["flops"] / conv["steps"] / 1e9, 2),
-                "hbm_algorithmic_gbs": round(conv["bytes"] / (conv["ms"] * 1e-3) / 1e9, 1) if conv["ms"] > 0 else None,
-                "whole_step_frac": round(536.63e9 * args.batch / (dt / args.steps) / (FP32_MATRIX_PEAK_TFLOPS * 1e12), 4),
+                "achieved": None if achieved_tf is None else round(achieved_tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": None if achieved_tf is None else round(achieved_tf / FP32_MATRIX_PEAK_TFLOPS, 4),
+                "equivalent_direct": None if equivalent_tf is None else round(equivalent_tf, 2),
+                "source": "HIP events around every conv launch of the first event_steps timed steps" if seen else
+                          "none: the step is a hipGraph replay (--graphs), no Python-side launch to bracket; see whole_step_frac",
+                "traffic": None if pmc is None else round(pmc["all_conv_launches"]["fetch_bytes_per_launch_x2_corrected"] + pmc["all_conv_launches"]["write_size_bytes_per_launch"]),
+                "traffic_stale": None if pmc is None else bool(pmc["_stale"]),
+                "traffic_unit": "HBM-side bytes per conv kernel launch, averaged over all conv launches of a step like algorithmic_bytes_per_launch (PMC FETCH_SIZE x2-corrected + WRITE_SIZE, separate passes, profiles/" + ((pmc or {}).get("_file") or "rNN_pmc.json") + "; traffic_stale = those passes ran on other kernel sources than this run)",
+                "algorithmic_bytes_per_launch": round(conv["bytes"] / conv["launches"]) if seen else None,
+                "launches_per_step": conv["launches"] // conv["steps"] if seen else None,
+                "event_steps": conv["steps"] if seen else 0,
+                "avg_launch_ms": round(conv["sum_ms"] / conv["launches"], 4) if seen else None,
+                "conv_busy_ms_per_step": round(conv["ms"] / conv["steps"], 3) if seen else None,
+                "algorithmic_gflop_per_step": round(conv["flops"] / conv["steps"] / 1e9, 2) if seen else round(536.63 * args.batch, 2),
+                "mfma_gflop_per_step": round(conv["mfma_flops"] / conv["steps"] / 1e9, 2) if seen else None,
+                "hbm_algorithmic_gbs": round(conv["bytes"] / (conv["ms"] * 1e-3) / 1e9, 1) if seen else None,
+                "whole_step_frac": round((conv["mfma_flops"] / conv["steps"] + 3.435e9 * args.batch if seen and args.winograd else 536.63e9 * args.batch)
+                                         / step_s / (FP32_MATRIX_PEAK_TFLOPS * 1e12), 4),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -317,6 +478,10 @@ def main():
             gpu_pix = model.decode([c.to(dev) for c in cpu_codes])
             out["cpu_baseline"] = base
             out["parity"] = parity_report([c[:nb] for c in codes], gpu_pix, cpu_codes, cpu_pix)
+        else:
+            sd_cpu = cpu_codes = cpu_pix = None
+        if world == 1 and not args.no_secondary and not args.winograd and not args.graphs:
+            out["secondary"] = secondary(model, x, dev, cpu_codes, cpu_pix, min(args.cpu_batch, args.batch))
     # RCCL writes its version banner through C stdio, which a pipe only sees at exit: every rank flushes it out before the
     # last barrier so that rank 0's ONE line below is the last thing on stdout
     try:

@@ -26,6 +26,12 @@
 extern "C" {
 #endif
 
+/* Bumped whenever a signature or struct in this header changes incompatibly (history in INTEGRATION.md section 2).  A binding
+ * compares it with mcq_abi_version() of the library it loaded before calling anything else: a stale .so under new
+ * prototypes (or the reverse) misaligns arguments silently otherwise.  3 = round 3 (mcq_rans_*_with_indexes take cdf_lens,
+ * mcq_gate_f32 takes out_silu -- both changed in round 2 without a bump --, GroupNorm / logits-gradient entry points). */
+#define MCQ_ABI_VERSION   3
+
 #define MCQ_OK            0
 #define MCQ_EINVAL       -1   /* NULL pointer / non-positive dimension / unsupported combination */
 #define MCQ_ELAUNCH      -2   /* hipLaunchKernel failed (hipGetLastError() != hipSuccess)        */
@@ -176,9 +182,13 @@ int mcq_vq_inner_f32(const float* x, const float* cb_packed, float* out, int32_t
                      int32_t k, void* stream);
 
 /* Backward of gumbelSoftmax(hard=True) + _logit per latent vector: ds_inout holds dSample on entry and d dist on
- * exit; rowsum[v] = sum_k d dist, dtrow[v] = the vector's contribution to d max(temperature, bound). */
+ * exit; rowsum[v] = sum_k d dist, dtrow[v] = the vector's contribution to d max(temperature, bound).
+ * `dlogits` (NULL = none): a gradient on the logits the forward returned (quantizer.py:232-239 returns them with their
+ * graph); it is added in front of `_logit`.  The random drop's `+= -1e9` (quantizer.py:194-200) passes gradients through,
+ * so dropped entries take part and `raw_logits` = the logits WITHOUT the drop (mcq_vq_logits_f32 again) must come along. */
 int mcq_vq_softmax_bwd_f32(const float* logits, const float* u_gumbel, float* ds_inout, const float* temperature, float bound,
-                           float* rowsum, float* dtrow, int32_t N, int32_t m, int32_t h, int32_t w, int32_t k, void* stream);
+                           float* rowsum, float* dtrow, const float* dlogits, const float* raw_logits,
+                           int32_t N, int32_t m, int32_t h, int32_t w, int32_t k, void* stream);
 
 /* Latent and codebook gradients of dist = |x|^2 + |c|^2 - 2 <x, c> given d dist, plus the codebook gradient of
  * sample @ codebook (rows sample_index scaled by sample_hot).  Deterministic (no atomics). */
@@ -341,6 +351,8 @@ int mcq_sqdiff_sum_u8(const uint8_t* x, const uint8_t* y, int64_t* out, int64_t 
 int mcq_selftest_launch_failure(void* stream);
 
 const char* mcq_version(void);
+/* MCQ_ABI_VERSION the library was built from. */
+int32_t mcq_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -63,8 +63,8 @@ SYMBOLS = {
     "mcq_vq_dequant_soft_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_int32, c_void_p]),
     "mcq_vq_inner_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
-    "mcq_vq_softmax_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int32, c_int32,
-                                         c_int32, c_int32, c_int32, c_void_p]),
+    "mcq_vq_softmax_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_vq_soft_bwd_f32": (c_int32, [c_void_p] * 10 + [c_int32] * 6 + [c_void_p]),
     "mcq_nchw_to_nhwc_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_conv2d_wgrad_workspace_floats": (c_size_t, [c_int32] * 7),
@@ -109,7 +109,10 @@ SYMBOLS = {
     "mcq_sqdiff_sum_u8": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "mcq_selftest_launch_failure": (c_int32, [c_void_p]),
     "mcq_version": (c_char_p, []),
+    "mcq_abi_version": (c_int32, []),
 }
+
+ABI_VERSION = 3          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
 
 _lib = None
 
@@ -124,6 +127,14 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: run `python -m mcquic_amd.build` (or __graft_entry__.build()). "
             "mcquic_amd has no CPU / PyTorch fallback for its HIP kernels.")
     lib = ctypes.CDLL(LIB_PATH)
+    try:
+        lib.mcq_abi_version.restype = c_int32
+        built = int(lib.mcq_abi_version())
+    except AttributeError:
+        built = None
+    if built != ABI_VERSION:        # a stale .so under these prototypes would misalign arguments silently
+        raise ImportError(f"{LIB_PATH} was built for ABI version {built}, this binding needs {ABI_VERSION}: "
+                          "rebuild with `python -m mcquic_amd.build --force`")
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = restype

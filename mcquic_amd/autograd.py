@@ -315,23 +315,48 @@ def _lockstep_backward(tape, dys, grads):
     return dys
 
 
+def _tape_flatten(obj, tensors):
+    """Tape -> the same nesting with every tensor replaced by its index into `tensors` (modules and strings stay)."""
+    if torch.is_tensor(obj):
+        tensors.append(obj)
+        return ("#t", len(tensors) - 1)
+    if isinstance(obj, (list, tuple)) and not (len(obj) == 2 and obj[0] == "#t"):
+        return type(obj)(_tape_flatten(o, tensors) for o in obj)
+    return obj
+
+
+def _tape_restore(spec, tensors):
+    if isinstance(spec, tuple) and len(spec) == 2 and spec[0] == "#t":
+        return tensors[spec[1]]
+    if isinstance(spec, (list, tuple)):
+        return type(spec)(_tape_restore(o, tensors) for o in spec)
+    return spec
+
+
 class LockstepFn(torch.autograd.Function):
     """k same-structure stacks (nn.Sequential of ResidualBlock / AttentionBlock / conv3x3) on k inputs as ONE autograd node.
-    apply(x_1 .. x_k, *parameters (all stacks', in `stack.parameters()` order), stacks) -> (y_1 .. y_k)."""
+    apply(x_1 .. x_k, *parameters (all stacks', in `stack.parameters()` order), stacks) -> (y_1 .. y_k).
+    The taped activations go through ctx.save_for_backward (version-checked, released with the graph, readable by a second
+    backward under retain_graph=True); ctx keeps only the tape's structure."""
 
     @staticmethod
     def forward(ctx, *args):
         stacks = args[-1]
         k = len(stacks)
         ys, tape = _lockstep_forward(stacks, args[:k], keep=True)
-        ctx.tape, ctx.stacks, ctx.k = tape, stacks, k
+        tensors = []
+        ctx.tape_spec = _tape_flatten([(kind, saved) for kind, _, saved in tape], tensors)
+        ctx.layers = [layer for _, layer, _ in tape]
+        ctx.save_for_backward(*tensors)
+        ctx.stacks, ctx.k = stacks, k
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
         grads = {}
-        dxs = _lockstep_backward(ctx.tape, list(dys), grads)
-        ctx.tape = None
+        entries = _tape_restore(ctx.tape_spec, ctx.saved_tensors)
+        tape = [(kind, layer, saved) for (kind, saved), layer in zip(entries, ctx.layers)]
+        dxs = _lockstep_backward(tape, list(dys), grads)
         params = [p for st in ctx.stacks for p in st.parameters()]
         return (*dxs, *[grads.get(id(p)) for p in params], None)
 
@@ -506,9 +531,13 @@ class SoftQuantizeFn(torch.autograd.Function):
     _multiCodebookDeQuantization.forward calls on its sample, quantizer.py:181-239,262-274):
         logit = (-dist / sqrt(k)) * max(T, eps) ; random drop ; sample = gumbelSoftmax(logit, hard=True)
         deq   = sample @ codebook                       (differentiable output; used by the residual AND the decoder)
-        code  = argmax(logit), logits                   (non-differentiable outputs)
+        logits                                          (differentiable output, as in the reference: a regulariser on them
+                                                         reaches the latents, codebook and temperature)
+        code  = argmax(logit)                           (non-differentiable)
     Backward: straight-through -- the gradient reaches `sample` through y_soft only -- then through the logits to the
-    latent, the codebook (distance terms + the sample @ codebook product) and the temperature."""
+    latent, the codebook (distance terms + the sample @ codebook product) and the temperature; a gradient on the returned
+    logits joins in front of `_logit` (the shipped losses, mcquic/loss/__init__.py:47-62, never produce one: then nothing
+    extra is launched)."""
 
     @staticmethod
     def forward(ctx, x, codebook, temperature, freq_ema, u_drop, u_gumbel, drop_exponent, packed, bound):
@@ -517,17 +546,23 @@ class SoftQuantizeFn(torch.autograd.Function):
         deq = ops.vq_dequant_soft(index, hot, packed)
         ctx.save_for_backward(x, logits, u_gumbel, index, hot, temperature)
         ctx.packed, ctx.bound = packed, bound
-        ctx.mark_non_differentiable(code, logits)
-        ctx.set_materialize_grads(False)        # (`_dlogits` would be a zero fill of the [n, m, h, w, k] logits: 134 MB at level 0)
+        ctx.mark_non_differentiable(code)
+        ctx.set_materialize_grads(False)        # (an unused `dlogits` would be a zero fill of the [n, m, h, w, k] logits: 134 MB at level 0)
         return deq, code, logits
 
     @staticmethod
-    def backward(ctx, ddeq, _dcode, _dlogits):
+    def backward(ctx, ddeq, _dcode, dlogits):
         x, logits, u_gumbel, index, hot, temperature = ctx.saved_tensors
         packed = ctx.packed
-        ddeq = ddeq.contiguous()
+        if ddeq is None and dlogits is None:
+            return (None,) * 9
+        ddeq = torch.zeros_like(x) if ddeq is None else ddeq.contiguous()
         ds = ops.vq_inner(ddeq, packed)                                        # dSample = dDeq . C^T
-        rowsum, dtrow = ops.vq_softmax_bwd(logits, u_gumbel, ds, temperature, ctx.bound)   # ds now holds d dist
+        raw = None
+        if dlogits is not None:                                                # the logits before the random drop, recomputed
+            dlogits = dlogits.contiguous()
+            raw = ops.vq_logits(x, packed, temperature, ctx.bound)
+        rowsum, dtrow = ops.vq_softmax_bwd(logits, u_gumbel, ds, temperature, ctx.bound, dlogits, raw)   # ds now holds d dist
         dx, dcb = ops.vq_soft_bwd(ds, rowsum, x, ddeq, index, hot, packed)
         dtb = ops.channel_sum(dtrow)                                           # [m]: d max(T, bound)
         t = temperature.detach().reshape(-1)

@@ -24,6 +24,20 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-f
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"]
 
 
+def csrc_sha() -> str:
+    """SHA-256 over the kernel sources (csrc/* and the public header, names + contents): what measurement artefacts are
+    stamped with (profiles/rNN_pmc.json) so that a number collected on older kernels can be recognised as stale."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "mcquic_hip.h")]
+    for f in files:
+        path = os.path.join(CSRC, f)
+        if os.path.isfile(path) and f.endswith((".hip", ".h", ".cpp")):
+            h.update(os.path.basename(f).encode() + b"\0")
+            h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
 def _headers():
     hs = [os.path.join(CSRC, h) for h in HEADERS]
     hs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") and os.path.join(CSRC, f) not in hs]

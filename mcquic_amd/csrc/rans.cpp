@@ -200,28 +200,36 @@ int decode_stream(const uint8_t* in, int64_t nbytes, const int32_t* indexes, int
 template <typename F>
 int run_pool(int64_t n_tasks, int32_t n_threads, F&& task) {
     if (n_tasks <= 0) return MCQ_OK;
-    std::vector<int> status((size_t)n_tasks, MCQ_OK);
-    int64_t workers = n_threads <= 0 ? (int64_t)std::thread::hardware_concurrency() : n_threads;
-    if (workers < 1) workers = 1;
-    if (workers > n_tasks) workers = n_tasks;
-    std::atomic<int64_t> next{0};
-    auto loop = [&]() {
-        for (;;) {
-            const int64_t i = next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n_tasks) return;
-            status[(size_t)i] = task(i);
-        }
-    };
-    if (workers == 1) loop();
-    else {
+    // Nothing may leave this function as an exception: inside a worker thread or across the extern "C" boundary that is
+    // std::terminate for the whole Python process.  bad_alloc (stream sizes come out of file headers) and system_error from
+    // thread creation (ulimit / cgroup limits) become MCQ_EINVAL / a smaller pool.
+    try {
+        std::vector<int> status((size_t)n_tasks, MCQ_OK);
+        int64_t workers = n_threads <= 0 ? (int64_t)std::thread::hardware_concurrency() : n_threads;
+        if (workers < 1) workers = 1;
+        if (workers > n_tasks) workers = n_tasks;
+        std::atomic<int64_t> next{0};
+        auto loop = [&]() noexcept {
+            for (;;) {
+                const int64_t i = next.fetch_add(1, std::memory_order_relaxed);
+                if (i >= n_tasks) return;
+                try { status[(size_t)i] = task(i); } catch (...) { status[(size_t)i] = MCQ_EINVAL; }
+            }
+        };
         std::vector<std::thread> pool;
-        pool.reserve((size_t)workers - 1);
-        for (int64_t w = 1; w < workers; ++w) pool.emplace_back(loop);
+        if (workers > 1) {
+            try {
+                pool.reserve((size_t)workers - 1);
+                for (int64_t w = 1; w < workers; ++w) pool.emplace_back(loop);
+            } catch (...) { /* fewer threads than asked for: the calling thread and whoever started share the tasks */ }
+        }
         loop();
         for (auto& th : pool) th.join();
+        for (int st : status) if (st != MCQ_OK) return st;
+        return MCQ_OK;
+    } catch (...) {
+        return MCQ_EINVAL;
     }
-    for (int st : status) if (st != MCQ_OK) return st;
-    return MCQ_OK;
 }
 
 }  // namespace
@@ -232,7 +240,7 @@ extern "C" int64_t mcq_rans_encode_with_indexes(const int32_t* symbols, const in
                                                 int64_t capacity) {
     const Tables t{cdfs, cdf_starts, cdf_sizes, cdf_lens, offsets, n_cdfs};
     if (!symbols || !indexes || !out || n < 0 || !t.ok()) return MCQ_EINVAL;
-    return encode_stream(symbols, indexes, n, t, out, capacity);
+    try { return encode_stream(symbols, indexes, n, t, out, capacity); } catch (...) { return MCQ_EINVAL; }
 }
 
 extern "C" int mcq_rans_decode_with_indexes(const uint8_t* in, int64_t nbytes, const int32_t* indexes, int64_t n,
@@ -240,7 +248,7 @@ extern "C" int mcq_rans_decode_with_indexes(const uint8_t* in, int64_t nbytes, c
                                             const int32_t* cdf_lens, const int32_t* offsets, int32_t n_cdfs, int32_t* out_symbols) {
     const Tables t{cdfs, cdf_starts, cdf_sizes, cdf_lens, offsets, n_cdfs};
     if (!in || !indexes || !out_symbols || n < 0 || !t.ok()) return MCQ_EINVAL;
-    return decode_stream(in, nbytes, indexes, n, t, out_symbols);
+    try { return decode_stream(in, nbytes, indexes, n, t, out_symbols); } catch (...) { return MCQ_EINVAL; }
 }
 
 extern "C" int mcq_rans_encode_batch_with_indexes(const int32_t* symbols, int64_t n_streams, int64_t n, const int32_t* indexes,

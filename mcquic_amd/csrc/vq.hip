@@ -426,4 +426,5 @@ extern "C" int mcq_detransform_u8(const float* x, uint8_t* out, int64_t n, void*
     return mcq_check_launch();
 }
 
-extern "C" const char* mcq_version(void) { return "mcquic_hip 0.1.0 gfx950"; }
+extern "C" const char* mcq_version(void) { return "mcquic_hip 0.3.0 gfx950"; }
+extern "C" int32_t mcq_abi_version(void) { return MCQ_ABI_VERSION; }

@@ -250,7 +250,8 @@ __global__ void vq_dequant_soft_kernel(const int64_t* __restrict__ index, const 
 __global__ __launch_bounds__(256) void vq_softmax_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ u_gumbel,
                                                              float* __restrict__ ds, const float* __restrict__ temperature,
                                                              float bound, float scale, float* __restrict__ rowsum,
-                                                             float* __restrict__ dtrow, int rows, int m, int hw, int k) {
+                                                             float* __restrict__ dtrow, const float* __restrict__ dlogits,
+                                                             const float* __restrict__ raw_logits, int rows, int m, int hw, int k) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -259,6 +260,11 @@ __global__ __launch_bounds__(256) void vq_softmax_bwd_kernel(const float* __rest
     const float* lr = logits + (size_t)row * k;
     const float* ug = u_gumbel + (size_t)row * k;
     float* dr = ds + (size_t)row * k;
+    // a gradient on the returned logits themselves (quantizer.py:232-239 hands back a graph-carrying tensor): it joins the
+    // soft-max's gradient in front of `_logit`; the random drop's `+= -1e9` passes gradients through, so dropped entries
+    // take part too and the temperature term needs their un-dropped values (raw_logits)
+    const float* dl = dlogits ? dlogits + (size_t)row * k : nullptr;
+    const float* rw = raw_logits ? raw_logits + (size_t)row * k : nullptr;
     const float eps = 1.1920928955078125e-07f;
     float mx = -INFINITY;
     for (int c = lane; c < k; c += 64) {
@@ -283,8 +289,11 @@ __global__ __launch_bounds__(256) void vq_softmax_bwd_kernel(const float* __rest
     for (int c = lane; c < k; c += 64) {
         const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
         const float y = expf((lr[c] + (-logf(-logf(u)))) - mx) * inv;
-        const float dz = y * (dr[c] - dot);
-        if (dz != 0.0f) dt += dz * (lr[c] / tb);  // dropped entries (logit = -1e9) have y = 0 exactly
+        float dz = y * (dr[c] - dot);
+        if (dl) {
+            dz += dl[c];
+            dt += dz * (rw[c] / tb);
+        } else if (dz != 0.0f) dt += dz * (lr[c] / tb);  // dropped entries (logit = -1e9) have y = 0 exactly
         const float dd = dz * dscale;
         dr[c] = dd;
         rs += dd;
@@ -412,14 +421,15 @@ extern "C" int mcq_vq_dequant_soft_f32(const int64_t* sample_index, const float*
 }
 
 extern "C" int mcq_vq_softmax_bwd_f32(const float* logits, const float* u_gumbel, float* ds_inout, const float* temperature,
-                                      float bound, float* rowsum, float* dtrow, int32_t N, int32_t m, int32_t h, int32_t w,
-                                      int32_t k, void* stream) {
+                                      float bound, float* rowsum, float* dtrow, const float* dlogits, const float* raw_logits,
+                                      int32_t N, int32_t m, int32_t h, int32_t w, int32_t k, void* stream) {
     if (!logits || !u_gumbel || !ds_inout || !temperature || !rowsum || !dtrow || N <= 0 || m <= 0 || h <= 0 || w <= 0 || k <= 0)
         return MCQ_EINVAL;
+    if ((dlogits != nullptr) != (raw_logits != nullptr)) return MCQ_EINVAL;
     const long long rows = (long long)N * m * h * w;
     if (rows > 0x7fffffffLL) return MCQ_ETOOLARGE;
     hipLaunchKernelGGL(vq_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, u_gumbel,
-                       ds_inout, temperature, bound, (float)sqrt((double)k), rowsum, dtrow, (int)rows, m, h * w, k);
+                       ds_inout, temperature, bound, (float)sqrt((double)k), rowsum, dtrow, dlogits, raw_logits, (int)rows, m, h * w, k);
     return mcq_check_launch();
 }
 

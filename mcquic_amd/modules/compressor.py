@@ -26,6 +26,12 @@ from ..utils.specification import VERSION as __version__   # the reference snaps
 
 
 _VERSION_OF = operator.attrgetter("_version")
+_DATA_PTR_OF = operator.methodcaller("data_ptr")
+
+
+def _forget_captures_hook(module, incompatible_keys):
+    """load_state_dict post-hook of BaseCompressor: new weights, so captured hipGraphs (which replay packed copies) are stale."""
+    module._forgetCaptures()
 
 
 class _GraphedCall:
@@ -83,14 +89,16 @@ class BaseCompressor(nn.Module):
         self._padding = AlignedPadding()
         self._graphs = None          # {(kind, shapes, device): _GraphedCall} once enableGraphs(True)
         self._graphStamp = None      # fingerprint of the weights the captures were taken under
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._forgetCaptures())
+        self.register_load_state_dict_post_hook(_forget_captures_hook)      # (module-level function: a lambda here made the model unpicklable)
 
     def enableGraphs(self, enabled: bool = True):
         """Replay `encode` / `decode` as captured hipGraphs (one per input shape).  For latency-bound small batches.
         A capture bakes in the addresses of the packed weights / codebooks it ran on, so every captured call first
-        compares a fingerprint of all parameters and buffers (version counters + storage addresses, ~0.1 ms) with the one
-        the captures were taken under: an optimizer step, `load_state_dict`, `reAssignCodebook`, `.to(...)` or any
-        other in-place update drops all captures before anything is replayed."""
+        compares a fingerprint of all parameters and buffers (version counters + storage addresses, ~0.15 ms) with the one
+        the captures were taken under: an optimizer step, `load_state_dict`, `reAssignCodebook`, `.to(...)`, `p.data = ...`
+        or any other in-place update drops all captures before anything is replayed.  Two things the fingerprint cannot
+        see: `p.data.copy_(...)` (no version bump, same address) and a Parameter OBJECT swapped for another one
+        (`module.weight = nn.Parameter(...)`): call `enableGraphs()` again after either."""
         self._graphs = {} if enabled else None
         self._graphStamp = None
         return self
@@ -100,10 +108,11 @@ class BaseCompressor(nn.Module):
         tensors = self.__dict__.get("_stampTensors")
         if tensors is None:                      # (walking the module tree costs ~3 ms: done once, redone after _apply)
             tensors = self.__dict__["_stampTensors"] = list(self.parameters()) + list(self.buffers())
-        try:                                     # version counters only: storage moves come through _apply / load hooks
-            return tuple(map(_VERSION_OF, tensors))
+        ptrs = tuple(map(_DATA_PTR_OF, tensors))   # `p.data = other` / set_() move the storage without touching the counter
+        try:
+            return tuple(map(_VERSION_OF, tensors)), ptrs
         except RuntimeError:                     # tensors created under torch.inference_mode() carry no counter
-            return tuple((ops.tensor_version(t), t.data_ptr()) for t in tensors)
+            return tuple(ops.tensor_version(t) for t in tensors), ptrs
 
     def _forgetCaptures(self):
         self.__dict__.pop("_stampTensors", None)
@@ -140,10 +149,8 @@ class BaseCompressor(nn.Module):
         reference.  With grad enabled the step runs through mcquic_amd.autograd (HIP kernels in both directions:
         xHat.backward(...) fills every parameter's .grad); under torch.no_grad() the fused inference kernels are used.
         `uniforms`: optional per-level (u_drop, u_gumbel) draws replacing the two `torch.rand_like(logit)` calls.
-        Divergence from the reference: the returned `logits` are VALUES only (marked non-differentiable by
-        autograd.SoftQuantizeFn).  In the reference they carry a graph back to the latents, codebooks and temperatures;
-        its shipped losses (mcquic/loss/__init__.py:47-62) never differentiate them, so the config-#5 step is the same,
-        but a logit-based regulariser would receive no gradient here -- it must be added inside SoftQuantizeFn.backward."""
+        The returned `logits` carry their graph like the reference's (autograd.SoftQuantizeFn: a gradient on them reaches
+        latents, codebooks and temperatures; the shipped losses, mcquic/loss/__init__.py:47-62, never produce one)."""
         if not self.training:
             return None
         self._check(x)
@@ -221,7 +228,22 @@ class BaseCompressor(nn.Module):
         header = [FileHeader(__version__, self._qp, codeSize, ImageSize(height=h, width=w, channel=c)) for codeSize in codeSizes]
         return codes, binaries, header
 
+    def _checkHeaderGeometry(self, headers: List[FileHeader]):
+        """Untrusted `.mcq` headers: the code sizes must be the ones THIS image size produces (level 0 = the 128-aligned
+        image at 1/16 resolution), before the coder allocates anything from them."""
+        for header in headers:
+            size, code = header.ImageSize, header.CodeSize
+            if not (0 < int(size.height) <= (1 << 20) and 0 < int(size.width) <= (1 << 20)):
+                raise RuntimeError("The header's image size is out of range.")
+            base = self._padding._base
+            ph, pw = -(-int(size.height) // base) * base, -(-int(size.width) // base) * base
+            if len(code.heights) < 1 or int(code.heights[0]) * 16 != ph or int(code.widths[0]) * 16 != pw:
+                raise RuntimeError(f"The header's code size {list(code.heights)} x {list(code.widths)} does not belong to a "
+                                   f"{size.height} x {size.width} image.")
+
     def decompress(self, binaries: List[List[bytes]], headers: List[FileHeader]) -> torch.Tensor:
+        if type(self)._encode_latent is BaseCompressor._encode_latent:       # (Compressor's 16x stem; Neon's geometry differs)
+            self._checkHeaderGeometry(headers)
         with torch.no_grad():
             restored = self._decoder(self._quantizer.decompress(binaries, [header.CodeSize for header in headers]))
         imageSize = headers[0].ImageSize

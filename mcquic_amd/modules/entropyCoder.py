@@ -232,6 +232,8 @@ class EntropyCoder(nn.Module):
 
     # what a header may ask the decoder to allocate: a side of 2^15 latent positions is a 2-megapixel-wide image 64 times over
     _MAX_SIDE = 1 << 15
+    _MAX_AREA = 1 << 24          # latent positions per level and image (16 M = a 64 k x 64 k pixel image at stride 16)
+    _MAX_SYMBOLS = 1 << 28       # n * m * h * w per level: what one call may stage (1 GiB of int32)
 
     @torch.inference_mode()
     def decompress(self, binaries: List[List[bytes]], codeSizes: List[CodeSize]) -> List[torch.Tensor]:
@@ -253,6 +255,14 @@ class EntropyCoder(nn.Module):
                 raise RuntimeError("The header's code heights / widths are out of range.")
             if list(codeSize.heights) != list(first.heights) or list(codeSize.widths) != list(first.widths):
                 raise RuntimeError("All images of one batch must share their code sizes.")
+        for lv in range(levels):
+            h, w = int(first.heights[lv]), int(first.widths[lv])
+            # the sides are bounded above, but so must be what they multiply to: h = w = 2^15 would stage 4 GiB * m per array
+            if h * w > self._MAX_AREA or len(binaries) * self._m * h * w > self._MAX_SYMBOLS:
+                raise RuntimeError("The header's code sizes ask for more symbols than a call may decode.")
+            # every level halves the one before it, rounding up (stride-2 convs with padding 1: ceil(h / 2))
+            if lv > 0 and (h != (int(first.heights[lv - 1]) + 1) // 2 or w != (int(first.widths[lv - 1]) + 1) // 2):
+                raise RuntimeError("The header's code sizes do not halve from level to level.")
         device = self._freqEMA[0].device
         n = len(binaries)
         out = []

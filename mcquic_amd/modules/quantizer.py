@@ -101,9 +101,10 @@ class _multiCodebookQuantization(nn.Module):
         """Every rank takes rank 0's codebook (reference: quantizer.py:138-142): one broadcast of a detached copy, written
         back in place so the Parameter object (and the optimizer state keyed on it) stays the same."""
         import torch.distributed as dist
-        buf = self._codebook.detach().clone()
+        from ..parallel import _staged
+        buf = _staged(self._codebook.detach().clone())
         dist.broadcast(buf, 0)
-        self._store(buf)
+        self._store(buf.to(self._codebook.device))
 
     def _store(self, value: torch.Tensor):
         """In-place update of the shared codebook Parameter that the packed-operand cache notices: `copy_` on the Parameter

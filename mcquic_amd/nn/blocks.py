@@ -33,15 +33,13 @@ __all__ = ["ResidualBlockWithStride", "ResidualBlockShuffle", "ResidualBlock", "
 # branch's workgroups, and the launch-latency-bound small levels run two kernels at once.  MCQUIC_AMD_BRANCH_STREAMS=0
 # turns it off (single stream, same results).
 _BRANCH_STREAMS = os.environ.get("MCQUIC_AMD_BRANCH_STREAMS", "1") != "0"
-_LEVEL_STREAMS = os.environ.get("MCQUIC_AMD_LEVEL_STREAMS", "1") != "0"      # lane 1: the level-granular forks of the training graph
 _side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
 _MULTI_MAX_PIXELS = int(os.environ.get("MCQUIC_AMD_MULTI_MAX_PIXELS", str(64 * 1024)))   # N * H * W up to which AttentionBlock stacks share launches
 
 
-def _side_stream(main: "torch.cuda.Stream", lane: int = 0) -> "torch.cuda.Stream":
-    """The side stream paired with `main` (one per main stream and lane, so pipelined sub-batches do not share one;
-    lane 0 = block-level branches, lane 1 = the level-granular forks of the training graph)."""
-    key = (main.device.index, main.cuda_stream, lane)
+def _side_stream(main: "torch.cuda.Stream") -> "torch.cuda.Stream":
+    """The side stream paired with `main` (one per main stream, so pipelined sub-batches do not share one)."""
+    key = (main.device.index, main.cuda_stream)
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=main.device)
@@ -52,11 +50,11 @@ class _fork:
     """`with _fork(x) as f:` runs the body on the side stream after everything enqueued so far; `f.join(t)` makes the
     main stream wait for it and hands tensor `t` (allocated on the side stream) over to the main stream."""
 
-    def __init__(self, x: torch.Tensor, lane: int = 0):
-        self.on = _BRANCH_STREAMS and x.is_cuda and (lane == 0 or _LEVEL_STREAMS)
+    def __init__(self, x: torch.Tensor):
+        self.on = _BRANCH_STREAMS and x.is_cuda
         if self.on:
             self.main = torch.cuda.current_stream(x.device)
-            self.side = _side_stream(self.main, lane)
+            self.side = _side_stream(self.main)
         self.ctx = None
 
     def __enter__(self):
@@ -76,14 +74,6 @@ class _fork:
             self.main.wait_stream(self.side)
             t.record_stream(self.main)
         return t
-
-    def hand_over(self, *tensors: torch.Tensor) -> None:
-        """Tensors allocated on the side stream that kernels of the main stream read after the join: the caching allocator
-        must not hand their memory to a later side-stream allocation before the main stream is done with them."""
-        if self.on:
-            for t in tensors:
-                if t is not None:
-                    t.record_stream(self.main)
 
 
 class _residulBlock(nn.Module):

@@ -693,16 +693,22 @@ def vq_inner(x: torch.Tensor, cb: PackedCodebook) -> torch.Tensor:
     return out
 
 
-def vq_softmax_bwd(logits: torch.Tensor, u_gumbel: torch.Tensor, ds: torch.Tensor, temperature: torch.Tensor, bound: float):
-    """In place on `ds` (dSample -> d dist); returns (rowsum, dtrow), each [n, m, h, w]."""
+def vq_softmax_bwd(logits: torch.Tensor, u_gumbel: torch.Tensor, ds: torch.Tensor, temperature: torch.Tensor, bound: float,
+                   dlogits: Optional[torch.Tensor] = None, raw_logits: Optional[torch.Tensor] = None):
+    """In place on `ds` (dSample -> d dist); returns (rowsum, dtrow), each [n, m, h, w].  `dlogits`: a gradient on the returned
+    logits themselves, with `raw_logits` = the logits before the random drop."""
     logits, u_gumbel, ds = _dev(logits, "logits"), _dev(u_gumbel, "u_gumbel"), _dev(ds, "ds")
+    if dlogits is not None:
+        dlogits, raw_logits = _dev(dlogits, "dlogits"), _dev(raw_logits, "raw_logits")
+        if dlogits.shape != logits.shape or raw_logits.shape != logits.shape:
+            raise ValueError("dlogits / raw_logits must have the logits' shape")
     n, m, h, w, k = logits.shape
     t = _dev(temperature.detach().reshape(-1), "temperature")
     rowsum = torch.empty((n, m, h, w), dtype=torch.float32, device=logits.device)
     dtrow = torch.empty_like(rowsum)
     with _guard(logits.device):
         check(_lib.load().mcq_vq_softmax_bwd_f32(_ptr(logits), _ptr(u_gumbel), _ptr(ds), _ptr(t), float(bound), _ptr(rowsum), _ptr(dtrow),
-                                                 n, m, h, w, k, _stream()), "mcq_vq_softmax_bwd_f32")
+                                                 _ptr(dlogits), _ptr(raw_logits), n, m, h, w, k, _stream()), "mcq_vq_softmax_bwd_f32")
     return rowsum, dtrow
 
 

@@ -70,10 +70,11 @@ def ideal_bpp(histograms: Sequence[torch.Tensor], total_pixels: int) -> float:
 
 
 @torch.inference_mode()
-def validate(model, images: torch.Tensor, group=None, msssim: bool = True) -> torch.Tensor:
+def validate(model, images: torch.Tensor, group=None, msssim: bool = True, gather: bool = True) -> torch.Tensor:
     """images: this rank's shard, fp32 [n, 3, h, w] in [-1, 1].  Returns float64 rows [psnr_db, ms_ssim_db, bpp] for ALL
     images (rank order) -- the [psnr, ms_ssim, bits] statistics of the reference's validator (validator.py:40-58).
-    `msssim=False` fills the MS-SSIM column with NaN (the metric is undefined for sides <= 160 pixels)."""
+    `msssim=False` fills the MS-SSIM column with NaN (the metric is undefined for sides <= 160 pixels); `gather=False`
+    returns this rank's rows only."""
     codes, binaries, headers = model.compress(images)
     restored = model.decompress(binaries, headers)
     a, b = ops.detransform(images.contiguous()), ops.detransform(restored.contiguous())
@@ -81,4 +82,5 @@ def validate(model, images: torch.Tensor, group=None, msssim: bool = True) -> to
     s = ms_ssim_db(a, b).double() if msssim else torch.full_like(p, float("nan"))
     pixels = images.shape[-2] * images.shape[-1]
     bpp = torch.tensor([sum(len(s_) for s_ in bi) * 8 / pixels for bi in binaries], dtype=torch.float64, device=images.device)
-    return parallel.gather_image_stats(torch.stack([p, s, bpp], 1), group)
+    rows = torch.stack([p, s, bpp], 1)
+    return parallel.gather_image_stats(rows, group) if gather else rows

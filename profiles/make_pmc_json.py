@@ -3,7 +3,11 @@
 it into the summary bench.py reads for `roofline.traffic` (profiles/rNN_pmc.json).
 usage: python profiles/make_pmc_json.py gpurun_out/r02/pmc_rows.json > profiles/rNN_pmc.json"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mcquic_amd.build import csrc_sha          # noqa: E402
 
 rows = json.load(open(sys.argv[1]))
 dom = max((r for r in rows if "conv_mfma" in r["kernel"]), key=lambda r: r["_dur_ns"] * r["launches"])["kernel"]
@@ -19,6 +23,7 @@ dur = sum(r["_dur_ns"] * r["launches"] for r in large)
 allc = [r for r in rows if "conv_mfma" in r["kernel"] or "conv_head16" in r["kernel"]]
 na = sum(r["launches"] for r in allc)
 out = {
+    "csrc_sha": csrc_sha(),      # the kernel sources these passes ran on; bench.py prints traffic_stale when its own differ
     "source": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE} --kernel-trace -- "
               "python bench.py --steps 1 --warmup 1 --no-cpu-baseline (three separate passes, single stream; "
               "tools/collect_profiles.sh, profiles/pmc_stats.py, profiles/make_pmc_json.py)",

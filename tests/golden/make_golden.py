@@ -41,6 +41,113 @@ def want(tag: str) -> bool:
     return not sel or tag in sel
 
 
+F5C_NEAR = 2e-5       # top-2 gaps below this are recorded as near-ties
+
+
+from mcquic_amd.utils.synthetic import bench_images, bench_state_dict      # noqa: E402  (bench.py's own workload generators)
+from mcquic_amd.utils.synthetic import code_hash as _code_hash              # noqa: E402
+
+
+def code_hash(code_img: torch.Tensor) -> np.ndarray:
+    return np.frombuffer(_code_hash(code_img), dtype=np.uint8)
+
+
+def capture_f5c(RQ, shards: int = 8, per_shard: int = 32, chunk: int = 8):
+    import copy
+    import time
+    sd = bench_state_dict()
+    model = ref_harness.reference_compressor(128, 2, [8192, 2048, 512], sd)
+    model64 = copy.deepcopy(model).double()
+    orig_distance = RQ._multiCodebookQuantization._distance
+    state = {}
+
+    def rec32(self, x):
+        dist = orig_distance(self, x)
+        top2 = torch.topk(dist, 2, dim=-1, largest=False)
+        state["top2"].append((top2.values.clone(), top2.indices.clone()))
+        state["dist32"].append(dist)
+        return dist
+
+    def rec64(self, x):
+        dist = orig_distance(self, x)
+        lv = len(state["d64"])
+        c32 = state["codes32"][lv]
+        state["d64"].append((dist.gather(-1, c32.unsqueeze(-1)).squeeze(-1) - dist.min(-1).values).clone())
+        return dist
+
+    hashes = np.zeros((shards * per_shard, 3, 8), dtype=np.uint8)
+    near, near_gap, flips, flip_g32, flip_g64 = [], [], [], [], []
+    downstream = 0
+    recs, xsha = [], []
+    thread_diffs = None
+    totals = [0, 0, 0]
+    t0 = time.time()
+    for r in range(shards):
+        x = bench_images(r, per_shard)
+        xsha.append(np.frombuffer(bytes.fromhex(sha(x)), dtype=np.uint8))
+        shard_codes = [[], [], []]
+        for lo in range(0, per_shard, chunk):
+            xs = x[lo:lo + chunk]
+            state.update(top2=[], dist32=[], d64=[])
+            RQ._multiCodebookQuantization._distance = rec32
+            try:
+                with torch.inference_mode():
+                    c32 = model.encode(xs)
+            finally:
+                RQ._multiCodebookQuantization._distance = orig_distance
+            state["codes32"] = c32
+            RQ._multiCodebookQuantization._distance = rec64
+            try:
+                with torch.inference_mode():
+                    c64 = model64.encode(xs.double())
+            finally:
+                RQ._multiCodebookQuantization._distance = orig_distance
+            alive = torch.ones(len(xs), dtype=torch.bool)
+            for lv in range(3):
+                vals, idx = state["top2"][lv]
+                gap = vals[..., 1] - vals[..., 0]
+                second = torch.where(idx[..., 0] == c32[lv], idx[..., 1], idx[..., 0])      # (exact ties: topk's order is not argmin's)
+                totals[lv] += c32[lv].numel()
+                for i in range(len(xs)):
+                    hashes[r * per_shard + lo + i, lv] = code_hash(c32[lv][i])
+                    shard_codes[lv].append(c32[lv][i])
+                for (i, g, yy, xx) in (gap < F5C_NEAR).nonzero().tolist():
+                    near.append((r, lo + i, lv, g, yy, xx, int(c32[lv][i, g, yy, xx]), int(second[i, g, yy, xx])))
+                    near_gap.append(float(gap[i, g, yy, xx]))
+                diff = c32[lv] != c64[lv]
+                downstream += int((diff & ~alive[:, None, None, None]).sum())
+                first = diff & alive[:, None, None, None]
+                for (i, g, yy, xx) in first.nonzero().tolist():
+                    a, b = int(c32[lv][i, g, yy, xx]), int(c64[lv][i, g, yy, xx])
+                    d32 = state["dist32"][lv][i, g, yy, xx]
+                    flips.append((r, lo + i, lv, g, yy, xx, a, b))
+                    flip_g32.append(float(d32[b] - d32[a]))
+                    flip_g64.append(float(state["d64"][lv][i, g, yy, xx]))
+                alive &= ~first.flatten(1).any(1)
+            if lo == 0:
+                with torch.inference_mode():
+                    recs.append(model.decode([c[:1] for c in c32])[..., ::16, ::16].numpy())
+            print(f"f5c: shard {r} images {lo}..{lo + len(xs) - 1}  near-ties {len(near)}  self-flips {len(flips)}  "
+                  f"{time.time() - t0:.0f} s", flush=True)
+        if r == 0:                               # the reference against itself with 1 thread instead of 8
+            torch.set_num_threads(1)
+            with torch.inference_mode():
+                c1 = model.encode(x[:8])
+            torch.set_num_threads(8)
+            thread_diffs = sum(int((a != torch.stack(shard_codes[lv][:8])).sum()) for lv, a in enumerate(c1))
+    sdsha = hashlib.sha256(b"".join(sd[k].contiguous().numpy().tobytes() for k in sorted(sd))).hexdigest()
+    out = {"shape": np.array([shards, per_shard, 768, 512]), "near_threshold": np.array([F5C_NEAR]),
+           "codes_per_level": np.array(totals), "code_hash": hashes,
+           "near": np.array(near, dtype=np.int32).reshape(-1, 8), "near_gap": np.array(near_gap, dtype=np.float32),
+           "selfflip": np.array(flips, dtype=np.int32).reshape(-1, 8), "selfflip_gap32": np.array(flip_g32, dtype=np.float32),
+           "selfflip_gap64": np.array(flip_g64, dtype=np.float64), "selfflip_downstream": np.array([downstream]),
+           "threads_1_vs_8_code_diffs_first8": np.array([thread_diffs]),
+           "rec_strided": np.concatenate(recs, 0), "x_sha": np.stack(xsha),
+           "state_dict_sha": np.frombuffer(bytes.fromhex(sdsha), dtype=np.uint8)}
+    np.savez_compressed(os.path.join(OUT, "f5c_config2_census.npz"), **out)
+    print(f"f5c: {len(near)} near-ties, {len(flips)} reference self-flips (float32 vs float64), gaps32 {flip_g32}")
+
+
 def main():
     C = ref_harness.load()
     import mcquic.nn as RN                      # the reference's layers
@@ -366,6 +473,16 @@ def main():
             f10[f"train_logit{lv}_strided"] = logitsT[lv].detach()[..., ::8].numpy()
             f10[f"train_ema{lv}"] = model._quantizer._entropyCoder._freqEMA[lv].detach().numpy()
         np.savez_compressed(os.path.join(OUT, "f10_neon.npz"), **f10)
+
+    # ---- F5c: BASELINE configs[2] -- the 256 images `bench.py --gpus 8` generates (8 rank-seeded shards of 32 x 768x512,
+    #           bench.py's own random-init qp=2 weights) through the REFERENCE in float32, and the reference's own
+    #           sensitivity on them: the same model in float64 (and shard 0 with 1 instead of 8 threads).  Stored: a hash
+    #           of every image's codes per level, every near-tie vector (top-2 gap < 2e-5 in the reference's own
+    #           distances) with both candidates, and the vectors where the reference DISAGREES WITH ITSELF (float32 vs
+    #           float64) with their gaps -- the data behind the near-tie protocol of DESIGN section 6.  ~25 min of CPU:
+    #           only when named (`python make_golden.py f5c`) -------------------------------------------------------
+    if "f5c" in [a.lower() for a in sys.argv[1:]]:
+        capture_f5c(RQ)
 
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):

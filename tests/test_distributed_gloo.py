@@ -102,3 +102,40 @@ def test_freq_ema_allreduce_and_codebook_sync_world2_gloo():
         p.join(180)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(world))
+
+
+def _ddp_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mcquic_amd import parallel
+    torch.manual_seed(rank)                                    # different initial weights: rank 0's must win
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    net = parallel.data_parallel(model, torch.device("cpu"), stage_through_host=True)     # the two-ranks-on-one-GPU code path
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.rand((8, 6), generator=g), torch.rand((8, 3), generator=g)
+    lo, hi = parallel.shard_range(8, rank, world)
+    torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi]).backward()
+    got = [p.grad.clone() for p in model.parameters()]
+    torch.manual_seed(0)
+    solo = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    torch.nn.functional.mse_loss(solo(x), y).backward()
+    ret[rank] = all(torch.allclose(a, p.grad, rtol=1e-5, atol=1e-7) for a, p in zip(got, solo.parameters())) and \
+        all(torch.equal(p, q) for p, q in zip(model.parameters(), solo.parameters()))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_host_staged_buckets_world2_gloo():
+    """parallel.data_parallel with the host-staged state broadcast + gradient buckets (what two ranks sharing one GPU under gloo
+    use): both ranks end with rank 0's weights and the gradient of the global mean loss."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world))

@@ -265,6 +265,83 @@ def test_full_training_step_gradients(dev, cfg):
     assert worst[1] < 2e-3, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"
 
 
+@pytest.mark.parametrize("cfg", [(8, 2, [32, 16, 8], 2, 128), (128, 2, [512, 64, 16], 1, 128)])
+def test_logits_carry_their_gradient(dev, cfg):
+    """The returned logits are differentiable like the reference's (mcquic/modules/quantizer.py:181-183,232-239): a loss on
+    them -- <logits_l, W_l>, every entry including the randomly dropped ones -- reaches latents, codebooks, temperatures and
+    everything upstream.  All parameter gradients of <xHat, G> + sum_l <logits_l, W_l> against CPU autograd through the oracle."""
+    from mcquic_amd import Compressor
+    ch, m, ks, n, hw = cfg
+    sd, x, us = _train_setup(ch, m, ks, n, hw, 23)
+    leaf = {k: (v.clone().requires_grad_() if v.is_floating_point() and "reparam" not in k and "_bound" not in k and "_freqEMA" not in k else v)
+            for k, v in sd.items()}
+    for lv in range(len(ks)):
+        cb = leaf[f"_quantizer._encoders.{lv}._quantizer._codebook"]
+        leaf[f"_quantizer._encoders.{lv}._dequantizer._codebook"] = cb
+        leaf[f"_quantizer._decoders.{lv}._dequantizer._codebook"] = cb
+    xHat, yHat, codes, logits, _ = R.forward_train(leaf, x, us)
+    gen = torch.Generator().manual_seed(6)
+    G = torch.rand(xHat.shape, generator=gen) - 0.5
+    Ws = [(torch.rand(lg.shape, generator=gen) - 0.5) * 0.05 for lg in logits]
+    ((xHat * G).sum() + sum((lg * w).sum() for lg, w in zip(logits, Ws))).backward()
+
+    model = Compressor(ch, m, ks)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    out = model(x.to(dev), uniforms=[(a.to(dev), b.to(dev)) for a, b in us])
+    assert all(lg.requires_grad for lg in out[3])
+    ((out[0] * G.to(dev)).sum() + sum((lg * w.to(dev)).sum() for lg, w in zip(out[3], Ws))).backward()
+    worst = ("", 0.0)
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        want, got = leaf[name].grad, p.grad.detach().cpu()
+        rel = (got - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+        if rel > worst[1]:
+            worst = (name, rel)
+    assert worst[1] < 2e-3, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"
+    # the logits term alone (no gradient on xHat at all): the quantizer-side parameters still receive theirs
+    for p in model.parameters():
+        p.grad = None
+    out = model(x.to(dev), uniforms=[(a.to(dev), b.to(dev)) for a, b in us])
+    (out[3][0] * Ws[0].to(dev)).sum().backward()
+    assert model._quantizer._encoders[0]._quantizer._temperature.grad is not None
+    assert model._encoder[0].weight.grad is not None and float(model._encoder[0].weight.grad.abs().max()) > 0
+
+
+def test_training_graph_survives_a_second_backward(dev):
+    """the lockstep heads keep their activations through ctx.save_for_backward, so two backward passes over one
+    graph (retain_graph=True: two losses, gradient penalties) work and accumulate like autograd's own nodes."""
+    from mcquic_amd import Compressor
+    sd, x, us = _train_setup(8, 2, [32, 16, 8], 2, 128, 25)
+    model = Compressor(8, 2, [32, 16, 8])
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    out = model(x.to(dev), uniforms=[(a.to(dev), b.to(dev)) for a, b in us])
+    G = (torch.rand(out[0].shape, generator=torch.Generator().manual_seed(7)) - 0.5).to(dev)
+    loss = (out[0] * G).sum()
+    loss.backward(retain_graph=True)
+    once = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    loss.backward()
+    for n, p in model.named_parameters():
+        if n in once:
+            assert torch.allclose(p.grad, 2 * once[n], rtol=1e-6, atol=1e-7), n
+
+
+def test_model_pickles(dev):
+    """no local lambdas on the module (torch.save(model) / multiprocessing spawn)."""
+    import io
+    from mcquic_amd import Compressor
+    model = Compressor(8, 2, [32, 16, 8]).to(dev).eval()
+    x = R.make_images(1, 128, 128).to(dev)
+    want = model.encode(x)
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    again = torch.load(buf, weights_only=False)
+    assert all(torch.equal(a, b) for a, b in zip(again.encode(x), want))
+
+
 @pytest.mark.parametrize("case", [(128, 128, 3, 1, 5), (128, 128, 3, 2, 3), (128, 128, 1, 1, 17), (40, 24, 3, 1, 2), (12, 128, 3, 1, 3),
                                   (128, 3, 3, 2, 1)])
 def test_grouped_pack_equals_single_packs(dev, case):

@@ -31,6 +31,18 @@ def test_bench_line_has_the_contract_fields(dev):
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0 < r["frac"] <= 1.0 and 0 < r["whole_step_frac"] <= 1.0
+    assert r["traffic_stale"] in (True, False, None)
+    # the round's other results ride in the same line, each with a fraction of the peak that is a true
+    # utilisation (real issued work / time / peak), never above 1
+    sec = d["secondary"]
+    for key in ("winograd2d", "train_step", "vq_config4", "batch1"):
+        assert key in sec and "error" not in sec[key], (key, sec.get(key))
+    assert 0 < sec["winograd2d"]["mfma_work_frac"] <= 1.0 and sec["winograd2d"]["images_s"] > 0
+    assert sec["winograd2d"]["mfma_gflop_per_step"] < sec["winograd2d"]["direct_form_gflop_per_step"]
+    assert sec["winograd2d"]["parity"]["decode_max_abs_err"] <= 1e-4
+    assert sec["train_step"]["graph"] is True and 0 < sec["train_step"]["frac_of_peak"] <= 1.0
+    assert 0 < sec["vq_config4"]["frac_of_peak"] <= 1.0 and 0 < sec["batch1"]["frac_of_peak"] <= 1.0
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
@@ -38,11 +50,24 @@ def test_bench_line_has_the_contract_fields(dev):
     assert d["parity"]["code_mismatches"] == 0
 
 
+def test_opt_in_modes_report_honest_roofline_fields(dev):
+    """--winograd: `frac` is the issued MFMA work over the peak (<= 1; the direct-form-equivalent rate sits beside it);
+    --graphs: nothing to bracket, so the per-kernel fields are null, not 0.0."""
+    w = _run("--no-cpu-baseline", "--winograd", "2")              # (opt-in modes never carry `secondary`)
+    assert "secondary" not in w
+    r = w["roofline"]
+    assert 0 < r["frac"] <= 1.0 and r["equivalent_direct"] > r["achieved"] and r["mfma_gflop_per_step"] < r["algorithmic_gflop_per_step"]
+    g = _run("--no-cpu-baseline", "--graphs")
+    r = g["roofline"]
+    assert r["achieved"] is None and r["frac"] is None and r["launches_per_step"] is None and r["avg_launch_ms"] is None
+    assert 0 < r["whole_step_frac"] <= 1.0 and g["value"] > 0
+
+
 def test_bench_under_a_process_group(dev):
     """RANK / WORLD_SIZE in the environment (what torch.distributed.run sets): RCCL path at world size 1."""
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
-                          "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+                          "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0 and "cpu_baseline" not in d
@@ -50,8 +75,8 @@ def test_bench_under_a_process_group(dev):
 
 
 def test_bench_without_a_launcher_takes_no_process_group(dev):
-    d = _run("--no-cpu-baseline")
-    assert d["n_gpus"] == 1 and d["rccl_world"] is None
+    d = _run("--no-cpu-baseline", "--no-secondary")
+    assert d["n_gpus"] == 1 and d["rccl_world"] is None and "secondary" not in d
 
 
 def test_bench_gpus_must_match_the_launcher(dev):

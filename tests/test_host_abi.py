@@ -207,3 +207,16 @@ def test_winograd_instance_keeps_its_accumulators_to_itself():
             w = re.match(r"(v_\w+)\s+(v\d+)", prev)
             assert not (w and not prev.startswith(("v_mfma", "v_accvgpr")) and w.group(2) in m.groups()), \
                 f"VALU result feeds an inline-asm MFMA {back} instruction(s) later: {prev!r} -> {ln!r}"
+
+
+def test_models_pickle_and_abi_version_is_checked():
+    """no local lambdas on the modules (torch.save(model), multiprocessing spawn); the binding refuses a library
+    built from another revision of the header."""
+    import pickle
+    from mcquic_amd import Compressor, Neon, _lib
+    assert pickle.loads(pickle.dumps(Compressor(8, 2, [32, 16, 8])))._qp == "-1"
+    pickle.dumps(Neon(32, 256, [8, 4, 2, 2]))
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "mcquic_hip.h")).read()
+    declared = int(re.search(r"#define\s+MCQ_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.mcq_abi_version() == declared == _lib.ABI_VERSION

@@ -86,3 +86,14 @@ def test_header_qp_is_only_opened_when_it_names_a_mcquic_file(tmp_path):
     assert detectLocalFile(str(tmp_path)) is None
     assert detectLocalFile("\x00bad") is None
     assert detectLocalFile(str(ckpt)) == ckpt
+
+
+def test_expected_document_is_what_the_msgpack_library_packs():
+    """The reference's serializer ends in `msgpack.packb(schema.dump(file), use_bin_type=True)` (specification.py:149-151).
+    The msgpack library IS installed: packing the dumped dict (fields in declaration order) must give the hand-derived bytes."""
+    import msgpack
+    doc = {"fileHeader": {"qp": "2", "version": "0.1.40",
+                          "codeSize": {"m": [2, 2, 2], "heights": [48, 24, 12], "widths": [32, 16, 8], "k": [8192, 2048, 512]},
+                          "imageSize": {"height": 768, "width": 512, "channel": 3}},
+           "contents": [b"\x01\x02\x03", b"\xff"]}
+    assert msgpack.packb(doc, use_bin_type=True) == EXPECTED

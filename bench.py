@@ -331,7 +331,7 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
         flops = 3.0 * 536.63e9 * 8 * (256 * 256) / (768 * 512)      # forward + input gradients + weight gradients
         sec["train_step"] = {"ms": round(ms, 3), "graph": True, "images_per_step": 8, "crop": 256,
                              "frac_of_peak": round(flops / (ms * 1e-3) / (FP32_MATRIX_PEAK_TFLOPS * 1e12), 4),
-                             "tflop_per_step": round(flops / 1e12, 3), "loss": round(float(static_loss), 6),
+                             "tflop_per_step": round(flops / 1e12, 3), "loss": round(float(static_loss.detach()), 6),
                              "workload": "forward + Gumbel straight-through backward, Compressor(128, 2, [8192, 2048, 512]), 8 x 3 x 256 x 256, one hipGraph"}
         del graph, tm
     except Exception as exc:                                  # noqa: BLE001

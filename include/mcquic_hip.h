@@ -345,6 +345,20 @@ void mcq_ms_ssim_window(float* out11);
  * (metrics.py:264-274) is 10 log10(255^2 / (out[n] / per_image + 1e-4)) in float64. */
 int mcq_sqdiff_sum_u8(const uint8_t* x, const uint8_t* y, int64_t* out, int64_t per_image, int32_t N, void* stream);
 
+/* ---- GroupNorm (`denseNorm=True`) ------------------------------------------------------------------------------------
+ * y = (x - mean) * rstd * gamma[c] + beta[c] over each (image, group) of C / groups adjacent channels, biased variance,
+ * rstd = 1 / sqrt(var + eps): nn.GroupNorm(groups, C) as the reference's ResidualBlock inserts it in place of its second
+ * activation when denseNorm is set (mcquic/nn/blocks.py:179-200).  gamma / beta may be NULL (1 / 0).  y_silu (NULL = none)
+ * receives silu(y).  mean_out / rstd_out [N * groups] (both or neither): what the backward pass needs. */
+int mcq_group_norm_f32(const float* x, const float* gamma, const float* beta, float* y, float* y_silu, float* mean_out,
+                       float* rstd_out, int32_t N, int32_t C, int32_t HW, int32_t groups, float eps, void* stream);
+/* Backward of the above: dx [N, C, HW], dgamma / dbeta [C] (NULL = not wanted) from x, dy and the forward's mean / rstd.
+ * workspace: mcq_group_norm_bwd_workspace_floats(N, C) floats.  Deterministic (no atomics). */
+size_t mcq_group_norm_bwd_workspace_floats(int32_t N, int32_t C);
+int mcq_group_norm_bwd_f32(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx,
+                           float* dgamma, float* dbeta, float* workspace, int32_t N, int32_t C, int32_t HW, int32_t groups,
+                           void* stream);
+
 /* Library / build identification: returns a static string "mcquic_hip <ver> gfx950". */
 /* Launches a kernel with an invalid configuration on purpose and returns what every entry point returns when its launch is
  * refused: MCQ_ELAUNCH.  Test hook for the error path (tests/test_gpu_ops.py); harmless (launch errors are not sticky). */

@@ -222,9 +222,9 @@ class AttentionBlockFn(torch.autograd.Function):
 # their AttentionBlocks).  15 + 15 convolutions become 10 launches each way.
 def _kind(m) -> str:
     name = type(m).__name__
-    if name == "ResidualBlock" and m._skip is None:
+    if name == "ResidualBlock" and m._skip is None and not getattr(m, "denseNorm", False):
         return "rb"
-    if name == "AttentionBlock":
+    if name == "AttentionBlock" and not getattr(m, "denseNorm", False):
         return "attn"
     if name == "Conv2d" and m.kernelSize == 3 and m.stride == 1:
         return "conv"
@@ -468,6 +468,28 @@ class GdnFn(torch.autograd.Function):
         dgamma, dbeta = ops.conv2d_wgrad(x, ds, 1, 1, square_x=True, want_bias=True)
         bb, gb = ctx.bounds
         return (dx, ops.nonneg_reparam_bwd(beta_p, dbeta, bb), ops.nonneg_reparam_bwd(gamma_p, dgamma[:, :, 0, 0], gb), None, None)
+
+
+class GroupNormFn(torch.autograd.Function):
+    """nn.GroupNorm(groups, C) with affine parameters (`denseNorm=True`, mcquic/nn/blocks.py:179-200), HIP both ways."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps):
+        y, mean, rstd = ops.group_norm(x, weight, bias, groups, eps, want_stats=True)
+        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        dx, dw, db = ops.group_norm_bwd(x, dy.contiguous(), weight, mean, rstd, ctx.groups,
+                                        want_params=ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, dw, db, None, None
+
+
+def group_norm(x, module):
+    return GroupNormFn.apply(x, module.weight, module.bias, module.num_groups, module.eps)
 
 
 def conv(x, module, res: Optional[torch.Tensor] = None, shuffle2: bool = False):

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libmcquic_hip.so")
-SOURCES = ["conv_mfma.hip", "vq.hip", "vq_train.hip", "train_ops.hip", "wgrad_rows.hip", "metrics.hip", "rans.cpp"]
+SOURCES = ["conv_mfma.hip", "vq.hip", "vq_train.hip", "train_ops.hip", "wgrad_rows.hip", "metrics.hip", "norm.hip", "rans.cpp"]
 HEADERS = ["mcq_common.h", "vq_common.h", "conv_head16.h", os.path.join("..", "..", "include", "mcquic_hip.h")]
 # -ffp-contract=off: element-wise epilogues keep the reference's one-rounding-per-op sequence
 #   (e.g. a * sigmoid(b) then + x are two torch kernels in mcquic/nn/blocks.py:286-287).
@@ -66,7 +66,7 @@ def _stale() -> bool:
 
 def build(force: bool = False, verbose: bool = False, extra_flags=(), lib: str = LIB) -> str:
     """Compile csrc/* into mcquic_amd/libmcquic_hip.so with hipcc (cross-compiles without a GPU).  `extra_flags` /
-    `lib`: kernel A/B variants (e.g. -DMCQ_ABLATE=1 into mcquic_amd/variants/...), always compiled from scratch."""
+    `lib`: kernel A/B variants (e.g. -DMCQ_PFB=36 into mcquic_amd/variants/...), always compiled from scratch."""
     variant = bool(extra_flags) or lib != LIB
     if not force and not variant and not _stale():
         return LIB

@@ -23,21 +23,8 @@
 #include "mcq_common.h"
 #include "../../include/mcquic_hip.h"
 
-// tuning ablations of the k-loop (never shipped; DESIGN.md section 4 has the numbers): 1 = every activation load reads
-// the same cache line, 2 = no activation loads, 3 = no weight loads, 4 = no loads at all (MFMAs + loop control: the
-// issue bound of this loop structure); MCQ_ABLATE_EPI = 1 skips the epilogue (no side loads, no stores)
-#ifndef MCQ_ABLATE
-#define MCQ_ABLATE 0
-#endif
-#ifndef MCQ_ABLATE_EPI
-#define MCQ_ABLATE_EPI 0
-#endif
-#ifndef MCQ_BAND_EPILOGUE
-#define MCQ_BAND_EPILOGUE 1
-#endif
-#ifndef MCQ_SCHED_FENCE
-#define MCQ_SCHED_FENCE 1
-#endif
+// (The ablation / stamp / packed-SiLU / peel build switches of rounds 1-2 are gone from this file: what they measured is in
+//  DESIGN.md section 4, the code in the history up to commit 0aa82a9.)
 // 3x3 ring depths in k-steps (weights / activations).  Activations 18 steps = two channel pairs ahead.
 #ifndef MCQ_PF42A
 #define MCQ_PF42A 9
@@ -48,42 +35,12 @@
 #ifndef MCQ_PFB
 #define MCQ_PFB 18
 #endif
-#ifndef MCQ_XCD_REMAP
-#define MCQ_XCD_REMAP 1
-#endif
-#ifndef MCQ_TILE_41
-#define MCQ_TILE_41 1
-#endif
-#ifndef MCQ_TILE_22A
-#define MCQ_TILE_22A 1
-#endif
-#ifndef MCQ_TILE_14
-#define MCQ_TILE_14 1
-#endif
-#ifndef MCQ_HEAD16
-#define MCQ_HEAD16 1
-#endif
-#ifndef MCQ_PEEL
-#define MCQ_PEEL 0
-#endif
-#ifndef MCQ_W2D_EXP
-#define MCQ_W2D_EXP 0
-#endif
 #ifndef MCQ_WINO_PERSIST
 #define MCQ_WINO_PERSIST 1          // workgroups per CU of the persistent 128-row Winograd instance; 0 = one workgroup per four tiles
 #endif
 // SiLU of the band epilogue two values at a time on packed fp32 instructions (mcq_silu2: bit-identical results, 15 issue
 // slots per pair instead of 24).  Measured on the direct kernel: 253.2 vs 256.2 images/s (same box, alternating runs) -- the
 // packed forms cost the co-resident wave's MFMA stream MORE than the scalar ones they replace: off.
-#ifndef MCQ_PK_SILU
-#define MCQ_PK_SILU 0
-#endif
-#ifndef MCQ_PK_SILU_W          // the same switch for the one-wave-per-SIMD Winograd instance's own epilogue: no difference (187.0 vs 186.9)
-#define MCQ_PK_SILU_W 0
-#endif
-#ifndef MCQ_ONLY_WINO
-#define MCQ_ONLY_WINO 0
-#endif
 #ifndef MCQ_WINO_PFB2
 #define MCQ_WINO_PFB2 48
 #endif
@@ -157,24 +114,6 @@ template <> __device__ __forceinline__ float mcq_wload<1>(__amdgpu_buffer_rsrc_t
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 
-#if MCQ_STAMPS
-// tuning aid (never shipped): per-wave s_memrealtime stamps (100 MHz) at entry / ring filled / k-loop done / stores issued
-__device__ unsigned long long* mcq_stamp_buf = nullptr;      // [0] = record counter, then 9 words per record
-__device__ __forceinline__ void mcq_stamp_write(unsigned long long t0, unsigned long long t1, unsigned long long t2, unsigned long long t3,
-                                                unsigned long long dA = 0, unsigned long long dB = 0, unsigned long long dC = 0) {
-    if (mcq_stamp_buf == nullptr || (threadIdx.x & 63) != 0) return;
-    const unsigned long long rec = atomicAdd(mcq_stamp_buf, 1ull);
-    if (rec >= (1ull << 20)) return;
-    unsigned hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    unsigned long long* o = mcq_stamp_buf + 1 + rec * 9;
-    o[0] = hw; o[1] = xcc; o[2] = t0; o[3] = t1; o[4] = t2; o[5] = t3; o[6] = dA; o[7] = dB; o[8] = dC;
-}
-#define MCQ_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
-#else
-#define MCQ_STAMP(var)
-#endif
 
 template <int MB, int NB, int PRO, int PFA, int PFB, int TAPS, int OCC>
 __global__ __launch_bounds__(TAPS >= 12 ? 256 : 512, OCC) void conv_mfma_kernel(ConvK p) {
@@ -210,7 +149,6 @@ __global__ __launch_bounds__(TAPS >= 12 ? 256 : 512, OCC) void conv_mfma_kernel(
     // by the inline-asm MFMAs below and read back element by element in the epilogue.  The compiler's own code stays within
     // the VGPR half (tests/test_host_abi.py checks the disassembly: no AGPR operand outside these instructions).
     constexpr bool WASM = WINO && MB * PG == 16;
-    MCQ_STAMP(st0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // this workgroup's problem (scalar selects; one problem per launch is the common case)
@@ -243,7 +181,7 @@ next_tile:
     int tile_zero = 0;
     if (WASM) asm volatile("" : "+s"(tile_zero));
     unsigned wg = vwg;
-    if (MCQ_XCD_REMAP) {
+    {
         const unsigned nwg = WASM ? (unsigned)p.total_wgs : gridDim.x, xcd = wg & 7u, slot = wg >> 3;   // (WASM: gridDim.x % 8 == 0)
         const unsigned base = xcd * (nwg >> 3) + (xcd < (nwg & 7u) ? xcd : (nwg & 7u));      // workgroups of the XCDs before this one
         wg = base + slot;
@@ -382,20 +320,13 @@ next_tile:
         };
         // the workgroup barrier WITHOUT the fence of __syncthreads(): that one waits for every outstanding vector load,
         // i.e. it would drain the prefetch rings once per channel pair
-#if MCQ_W2D_EXP == 1
-        auto wg_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-#elif MCQ_W2D_EXP == 2
-        auto wg_barrier = [&]() __attribute__((always_inline)) { asm volatile("" ::: "memory"); };
-#else
         auto wg_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-#endif
         float Vn[16];
         f32x4v tq[4];
         row_to_lds(0, 0);
         wg_barrier();
         lds_rows(0, tq);
         rows_to_v(tq, Vn);
-        MCQ_STAMP(st1w);
         // The first body is peeled off the loop: hipcc's wait-count pass merges the loop-entry state (operands requested by the
         // preload above, back to back) with the back-edge state (requested one body ago, 80 loads apart) and would wait at every
         // use as if the loads had only just been issued -- draining the rings once per channel pair (55 instead of 155 "TFLOP/s").
@@ -464,7 +395,6 @@ next_tile:
 #pragma unroll
     for (int i = 0; i < PGV; ++i) Vn[i] = 0.0f;
     if (WINO && active) wino_transform(0, Vn);
-    MCQ_STAMP(st1);
     auto kbody = [&](const int sp) __attribute__((always_inline)) {
         // Every VALU instruction between two MFMAs costs the matrix pipe ~10 cycles (tools/probes/mfma_issue.hip), so
         // the k-loop has none: the channel-pair offset of an activation load lives in its buffer descriptor -- one per
@@ -530,40 +460,20 @@ next_tile:
                         acc[mb][at % NACC] =
                             __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[sa], mb), bv[nb], acc[mb][at % NACC], 0, 0, 0);
                 }
-#if MCQ_ABLATE == 2 || MCQ_ABLATE == 4
-                asm volatile("" : "+v"(B[sb][nb]));
-#elif MCQ_ABLATE == 1
-                B[sb][nb] = mcq_buffer_load(rsrc[nb], voff[nb][TAPS != 1 ? 4 : 0]);
-#else
                 B[sb][nb] = mcq_buffer_load(rB[nb][ds - PFBP], voff[nb][tl]);
-#endif
             }
-#if MCQ_ABLATE < 3
             A[sa] = mcq_wload<MB>(wr, wlane, wso);
             wso += 256 * MB;
-#endif
-#if MCQ_SCHED_FENCE
             // keep the software pipeline as written: without this fence the scheduler sinks the loads of all U
             // steps to the end of the (branch-free) body and waits for them one step later
             __builtin_amdgcn_sched_barrier(0);
-#endif
         }
         soff += (unsigned)PAIRS_PER_ITER * step_bytes;
     };
-#if MCQ_PEEL
-    // (first body peeled: see the F(2x2, 3x3) loop -- the wait counts of the looped copy then reflect the steady state)
-    if (npairs > 0) kbody(0);
-    for (int sp = PAIRS_PER_ITER; sp < npairs; sp += PAIRS_PER_ITER) kbody(sp);
-#else
     for (int sp = 0; sp < npairs; sp += PAIRS_PER_ITER) kbody(sp);
-#endif
     }       // (!W2D)
 
     if (WASM) asm volatile("s_nop 15\n\ts_nop 15");       // (the last MFMAs' results must have landed before the first v_accvgpr_read)
-    MCQ_STAMP(st2);
-#if MCQ_STAMPS
-    unsigned long long ph_a = 0, ph_b = 0, ph_c = 0;     // band epilogue: side loads issued / arithmetic done / stores issued
-#endif
     // ---- epilogue ---------------------------------------------------------------------------
     // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row tile, the 16 output channels
     // row(r) + 4 hi, row(r) = (r & 3) + 8 (r >> 2).  Element (co, pixel) of image n sits at byte (co HoWo + pixel) 4 of
@@ -608,7 +518,6 @@ next_tile:
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 bias16[r] = mcq_buffer_load_s(br, (unsigned)hi * 16u, (co_row0 + (unsigned)mcq_drow(r, 0)) * 4u);
-#if MCQ_BAND_EPILOGUE
             // The four flag sets that make up the network's 3x3 layers (plain, SiLU, residual, residual + SiLU twin) finish a
             // whole 32-row band in three phases -- side loads of all its pixel blocks, then all arithmetic, then all stores --
             // instead of block by block with loads, activation and stores alternating (measured: +1.8 % on a 384x256 layer
@@ -619,14 +528,12 @@ next_tile:
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sob[r] = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
                 float vv[NB][16], rvv[NB][16], tw[NB][16];
-                MCQ_STAMP(pe0);
                 if (EF & MCQ_CONV_RESIDUAL) {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) rvv[nb][r] = mcq_buffer_load_s(rr_[nb], pvo[nb], sob[r]);
                 }
-                MCQ_STAMP(pe1);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     get_acc(mi, nb, vv[nb]);
@@ -636,23 +543,6 @@ next_tile:
 #pragma unroll
                         for (int r = 0; r < 16; ++r) vv[nb][r] = vv[nb][r] + p.res_scale * rvv[nb][r];
                     }
-#if MCQ_PK_SILU
-                    // two values per call: the multiplies / FMAs / adds of the activation as packed instructions (same results)
-                    if (EF & MCQ_CONV_SILU_OUT) {
-#pragma unroll
-                        for (int r = 0; r < 16; r += 2) {
-                            const f32x2v sv = mcq_silu2(f32x2v{vv[nb][r], vv[nb][r + 1]});
-                            vv[nb][r] = sv[0]; vv[nb][r + 1] = sv[1];
-                        }
-                    }
-                    if (EF & MCQ_CONV_DUAL_SILU) {
-#pragma unroll
-                        for (int r = 0; r < 16; r += 2) {
-                            const f32x2v sv = mcq_silu2(f32x2v{vv[nb][r], vv[nb][r + 1]});
-                            tw[nb][r] = sv[0]; tw[nb][r + 1] = sv[1];
-                        }
-                    }
-#else
                     if (EF & MCQ_CONV_SILU_OUT) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) vv[nb][r] = mcq_silu(vv[nb][r]);
@@ -661,12 +551,7 @@ next_tile:
 #pragma unroll
                         for (int r = 0; r < 16; ++r) tw[nb][r] = mcq_silu(vv[nb][r]);
                     }
-#endif
                 }
-#if MCQ_STAMPS
-                asm volatile("" :: "v"(vv[0][0]), "v"(vv[NB - 1][15]), "v"(tw[0][0]), "v"(tw[NB - 1][15]));
-#endif
-                MCQ_STAMP(pe2);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -676,12 +561,8 @@ next_tile:
                         for (int r = 0; r < 16; ++r) mcq_buffer_store_s(tw[nb][r], y2r[nb], pvo[nb], sob[r]);
                     }
                 }
-#if MCQ_STAMPS
-                { MCQ_STAMP(pe3); ph_a += pe1 - pe0; ph_b += pe2 - pe1; ph_c += pe3 - pe2; }
-#endif
                 continue;
             }
-#endif
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 float v[16];
@@ -880,8 +761,8 @@ next_tile:
                         y[nb] = (nb == 0 ? (a + b) + c : (a - b) - c) + ball[mb][r];
                         if (EF & MCQ_CONV_RESIDUAL) y[nb] = y[nb] + p.res_scale * rall[mb][r][nb];
                     }
-                    if (EF & MCQ_CONV_SILU_OUT) y = MCQ_PK_SILU_W ? mcq_silu2(y) : f32x2v{mcq_silu(y[0]), mcq_silu(y[1])};
-                    if (EF & MCQ_CONV_DUAL_SILU) tw = MCQ_PK_SILU_W ? mcq_silu2(y) : f32x2v{mcq_silu(y[0]), mcq_silu(y[1])};
+                    if (EF & MCQ_CONV_SILU_OUT) y = f32x2v{mcq_silu(y[0]), mcq_silu(y[1])};
+                    if (EF & MCQ_CONV_DUAL_SILU) tw = f32x2v{mcq_silu(y[0]), mcq_silu(y[1])};
                     const unsigned so = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
                     if (wide) {
                         mcq_buffer_store2_s(y, yr, pvo[0], so);
@@ -900,22 +781,13 @@ next_tile:
         (void)ef; (void)SIMPLE_W;
         if constexpr (WEF != RUNTIME_FLAGS) {
             wasm_epilogue(std::integral_constant<unsigned, WEF>{});
-#if MCQ_STAMPS
-            { MCQ_STAMP(st3); mcq_stamp_write(st0, st1, st2, st3, 0, 0, 0); }
-#endif
             vwg += gridDim.x;
             if (vwg < (unsigned)p.total_wgs) goto next_tile;
             return;
         }
     }
     if (KS == 1) {
-#if MCQ_ABLATE_EPI
-        float keep = 0.0f;
-        for (int mb = 0; mb < MB; ++mb) for (int nb = 0; nb < NB; ++nb) for (int r = 0; r < 16; ++r) keep += acc[mb][nb][r];
-        run_epilogue(keep == 12345.678f, [&](int mi, int nb, float (&v)[16]) {
-#else
         run_epilogue(true, [&](int mi, int nb, float (&v)[16]) {           // (mi, nb are constants once unrolled)
-#endif
             if (WINO) {
                 // back from the transform positions to the pixels of the pair / tile, band by band (all accumulator tiles at
                 // once would need every accumulator in a VALU-readable register at the same time)
@@ -945,9 +817,6 @@ next_tile:
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = acc[mi][nb][r];
         }, 0, std::integral_constant<int, MB>{});
-#if MCQ_STAMPS
-        { MCQ_STAMP(st3); mcq_stamp_write(st0, st1, st2, st3, ph_a, ph_b, ph_c); }
-#endif
         if constexpr (WASM) {
             vwg += gridDim.x;
             if (vwg < (unsigned)p.total_wgs) goto next_tile;
@@ -990,9 +859,6 @@ next_tile:
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = own[nb][r];
     }, kslice, std::integral_constant<int, 1>{});
-#if MCQ_STAMPS
-    { MCQ_STAMP(st3); mcq_stamp_write(st0, st1, st2, st3, 0, 0, 0); }
-#endif
 }
 
 // OIHW -> [Cout/(32 bands)][TP][64 lanes][bands]: lane l, slot q holds W[co = 32 bands T + 32 q + (l & 31)][ci = 2 s + (l >> 5)][tap]
@@ -1231,7 +1097,7 @@ extern "C" int32_t mcq_conv2d_winograd_ok(int32_t N, int32_t Cin, int32_t H, int
 
 extern "C" size_t mcq_packed_conv_weight_floats(int32_t Cout, int32_t Cin, int32_t ksize) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
-    return general_floats(Cout, Cin, ksize) + (MCQ_HEAD16 && head16_shape(Cout, ksize) ? head16_floats(Cin) : 0);
+    return general_floats(Cout, Cin, ksize) + (head16_shape(Cout, ksize) ? head16_floats(Cin) : 0);
 }
 
 extern "C" int mcq_pack_conv_weight_f32(const float* w, int32_t Cout, int32_t Cin, int32_t ksize, float* out,
@@ -1241,7 +1107,7 @@ extern "C" int mcq_pack_conv_weight_f32(const float* w, int32_t Cout, int32_t Ci
     const int S = pairs_padded(Cin, ksize), TP = steps_padded(Cin, ksize);
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
                        ksize, S, TP, out, section_floats(Cout, Cin, ksize, 4), section_floats(Cout, Cin, ksize, 2), total, 0, Cout, Cin, 1.0f);
-    if (MCQ_HEAD16 && head16_shape(Cout, ksize)) {      // second copy in the 16-row operand order of conv_head16_kernel
+    if (head16_shape(Cout, ksize)) {      // second copy in the 16-row operand order of conv_head16_kernel
         const size_t t16 = head16_floats(Cin);
         hipLaunchKernelGGL(pack_head16_kernel, dim3((unsigned)((t16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
                            (Cin + 3) / 4, out + total, t16, 0, Cout, Cin, 1.0f);
@@ -1266,7 +1132,7 @@ extern "C" int mcq_pack_conv_dgrad_weight_f32(const float* w, int32_t Cout, int3
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, co_d, ci_d,
                        ksize, S, TP, out, section_floats(co_d, ci_d, ksize, 4), section_floats(co_d, ci_d, ksize, 2), total,
                        stride == 1 ? 1 : 2, Cout, Cin, scale);
-    if (MCQ_HEAD16 && head16_shape(co_d, ksize)) {      // narrow input gradients (the 8-channel fixture models) take the 16-row kernel
+    if (head16_shape(co_d, ksize)) {      // narrow input gradients (the 8-channel fixture models) take the 16-row kernel
         const size_t t16 = head16_floats(ci_d);
         hipLaunchKernelGGL(pack_head16_kernel, dim3((unsigned)((t16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, co_d, ci_d,
                            (ci_d + 3) / 4, out + total, t16, stride == 1 ? 1 : 2, Cout, Cin, scale);
@@ -1285,7 +1151,7 @@ extern "C" int mcq_pack_conv_weight_multi_f32(const float* const* w, float* cons
         if (mcq_dgrad_weight_shape(Cout, Cin, ksize, stride, &co, &ci) != MCQ_OK) return MCQ_EINVAL;
         mode = stride == 1 ? 1 : 2;
     }
-    if (MCQ_HEAD16 && head16_shape(co, ksize)) return MCQ_EINVAL;          // (narrow layers carry a second copy: one by one)
+    if (head16_shape(co, ksize)) return MCQ_EINVAL;          // (narrow layers carry a second copy: one by one)
     PackTable t;
     for (int c = 0; c < PACK_MAX_MULTI; ++c) {
         const int k = c < n ? c : 0;
@@ -1413,7 +1279,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     }
 
     // <= 16 output channels, 3x3, stride 1, nothing but bias / PixelShuffle in the epilogue: the 16-row MFMA kernel
-    if (MCQ_HEAD16 && nprob == 1 && head16_shape(d->Cout, d->ksize) && d->stride == 1 && (d->tile & 0xff) == 0 &&
+    if (nprob == 1 && head16_shape(d->Cout, d->ksize) && d->stride == 1 && (d->tile & 0xff) == 0 &&
         (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN)) == 0) {
         if ((uint64_t)d->Cout * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
         Head16K h;
@@ -1457,7 +1323,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     else if (co32 == 1) {
         // <= 32 output channels (the 12-channel head, the tiny fixture models): one weight load feeds NB MFMAs, so the
         // widest pixel tile that still leaves >= 2048 waves amortises it best (head conv 2.34 -> 2.05 ms with NB = 4)
-        MB = 1; NB = (MCQ_TILE_14 && tb * nprob >= 4 * 2048) ? 4 : 2;
+        MB = 1; NB = (tb * nprob >= 4 * 2048) ? 4 : 2;
     }
     else {
         // (the 128 x 32 tile <4, 1> is instantiated and reachable through `tile`; an automatic rule preferring it on
@@ -1478,14 +1344,14 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         while (ksl1 < 3 && (tiles1 << ksl1) < 2048) ++ksl1;
         // an 8-way split of the 128 x 64 tile runs as a 4-way split of the 128 x 32 tile instead: the same number of
         // waves, half the LDS reduction depth, 3 waves / SIMD resident (8 x 128 x 32 x 32 layer: 50 -> 28 us)
-        // MCQ_TILE_22A: a 4-way split 128 x 64 tile that needs 1.5 rounds at 2 waves / SIMD -- the 48x32 level -- runs as
+        // a 4-way split 128 x 64 tile that needs 1.5 rounds at 2 waves / SIMD -- the 48x32 level -- runs as
         // the 64 x 64 tile split 2 ways, all waves resident at 3 / SIMD (120 -> 111 us per launch, +0.4 % images/s; with
         // the earlier k-loop, whose address arithmetic weighed twice as much on the smaller tile, it cost 0.4 %)
         // (judged per problem: two such problems in one launch are 6144 waves = two full rounds at 3 / SIMD, 204 us per pair,
         //  where the 128 x 64 tile split 2 ways would be 1.5 rounds at 2 / SIMD, 224 us)
-        if (MCQ_TILE_22A && MB == 4 && NB == 2 && ksl1 == 2 && tiles1 * 4 > 2048 && tiles1 * 4 <= 3072 && d->ksize == 3 &&
+        if (MB == 4 && NB == 2 && ksl1 == 2 && tiles1 * 4 > 2048 && tiles1 * 4 <= 3072 && d->ksize == 3 &&
             k.S % 2 == 0 && (k.S >> 1) >= 8) { MB = 2; NB = 2; ksl = 1; }
-        if (MCQ_TILE_41 && MB == 4 && NB == 2 && ksl == 3 && d->ksize == 3 && k.S % 4 == 0 && (k.S >> 2) >= 8) { NB = 1; ksl = 2; }
+        if (MB == 4 && NB == 2 && ksl == 3 && d->ksize == 3 && k.S % 4 == 0 && (k.S >> 2) >= 8) { NB = 1; ksl = 2; }
     }
     const int pro = (fl & MCQ_CONV_SILU_IN) ? PRO_SILU : (fl & MCQ_CONV_SQUARE_IN) ? PRO_SQUARE : PRO_NONE;
     const long long ptiles = (tb + NB - 1) / NB;
@@ -1494,9 +1360,6 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     // rows of the last cout tile included
     if ((uint64_t)co_tiles * 32u * (unsigned)MB * (uint64_t)k.Ho * k.Wo * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
     hipStream_t s = (hipStream_t)stream;
-#if MCQ_ONLY_WINO          // (tuning aid: compile the Winograd instances alone)
-    return MCQ_EINVAL;
-#else
     if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42A, MCQ_PF42B, 4>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 2) return launch_tile<2, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
@@ -1505,7 +1368,6 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     if (MB == 1 && NB == 2) return launch_tile<1, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 1 && NB == 1) return launch_tile<1, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
     return MCQ_EINVAL;
-#endif
 }
 
 }  // namespace
@@ -1530,8 +1392,3 @@ extern "C" int mcq_conv2d_multi_f32(const mcq_conv_desc* descs, int32_t n, void*
     return conv_launch(descs, n, stream);
 }
 
-#if MCQ_STAMPS
-extern "C" int mcq_stamp_buffer(void* buf) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(mcq_stamp_buf), &buf, sizeof(buf));
-}
-#endif

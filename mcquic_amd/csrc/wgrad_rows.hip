@@ -26,14 +26,6 @@
 #ifndef MCQ_WGRAD_MAX_GROUP
 #define MCQ_WGRAD_MAX_GROUP 16
 #endif
-// tuning ablations (never shipped): 1 = every lane reads channel 0 (no divergence between lanes), 2 = no loads inside the row loop,
-// 3 = no row loop at all (prologue + LDS tree + stores: the fixed cost of a launch), 4 = no LDS tree / stores (row loop only)
-#ifndef MCQ_WGROWS_ABLATE
-#define MCQ_WGROWS_ABLATE 0
-#endif
-#ifndef MCQ_WGROWS_WIDE
-#define MCQ_WGROWS_WIDE 1
-#endif
 #ifndef MCQ_WGROWS_WAVES
 #define MCQ_WGROWS_WAVES 2048          // resident waves aimed at (2 per SIMD)
 #endif
@@ -63,7 +55,7 @@ inline bool rows_plan(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int t
     if ((uint64_t)N * Cin * H * W * (stride2 ? 16ull : 4ull) >= 0x40000000ull || (uint64_t)N * Cout * H * W * 4ull >= 0x40000000ull) return false;
     const int tile = taps == 9 ? 32 : 64;                                    // the 1x1 kernel owns 64 x 64 tiles
     const long long tiles = (long long)((Cout + tile - 1) / tile) * ((Cin + tile - 1) / tile);
-    r.F = (W % 16 == 0 && MCQ_WGROWS_WIDE && !stride2) ? 8 : 4;              // floats per lane and row: strips of 16 / 8 pixels
+    r.F = (W % 16 == 0 && !stride2) ? 8 : 4;              // floats per lane and row: strips of 16 / 8 pixels
     r.strips = W / (2 * r.F);
     const int rb = (taps == 1 || stride2) ? 2 : r.F == 4 ? 8 : 4;             // rows per loop body
     const long long sr = (long long)N * H * r.strips;                       // strip-rows in all
@@ -137,13 +129,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WgRowsK p) {
         int y1 = y0 + p.rpc;
         if (y1 > p.H) y1 = p.H;
         const int xl = sx * (2 * F) + F * kh;                 // this lane's first column
-#if MCQ_WGROWS_ABLATE == 1
-        const unsigned vA = (unsigned)(((n * p.Cout + co_base) * p.H * p.W + xl) * 4);
-        const unsigned vB = (unsigned)(((n * p.Cin + ci_base) * p.H * p.W + xl) * 4);
-#else
         const unsigned vA = co_ok ? (unsigned)(((n * p.Cout + co_base + j) * p.H * p.W + xl) * 4) : MCQ_OOB;
         const unsigned vB = ci_ok ? (unsigned)(((n * p.Cin + ci_base + j) * p.H * p.W + xl) * 4) : MCQ_OOB;
-#endif
         const unsigned vBl = (ci_ok && xl > 0) ? vB - 4u : MCQ_OOB;
         const unsigned vBr = (ci_ok && xl + F < p.W) ? vB + 4u * F : MCQ_OOB;
 
@@ -173,20 +160,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WgRowsK p) {
 #pragma unroll
         for (int s = 0; s < LB; ++s) loadB(s, y0 + s);
 
-#if MCQ_WGROWS_ABLATE == 3
-        if (p.N > 100000)
-#endif
         for (int yb = y0; yb < y1; yb += RB) {
 #pragma unroll
             for (int uu = 0; uu < RB; ++uu) {
                 const int y = yb + uu;
                 const int sa = uu % RA, sprev = (uu + RB - 1) % RB, snext = (uu + 1) % RB;
-#if MCQ_WGROWS_ABLATE != 2
                 loadB((uu + LB) % RB, y + LB);                // (a slot no row of y - 1 .. y + 1 lives in)
                 loadA((uu + LA) % RA, y + LA);                // (the slot of row y - 1)
-#else
-                asm volatile("" : "+v"(A[(uu + LA) % RA][0]), "+v"(Bw[(uu + LB) % RB][0]));
-#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < F; ++q)
@@ -214,9 +194,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WgRowsK p) {
         }
     }
 
-#if MCQ_WGROWS_ABLATE == 4
-    if (acc[0][0] + acc[4][3] + acc[8][15] != 12345.678f) return;
-#endif
     // ---- the four waves of the workgroup meet in LDS: (w0 + w1) + (w2 + w3), five taps at a time --------------------
 #pragma unroll
     for (int half = 0; half < 2; ++half) {

@@ -293,7 +293,7 @@ class Neon(BaseCompressor):
     """The stage-1 model of the reference's generative branch (mcquic/modules/compressor.py:181-241; what the snapshot's
     trainer builds, mcquic/train/ddp.py:79-83): a 3x-strided encoder / decoder around a `ResidualBackwardQuantizer`.
     Same constructor, module tree and state_dict keys; `checkpoint_wrapper` (fairscale activation checkpointing, a
-    training-memory measure) is not applied.  `groups` / `denseNorm`: see nn/blocks.py (`denseNorm=False` only)."""
+    training-memory measure) is not applied.  `groups` / `denseNorm`: see nn/blocks.py (GroupNorm on csrc/norm.hip)."""
 
     def __init__(self, channel: int, k: int, size: List[int], denseNorm: bool = False, *_, **__):
         quantizer = ResidualBackwardQuantizer(k, size, denseNorm)

@@ -86,29 +86,38 @@ class _residulBlock(nn.Module):
         self._skip = skip
 
 
-def _no_dense_norm(denseNorm: bool):
-    # In this snapshot of the reference the `groups` argument of the blocks only sets the group count of the GroupNorm that
-    # `denseNorm=True` puts in place of the second activation (mcquic/nn/blocks.py:179-200: conv3x3 is called without it):
-    # with denseNorm=False -- the default everywhere, Neon included -- every convolution is dense and `groups` is unused.
-    if denseNorm:
-        raise NotImplementedError("denseNorm=True (GroupNorm in place of the second activation) is not built")
+class GroupNorm(nn.GroupNorm):
+    """nn.GroupNorm(groups, C) (affine, eps 1e-5: same parameters `weight`, `bias` and state_dict keys) on the HIP kernel of
+    csrc/norm.hip.  In this snapshot of the reference the blocks' `groups` argument only sets the group count of this layer,
+    which `denseNorm=True` puts in place of a ResidualBlock's second activation (mcquic/nn/blocks.py:179-200: conv3x3 is called
+    without `groups`): every convolution stays dense."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():
+            return AG.group_norm(x, self)
+        return ops.group_norm(x, self.weight, self.bias, self.num_groups, self.eps)
 
 
 class ResidualBlock(_residulBlock):
-    """SiLU, conv3, SiLU, conv3, + x; with different widths the skip is a 1x1 conv (mcquic/nn/blocks.py:179-182)."""
+    """SiLU, conv3, SiLU, conv3, + x; with different widths the skip is a 1x1 conv (mcquic/nn/blocks.py:179-182).
+    `denseNorm=True`: GroupNorm(groups, outChannels) stands where the second SiLU was (:196)."""
 
     def __init__(self, inChannels: int, outChannels: int, groups: int = 1, denseNorm: bool = False):
-        _no_dense_norm(denseNorm)
-        super().__init__(nn.SiLU(), conv3x3(inChannels, outChannels), nn.SiLU(), conv3x3(outChannels, outChannels),
-                         conv1x1(inChannels, outChannels) if inChannels != outChannels else None)
+        super().__init__(nn.SiLU(), conv3x3(inChannels, outChannels), GroupNorm(groups, outChannels) if denseNorm else nn.SiLU(),
+                         conv3x3(outChannels, outChannels), conv1x1(inChannels, outChannels) if inChannels != outChannels else None)
+        self.denseNorm = bool(denseNorm)
 
     def forward(self, x: torch.Tensor, res2: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
-            if self._skip is None:                                # training graph: two fused launches each way
+            if self._skip is None and not self.denseNorm:         # training graph: two fused launches each way
                 return AG.residual_block(x, self)
-            t = self._branch[1](AG.silu(x))                       # (width-changing blocks: op-by-op autograd)
-            return self._branch[3](AG.silu(t), res=self._skip(x))
-        t = self._branch[1](x, silu_in=True, silu_out=True)      # silu(conv1(silu(x)))
+            t = self._branch[1](AG.silu(x))                       # (width-changing / normalised blocks: op-by-op autograd)
+            t = self._branch[2](t) if self.denseNorm else AG.silu(t)
+            return self._branch[3](t, res=x if self._skip is None else self._skip(x))
+        if self.denseNorm:
+            t = self._branch[2](self._branch[1](x, silu_in=True))     # GroupNorm(conv1(silu(x))): no activation in front of conv2
+        else:
+            t = self._branch[1](x, silu_in=True, silu_out=True)  # silu(conv1(silu(x)))
         identity = x if self._skip is None else self._skip(x)
         return self._branch[3](t, res=identity, dual_silu=True)   # conv2(.) + identity
 
@@ -117,7 +126,7 @@ class ResidualBlockWithStride(_residulBlock):
     """SiLU, conv3 s2, GDN, conv3, + conv3 s2 skip."""
 
     def __init__(self, inChannels: int, outChannels: int, stride: int = 2, groups: int = 1, denseNorm: bool = False):
-        _no_dense_norm(denseNorm)
+        # (`groups` / `denseNorm` are accepted and unused, exactly like the reference's strided / shuffle blocks, :98-159)
         if stride != 2:
             raise NotImplementedError("only stride-2 ResidualBlockWithStride is on the path")
         super().__init__(nn.SiLU(), conv3x3(inChannels, outChannels, stride=stride), GenDivNorm(outChannels),
@@ -138,7 +147,6 @@ class ResidualBlockShuffle(_residulBlock):
     """SiLU, pixelShuffle3x3 (x2), IGDN, conv3, + pixelShuffle3x3 skip."""
 
     def __init__(self, inChannels: int, outChannels: int, upsample: int = 2, groups: int = 1, denseNorm: bool = False):
-        _no_dense_norm(denseNorm)
         if upsample != 2:
             raise NotImplementedError("only 2x ResidualBlockShuffle is on the path")
         super().__init__(nn.SiLU(), pixelShuffle3x3(inChannels, outChannels, upsample), InvGenDivNorm(outChannels),
@@ -163,11 +171,14 @@ class AttentionBlock(nn.Module):
         self._mainBranch = nn.Sequential(*[ResidualBlock(channel, channel, groups, denseNorm) for _ in range(3)])
         self._sideBranch = nn.Sequential(*[ResidualBlock(channel, channel, groups, denseNorm) for _ in range(3)],
                                          conv1x1(channel, channel))
+        self.denseNorm = bool(denseNorm)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
+            if self.denseNorm:                                    # normalised blocks: op-by-op autograd
+                return AG.gate(self._mainBranch(x), self._sideBranch(x), x)
             return AG.attention_block(x, self)
-        if ops._MULTI and x.shape[0] * x.shape[2] * x.shape[3] <= _MULTI_MAX_PIXELS:
+        if ops._MULTI and not self.denseNorm and x.shape[0] * x.shape[2] * x.shape[3] <= _MULTI_MAX_PIXELS:
             # the two stacks apply the same layer shapes to different tensors: layer by layer they share a launch
             # (mcq_conv2d_multi_f32) -- twice the workgroups per launch, half the launches.  Measured on one MI355X: batch 1
             # with hipGraphs 7.40 -> 7.09 ms per encode+decode; at batch 32 the big maps do better with the stacks on two

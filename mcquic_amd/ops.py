@@ -470,6 +470,45 @@ def add(a: torch.Tensor, b: torch.Tensor, dual_silu: bool = False) -> torch.Tens
     return out
 
 
+def group_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], groups: int, eps: float = 1e-5,
+               dual_silu: bool = False, want_stats: bool = False):
+    """nn.GroupNorm(groups, C) on [n, C, h, w] (mcq_group_norm_f32; `denseNorm=True`, mcquic/nn/blocks.py:179-200).
+    With `want_stats` returns (y, mean, rstd), the per-(image, group) statistics the backward pass needs."""
+    x = _dev(x, "x")
+    n, c, h, w = x.shape
+    if c % groups != 0:
+        raise ValueError(f"GroupNorm: {c} channels do not divide into {groups} groups")
+    weight = None if weight is None else _dev(weight.detach(), "weight")
+    bias = None if bias is None else _dev(bias.detach(), "bias")
+    y = torch.empty_like(x)
+    y2 = torch.empty_like(x) if dual_silu else None
+    mean = torch.empty(n * groups, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty_like(mean) if want_stats else None
+    with _guard(x.device):
+        check(_lib.load().mcq_group_norm_f32(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(y2), _ptr(mean), _ptr(rstd), n, c, h * w,
+                                             groups, float(eps), _stream()), "mcq_group_norm_f32")
+    if y2 is not None:
+        set_silu_twin(y, y2)
+    return (y, mean, rstd) if want_stats else y
+
+
+def group_norm_bwd(x: torch.Tensor, dy: torch.Tensor, weight: Optional[torch.Tensor], mean: torch.Tensor, rstd: torch.Tensor,
+                   groups: int, want_params: bool = True):
+    """(dx, dweight, dbias) of group_norm (mcq_group_norm_bwd_f32)."""
+    x, dy = _dev(x, "x"), _dev(dy, "dy")
+    n, c, h, w = x.shape
+    weight = None if weight is None else _dev(weight.detach(), "weight")
+    lib = _lib.load()
+    ws = torch.empty(lib.mcq_group_norm_bwd_workspace_floats(n, c), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dw = torch.empty(c, dtype=torch.float32, device=x.device) if want_params else None
+    db = torch.empty(c, dtype=torch.float32, device=x.device) if want_params else None
+    with _guard(x.device):
+        check(lib.mcq_group_norm_bwd_f32(_ptr(x), _ptr(dy), _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws),
+                                         n, c, h * w, groups, _stream()), "mcq_group_norm_bwd_f32")
+    return dx, dw, db
+
+
 def detransform(x: torch.Tensor) -> torch.Tensor:
     """[-1, 1] fp32 -> uint8 (mcquic/utils/vision.py:143-146)."""
     x = _dev(x, "x")

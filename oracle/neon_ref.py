@@ -10,8 +10,10 @@ Functional over the reference's `state_dict` layout:
   _quantizer._backwards.{i} / _decoders.{i}.{0: conv1x1(8->32, no bias), 1: RBShuffle | RB, 2: Attn, 3: RB(32->8)}
   _quantizer._quantizers.{i}.{_codebook [1,k,8] (ONE tensor shared by all levels), _temperature, _freqEMA, _bound.bound}
 In this snapshot the `groups` argument of the blocks only parametrises GroupNorm under `denseNorm=True`
-(mcquic/nn/blocks.py:179-200: `conv3x3(inChannels, outChannels)` is called without it), so with the default
-`denseNorm=False` every convolution is dense.
+(mcquic/nn/blocks.py:179-200: `conv3x3(inChannels, outChannels)` is called without it), so every convolution is dense.
+`denseNorm=True` (a state_dict that holds `..._branch.2.weight`: nn.GroupNorm's affine parameters where the second SiLU
+was) is followed as well; the group counts are the constructor's (compressor.py:184-225: 32 for the `channel`-wide blocks,
+1 for the blocks that touch the 8-channel latent; quantizer.py:600-651: 1) and are passed down as arguments.
 """
 from __future__ import annotations
 
@@ -26,18 +28,32 @@ from . import mcquic_ref as R
 StateDict = R.StateDict
 
 
-def residual_block(sd: StateDict, pre: str, x: torch.Tensor) -> torch.Tensor:
-    """mcquic/nn/blocks.py:162-200 + :70-78: SiLU, conv3, SiLU, conv3, `out += identity`; identity = conv1x1(x) when the
-    widths differ (:179-182)."""
+def residual_block(sd: StateDict, pre: str, x: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """mcquic/nn/blocks.py:162-200 + :70-78: SiLU, conv3, SiLU | GroupNorm(groups, C) (`denseNorm`, :196), conv3,
+    `out += identity`; identity = conv1x1(x) when the widths differ (:179-182)."""
     out = R.conv3x3(sd, pre + "_branch.1.", F.silu(x))
-    out = R.conv3x3(sd, pre + "_branch.3.", F.silu(out))
+    if pre + "_branch.2.weight" in sd:                     # denseNorm=True: nn.GroupNorm in place of the second activation
+        out = F.group_norm(out, groups, sd[pre + "_branch.2.weight"], sd[pre + "_branch.2.bias"], 1e-5)
+    else:
+        out = F.silu(out)
+    out = R.conv3x3(sd, pre + "_branch.3.", out)
     identity = R.conv1x1(sd, pre + "_skip.", x) if pre + "_skip.weight" in sd else x
     out += identity
     return out
 
 
-def attention_block(sd: StateDict, pre: str, x: torch.Tensor) -> torch.Tensor:
-    return R.attention_block(sd, pre, x)
+def attention_block(sd: StateDict, pre: str, x: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """mcquic/nn/blocks.py:245-288 over this file's residual_block (GroupNorm-aware)."""
+    a = x
+    for i in range(3):
+        a = residual_block(sd, f"{pre}_mainBranch.{i}.", a, groups)
+    b = x
+    for i in range(3):
+        b = residual_block(sd, f"{pre}_sideBranch.{i}.", b, groups)
+    b = R.conv1x1(sd, pre + "_sideBranch.3.", b)
+    out = a * torch.sigmoid(b)
+    out += x
+    return out
 
 
 def conv1x1_nobias(sd: StateDict, pre: str, x: torch.Tensor) -> torch.Tensor:
@@ -48,35 +64,37 @@ def conv1x1_nobias(sd: StateDict, pre: str, x: torch.Tensor) -> torch.Tensor:
 def encoder(sd: StateDict, x: torch.Tensor, pre: str = "_encoder.") -> torch.Tensor:
     """compressor.py:184-205."""
     y = R.conv3x3(sd, pre + "0.", x)
-    y = attention_block(sd, pre + "1.", y)
-    y = residual_block(sd, pre + "2.", y)
-    y = residual_block(sd, pre + "3.", y)
+    y = attention_block(sd, pre + "1.", y, 32)
+    y = residual_block(sd, pre + "2.", y, 32)
+    y = residual_block(sd, pre + "3.", y, 32)
     y = R.residual_block_with_stride(sd, pre + "4.", y)
-    y = residual_block(sd, pre + "5.", y)
+    y = residual_block(sd, pre + "5.", y, 32)
     y = R.residual_block_with_stride(sd, pre + "6.", y)
-    y = residual_block(sd, pre + "7.", y)
+    y = residual_block(sd, pre + "7.", y, 32)
     y = R.residual_block_with_stride(sd, pre + "8.", y)
-    y = attention_block(sd, pre + "9.", y)
-    for i in range(10, 15):
-        y = residual_block(sd, f"{pre}{i}.", y)
-    return attention_block(sd, pre + "15.", y)
+    y = attention_block(sd, pre + "9.", y, 32)
+    for i in range(10, 14):
+        y = residual_block(sd, f"{pre}{i}.", y, 32)
+    y = residual_block(sd, pre + "14.", y, 1)              # ResidualBlock(2 * channel, 8, 1, denseNorm) (:203)
+    return attention_block(sd, pre + "15.", y, 1)
 
 
 def decoder(sd: StateDict, y: torch.Tensor, pre: str = "_decoder.") -> torch.Tensor:
     """compressor.py:206-225."""
-    x = attention_block(sd, pre + "0.", y)
-    for i in range(1, 6):
-        x = residual_block(sd, f"{pre}{i}.", x)
-    x = attention_block(sd, pre + "6.", x)
-    x = residual_block(sd, pre + "7.", x)
+    x = attention_block(sd, pre + "0.", y, 1)
+    x = residual_block(sd, pre + "1.", x, 1)               # ResidualBlock(8, 2 * channel, 1, denseNorm) (:207)
+    for i in range(2, 6):
+        x = residual_block(sd, f"{pre}{i}.", x, 32)
+    x = attention_block(sd, pre + "6.", x, 32)
+    x = residual_block(sd, pre + "7.", x, 32)
     x = R.residual_block_shuffle(sd, pre + "8.", x)
-    x = residual_block(sd, pre + "9.", x)
+    x = residual_block(sd, pre + "9.", x, 32)
     x = R.residual_block_shuffle(sd, pre + "10.", x)
-    x = residual_block(sd, pre + "11.", x)
+    x = residual_block(sd, pre + "11.", x, 32)
     x = R.residual_block_shuffle(sd, pre + "12.", x)
-    x = residual_block(sd, pre + "13.", x)
-    x = residual_block(sd, pre + "14.", x)
-    x = attention_block(sd, pre + "15.", x)
+    x = residual_block(sd, pre + "13.", x, 32)
+    x = residual_block(sd, pre + "14.", x, 32)
+    x = attention_block(sd, pre + "15.", x, 32)
     return R.conv3x3(sd, pre + "16.", x)
 
 
@@ -208,15 +226,29 @@ def forward_train(sd: StateDict, x: torch.Tensor, uniforms):
 # ----------------------------------------------------------------------------------------------
 # seeded synthetic weights in the reference's layout (the same generator family as mcquic_ref.make_state_dict)
 # ----------------------------------------------------------------------------------------------
+_DENSE_NORM = [False]        # set by make_state_dict(..., denseNorm=True) while it builds
+
+
 def _rb(sd, pre, cin, cout, seed):
     R._conv_params(sd, pre + "_branch.1.", cout, cin, 3, seed)
     R._conv_params(sd, pre + "_branch.3.", cout, cout, 3, seed + 1)
     if cin != cout:
         R._conv_params(sd, pre + "_skip.", cout, cin, 1, seed + 2)
+    _group_norm_params(sd, pre, cout, seed)
+
+
+def _group_norm_params(sd, pre, c, seed):
+    if _DENSE_NORM[0]:                                     # nn.GroupNorm's affine pair, away from its (1, 0) initial values
+        import numpy as np
+        sd[pre + "_branch.2.weight"] = torch.from_numpy(R._rng(pre + "_branch.2.weight", seed).uniform(0.5, 1.5, c).astype(np.float32))
+        sd[pre + "_branch.2.bias"] = torch.from_numpy(R._rng(pre + "_branch.2.bias", seed).uniform(-0.1, 0.1, c).astype(np.float32))
 
 
 def _attn(sd, pre, c, seed):
-    R._attn(sd, pre, c, seed)
+    R._attn(sd, pre, c, seed)                              # (the convolutions of F10's denseNorm=False state_dict, unchanged)
+    for i in range(3):
+        _group_norm_params(sd, f"{pre}_mainBranch.{i}.", c, seed)
+        _group_norm_params(sd, f"{pre}_sideBranch.{i}.", c, seed)
 
 
 def _conv_nobias(sd, pre, cout, cin, seed):
@@ -225,9 +257,17 @@ def _conv_nobias(sd, pre, cout, cin, seed):
     sd[pre + "weight"] = tmp["t.weight"]
 
 
-def make_state_dict(channel: int, k: int, size: List[int], seed: int = 0) -> StateDict:
-    """Every tensor of `Neon(channel, k, size)` (denseNorm=False) with seeded synthetic values, keys and shapes as the
-    reference's `state_dict()`."""
+def make_state_dict(channel: int, k: int, size: List[int], seed: int = 0, denseNorm: bool = False) -> StateDict:
+    """Every tensor of `Neon(channel, k, size, denseNorm)` with seeded synthetic values, keys and shapes as the reference's
+    `state_dict()`."""
+    _DENSE_NORM[0] = bool(denseNorm)
+    try:
+        return _make_state_dict(channel, k, size, seed)
+    finally:
+        _DENSE_NORM[0] = False
+
+
+def _make_state_dict(channel: int, k: int, size: List[int], seed: int) -> StateDict:
     sd: StateDict = {}
     c, c2, qc = channel, 2 * channel, 8
     s = seed * 100000

@@ -148,6 +148,118 @@ def capture_f5c(RQ, shards: int = 8, per_shard: int = 32, chunk: int = 8):
     print(f"f5c: {len(near)} near-ties, {len(flips)} reference self-flips (float32 vs float64), gaps32 {flip_g32}")
 
 
+def capture_f5c_backend(RQ, chunk: int = 8):
+    """Second sensitivity probe, merged into f5c_config2_census.npz: the reference in float32 with oneDNN switched off
+    (`torch.backends.mkldnn.flags(enabled=False)`: ATen's native convolution = another float32 summation order, the analogue
+    of what a different kernel does) against its own default run -- images whose code hashes differ are re-run with
+    recording to find the first flips and the default run's gaps there."""
+    import time
+    path = os.path.join(OUT, "f5c_config2_census.npz")
+    d = dict(np.load(path))
+    shards, per = int(d["shape"][0]), int(d["shape"][1])
+    sd = bench_state_dict()
+    model = ref_harness.reference_compressor(128, 2, [8192, 2048, 512], sd)
+    orig_distance = RQ._multiCodebookQuantization._distance
+    flips, gaps, downstream, t0 = [], [], 0, time.time()
+    for r in range(shards):
+        x = bench_images(r, per)
+        for lo in range(0, per, chunk):
+            xs = x[lo:lo + chunk]
+            with torch.backends.mkldnn.flags(enabled=False), torch.inference_mode():
+                alt = model.encode(xs)
+            differs = [i for i in range(len(xs))
+                       if any(code_hash(alt[lv][i]).tobytes() != d["code_hash"][r * per + lo + i, lv].tobytes() for lv in range(3))]
+            for i in differs:
+                dists = []
+
+                def rec(self, xx):
+                    dist = orig_distance(self, xx)
+                    dists.append(dist)
+                    return dist
+                RQ._multiCodebookQuantization._distance = rec
+                try:
+                    with torch.inference_mode():
+                        c32 = model.encode(xs[i:i + 1])
+                finally:
+                    RQ._multiCodebookQuantization._distance = orig_distance
+                alive = True
+                for lv in range(3):
+                    bad = (c32[lv][0] != alt[lv][i]).nonzero().tolist()
+                    if not alive:
+                        downstream += len(bad)
+                        continue
+                    for g, yy, xx in bad:
+                        a, b = int(c32[lv][0, g, yy, xx]), int(alt[lv][i, g, yy, xx])
+                        flips.append((r, lo + i, lv, g, yy, xx, a, b))
+                        gaps.append(float(dists[lv][0, g, yy, xx, b] - dists[lv][0, g, yy, xx, a]))
+                    alive = alive and not bad
+            print(f"f5c backend: shard {r} images {lo}..{lo + len(xs) - 1}  self-flips {len(flips)}  {time.time() - t0:.0f} s", flush=True)
+    d["selfflip_backend"] = np.array(flips, dtype=np.int32).reshape(-1, 8)
+    d["selfflip_backend_gap32"] = np.array(gaps, dtype=np.float32)
+    d["selfflip_backend_downstream"] = np.array([downstream])
+    np.savez_compressed(path, **d)
+    print(f"f5c backend: {len(flips)} reference self-flips (oneDNN vs native convolution), gaps32 {gaps}")
+
+
+def capture_neon(C, RQ, dense: bool, fname: str):
+    from oracle import neon_ref as NR            # generators only
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    ch, k, size = 32, 256, [8, 4, 2, 2]
+    sd = NR.make_state_dict(ch, k, size, seed=3, denseNorm=dense)
+    model = C.Neon(ch, k, size, dense).eval()
+    model.load_state_dict(sd, strict=True)
+    xi = R.make_images(2, 128, 128, seed=5)
+    f10 = {"config": np.array([ch, k] + size), "n_state_dict_entries": np.array([len(model.state_dict())])}
+    gaps = []
+    orig_distance = RQ._multiCodebookQuantization._distance
+
+    def recording_distance(self, x):
+        dist_ = orig_distance(self, x)
+        top2 = torch.topk(dist_, 2, dim=-1, largest=False).values
+        gaps.append((top2[..., 1] - top2[..., 0]).clone())
+        return dist_
+    RQ._multiCodebookQuantization._distance = recording_distance
+    try:
+        with torch.inference_mode():
+            codes = model.encode(xi)
+    finally:
+        RQ._multiCodebookQuantization._distance = orig_distance
+    with torch.inference_mode():
+        rec = model.decode(codes)
+        rb = model.residual_backward(codes[1], 2)
+        rf0 = model.residual_forward(codes[0], None, 0)
+        rf1 = model.residual_forward(codes[1], rf0, 1)
+    for lv, cd in enumerate(codes):
+        f10[f"code{lv}"] = cd.numpy().astype(np.int16)
+        f10[f"gap{lv}"] = gaps[lv].numpy()
+    f10["rec_strided"] = rec[..., ::4, ::4].numpy()
+    f10["rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
+    f10["residual_backward_1_2"] = rb.numpy()
+    f10["residual_forward_1"] = rf1.numpy()
+    model.train()
+    g = torch.Generator().manual_seed(9)
+    shapes = [(2, 1, 2, 2, k), (2, 1, 2, 2, k), (2, 1, 4, 4, k), (2, 1, 8, 8, k)]
+    us = [(torch.rand(sh, generator=g), torch.rand(sh, generator=g)) for sh in shapes]
+    it = iter([u for pair in us for u in pair])
+    orig = torch.rand_like
+    torch.rand_like = lambda t, **kw: next(it).clone()
+    try:
+        xHat, yHat, codesT, logitsT = model(xi.clone())
+    finally:
+        torch.rand_like = orig
+    f10["train_xHat_strided"] = xHat.detach()[..., ::4, ::4].numpy()
+    f10["train_yHat"] = yHat.detach().numpy()
+    for lv in range(len(size)):
+        f10[f"train_code{lv}"] = codesT[lv].numpy().astype(np.int16)
+        f10[f"train_logit{lv}_strided"] = logitsT[lv].detach()[..., ::8].numpy()
+        f10[f"train_ema{lv}"] = model._quantizer._entropyCoder._freqEMA[lv].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, fname), **f10)
+
+
 def main():
     C = ref_harness.load()
     import mcquic.nn as RN                      # the reference's layers
@@ -414,65 +526,13 @@ def main():
             f9[f"new_codebook_{ci}"] = q._codebook.detach().numpy()
             f9[f"changed_{ci}"] = changed.numpy()
         np.savez_compressed(os.path.join(OUT, "f9_reassign.npz"), **f9)
-    # ---- F10: the Neon model family (mcquic/modules/compressor.py:181-241, ResidualBackwardQuantizer quantizer.py:577-765):
-    #           encode / decode / residual_backward / residual_forward and the training-mode forward -------------------
+    # ---- F10 / F11: the Neon model family (mcquic/modules/compressor.py:181-241, ResidualBackwardQuantizer quantizer.py:577-765):
+    #           encode / decode / residual_backward / residual_forward and the training-mode forward; F11 = the same with
+    #           denseNorm=True (nn.GroupNorm in place of the ResidualBlocks' second activation, nn/blocks.py:179-200) -------
     if want("f10"):
-        from oracle import neon_ref as NR            # generators only
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29541")
-            dist.init_process_group("gloo", rank=0, world_size=1)
-        ch, k, size = 32, 256, [8, 4, 2, 2]
-        sd = NR.make_state_dict(ch, k, size, seed=3)
-        model = C.Neon(ch, k, size).eval()
-        model.load_state_dict(sd, strict=True)
-        xi = R.make_images(2, 128, 128, seed=5)
-        f10 = {"config": np.array([ch, k] + size), "n_state_dict_entries": np.array([len(model.state_dict())])}
-        gaps = []
-        orig_distance = RQ._multiCodebookQuantization._distance
-
-        def recording_distance(self, x):
-            dist_ = orig_distance(self, x)
-            top2 = torch.topk(dist_, 2, dim=-1, largest=False).values
-            gaps.append((top2[..., 1] - top2[..., 0]).clone())
-            return dist_
-        RQ._multiCodebookQuantization._distance = recording_distance
-        try:
-            with torch.inference_mode():
-                codes = model.encode(xi)
-        finally:
-            RQ._multiCodebookQuantization._distance = orig_distance
-        with torch.inference_mode():
-            rec = model.decode(codes)
-            rb = model.residual_backward(codes[1], 2)
-            rf0 = model.residual_forward(codes[0], None, 0)
-            rf1 = model.residual_forward(codes[1], rf0, 1)
-        for lv, cd in enumerate(codes):
-            f10[f"code{lv}"] = cd.numpy().astype(np.int16)
-            f10[f"gap{lv}"] = gaps[lv].numpy()
-        f10["rec_strided"] = rec[..., ::4, ::4].numpy()
-        f10["rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
-        f10["residual_backward_1_2"] = rb.numpy()
-        f10["residual_forward_1"] = rf1.numpy()
-        model.train()
-        g = torch.Generator().manual_seed(9)
-        shapes = [(2, 1, 2, 2, k), (2, 1, 2, 2, k), (2, 1, 4, 4, k), (2, 1, 8, 8, k)]
-        us = [(torch.rand(sh, generator=g), torch.rand(sh, generator=g)) for sh in shapes]
-        it = iter([u for pair in us for u in pair])
-        orig = torch.rand_like
-        torch.rand_like = lambda t, **kw: next(it).clone()
-        try:
-            xHat, yHat, codesT, logitsT = model(xi.clone())
-        finally:
-            torch.rand_like = orig
-        f10["train_xHat_strided"] = xHat.detach()[..., ::4, ::4].numpy()
-        f10["train_yHat"] = yHat.detach().numpy()
-        for lv in range(len(size)):
-            f10[f"train_code{lv}"] = codesT[lv].numpy().astype(np.int16)
-            f10[f"train_logit{lv}_strided"] = logitsT[lv].detach()[..., ::8].numpy()
-            f10[f"train_ema{lv}"] = model._quantizer._entropyCoder._freqEMA[lv].detach().numpy()
-        np.savez_compressed(os.path.join(OUT, "f10_neon.npz"), **f10)
+        capture_neon(C, RQ, False, "f10_neon.npz")
+    if want("f11"):
+        capture_neon(C, RQ, True, "f11_neon_dense_norm.npz")
 
     # ---- F5c: BASELINE configs[2] -- the 256 images `bench.py --gpus 8` generates (8 rank-seeded shards of 32 x 768x512,
     #           bench.py's own random-init qp=2 weights) through the REFERENCE in float32, and the reference's own
@@ -483,6 +543,8 @@ def main():
     #           only when named (`python make_golden.py f5c`) -------------------------------------------------------
     if "f5c" in [a.lower() for a in sys.argv[1:]]:
         capture_f5c(RQ)
+    if "f5c" in [a.lower() for a in sys.argv[1:]] or "f5c_backend" in [a.lower() for a in sys.argv[1:]]:
+        capture_f5c_backend(RQ)
 
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):

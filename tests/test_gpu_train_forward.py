@@ -88,7 +88,7 @@ def test_training_forward_against_reference_vectors(dev):
     xHat, yHat, codes, logits = out
     for lv in range(3):
         assert torch.equal(codes[lv].cpu(), torch.from_numpy(z[f"code{lv}"].astype(np.int64))), f"codes level {lv}"
-        np.testing.assert_allclose(logits[lv].cpu().numpy(), z[f"logit{lv}"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(logits[lv].detach().cpu().numpy(), z[f"logit{lv}"], rtol=1e-5, atol=2e-5)
         np.testing.assert_allclose(model._quantizer._entropyCoder._freqEMA[lv].detach().cpu().numpy(), z[f"ema{lv}"],
                                    rtol=0, atol=1e-6)
     np.testing.assert_allclose(yHat.detach().cpu().numpy(), z["yHat"], rtol=0, atol=1e-4)

@@ -11,7 +11,13 @@ from oracle import mcquic_ref as R
 from oracle import neon_ref as N
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f10_neon.npz")
+G_DENSE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f11_neon_dense_norm.npz")     # denseNorm=True
 CFG = (32, 256, [8, 4, 2, 2])
+DENSE = pytest.mark.parametrize("dense", [False, True], ids=["plain", "denseNorm"])
+
+
+def _golden(dense):
+    return np.load(G_DENSE if dense else G)
 
 
 def _uniforms(k, seed=9):
@@ -20,11 +26,12 @@ def _uniforms(k, seed=9):
     return [(torch.rand(s, generator=g), torch.rand(s, generator=g)) for s in shapes]
 
 
-def test_neon_oracle_matches_reference_vectors():
-    z = np.load(G)
+@DENSE
+def test_neon_oracle_matches_reference_vectors(dense):
+    z = _golden(dense)
     ch, k, size = CFG
     assert [int(v) for v in z["config"]] == [ch, k] + size
-    sd = N.make_state_dict(ch, k, size, seed=3)
+    sd = N.make_state_dict(ch, k, size, seed=3, denseNorm=dense)
     assert len(sd) == int(z["n_state_dict_entries"][0])
     x = R.make_images(2, 128, 128, seed=5)
     codes = N.encode(sd, x)
@@ -64,19 +71,20 @@ def test_various_m_coder_round_trip_and_errors():
     assert torch.allclose(coder._freqEMA[1], R.freq_ema_update(before, counts, ema=0.998), atol=1e-7)
 
 
-def _model(dev):
+def _model(dev, dense=False):
     from mcquic_amd import Neon
     ch, k, size = CFG
-    sd = N.make_state_dict(ch, k, size, seed=3)
-    model = Neon(ch, k, size)
+    sd = N.make_state_dict(ch, k, size, seed=3, denseNorm=dense)
+    model = Neon(ch, k, size, dense)
     model.load_state_dict(sd, strict=True)
     return model.to(dev), sd
 
 
 @pytest.mark.gpu
-def test_neon_hip_against_oracle_and_reference_vectors(dev):
-    z = np.load(G)
-    model, sd = _model(dev)
+@DENSE
+def test_neon_hip_against_oracle_and_reference_vectors(dev, dense):
+    z = _golden(dense)
+    model, sd = _model(dev, dense)
     model.eval()
     x = R.make_images(2, 128, 128, seed=5)
     codes = [c.cpu() for c in model.encode(x.to(dev))]
@@ -108,12 +116,14 @@ def test_neon_hip_against_oracle_and_reference_vectors(dev):
 
 
 @pytest.mark.gpu
-def test_neon_training_forward_and_gradients(dev):
-    """Training-mode forward against the reference's vectors (F10) and every parameter gradient against CPU autograd
-    through the oracle (same weights, same uniform draws, loss = <xHat, G>)."""
-    z = np.load(G)
+@DENSE
+def test_neon_training_forward_and_gradients(dev, dense):
+    """Training-mode forward against the reference's vectors (F10; F11 with denseNorm=True: GroupNorm forward and backward on
+    csrc/norm.hip) and every parameter gradient against CPU autograd through the oracle (same weights, same uniform draws,
+    loss = <xHat, G>)."""
+    z = _golden(dense)
     ch, k, size = CFG
-    model, sd = _model(dev)
+    model, sd = _model(dev, dense)
     model.train()
     x = R.make_images(2, 128, 128, seed=5)
     us = _uniforms(k)

@@ -62,14 +62,16 @@ def test_metrics_oracle_against_reference_handlers():
     assert abs(M.ideal_bpp(hist, count, 3 * 3 * 768 * 512) - handler.Result) <= 1e-6 * handler.Result
 
 
-def test_neon_oracle_bit_equal_to_reference():
+@pytest.mark.parametrize("dense", [False, True], ids=["plain", "denseNorm"])
+def test_neon_oracle_bit_equal_to_reference(dense):
     """oracle/neon_ref.py against the reference's Neon / ResidualBackwardQuantizer, live: state_dict layout, encode,
-    decode, residual_backward, residual_forward."""
+    decode, residual_backward, residual_forward; with denseNorm=True (nn.GroupNorm(groups, C) in place of the ResidualBlocks'
+    second activation, mcquic/nn/blocks.py:179-200; 32 groups need a width that is a multiple of 32)."""
     from oracle import neon_ref as N
     C = ref_harness.load()
-    ch, k, size = 16, 64, [4, 2, 2]
-    sd = N.make_state_dict(ch, k, size, seed=11)
-    model = C.Neon(ch, k, size).eval()
+    ch, k, size = (32 if dense else 16), 64, [4, 2, 2]
+    sd = N.make_state_dict(ch, k, size, seed=11, denseNorm=dense)
+    model = C.Neon(ch, k, size, dense).eval()
     ref = model.state_dict()
     assert set(sd) == set(ref)
     for key in ref:
@@ -86,6 +88,15 @@ def test_neon_oracle_bit_equal_to_reference():
     assert torch.equal(rd, N.decode(sd, oc))
     assert torch.equal(rb, N.residual_backward(sd, oc[1], 2))
     assert torch.equal(rf, N.residual_forward(sd, oc[1], N.residual_forward(sd, oc[0], None, 0), 1))
+
+
+def test_hip_neon_dense_norm_module_tree_matches_reference_keys():
+    from mcquic_amd import Neon
+    C = ref_harness.load()
+    ref = C.Neon(32, 256, [8, 4, 2, 2], True).state_dict()
+    mine = Neon(32, 256, [8, 4, 2, 2], True).state_dict()
+    assert list(mine) == list(ref)
+    assert all(tuple(mine[k].shape) == tuple(ref[k].shape) for k in ref)
 
 
 def test_hip_neon_module_tree_matches_reference_keys():

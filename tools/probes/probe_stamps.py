@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Where a conv tile's time goes outside the k-loop (kernel tuning aid; needs a library built with -DMCQ_STAMPS=1):
+"""HISTORICAL probe (rounds 1-2): the `MCQ_STAMPS` hooks it reads were removed from csrc/conv_mfma.hip in round 3 -- check out
+commit 0aa82a9 to build a library that carries them; the findings are in DESIGN.md section 4.
+Where a conv tile's time goes outside the k-loop (kernel tuning aid; needs a library built with -DMCQ_STAMPS=1):
 
     hipcc ... -DMCQ_STAMPS=1 -o tools/variants/stamps.so mcquic_amd/csrc/*.hip mcquic_amd/csrc/rans.cpp
     MCQUIC_AMD_LIB=tools/variants/stamps.so python tools/probe_stamps.py

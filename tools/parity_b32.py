@@ -90,6 +90,8 @@ def load_fixture():
     near = {tuple(int(v) for v in row[:6]): (int(row[6]), int(row[7]), float(gap)) for row, gap in zip(d["near"], d["near_gap"])}
     return {"hash": d["code_hash"], "near": near, "rec_strided": d["rec_strided"], "state_dict_sha": bytes(d["state_dict_sha"]).hex(),
             "x_sha": d["x_sha"], "selfflip_gap32": d["selfflip_gap32"].tolist(), "selfflip": d["selfflip"].tolist(),
+            "selfflip_backend_gap32": d["selfflip_backend_gap32"].tolist() if "selfflip_backend_gap32" in d.files else [],
+            "selfflip_backend": d["selfflip_backend"].tolist() if "selfflip_backend" in d.files else [],
             "codes_per_level": d["codes_per_level"].tolist()}
 
 
@@ -154,6 +156,9 @@ def main():
             "first_flips_inside_the_reference_near_tie_set": sum(1 for f in rec["flips"] if f.get("in_reference_near_ties")),
             "first_flips_that_took_the_reference_runner_up": sum(1 for f in rec["flips"] if f.get("hip_took_the_reference_runner_up")),
             "reference_self_flips_float32_vs_float64": len(ref_gaps), "reference_self_flip_gaps_float32": ref_gaps,
+            "reference_self_flips_onednn_vs_native_conv": len(fixture["selfflip_backend_gap32"]),
+            "reference_self_flip_gaps_onednn_vs_native_conv": fixture["selfflip_backend_gap32"],
+            "reference_self_flip_sites": [f[:6] for f in fixture["selfflip"] + fixture["selfflip_backend"]],
             "reference_near_ties_below_2e-5": len(fixture["near"]),
             "decode_max_abs_err_vs_reference_strided_first_image_of_each_shard": rec["pix_err_vs_reference"]}
     path = a.out or os.path.join(ROOT, "gpurun_out", "parity_b256.json" if a.shards else "parity_b32.json")

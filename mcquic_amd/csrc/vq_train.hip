@@ -174,6 +174,36 @@ __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
 //   logit[c] += -1e9 where u_drop[c] ** p < freq[g, c]
 //   code   = argmax_c logit[c]
 //   index  = argmax_c (logit[c] + gumbel(u_gumbel[c]));  s = softmax(.)[index];  hot = (1 - s) + s
+// u^e < f, decided like `powf(u, e) < f`.  The hardware pair v_log_f32 / v_exp_f32 gives u^e to ~1e-4 relative at the
+// exponents in use (e <= 13, |log2 u| <= 24); only when that estimate is within 1e-3 of f does the libm powf decide (about
+// one lane in 10^4).  The decision is therefore powf's own, bit for bit, at a fifth of its instruction count.
+__device__ __forceinline__ bool drop_decision(float u, float e, float f) {
+    const float est = __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(u));      // (u = 0: log2 = -inf, est = 0 like powf)
+    const float tol = 1e-3f * fmaxf(est, f);
+    if (fabsf(est - f) > tol) return est < f;
+    return powf(u, e) < f;
+}
+
+// Gumbel noise -log(-log u) for u in [eps, 1 - eps].  The inner logarithm keeps libm's logf: near u = 1 -- where the LARGEST
+// noise values, the ones that decide the arg-max, come from -- it is a difference of nearly equal numbers and needs the full
+// relative accuracy.  The outer one sees t = -log u in [1.2e-7, 16] and runs on v_log_f32 (1 ulp in log2 t, i.e. an absolute
+// error below 1e-6 on a noise value of order 1..16: the size of one float32 rounding of the perturbed logit itself).
+__device__ __forceinline__ float gumbel_noise(float u) {
+    return -(__builtin_amdgcn_logf(-logf(u)) * 0.693147182464599609375f);
+}
+
+// exp(x) for x <= 0 (soft-max terms relative to the row maximum) on v_exp_f32: x log2(e) is split like the SiLU of
+// mcq_common.h (product error recovered with an fma and folded back through 2^t (1 + t_lo ln 2)), so the result carries
+// ~1 ulp wherever it matters (x near 0) and terms below 2^-126 flush to 0 like expf's do once they leave float range.
+__device__ __forceinline__ float exp_nonpos(float x) {
+    const float c_hi = 1.44269502162933349609375f, c_lo = 1.925963033500971e-8f;
+    float t = x * c_hi;
+    const float tl = __builtin_fmaf(x, c_lo, __builtin_fmaf(x, c_hi, -t));
+    t = fmaxf(t, -150.0f);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(e, tl * 0.693147182464599609375f, e);
+}
+
 __global__ __launch_bounds__(256) void vq_gumbel_sample_kernel(float* __restrict__ logits, const float* __restrict__ u_drop,
                                                                const float* __restrict__ u_gumbel,
                                                                const float* __restrict__ freq, const float* __restrict__ drop_exponent_ptr,
@@ -194,10 +224,10 @@ __global__ __launch_bounds__(256) void vq_gumbel_sample_kernel(float* __restrict
     int code = 0, idx = 0;
     for (int c = lane; c < k; c += 64) {
         float l = lr[c];
-        if (powf(ud[c], drop_exponent) < fr[c]) l = l + -1e9f;
+        if (drop_decision(ud[c], drop_exponent, fr[c])) l = l + -1e9f;
         lr[c] = l;
         const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
-        const float y = l + (-logf(-logf(u)));
+        const float y = l + gumbel_noise(u);
         if (l > best_l) { best_l = l; code = c; }
         if (y > best_y) { best_y = y; idx = c; }
     }
@@ -213,7 +243,7 @@ __global__ __launch_bounds__(256) void vq_gumbel_sample_kernel(float* __restrict
     float sum = 0.0f;
     for (int c = lane; c < k; c += 64) {
         const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
-        sum += expf((lr[c] + (-logf(-logf(u)))) - best_y);
+        sum += exp_nonpos((lr[c] + gumbel_noise(u)) - best_y);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
@@ -269,14 +299,14 @@ __global__ __launch_bounds__(256) void vq_softmax_bwd_kernel(const float* __rest
     float mx = -INFINITY;
     for (int c = lane; c < k; c += 64) {
         const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
-        mx = fmaxf(mx, lr[c] + (-logf(-logf(u))));
+        mx = fmaxf(mx, lr[c] + gumbel_noise(u));
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     float sum = 0.0f, dot = 0.0f;
     for (int c = lane; c < k; c += 64) {
         const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
-        const float e = expf((lr[c] + (-logf(-logf(u)))) - mx);
+        const float e = exp_nonpos((lr[c] + gumbel_noise(u)) - mx);
         sum += e;
         dot += e * dr[c];
     }
@@ -288,7 +318,7 @@ __global__ __launch_bounds__(256) void vq_softmax_bwd_kernel(const float* __rest
     const float dscale = -tb / scale;
     for (int c = lane; c < k; c += 64) {
         const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
-        const float y = expf((lr[c] + (-logf(-logf(u)))) - mx) * inv;
+        const float y = exp_nonpos((lr[c] + gumbel_noise(u)) - mx) * inv;
         float dz = y * (dr[c] - dot);
         if (dl) {
             dz += dl[c];

@@ -188,16 +188,25 @@ class _quantizerEncoder(nn.Module):
         return self._quantizer.reAssignCodebook(freq)
 
     def encode(self, x: torch.Tensor):
+        from ..nn import blocks
         z = self._latentStageEncoder(x)
-        code = self._quantizer.encode(self._quantizationHead(z))
-        if self._latentHead is None:
-            return None, code
+        head = self._latentHead
+        if head is None:
+            return None, self._quantizer.encode(self._quantizationHead(z))
+        if blocks.lockstep_ok([self._quantizationHead, head], [z, z]):
+            # latentHead(z) does not depend on the codes until its closing conv: everything before that runs in lockstep with
+            # quantizationHead (same layer shapes on the same z: one multi-problem launch per layer, four problems in the
+            # AttentionBlocks)
+            last = len(head) - 1
+            q, t = blocks.lockstep_infer([self._quantizationHead, head], [z, z], layers=last)
+            code = self._quantizer.encode(self._quantizationHead[last](q))
+        else:
+            code = self._quantizer.encode(self._quantizationHead(z))
+            t = z
+            for i in range(len(head) - 1):
+                t = head[i](t)
         deq = self._dequantizer.decode(code)
         # z' - dequant(code): the subtraction is the epilogue of latentHead's closing conv3x3 (:318)
-        head = self._latentHead
-        t = z
-        for i in range(len(head) - 1):
-            t = head[i](t)
         return head[len(head) - 1](t, res=deq, res_scale=-1.0, dual_silu=True), code
 
 
@@ -238,12 +247,15 @@ class _quantizerDecoder(nn.Module):
         self._restoreHead = restoreHead
 
     def decode(self, code: torch.Tensor, formerLevel: Optional[torch.Tensor]):
-        q = self._dequantizationHead(self._dequantizer.decode(code, dual_silu=True))
-        if self._sideHead is not None:
-            xHat = ops.add(q, self._sideHead(formerLevel), dual_silu=True)     # q + sideHead(formerLevel) (:354)
+        from ..nn import blocks
+        deq = self._dequantizer.decode(code, dual_silu=True)
+        if self._sideHead is None:
+            return self._restoreHead(self._dequantizationHead(deq))
+        if blocks.lockstep_ok([self._dequantizationHead, self._sideHead], [deq, formerLevel]):
+            q, side = blocks.lockstep_infer([self._dequantizationHead, self._sideHead], [deq, formerLevel])    # independent until their sum
         else:
-            xHat = q
-        return self._restoreHead(xHat)
+            q, side = self._dequantizationHead(deq), self._sideHead(formerLevel)
+        return self._restoreHead(ops.add(q, side, dual_silu=True))                # q + sideHead(formerLevel) (:354)
 
 
     def forward(self, q, formerLevel: Optional[torch.Tensor]):

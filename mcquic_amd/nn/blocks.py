@@ -195,3 +195,65 @@ class AttentionBlock(nn.Module):
                 b = self._sideBranch[i](b)
         a = self._mainBranch(x)
         return self._sideBranch[3](f.join(b), gate_mul=a, gate_id=x, dual_silu=True)
+
+
+# ---- same-structure stacks in lockstep (inference) -----------------------------------------------------------------------------
+# `latentHead` / `quantizationHead` (ResidualBlock, AttentionBlock, conv3x3 on the same z; mcquic/modules/compressor.py:148-160)
+# and `dequantizationHead` / `sideHead` (AttentionBlock, conv3x3, ResidualBlock; :166-175) apply the same layer shapes to
+# different tensors: layer by layer the stacks share ONE launch (ops.conv2d_multi; four problems inside their AttentionBlocks).
+# On the 48x32 ... 12x8 latent maps a launch is one round of waves or less -- prologue, LDS reduction and epilogue exposed --
+# so two or four problems per launch fill the chip where one does not (the training graph does the same: autograd.LockstepFn).
+def _infer_kind(m) -> Optional[str]:
+    if isinstance(m, ResidualBlock) and m._skip is None and not m.denseNorm:
+        return "rb"
+    if isinstance(m, AttentionBlock) and not m.denseNorm:
+        return "attn"
+    if type(m).__name__ == "Conv2d" and m.kernelSize == 3 and m.stride == 1:
+        return "conv"
+    return None
+
+
+def lockstep_ok(stacks, xs) -> bool:
+    """Can `lockstep_infer` take these stacks?  Same layer kinds, same input shapes, maps small enough for shared launches."""
+    if not (ops._MULTI and len(stacks) >= 2):
+        return False
+    kinds = [[_infer_kind(m) for m in st] for st in stacks]
+    if any(None in k for k in kinds) or any(k != kinds[0] for k in kinds[1:]):
+        return False
+    if any(x.shape != xs[0].shape for x in xs[1:]):
+        return False
+    return xs[0].shape[0] * xs[0].shape[2] * xs[0].shape[3] <= _MULTI_MAX_PIXELS
+
+
+def lockstep_infer(stacks, xs, layers: Optional[int] = None):
+    """Run the first `layers` layers (default: all) of k same-structure stacks on k inputs, one multi-problem launch per
+    convolution layer.  Returns the k outputs; every output carries its SiLU twin (the next consumer's act1)."""
+    k = len(stacks)
+    xs = list(xs)
+    for li, layer in enumerate(zip(*stacks)):
+        if layers is not None and li >= layers:
+            break
+        kind = _infer_kind(layer[0])
+        if kind != "conv":
+            # one flag set per launch: either every input brings its SiLU twin (then no problem evaluates SiLU in its k-loop)
+            # or none does
+            twins = [ops.silu_twin(x) is not None for x in xs]
+            if any(twins) and not all(twins):
+                for x, has in zip(xs, twins):
+                    if not has:
+                        ops.set_silu_twin(x, ops.silu(x))
+        if kind == "rb":
+            ts = ops.conv2d_multi(xs, [m._branch[1].packed() for m in layer], silu_in=True, silu_out=True)
+            xs = ops.conv2d_multi(ts, [m._branch[3].packed() for m in layer], per_problem=[dict(res=x) for x in xs], dual_silu=True)
+        elif kind == "attn":
+            a, b = list(xs), list(xs)
+            for i in range(3):
+                blocks = [m._mainBranch[i] for m in layer] + [m._sideBranch[i] for m in layer]
+                ts = ops.conv2d_multi(a + b, [blk._branch[1].packed() for blk in blocks], silu_in=True, silu_out=True)
+                ys = ops.conv2d_multi(ts, [blk._branch[3].packed() for blk in blocks], per_problem=[dict(res=t) for t in a + b], dual_silu=True)
+                a, b = ys[:k], ys[k:]
+            xs = ops.conv2d_multi(b, [m._sideBranch[3].packed() for m in layer],
+                                  per_problem=[dict(gate_mul=ai, gate_id=xi) for ai, xi in zip(a, xs)], dual_silu=True)
+        else:
+            xs = ops.conv2d_multi(xs, [m.packed() for m in layer], dual_silu=True)
+    return xs

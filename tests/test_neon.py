@@ -147,6 +147,7 @@ def test_neon_training_forward_and_gradients(dev, dense):
     (out[0] * Gm.to(dev)).sum().backward()
     worst = ("", 0.0)
     seen = set()
+    scale = max(float(v.grad.abs().max()) for v in leaf.values() if torch.is_tensor(v) and v.grad is not None)
     for name, p in model.named_parameters():
         if not p.requires_grad or id(p) in seen:
             continue
@@ -157,7 +158,11 @@ def test_neon_training_forward_and_gradients(dev, dense):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0
             continue
         assert p.grad is not None, f"no grad for {name}"
-        rel = (p.grad.detach().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+        # (denseNorm: a conv bias in front of a GroupNorm whose groups are single channels -- 32 channels, 32 groups -- has a
+        #  structurally ZERO gradient, the normalisation removes any per-channel shift; both sides then hold rounding noise of
+        #  the size 1e-6 x the neighbouring gradients: the error is measured against the larger of the tensor's own scale and
+        #  1e-3 of the largest gradient in the model)
+        rel = (p.grad.detach().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-3 * scale, 1e-6)
         if rel > worst[1]:
             worst = (name, rel)
     assert worst[1] < 2e-3, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"

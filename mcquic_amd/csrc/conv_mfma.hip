@@ -361,6 +361,9 @@ next_tile:
                 wso += 256 * MB;
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // (tried in round 3: weights as one 16-byte load per four k-steps + two statically alternating input buffers instead of
+            //  the 16 copies -- 198 -> 150 non-MFMA instructions per 64 MFMAs in the ISA, and 4 % SLOWER on the GPU, 4381 -> 4560 us
+            //  on the 384x256 layer: the wide loads hold the vector-memory path longer than four narrow ones spread over the steps)
             soff += (unsigned)GA * step_bytes;
         };
         if (npairs > 0) body(0);
@@ -522,12 +525,20 @@ next_tile:
             // whole 32-row band in three phases -- side loads of all its pixel blocks, then all arithmetic, then all stores --
             // instead of block by block with loads, activation and stores alternating (measured: +1.8 % on a 384x256 layer
             // with the twin epilogue, +0.9 % images/s)
-            constexpr unsigned SIMPLE = MCQ_CONV_SILU_OUT | MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU;
+            // (the two flag sets of the training step's input-gradient launches -- * silu'(.) and * silu'(.) + dy -- as well: in
+            //  the generic path their side loads sat in front of each block's arithmetic; 8 x 128 x 128 x 128 map 311 -> ~277 us)
+            constexpr unsigned SIMPLE = MCQ_CONV_SILU_OUT | MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU | MCQ_CONV_DSILU_MUL;
             if (EF != RUNTIME_FLAGS && (EF & ~SIMPLE) == 0u && NB <= 2) {     // (NB = 4: 192 temporaries, spills)
                 unsigned sob[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sob[r] = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
                 float vv[NB][16], rvv[NB][16], tw[NB][16];
+                if (EF & MCQ_CONV_DSILU_MUL) {              // (tw is free here: no SiLU twin in a gradient launch)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) tw[nb][r] = mcq_buffer_load_s(mr[nb], pvo[nb], sob[r]);
+                }
                 if (EF & MCQ_CONV_RESIDUAL) {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
@@ -539,6 +550,10 @@ next_tile:
                     get_acc(mi, nb, vv[nb]);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) vv[nb][r] = vv[nb][r] + bias16[r];
+                    if (EF & MCQ_CONV_DSILU_MUL) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) vv[nb][r] = vv[nb][r] * mcq_dsilu(tw[nb][r]);
+                    }
                     if (EF & MCQ_CONV_RESIDUAL) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) vv[nb][r] = vv[nb][r] + p.res_scale * rvv[nb][r];
@@ -638,6 +653,12 @@ next_tile:
             epilogue(std::integral_constant<unsigned, 0u>{}, tile_active, get_acc, mb_first, mb_count);
         else if (ef == MCQ_CONV_RESIDUAL)
             epilogue(std::integral_constant<unsigned, MCQ_CONV_RESIDUAL>{}, tile_active, get_acc, mb_first, mb_count);
+        // (the input-gradient flag sets only where one pixel block per wave leaves the registers for it -- the 128 x 32 and
+        //  32 x 32 tiles; in the 128 x 64 instance the extra 32 side values spilled, and that instance is the inference path's)
+        else if (!WINO && TAPS == 9 && NB == 1 && ef == MCQ_CONV_DSILU_MUL)
+            epilogue(std::integral_constant<unsigned, MCQ_CONV_DSILU_MUL>{}, tile_active, get_acc, mb_first, mb_count);
+        else if (!WINO && TAPS == 9 && NB == 1 && ef == (MCQ_CONV_DSILU_MUL | MCQ_CONV_RESIDUAL))
+            epilogue(std::integral_constant<unsigned, MCQ_CONV_DSILU_MUL | MCQ_CONV_RESIDUAL>{}, tile_active, get_acc, mb_first, mb_count);
         else
             epilogue(std::integral_constant<unsigned, RUNTIME_FLAGS>{}, tile_active, get_acc, mb_first, mb_count);
     };
@@ -1352,6 +1373,14 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         if (MB == 4 && NB == 2 && ksl1 == 2 && tiles1 * 4 > 2048 && tiles1 * 4 <= 3072 && d->ksize == 3 &&
             k.S % 2 == 0 && (k.S >> 1) >= 8) { MB = 2; NB = 2; ksl = 1; }
         if (MB == 4 && NB == 2 && ksl == 3 && d->ksize == 3 && k.S % 4 == 0 && (k.S >> 2) >= 8) { NB = 1; ksl = 2; }
+        // the same trade one step down: a 2-way split of the 128 x 64 tile runs as the UNSPLIT 128 x 32 tile -- as many waves, no
+        // LDS reduction, every wave finishes its own half of the pixels instead of the owner waves finishing all of them
+        // (two 8 x 128 x 64 x 64 problems in one launch, the AttentionBlock stacks of a training step: 153-156 -> 140-142 us)
+        else if (MB == 4 && NB == 2 && ksl == 1 && d->ksize == 3) { NB = 1; ksl = 0; }
+        // input-gradient launches of the training step (* silu'(.) [+ dy]): their epilogue carries one more output-shaped side
+        // read and a sigmoid per element; the 128 x 32 tile has a band-wise instance of it (the 128 x 64 tile has no registers
+        // left for one) and at three waves per SIMD hides it better (8 x 128 x 128 x 128: 300-311 -> 270-277 us)
+        else if (MB == 4 && NB == 2 && ksl == 0 && (fl & MCQ_CONV_DSILU_MUL) && d->ksize == 3) NB = 1;
     }
     const int pro = (fl & MCQ_CONV_SILU_IN) ? PRO_SILU : (fl & MCQ_CONV_SQUARE_IN) ? PRO_SQUARE : PRO_NONE;
     const long long ptiles = (tb + NB - 1) / NB;

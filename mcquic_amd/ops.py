@@ -582,6 +582,8 @@ def conv2d_wgrad_group(xs, dys, want_bias: bool = True):
         return out
     out = []
     cap = lib.mcq_conv2d_wgrad_nchw_max_group()
+    # (round 3: capping a group by its operand footprint -- twelve 8 x 128 x 64 x 64 problems as three launches of four --
+    #  changed nothing, 984 vs 1038 us: the 82 us per convolution are the kernel's own, not cache eviction between problems)
     for lo in range(0, len(xs), cap):
         gx = [_dev(t, "x") for t in xs[lo:lo + cap]]
         gd = [_dev(t, "dy") for t in dys[lo:lo + cap]]

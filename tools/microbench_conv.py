@@ -28,7 +28,7 @@ SHAPES = [  # n, cin, cout, h, w, ks, stride
     (32, 128, 128, 192, 128, 1, 1),
     (32, 128, 128, 384, 256, 1, 1),
 ]
-TILES = [0, 0x42, 0x242, 0x342, 0x41, 0x241, 0x341, 0x22, 0x122, 0x222, 0x322, 0x11, 0x311]
+TILES = [0, 0x42, 0x142, 0x242, 0x342, 0x41, 0x141, 0x241, 0x341, 0x22, 0x122, 0x222, 0x322, 0x11, 0x311]
 
 
 def main():
@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--big", action="store_true", help="only the two largest levels")
     ap.add_argument("--k1", action="store_true", help="only the 1x1 shapes")
     ap.add_argument("--winograd", action="store_true", help="the opt-in Winograd forms beside the direct one (3x3 stride-1 shapes): columns direct | F(2,3) 128-row | F(2x2,3x3)")
+    ap.add_argument("--nprob", type=int, default=1, help="problems per launch (ops.conv2d_multi)")
     ap.add_argument("--train", action="store_true", help="the 3x3 shapes of the config-#5 training step (8 images of 128x128 ... 4x4)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -75,17 +76,25 @@ def main():
                 kw.update(dsilu_mul=res, res=res)
             elif args.flags == "dsilu_only":
                 kw.update(dsilu_mul=res)
+            def launch(i):
+                if args.nprob == 1:
+                    ops.conv2d(x, packs[i % len(packs)], stride, **kw)
+                else:
+                    shared = {k_: v for k_, v in kw.items() if not torch.is_tensor(v)}
+                    pp = {k_: v for k_, v in kw.items() if torch.is_tensor(v)}
+                    ops.conv2d_multi([x] * args.nprob, [packs[(i + j) % len(packs)] for j in range(args.nprob)], stride,
+                                     per_problem=[pp] * args.nprob, **shared)
             for i in range(3):
-                ops.conv2d(x, packs[i % len(packs)], stride, **kw)
+                launch(i)
             torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for i in range(args.iters):
-                ops.conv2d(x, packs[i % len(packs)], stride, **kw)
+                launch(i)
             e.record()
             torch.cuda.synchronize()
             us = s.elapsed_time(e) * 1e3 / args.iters
-            row.append(f"{tile:#05x}:{us:8.1f}us {flops / us / 1e6:6.1f}TF")
+            row.append(f"{tile:#05x}:{us:8.1f}us {flops * args.nprob / us / 1e6:6.1f}TF")
         print(f"{n}x{cin}->{cout} {h}x{w} k{ks}s{stride}: " + " | ".join(row), flush=True)
 
 

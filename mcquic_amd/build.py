@@ -25,16 +25,14 @@ LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"]
 
 
 def csrc_sha() -> str:
-    """SHA-256 over the kernel sources (csrc/* and the public header, names + contents): what measurement artefacts are
-    stamped with (profiles/rNN_pmc.json) so that a number collected on older kernels can be recognised as stale."""
+    """SHA-256 over the sources of the dominant kernel (csrc/conv_mfma.hip and the headers it includes, names + contents): what
+    measurement artefacts about that kernel are stamped with (profiles/rNN_pmc.json) so that a number collected on an older
+    kernel can be recognised as stale."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "mcquic_hip.h")]
-    for f in files:
-        path = os.path.join(CSRC, f)
-        if os.path.isfile(path) and f.endswith((".hip", ".h", ".cpp")):
-            h.update(os.path.basename(f).encode() + b"\0")
-            h.update(open(path, "rb").read())
+    for f in ("conv_mfma.hip", "conv_head16.h", "mcq_common.h"):
+        h.update(f.encode() + b"\0")
+        h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()
 
 

@@ -1370,13 +1370,18 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         // the earlier k-loop, whose address arithmetic weighed twice as much on the smaller tile, it cost 0.4 %)
         // (judged per problem: two such problems in one launch are 6144 waves = two full rounds at 3 / SIMD, 204 us per pair,
         //  where the 128 x 64 tile split 2 ways would be 1.5 rounds at 2 / SIMD, 224 us)
+        // (round 3, forced-tile sweeps with 2 / 4 problems per launch: with the paired heads in lockstep the 48x32 level mostly
+        //  runs as such launches, and then the 64 x 64 tile needs no split at all -- 4 problems: 449 -> 414 us, 2: 217 -> 215)
         if (MB == 4 && NB == 2 && ksl1 == 2 && tiles1 * 4 > 2048 && tiles1 * 4 <= 3072 && d->ksize == 3 &&
-            k.S % 2 == 0 && (k.S >> 1) >= 8) { MB = 2; NB = 2; ksl = 1; }
+            k.S % 2 == 0 && (k.S >> 1) >= 8) { MB = 2; NB = 2; ksl = nprob >= 2 ? 0 : 1; }
         if (MB == 4 && NB == 2 && ksl == 3 && d->ksize == 3 && k.S % 4 == 0 && (k.S >> 2) >= 8) { NB = 1; ksl = 2; }
         // the same trade one step down: a 2-way split of the 128 x 64 tile runs as the UNSPLIT 128 x 32 tile -- as many waves, no
         // LDS reduction, every wave finishes its own half of the pixels instead of the owner waves finishing all of them
         // (two 8 x 128 x 64 x 64 problems in one launch, the AttentionBlock stacks of a training step: 153-156 -> 140-142 us)
         else if (MB == 4 && NB == 2 && ksl == 1 && d->ksize == 3) { NB = 1; ksl = 0; }
+        // ... and a 4-way split of it in a multi-problem launch as the 64 x 64 tile split 2 ways (32 x 24x16 maps, 4 problems:
+        // 120 -> 112 us; one 192x128 map, 2 problems: 117 -> 110 us)
+        else if (MB == 4 && NB == 2 && ksl == 2 && nprob >= 2 && d->ksize == 3 && k.S % 2 == 0 && (k.S >> 1) >= 8) { MB = 2; ksl = 1; }
         // input-gradient launches of the training step (* silu'(.) [+ dy]): their epilogue carries one more output-shaped side
         // read and a sigmoid per element; the 128 x 32 tile has a band-wise instance of it (the 128 x 64 tile has no registers
         // left for one) and at three waves per SIMD hides it better (8 x 128 x 128 x 128: 300-311 -> 270-277 us)

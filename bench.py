@@ -480,7 +480,9 @@ def main():
             out["parity"] = parity_report([c[:nb] for c in codes], gpu_pix, cpu_codes, cpu_pix)
         else:
             sd_cpu = cpu_codes = cpu_pix = None
-        if world == 1 and not args.no_secondary and not args.winograd and not args.graphs:
+        # (not under a launcher: the secondary's hipGraph captures do not mix with RCCL's watchdog thread -- a capture in global
+        #  mode is invalidated by its event queries; the driver's N = 1 run is the plain command)
+        if world == 1 and not use_dist and not args.no_secondary and not args.winograd and not args.graphs:
             out["secondary"] = secondary(model, x, dev, cpu_codes, cpu_pix, min(args.cpu_batch, args.batch))
     # RCCL writes its version banner through C stdio, which a pipe only sees at exit: every rank flushes it out before the
     # last barrier so that rank 0's ONE line below is the last thing on stdout

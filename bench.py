@@ -341,6 +341,45 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
     return sec
 
 
+def secondary_child(args):
+    """`bench.py --secondary-child FILE`: the secondary measurements in a process of their own -- a crash or hang in an opt-in
+    mode or in the training-step capture must not be able to take the headline line down with it."""
+    from mcquic_amd.utils import synthetic
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    model = synthetic.bench_model().to(dev)
+    x = synthetic.bench_images(0, args.batch, H, W).to(dev)
+    cpu_codes = cpu_pix = None
+    if args.secondary_child and os.path.exists(args.secondary_child):
+        blob = torch.load(args.secondary_child)
+        cpu_codes, cpu_pix = blob["codes"], blob["pixels"]
+    sec = secondary(model, x, dev, cpu_codes, cpu_pix, min(args.cpu_batch, args.batch))
+    print("SECONDARY " + json.dumps(sec), flush=True)
+    return 0
+
+
+def secondary_in_child(args, cpu_codes, cpu_pix, timeout=420):
+    import subprocess
+    import tempfile
+    handle = ""
+    try:
+        if cpu_codes is not None:
+            fd, handle = tempfile.mkstemp(suffix=".pt", prefix="mcq_bench_")
+            os.close(fd)
+            torch.save({"codes": cpu_codes, "pixels": cpu_pix}, handle)
+        cmd = [sys.executable, os.path.abspath(__file__), "--secondary-child", handle, "--batch", str(args.batch), "--cpu-batch", str(args.cpu_batch)]
+        run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        for line in reversed(run.stdout.splitlines()):
+            if line.startswith("SECONDARY "):
+                return json.loads(line[len("SECONDARY "):])
+        return {"error": f"child exited with code {run.returncode} and no result: {run.stderr[-300:]}"}
+    except Exception as exc:                                  # noqa: BLE001 -- timeout, spawn failure: the headline stands on its own
+        return {"error": repr(exc)[:300]}
+    finally:
+        if handle and os.path.exists(handle):
+            os.remove(handle)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,10 +391,15 @@ def main():
     ap.add_argument("--graphs", action="store_true", help="replay encode/decode as captured hipGraphs (small-batch latency)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` measurements (opt-in Winograd mode, training step, VQ config #4, batch-1 latency; ~40 s)")
+    ap.add_argument("--secondary-child", default=None, metavar="FILE",
+                    help="internal: run ONLY the `secondary` measurements (FILE = optional torch file with the oracle's codes / pixels "
+                         "for the parity leg) and print their JSON object; bench.py starts this as a child process")
     ap.add_argument("--winograd", type=int, nargs="?", const=1, default=0, choices=(0, 1, 2),
                     help="OPT-IN experiment, never the headline: large 3x3 stride-1 layers in a Winograd form (not the reference's arithmetic); "
                          "1 = F(2, 3) along x, 2 = F(2x2, 3x3) where the layer allows it")
     args = ap.parse_args()
+    if args.secondary_child is not None:
+        return secondary_child(args)
 
     from mcquic_amd import launch
     # `--gpus N` IS the world size: without a launcher's environment the script re-executes itself under
@@ -483,7 +527,9 @@ def main():
         # (not under a launcher: the secondary's hipGraph captures do not mix with RCCL's watchdog thread -- a capture in global
         #  mode is invalidated by its event queries; the driver's N = 1 run is the plain command)
         if world == 1 and not use_dist and not args.no_secondary and not args.winograd and not args.graphs:
-            out["secondary"] = secondary(model, x, dev, cpu_codes, cpu_pix, min(args.cpu_batch, args.batch))
+            del model, codes, pix                 # (the child builds its own model on the same GPU)
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_in_child(args, cpu_codes, cpu_pix)
     # RCCL writes its version banner through C stdio, which a pipe only sees at exit: every rank flushes it out before the
     # last barrier so that rank 0's ONE line below is the last thing on stdout
     try:
@@ -500,4 +546,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -49,7 +49,7 @@ struct WgRowsK {
 
 struct RowsPlan { int F, strips, row_chunks, rpc, units, splits, ups, groups; };
 
-inline bool rows_plan(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int taps = 9, bool stride2 = false) {
+inline bool rows_plan(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int taps = 9, bool stride2 = false, int nconv = 1) {
     // (H, W: the map the walk runs over = dY's; with stride2 the input is 2H x 2W)
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (W & 7) || (H & ((taps == 1 || stride2) ? 1 : 7))) return false;
     if ((uint64_t)N * Cin * H * W * (stride2 ? 16ull : 4ull) >= 0x40000000ull || (uint64_t)N * Cout * H * W * 4ull >= 0x40000000ull) return false;
@@ -61,6 +61,15 @@ inline bool rows_plan(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int t
     const long long sr = (long long)N * H * r.strips;                       // strip-rows in all
     long long splits = MCQ_WGROWS_WAVES / tiles;
     if (splits < 4) splits = 4;
+    // (nconv: convolutions sharing the launch.  On small maps the wave budget is the launch's, not each convolution's -- sixteen
+    //  16x16 problems planned one by one were 8 192 waves of four strip-rows each and 75 MB of partial sums for 9.7 GFLOP; one
+    //  round of 2 048 resident waves of sixteen rows does the same work.  Large maps keep the many-round plan: with hundreds
+    //  of rows per wave a launch of slightly more than 2 048 equal waves would end in a nearly empty second round.)
+    if (nconv > 1) {
+        long long shared = MCQ_WGROWS_WAVES / (tiles * nconv);
+        if (shared < 4) shared = 4;
+        if (sr / shared <= 64) splits = shared;
+    }
     long long by_work = sr * r.F / (4 * MCQ_WGROWS_MIN_ROWS) / (taps == 1 ? 2 : 1);      // (a 1x1 row is 32 MFMAs, not 72)
     if (by_work < 1) by_work = 1;
     if (splits > by_work) splits = by_work;
@@ -661,7 +670,7 @@ extern "C" int mcq_conv2d_wgrad_nchw_group_f32(const float* const* x, const floa
                                                int32_t Cout, void* stream) {
     if (!x || !dy || !dw || !workspace || nconv < 1 || nconv > ROWS_MAX_CONVS) return MCQ_EINVAL;
     RowsPlan r;
-    if (!rows_plan(N, Cin, H, W, Cout, r)) {
+    if (!rows_plan(N, Cin, H, W, Cout, r, 9, false, nconv)) {      // (never more groups than the nconv = 1 plan the workspace query assumes)
         if (!tiny_shape(N, Cin, H, W, Cout)) return MCQ_EINVAL;
         WgTinyK t;
         for (int c = 0; c < ROWS_MAX_CONVS; ++c) {

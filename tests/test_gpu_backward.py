@@ -140,13 +140,19 @@ def test_wgrad_small_map_kernel(dev, case):
     dw, db = ops.conv2d_wgrad(x.to(dev), gy.to(dev), 3, 1, want_bias=True)
     _close(dw, wr.grad, 3e-6, f"dW {case}")
     _close(db, br.grad, 3e-6, f"db {case}")
+    # (a grouped launch may cut the rows into other ranges than the single launch -- its wave budget is shared by the
+    #  convolutions -- so the sums agree to float32 rounding, not bit for bit; two problems of one launch are cut alike)
     (dw2, db2), (dw3, _) = ops.conv2d_wgrad_group([x.to(dev), x.to(dev)], [gy.to(dev), gy.to(dev)], want_bias=True)
-    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dw, dw3)
+    _close(dw2, wr.grad, 3e-6, f"grouped dW {case}")
+    _close(db2, br.grad, 3e-6, f"grouped db {case}")
+    assert torch.equal(dw2, dw3)
 
 
 @pytest.mark.parametrize("case", [(3, 2, 128, 128, 16, 16), (16, 8, 128, 128, 8, 8), (19, 1, 32, 64, 8, 16)])
 def test_wgrad_rows_grouped_launch(dev, case):
-    """Several convolutions of one shape in one launch pair: every (dW, db) equals the single-conv launch bit for bit."""
+    """Several convolutions of one shape in one launch pair: every (dW, db) equals the single-conv launch to float32 rounding
+    (the grouped plan shares the launch's wave budget between the convolutions, i.e. sums the rows in other ranges), and the
+    launch is deterministic: the same call twice gives the same bits."""
     from mcquic_amd import ops
     k, n, cin, cout, h, w = case
     xs = [_rand((n, cin, h, w), 100 + i).to(dev) for i in range(k)]
@@ -155,9 +161,13 @@ def test_wgrad_rows_grouped_launch(dev, case):
     assert len(got) == k
     for i, (dw, db) in enumerate(got):
         dw1, db1 = ops.conv2d_wgrad(xs[i], dys[i], 3, 1, want_bias=True)
-        assert torch.equal(dw, dw1) and torch.equal(db, db1), i
+        _close(dw, dw1.cpu(), 3e-6, f"dW {i}")
+        _close(db, db1.cpu(), 3e-6, f"db {i}")
+    again = ops.conv2d_wgrad_group(xs, dys, want_bias=True)
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(got, again))
     nb = ops.conv2d_wgrad_group(xs[:2], dys[:2], want_bias=False)
-    assert nb[1][1] is None and torch.equal(nb[1][0], got[1][0])
+    assert nb[1][1] is None and nb[1][0].shape == got[1][0].shape
+    _close(nb[1][0], got[1][0].cpu(), 3e-6, "without bias")
 
 
 def test_pixel_shuffle_conv_backward(dev):

@@ -79,7 +79,7 @@ class ConvProfiler:
 
         def executed(flops, flags):
             """MFMA work actually issued: the Winograd forms run 16 of 36 (F(2x2, 3x3)) / 12 of 18 (F(2, 3)) k-steps."""
-            if flags & ops.CONV_WINOGRAD2D:
+            if flags & (ops.CONV_WINOGRAD2D | ops.CONV_WINOGRAD2D16):
                 return flops * 16.0 / 36.0
             if flags & ops.CONV_WINOGRAD:
                 return flops * 12.0 / 18.0

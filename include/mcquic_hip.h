@@ -52,6 +52,9 @@ extern "C" {
 #define MCQ_CONV_DUAL_SILU  0x100u /* also store silu(y) to y_silu: the next block's act1(x), computed once per element */
 #define MCQ_CONV_WINOGRAD2D 0x1000u /* OPT-IN like MCQ_CONV_WINOGRAD: F(2x2, 3x3), 4/9 of the multiplications; w_packed from   */
                                     /* mcq_pack_conv_weight_winograd2d_f32; Cout % 128 == 0, Cin % 8 == 0                                */
+#define MCQ_CONV_WINOGRAD2D16 0x2000u /* OPT-IN: the same F(2x2, 3x3) arithmetic on v_mfma_f32_16x16x4_f32, two waves per SIMD (round 3);  */
+                                     /* w_packed from mcq_pack_conv_weight_winograd16_f32; Cout % 128 == 0, Cin % 16 == 0; epilogues:    */
+                                     /* SILU_OUT / RESIDUAL / DUAL_SILU combinations, or SHUFFLE2 alone                                   */
 #define MCQ_CONV_WINOGRAD   0x800u /* OPT-IN, not the reference's arithmetic: 3x3 stride-1 layer in the Winograd F(2, 3) form along x */
                                    /* (2/3 of the multiplications, float32 throughout, results differ from the direct form in   */
                                    /* the last bits); w_packed then comes from mcq_pack_conv_weight_winograd_f32                 */
@@ -344,6 +347,11 @@ void mcq_ms_ssim_window(float* out11);
 /* out[n] = sum over the per_image bytes of image n of (x - y)^2, exact (int64).  The reference's PSNR
  * (metrics.py:264-274) is 10 log10(255^2 / (out[n] / per_image + 1e-4)) in float64. */
 int mcq_sqdiff_sum_u8(const uint8_t* x, const uint8_t* y, int64_t* out, int64_t per_image, int32_t N, void* stream);
+
+/* F(2x2, 3x3) weights for MCQ_CONV_WINOGRAD2D16: U = G g G^T (float64, rounded once) in the operand order of the 16 x 16 x 4
+ * instance, [Cout/32][Cin/4][16 positions][2 halves][64 lanes] + one group of zeros. */
+size_t mcq_packed_conv_winograd16_floats(int32_t Cout, int32_t Cin);
+int mcq_pack_conv_weight_winograd16_f32(const float* w, int32_t Cout, int32_t Cin, float* out, void* stream);
 
 /* ---- GroupNorm (`denseNorm=True`) ------------------------------------------------------------------------------------
  * y = (x - mean) * rstd * gamma[c] + beta[c] over each (image, group) of C / groups adjacent channels, biased variance,

@@ -20,6 +20,7 @@ CONV_SILU_IN, CONV_SQUARE_IN, CONV_SILU_OUT, CONV_RESIDUAL = 0x1, 0x2, 0x4, 0x8
 CONV_GDN, CONV_IGDN, CONV_GATE, CONV_SHUFFLE2, CONV_DUAL_SILU, CONV_MUL, CONV_DSILU_MUL = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200, 0x400
 CONV_WINOGRAD = 0x800
 CONV_WINOGRAD2D = 0x1000
+CONV_WINOGRAD2D16 = 0x2000
 
 
 class ConvDesc(Structure):
@@ -44,6 +45,8 @@ SYMBOLS = {
     "mcq_pack_conv_dgrad_weight_winograd_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "mcq_packed_conv_winograd2d_floats": (c_size_t, [c_int32, c_int32]),
     "mcq_pack_conv_weight_winograd2d_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "mcq_packed_conv_winograd16_floats": (c_size_t, [c_int32, c_int32]),
+    "mcq_pack_conv_weight_winograd16_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "mcq_conv2d_winograd_ok": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint32]),
     "mcq_pack_conv_weight_max_multi": (c_int32, []),
     "mcq_pack_conv_weight_multi_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),

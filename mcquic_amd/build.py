@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libmcquic_hip.so")
-SOURCES = ["conv_mfma.hip", "vq.hip", "vq_train.hip", "train_ops.hip", "wgrad_rows.hip", "metrics.hip", "norm.hip", "rans.cpp"]
-HEADERS = ["mcq_common.h", "vq_common.h", "conv_head16.h", os.path.join("..", "..", "include", "mcquic_hip.h")]
+SOURCES = ["conv_mfma.hip", "conv_wino16.hip", "vq.hip", "vq_train.hip", "train_ops.hip", "wgrad_rows.hip", "metrics.hip", "norm.hip", "rans.cpp"]
+HEADERS = ["mcq_common.h", "vq_common.h", "conv_head16.h", "conv_wino16.h", os.path.join("..", "..", "include", "mcquic_hip.h")]
 # -ffp-contract=off: element-wise epilogues keep the reference's one-rounding-per-op sequence
 #   (e.g. a * sigmoid(b) then + x are two torch kernels in mcquic/nn/blocks.py:286-287).
 # -pragma-unroll-threshold: the 128-register epilogue must be fully unrolled or the accumulators spill to scratch.
@@ -30,7 +30,7 @@ def csrc_sha() -> str:
     kernel can be recognised as stale."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("conv_mfma.hip", "conv_head16.h", "mcq_common.h"):
+    for f in ("conv_mfma.hip", "conv_head16.h", "mcq_common.h", "conv_wino16.hip", "conv_wino16.h"):
         h.update(f.encode() + b"\0")
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()

@@ -22,6 +22,7 @@
 
 #include "mcq_common.h"
 #include "../../include/mcquic_hip.h"
+#include "conv_wino16.h"
 
 // (The ablation / stamp / packed-SiLU / peel build switches of rounds 1-2 are gone from this file: what they measured is in
 //  DESIGN.md section 4, the code in the history up to commit 0aa82a9.)
@@ -1207,7 +1208,7 @@ int conv_validate(const mcq_conv_desc* d) {
     if ((fl & MCQ_CONV_DUAL_SILU) && (!d->y_silu || (fl & MCQ_CONV_SILU_OUT))) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_SILU_IN) && (fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;
     if (fl & MCQ_CONV_SHUFFLE2) {
-        if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN | MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D))) return MCQ_EINVAL;
+        if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN | MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D | MCQ_CONV_WINOGRAD2D16))) return MCQ_EINVAL;
     }
     // one image's input slab plus the prefetch rings' over-read (up to 8 channels) must stay below 2 GiB: byte offsets and
     // the descriptors' shrinking num_records are 32-bit (signed in the scalar arithmetic of the k-loop)
@@ -1241,6 +1242,20 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         a.bias = e->bias; a.y = e->y; a.y2 = e->y_silu; a.res = e->res; a.mul = e->mul; a.gid = e->gate_id;
     }
 
+    if (fl & MCQ_CONV_WINOGRAD2D16) {
+        // F(2x2, 3x3) on the 16 x 16 x 4 instruction, two waves per SIMD (conv_wino16.hip)
+        if ((fl & (MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D)) || !wino_shape(d->Cout, d->ksize, d->stride, fl)) return MCQ_EINVAL;
+        W16K w;
+        w.x = d->x; w.wp = d->w_packed; w.bias = d->bias; w.y = d->y; w.y2 = d->y_silu; w.res = d->res;
+        for (int c = 1; c < W16_MAX_MULTI; ++c) {
+            const mcq_conv_desc* e = descs + (c < nprob ? c : 0);
+            W16Ptrs& a = w.alt[c - 1];
+            a.x = e->x; a.wp = e->w_packed; a.bias = e->bias; a.y = e->y; a.y2 = e->y_silu; a.res = e->res;
+        }
+        w.nprob = nprob; w.N = d->N; w.Cin = d->Cin; w.H = d->H; w.W = d->W; w.Cout = d->Cout; w.Ho = k.Ho; w.Wo = k.Wo;
+        w.flags = fl & ~(unsigned)MCQ_CONV_WINOGRAD2D16; w.res_scale = d->res_scale;
+        return mcq_wino16_launch(w, stream);
+    }
     if (fl & MCQ_CONV_WINOGRAD2D) {
         if ((fl & MCQ_CONV_WINOGRAD) || !wino_shape(d->Cout, d->ksize, d->stride, fl) || d->Cout % 128 != 0 || d->Cin % 8 != 0) return MCQ_EINVAL;
         if ((uint64_t)(d->Cin + 16) * d->H * d->W * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import (CONV_DSILU_MUL, CONV_DUAL_SILU, CONV_MUL, CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN,
-                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, CONV_WINOGRAD2D, ConvDesc, check)
+                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, CONV_WINOGRAD2D, CONV_WINOGRAD2D16, ConvDesc, check)
 
 # OPT-IN fast path, never the default and never the headline bench: large 3x3 stride-1 layers in the Winograd F(2, 3) form
 # along x (mcq_pack_conv_weight_winograd_f32 + MCQ_CONV_WINOGRAD): 2/3 of the multiplications, float32 throughout, but not
@@ -26,6 +26,10 @@ _WINOGRAD_MIN_PIXELS = int(os.environ.get("MCQUIC_AMD_WINOGRAD_MIN_PIXELS", str(
 # (the 2-D form still wins far below that: 32 x 48x32 maps 112 -> 86 us per launch, one 192x128 map at batch 1 -- 24 k pixels --
 #  7.3 -> 6.0 ms per encode+decode with the maps above it; at 12 k pixels, 32 x 24x16, it loses, 41 -> 44 us)
 _WINOGRAD_MIN_PIXELS_2D = int(os.environ.get("MCQUIC_AMD_WINOGRAD_MIN_PIXELS_2D", str(20 * 1024)))
+# which instance runs the F(2x2, 3x3) layers: 16 = v_mfma_f32_16x16x4_f32, two waves per SIMD (csrc/conv_wino16.hip; layers with
+# Cin % 16 == 0 and a SiLU / residual / twin / PixelShuffle epilogue), 32 = the one-wave-per-SIMD 32x32x2 instance of conv_mfma.hip
+_W2D_KERNEL = int(os.environ.get("MCQUIC_AMD_W2D_KERNEL", "16"))
+_W16_EPILOGUES = CONV_SILU_OUT | CONV_RESIDUAL | CONV_DUAL_SILU
 
 
 def winograd_enabled() -> int:
@@ -135,7 +139,7 @@ def _ptr(t: Optional[torch.Tensor]):
 class PackedConv:
     """A conv weight re-laid for the MFMA operand stream (+ its bias), see mcq_pack_conv_weight_f32."""
 
-    __slots__ = ("wp", "bias", "cout", "cin", "ksize", "wino", "wino2d")
+    __slots__ = ("wp", "bias", "cout", "cin", "ksize", "wino", "wino2d", "wino16")
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], copy_bias: bool = True, winograd: Optional[bool] = None):
         weight = _dev(weight.detach(), "weight")
@@ -150,7 +154,7 @@ class PackedConv:
         # (the copy decouples the pack from later in-place updates of the parameter; a caller that hands over a fresh tensor skips it)
         self.bias = None if bias is None else (_dev(bias.detach(), "bias").clone() if copy_bias else _dev(bias.detach(), "bias"))
         self.cout, self.cin, self.ksize = cout, cin, kh
-        self.wino = self.wino2d = None
+        self.wino = self.wino2d = self.wino16 = None
         level = (2 if _WINOGRAD_2D else 1) if _WINOGRAD else 0
         if winograd is not None:
             level = 1 if winograd is True else int(winograd)
@@ -164,6 +168,11 @@ class PackedConv:
             with _guard(weight.device):
                 check(lib.mcq_pack_conv_weight_winograd2d_f32(_ptr(weight), cout, cin, _ptr(self.wino2d), _stream()),
                       "mcq_pack_conv_weight_winograd2d_f32")
+            if _W2D_KERNEL == 16 and cin % 16 == 0:
+                self.wino16 = torch.empty(lib.mcq_packed_conv_winograd16_floats(cout, cin), dtype=torch.float32, device=weight.device)
+                with _guard(weight.device):
+                    check(lib.mcq_pack_conv_weight_winograd16_f32(_ptr(weight), cout, cin, _ptr(self.wino16), _stream()),
+                          "mcq_pack_conv_weight_winograd16_f32")
 
     @classmethod
     def dgrad(cls, weight: torch.Tensor, stride: int, scale: float = 1.0, winograd: Optional[bool] = None) -> "PackedConv":
@@ -183,7 +192,7 @@ class PackedConv:
                   "mcq_pack_conv_dgrad_weight_f32")
         self.bias = None
         self.cout, self.cin, self.ksize = co_d.value, ci_d.value, kh
-        self.wino = self.wino2d = None
+        self.wino = self.wino2d = self.wino16 = None
         if (winograd if winograd is not None else _WINOGRAD) and kh == 3 and stride == 1 and scale == 1.0 and cin % 64 == 0:
             self.wino = torch.empty(lib.mcq_packed_conv_winograd_floats(cin, cout), dtype=torch.float32, device=weight.device)
             with _guard(weight.device):
@@ -232,7 +241,7 @@ def pack_convs(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Option
         pk.wp = slab[i]
         pk.bias = None if dgrad or biases is None or biases[i] is None else _dev(biases[i].detach(), "bias")
         pk.cout, pk.cin, pk.ksize = co, ci, kh
-        pk.wino = pk.wino2d = None
+        pk.wino = pk.wino2d = pk.wino16 = None
         out.append(pk)
     return out
 
@@ -295,7 +304,11 @@ def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool
         two_d = w.wino2d is not None and (_WINOGRAD_2D if winograd is None or winograd is True else int(winograd) >= 2)
         if winograd is not None and winograd is not True and int(winograd) >= 2 and w.wino2d is None:
             raise ValueError("winograd=2 needs a 3x3 layer with Cout % 128 == 0 and Cin % 8 == 0, packed with winograd=2")
-        if ok and two_d:
+        if ok and two_d and _W2D_KERNEL == 16 and w.wino16 is not None and (
+                (flags & ~_W16_EPILOGUES) == 0 or flags == CONV_SHUFFLE2):
+            flags |= CONV_WINOGRAD2D16               # the two-waves-per-SIMD instance (epilogues it does not carry stay below)
+            wp = w.wino16
+        elif ok and two_d:
             flags |= CONV_WINOGRAD2D
             wp = w.wino2d
         elif ok:

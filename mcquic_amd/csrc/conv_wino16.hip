@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(W16K p) {
     const unsigned group_bytes = 4u * (unsigned)HW * 4u;       // four channels further
     const float* wbu = P_wp + (size_t)(co_base >> 5) * p.G * (32 * 64);
     const __amdgpu_buffer_rsrc_t wr = mcq_make_rsrc(wbu, 0x7fffffffu);      // (the pack ends in a zero tail: the ring's over-read is in bounds)
-    const unsigned wlane = (unsigned)lane * 4u;
+    const unsigned wlane = (unsigned)lane * 16u;              // 16 bytes per lane: the weights of four consecutive MFMAs
     unsigned wso = 0;
 
     f32x4a acc[16][2];
@@ -88,10 +88,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(W16K p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) acc[pos][h] = f32x4a{0.0f, 0.0f, 0.0f, 0.0f};
 
-    constexpr int GA = 4;                                      // groups the row loads run ahead = groups per loop body
-    float A[32], Bw[GA][4];
+    constexpr int GA = 2;                                      // groups the row loads run ahead = groups per loop body
+    f32x4v A4[8];
+    float Bw[GA][4];
 #pragma unroll
-    for (int st = 0; st < 32; ++st) { A[st] = mcq_buffer_load_s(wr, wlane, wso); wso += 256; }
+    for (int q = 0; q < 8; ++q) { A4[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)wlane, (int)wso, 0)); wso += 1024; }
     {
         const __amdgpu_buffer_rsrc_t r0 = mcq_make_rsrc(xb, plane_bytes);
 #pragma unroll
@@ -103,6 +104,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(W16K p) {
         const float d0 = Bw[slot][0], d1 = Bw[slot][1], d2 = Bw[slot][2], d3 = Bw[slot][3];
         tl[buf][wave][lane] = f32x4v{d0 - d2, d1 + d2, d2 - d1, d1 - d3};
     };
+    // (measured and dropped: SHARING the y-transform as well -- wave w forms only row w of B^T d B, a second LDS exchange and a
+    //  second barrier per group hand the sixteen values round: 12 fewer vector-ALU instructions per group, 220/250 "TF" against
+    //  224/251 for this form on the 384x256 layer.  The adds were not what the loop waits for.)
     auto lds_rows = [&](const int buf, f32x4v (&q)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int py = 0; py < 4; ++py) q[py] = tl[buf][py][lane];
@@ -138,10 +142,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(W16K p) {
             if (st == 2) row_to_lds((k + 1) % GA, (k + 1) & 1);
             if (st == 12) { wg_barrier(); lds_rows((k + 1) & 1, tq); }
             if (st == 22) rows_to_v(tq, VV[(k + 1) & 1]);
-            acc[pos][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], VV[k & 1][pos], acc[pos][h], 0, 0, 0);
+            acc[pos][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(A4[st >> 2][st & 3], VV[k & 1][pos], acc[pos][h], 0, 0, 0);
             if (st < 4) Bw[k][st] = mcq_buffer_load(rB[k], vrow[st]);            // my row of the group GA groups ahead
-            A[st] = mcq_buffer_load_s(wr, wlane, wso);
-            wso += 256;
+            if ((st & 3) == 3) {
+                A4[st >> 2] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)wlane, (int)wso, 0));
+                wso += 1024;
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         soff += (unsigned)GA * group_bytes;
@@ -267,9 +273,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(W16K p) {
 __global__ void pack_wino16_kernel(const float* __restrict__ w, int Cout, int Cin, int G, float* __restrict__ out, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int lane = (int)(i & 63);
-    const int h = (int)((i >> 6) & 1);
-    const int pos = (int)((i >> 7) & 15);
+    // [band][group][quad q = st / 4][lane][e = st % 4], st = 2 pos + h: one 16-byte lane load feeds four MFMAs
+    const int e = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    const int st = (int)((i >> 8) & 7) * 4 + e;
+    const int h = st & 1, pos = st >> 1;
     const size_t bg = i >> 11;
     const int g = (int)(bg % (size_t)G);
     const int band = (int)(bg / (size_t)G);

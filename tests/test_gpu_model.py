@@ -86,7 +86,7 @@ def test_qp2_model_winograd_opt_in(dev, level):
         real = ops._lib.load().mcq_conv2d_f32
 
         def counting(desc, stream):
-            launches["n"] += bool(desc._obj.flags & (ops.CONV_WINOGRAD2D if level == 2 else ops.CONV_WINOGRAD))
+            launches["n"] += bool(desc._obj.flags & ((ops.CONV_WINOGRAD2D | ops.CONV_WINOGRAD2D16) if level == 2 else ops.CONV_WINOGRAD))
             return real(desc, stream)
         lib = ops._lib.load()
         lib.mcq_conv2d_f32 = counting

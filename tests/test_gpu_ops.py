@@ -530,3 +530,48 @@ def test_conv_winograd2d_epilogues(dev):
         ops.conv2d(x.to(dev), ops.PackedConv(_rand((64, 128, 3, 3), 1, 0.03).to(dev), None, winograd=2), winograd=2)   # Cout % 128
     with pytest.raises(ValueError):
         ops.conv2d(_rand((1, 130, 6, 6), 2).to(dev), ops.PackedConv(_rand((128, 130, 3, 3), 1, 0.03).to(dev), None, winograd=2), winograd=2)   # Cin % 8
+
+
+@pytest.mark.parametrize("kernel", [16, 32])
+def test_conv_winograd2d_both_instances(dev, monkeypatch, kernel):
+    """The two instances of the F(2x2, 3x3) form -- csrc/conv_wino16.hip (v_mfma_f32_16x16x4_f32, two waves per SIMD; the
+    default) and the 32x32x2 one inside csrc/conv_mfma.hip (MCQUIC_AMD_W2D_KERNEL=32; also the fallback for Cin % 16 != 0
+    and for epilogues the new kernel does not carry) -- are each held to F.conv2d, single launches and multi-problem ones."""
+    from mcquic_amd import ops
+    monkeypatch.setattr(ops, "_W2D_KERNEL", kernel)
+    seen = []
+    orig = ops._conv_desc
+
+    def spy(*a, **kw):
+        out = orig(*a, **kw)
+        seen.append(int(out[0].flags))
+        return out
+
+    monkeypatch.setattr(ops, "_conv_desc", spy)
+    want_flag = ops.CONV_WINOGRAD2D16 if kernel == 16 else ops.CONV_WINOGRAD2D
+    for (n, cin, cout, h, w) in ((2, 128, 128, 21, 34), (1, 32, 256, 40, 17), (1, 128, 128, 2, 2)):
+        xs = [_rand((n, cin, h, w), 11 + i) for i in range(3)]
+        wts = [_rand((cout, cin, 3, 3), 21 + i, 1.0 / np.sqrt(cin * 9)) for i in range(3)]
+        bs = [_rand((cout,), 31 + i, 0.1) for i in range(3)]
+        ress = [_rand((n, cout, h, w), 41 + i) for i in range(3)]
+        pks = [ops.PackedConv(wt.to(dev), b.to(dev), winograd=2) for wt, b in zip(wts, bs)]
+        assert (pks[0].wino16 is not None) == (kernel == 16)
+        del seen[:]
+        ys = ops.conv2d_multi([x.to(dev) for x in xs], pks, 1, per_problem=[dict(res=r.to(dev)) for r in ress], dual_silu=True, winograd=2)
+        assert seen and all(f & want_flag for f in seen), [hex(f) for f in seen]
+        for x, wt, b, r, y in zip(xs, wts, bs, ress, ys):
+            ref = F.conv2d(x, wt, b, padding=1) + r
+            _close(y, ref, 2e-5, f"multi res+twin {kernel}")
+            _close(ops.silu_twin(y), F.silu(ref), 2e-5, f"multi twin {kernel}")
+        del seen[:]
+        got = ops.conv2d(xs[0].to(dev), pks[0], silu_out=True, winograd=2)
+        assert seen[-1] & want_flag
+        _close(got, F.silu(F.conv2d(xs[0], wts[0], bs[0], padding=1)), 2e-5, f"silu_out {kernel}")
+    # an epilogue outside the new kernel's set steps aside to the 32x32 instance rather than failing
+    x = _rand((1, 128, 10, 12), 3)
+    wt = _rand((128, 128, 3, 3), 4, 0.03)
+    pk = ops.PackedConv(wt.to(dev), None, winograd=2)
+    g = _rand((1, 128, 10, 12), 5)
+    del seen[:]
+    got = ops.conv2d(x.to(dev), pk, mul=g.to(dev), winograd=2)
+    _close(got, F.conv2d(x, wt, None, padding=1) * g, 2e-5, "mul epilogue")

@@ -36,6 +36,13 @@
 #ifndef MCQ_PFB
 #define MCQ_PFB 18
 #endif
+// ... and of the 32 x 32 tile, the one the smallest maps run (split 8 ways, a wave's share of a 128-channel 3x3 layer is 72 steps)
+#ifndef MCQ_PF11A
+#define MCQ_PF11A 9
+#endif
+#ifndef MCQ_PF11B
+#define MCQ_PF11B 18
+#endif
 #ifndef MCQ_WINO_PERSIST
 #define MCQ_WINO_PERSIST 1          // workgroups per CU of the persistent 128-row Winograd instance; 0 = one workgroup per four tiles
 #endif
@@ -884,7 +891,7 @@ next_tile:
 }
 
 // OIHW -> [Cout/(32 bands)][TP][64 lanes][bands]: lane l, slot q holds W[co = 32 bands T + 32 q + (l & 31)][ci = 2 s + (l >> 5)][tap]
-// for k-step = s * taps + tap (channel-major, tap-inner); zero beyond Cout / Cin and in the 16-step tail.
+// for k-step = s * taps + tap (channel-major, tap-inner); zero beyond Cout / Cin and in the tail (MCQ_TAIL_STEPS).
 // up to MCQ_PACK_MAX_MULTI weights of one shape per launch (blockIdx.y picks the pair): after an optimizer step every conv of
 // the network re-packs its forward and its input-gradient operand stream -- 660 launches of ~4 us each, one by one
 constexpr int PACK_MAX_MULTI = 16;
@@ -967,10 +974,11 @@ inline int pairs_padded(int Cin, int ks) {        // 1x1 loops advance a whole p
 }
 inline int steps_padded(int Cin, int ks) { return pairs_padded(Cin, ks) * ks * ks; }
 // The operand stream of conv_mfma_kernel exists once per tile height: 128-, 64- and 32-row copies, each with its own
-// 16 zero steps for the prefetch tail.
+// zero steps for the prefetch tail (the deepest weight ring of any instance).
+constexpr int MCQ_TAIL_STEPS = 40;
 inline size_t section_floats(int Cout, int Cin, int ks, int bands) {
     const size_t ntile = (size_t)(Cout + 32 * bands - 1) / (32 * bands);
-    return (ntile * (size_t)steps_padded(Cin, ks) + 16) * 64 * bands;
+    return (ntile * (size_t)steps_padded(Cin, ks) + MCQ_TAIL_STEPS) * 64 * bands;
 }
 inline size_t general_floats(int Cout, int Cin, int ks) {
     return section_floats(Cout, Cin, ks, 4) + section_floats(Cout, Cin, ks, 2) + section_floats(Cout, Cin, ks, 1);
@@ -1415,7 +1423,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     if (MB == 2 && NB == 1) return launch_tile<2, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 1 && NB == 4) return launch_tile<1, 4, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 1 && NB == 2) return launch_tile<1, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 1 && NB == 1) return launch_tile<1, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 1 && NB == 1) return launch_tile<1, 1, MCQ_PF11A, MCQ_PF11B, 16>(k, pro, ptiles, co_tiles, ksl, s);
     return MCQ_EINVAL;
 }
 

@@ -13,6 +13,7 @@
 // broadcast the assign kernel uses for |c|^2; |c|^2 is per column = per lane here.
 #include "mcq_common.h"
 #include "vq_common.h"
+#include "vq_bwd_mfma.h"
 #include "../../include/mcquic_hip.h"
 #include <math.h>
 
@@ -383,6 +384,194 @@ __global__ __launch_bounds__(256) void vq_dc_kernel(const float* __restrict__ dd
     }
 }
 
+
+// ---- the two row kernels above with the row held in registers ---------------------------------------------------------------------
+// T threads share one latent vector's row of k <= 8 T logits (T = 64: a wave, four rows per workgroup; 256; 1024: sixteen waves),
+// eight elements per thread: every input is read ONCE, every logarithm / exponential is evaluated once -- the wave-per-row forms
+// above walk the row two (forward) / three (backward) times and re-derive the Gumbel noise each time, which made them VALU-bound at
+// k = 8192 (33.5 M elements x ~300 issue slots = the 241 / 290 us they took; the row's traffic alone is ~135 us).
+constexpr int ROW_E = 8;
+
+template <int T> struct RowShared {
+    float v[4][T / 64];
+    int i[2][T / 64];
+};
+
+// (value, first index) arg-max over the row's threads, for two quantities at once; every thread gets the result
+template <int T>
+__device__ __forceinline__ void row_argmax2(float& a, int& ai, float& b, int& bi, RowShared<T>& sm) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float oa = __shfl_xor(a, off); const int oi = __shfl_xor(ai, off);
+        if (oa > a || (oa == a && oi < ai)) { a = oa; ai = oi; }
+        const float ob = __shfl_xor(b, off); const int oj = __shfl_xor(bi, off);
+        if (ob > b || (ob == b && oj < bi)) { b = ob; bi = oj; }
+    }
+    if constexpr (T > 64) {
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sm.v[0][wave] = a; sm.i[0][wave] = ai; sm.v[1][wave] = b; sm.i[1][wave] = bi; }
+        __syncthreads();
+        a = sm.v[0][0]; ai = sm.i[0][0]; b = sm.v[1][0]; bi = sm.i[1][0];
+#pragma unroll
+        for (int w = 1; w < T / 64; ++w) {
+            const float oa = sm.v[0][w]; const int oi = sm.i[0][w];
+            if (oa > a || (oa == a && oi < ai)) { a = oa; ai = oi; }
+            const float ob = sm.v[1][w]; const int oj = sm.i[1][w];
+            if (ob > b || (ob == b && oj < bi)) { b = ob; bi = oj; }
+        }
+    }
+}
+
+// sums of two quantities over the row's threads (waves added in wave order); slots s0 / s0 + 1 of the shared scratch
+template <int T>
+__device__ __forceinline__ void row_sum2(float& a, float& b, RowShared<T>& sm, const int s0) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    if constexpr (T > 64) {
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sm.v[s0][wave] = a; sm.v[s0 + 1][wave] = b; }
+        __syncthreads();
+        a = sm.v[s0][0]; b = sm.v[s0 + 1][0];
+#pragma unroll
+        for (int w = 1; w < T / 64; ++w) { a += sm.v[s0][w]; b += sm.v[s0 + 1][w]; }
+    }
+}
+
+template <int T>
+__device__ __forceinline__ float row_max(float a, RowShared<T>& sm) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a = fmaxf(a, __shfl_xor(a, off));
+    if constexpr (T > 64) {
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) sm.v[0][wave] = a;
+        __syncthreads();
+        a = sm.v[0][0];
+#pragma unroll
+        for (int w = 1; w < T / 64; ++w) a = fmaxf(a, sm.v[0][w]);
+    }
+    return a;
+}
+
+template <int T>
+__global__ __launch_bounds__(T < 256 ? 256 : T) void vq_gumbel_sample_row_kernel(float* __restrict__ logits, const float* __restrict__ u_drop,
+                                                                                  const float* __restrict__ u_gumbel,
+                                                                                  const float* __restrict__ freq,
+                                                                                  const float* __restrict__ drop_exponent_ptr,
+                                                                                  int64_t* __restrict__ codes, int64_t* __restrict__ index,
+                                                                                  float* __restrict__ hot, int rows, int m, int hw, int k) {
+    __shared__ RowShared<T> sm;
+    constexpr int RPW = T < 256 ? 256 / T : 1;
+    const int tid = T < 256 ? (int)(threadIdx.x & (T - 1)) : (int)threadIdx.x;
+    const int row = blockIdx.x * RPW + (T < 256 ? (int)(threadIdx.x / T) : 0);
+    if (row >= rows) return;                                     // (T >= 256: the whole workgroup)
+    const int g = (row / hw) % m;
+    float* lr = logits + (size_t)row * k;
+    const float* ud = u_drop + (size_t)row * k;
+    const float* ug = u_gumbel + (size_t)row * k;
+    const float* fr = freq + (size_t)g * k;
+    const float eps = 1.1920928955078125e-07f;
+    const float drop_exponent = drop_exponent_ptr[0];
+    float l[ROW_E], vd[ROW_E], vg[ROW_E], vf[ROW_E], y[ROW_E];
+#pragma unroll
+    for (int e = 0; e < ROW_E; ++e) {
+        const int c = tid + T * e;
+        const bool ok = c < k;
+        l[e] = ok ? lr[c] : -INFINITY; vd[e] = ok ? ud[c] : 1.0f; vg[e] = ok ? ug[c] : 0.5f; vf[e] = ok ? fr[c] : 0.0f;
+    }
+    float best_l = -INFINITY, best_y = -INFINITY;
+    int code = 0x7fffffff, idx = 0x7fffffff;
+#pragma unroll
+    for (int e = 0; e < ROW_E; ++e) {
+        const int c = tid + T * e;
+        if (c < k) {
+            if (drop_decision(vd[e], drop_exponent, vf[e])) l[e] = l[e] + -1e9f;
+            lr[c] = l[e];
+            const float u = fminf(fmaxf(vg[e], eps), 1.0f - eps);
+            y[e] = l[e] + gumbel_noise(u);
+            if (l[e] > best_l) { best_l = l[e]; code = c; }
+            if (y[e] > best_y) { best_y = y[e]; idx = c; }
+        } else
+            y[e] = -INFINITY;
+    }
+    // (a thread whose elements are all -inf / NaN keeps index INT_MAX: it loses every tie, like the serial scan that starts at 0)
+    row_argmax2<T>(best_l, code, best_y, idx, sm);
+    float sum = 0.0f, unused = 0.0f;
+#pragma unroll
+    for (int e = 0; e < ROW_E; ++e) sum += tid + T * e < k ? exp_nonpos(y[e] - best_y) : 0.0f;      // (exp_nonpos(-inf) is NaN)
+    row_sum2<T>(sum, unused, sm, 2);
+    if (tid == 0) {
+        const float s = 1.0f / sum;
+        codes[row] = code == 0x7fffffff ? 0 : code;
+        index[row] = idx == 0x7fffffff ? 0 : idx;
+        hot[row] = (1.0f - s) + s;
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(T < 256 ? 256 : T) void vq_softmax_bwd_row_kernel(const float* __restrict__ logits, const float* __restrict__ u_gumbel,
+                                                                                float* __restrict__ ds, const float* __restrict__ temperature,
+                                                                                float bound, float scale, float* __restrict__ rowsum,
+                                                                                float* __restrict__ dtrow, const float* __restrict__ dlogits,
+                                                                                const float* __restrict__ raw_logits, int rows, int m, int hw, int k) {
+    __shared__ RowShared<T> sm;
+    constexpr int RPW = T < 256 ? 256 / T : 1;
+    const int tid = T < 256 ? (int)(threadIdx.x & (T - 1)) : (int)threadIdx.x;
+    const int row = blockIdx.x * RPW + (T < 256 ? (int)(threadIdx.x / T) : 0);
+    if (row >= rows) return;
+    const int g = (row / hw) % m;
+    const float tb = fmaxf(temperature[g], bound);
+    const float* lr = logits + (size_t)row * k;
+    const float* ug = u_gumbel + (size_t)row * k;
+    float* dr = ds + (size_t)row * k;
+    const float* dl = dlogits ? dlogits + (size_t)row * k : nullptr;
+    const float* rw = raw_logits ? raw_logits + (size_t)row * k : nullptr;
+    const float eps = 1.1920928955078125e-07f;
+    float l[ROW_E], y[ROW_E], dd[ROW_E];
+#pragma unroll
+    for (int e = 0; e < ROW_E; ++e) {
+        const int c = tid + T * e;
+        const bool ok = c < k;
+        l[e] = ok ? lr[c] : -INFINITY; y[e] = ok ? ug[c] : 0.5f; dd[e] = ok ? dr[c] : 0.0f;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < ROW_E; ++e) {
+        const float u = fminf(fmaxf(y[e], eps), 1.0f - eps);
+        y[e] = l[e] + gumbel_noise(u);                           // (-inf beyond the row)
+        mx = fmaxf(mx, y[e]);
+    }
+    mx = row_max<T>(mx, sm);
+    float sum = 0.0f, dot = 0.0f;
+#pragma unroll
+    for (int e = 0; e < ROW_E; ++e) {
+        y[e] = tid + T * e < k ? exp_nonpos(y[e] - mx) : 0.0f;
+        sum += y[e];
+        dot += y[e] * dd[e];
+    }
+    row_sum2<T>(sum, dot, sm, 1);
+    const float inv = 1.0f / sum;
+    dot *= inv;
+    float rs = 0.0f, dt = 0.0f;
+    const float dscale = -tb / scale;
+#pragma unroll
+    for (int e = 0; e < ROW_E; ++e) {
+        const int c = tid + T * e;
+        if (c < k) {
+            float dz = (y[e] * inv) * (dd[e] - dot);
+            if (dl) {
+                dz += dl[c];
+                dt += dz * (rw[c] / tb);
+            } else if (dz != 0.0f) dt += dz * (l[e] / tb);
+            const float dv = dz * dscale;
+            dr[c] = dv;
+            rs += dv;
+        }
+    }
+    if constexpr (T > 64) __syncthreads();                       // (slot 1 / 2 of the scratch are read by the sum above: reuse 2 / 3)
+    row_sum2<T>(rs, dt, sm, 2);
+    if (tid == 0) { rowsum[row] = rs; dtrow[row] = dt; }
+}
+
 }  // namespace
 
 extern "C" int mcq_vq_logits_f32(const float* x, const float* cb_packed, const float* temperature, float bound, float* logits,
@@ -436,8 +625,19 @@ extern "C" int mcq_vq_gumbel_sample_f32(float* logits, const float* u_drop, cons
     if (N <= 0 || m <= 0 || h <= 0 || w <= 0 || k <= 0) return MCQ_EINVAL;
     const long long rows = (long long)N * m * h * w;
     if (rows > 0x7fffffffLL) return MCQ_ETOOLARGE;
-    hipLaunchKernelGGL(vq_gumbel_sample_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits,
-                       u_drop, u_gumbel, freq_ema, drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
+    hipStream_t s = (hipStream_t)stream;
+    if (k <= 64 * ROW_E)
+        hipLaunchKernelGGL(vq_gumbel_sample_row_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, u_drop, u_gumbel,
+                           freq_ema, drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
+    else if (k <= 256 * ROW_E)
+        hipLaunchKernelGGL(vq_gumbel_sample_row_kernel<256>, dim3((unsigned)rows), dim3(256), 0, s, logits, u_drop, u_gumbel, freq_ema,
+                           drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
+    else if (k <= 1024 * ROW_E)
+        hipLaunchKernelGGL(vq_gumbel_sample_row_kernel<1024>, dim3((unsigned)rows), dim3(1024), 0, s, logits, u_drop, u_gumbel, freq_ema,
+                           drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
+    else
+        hipLaunchKernelGGL(vq_gumbel_sample_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits,
+                           u_drop, u_gumbel, freq_ema, drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
     return mcq_check_launch();
 }
 
@@ -458,8 +658,20 @@ extern "C" int mcq_vq_softmax_bwd_f32(const float* logits, const float* u_gumbel
     if ((dlogits != nullptr) != (raw_logits != nullptr)) return MCQ_EINVAL;
     const long long rows = (long long)N * m * h * w;
     if (rows > 0x7fffffffLL) return MCQ_ETOOLARGE;
-    hipLaunchKernelGGL(vq_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, u_gumbel,
-                       ds_inout, temperature, bound, (float)sqrt((double)k), rowsum, dtrow, dlogits, raw_logits, (int)rows, m, h * w, k);
+    hipStream_t s = (hipStream_t)stream;
+    const float scale = (float)sqrt((double)k);
+    if (k <= 64 * ROW_E)
+        hipLaunchKernelGGL(vq_softmax_bwd_row_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, u_gumbel, ds_inout,
+                           temperature, bound, scale, rowsum, dtrow, dlogits, raw_logits, (int)rows, m, h * w, k);
+    else if (k <= 256 * ROW_E)
+        hipLaunchKernelGGL(vq_softmax_bwd_row_kernel<256>, dim3((unsigned)rows), dim3(256), 0, s, logits, u_gumbel, ds_inout, temperature,
+                           bound, scale, rowsum, dtrow, dlogits, raw_logits, (int)rows, m, h * w, k);
+    else if (k <= 1024 * ROW_E)
+        hipLaunchKernelGGL(vq_softmax_bwd_row_kernel<1024>, dim3((unsigned)rows), dim3(1024), 0, s, logits, u_gumbel, ds_inout, temperature,
+                           bound, scale, rowsum, dtrow, dlogits, raw_logits, (int)rows, m, h * w, k);
+    else
+        hipLaunchKernelGGL(vq_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, u_gumbel,
+                           ds_inout, temperature, bound, scale, rowsum, dtrow, dlogits, raw_logits, (int)rows, m, h * w, k);
     return mcq_check_launch();
 }
 
@@ -596,13 +808,21 @@ extern "C" int mcq_vq_soft_bwd_f32(const float* ddist, const float* rowsum, cons
     if (rows > 0x7fffffffLL) return MCQ_ETOOLARGE;
     hipStream_t s = (hipStream_t)stream;
     const int hw = h * w;
-    if (d <= 64 && hw % DX_R == 0 && k % 16 == 0)
+    VqBwdK q;
+    q.ddist = ddist; q.rowsum = rowsum; q.x = x; q.xt = x_nhwc; q.dqt = ddeq_nhwc; q.index = sample_index; q.hot = sample_hot;
+    q.cb = codebook; q.dx = dx; q.dcb = dcodebook; q.N = N; q.m = m; q.d = d; q.hw = hw; q.k = k; q.rows = (int)rows;
+    // the MFMA forms (vq_bwd_mfma.hip) wherever their tiling fits; the lane-per-channel forms below for the rest
+    if (mcq_vq_dx_mfma_ok(q))
+        mcq_vq_dx_mfma_launch(q, stream);
+    else if (d <= 64 && hw % DX_R == 0 && k % 16 == 0)
         hipLaunchKernelGGL(vq_dx_tiled_kernel, dim3((unsigned)(rows / DX_R)), dim3(256), 0, s, ddist, rowsum, x, codebook, dx,
                            (int)rows, m, d, hw, k);
     else
         hipLaunchKernelGGL(vq_dx_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ddist, rowsum, x, codebook, dx, (int)rows, m, d,
                            hw, k);
-    if (d <= 64 && k % DC_W == 0)
+    if (mcq_vq_dc_mfma_ok(q))
+        mcq_vq_dc_mfma_launch(q, stream);
+    else if (d <= 64 && k % DC_W == 0)
         hipLaunchKernelGGL(vq_dc_tiled_kernel, dim3((unsigned)(k / DC_W), (unsigned)m), dim3(256), 0, s, ddist, x_nhwc, ddeq_nhwc,
                            sample_index, sample_hot, codebook, dcodebook, N, m, d, hw, k);
     else

@@ -417,3 +417,43 @@ def test_winograd_input_gradient_pack(dev):
     assert back.wino is not None and (back.cout, back.cin) == (128, 64)
     _close(ops.conv2d(dy.to(dev), back, winograd=True), x.grad, 1e-5, "winograd input gradient")
     _close(ops.conv2d(dy.to(dev), back, winograd=False), x.grad, 2e-6, "direct input gradient")
+
+
+@pytest.mark.parametrize("case", [(8, 2, 64, 16, 16, 8192),     # config #5, first level: both MFMA forms
+                                  (8, 2, 64, 8, 8, 2048),       # second level: both MFMA forms
+                                  (8, 2, 64, 4, 4, 512),        # third level: dC on the MFMA form, dx on the lane-per-channel one
+                                  (2, 3, 24, 4, 16, 512),       # d < 32: one channel block empty, the other partly
+                                  (1, 2, 40, 8, 8, 1024),       # d between the blocks
+                                  (3, 2, 16, 3, 5, 48)])        # nothing fits: both lane-per-channel forms
+def test_soft_assignment_backward_contractions(dev, case):
+    """mcq_vq_soft_bwd_f32 (the MFMA forms of csrc/vq_bwd_mfma.hip and the forms they replace) against the two contractions
+    written out in float64: dx = 2 x rowsum - 2 ddist C, dC = 2 C colsum - 2 ddist^T x + scatter(hot dDeq)."""
+    import numpy as np
+    from mcquic_amd import ops
+    n, m, d, h, w, k = case
+    hw = h * w
+    ddist = _rand((n, m, h, w, k), 1, 1e-3)
+    x = _rand((n, m * d, h, w), 2)
+    ddeq = _rand((n, m * d, h, w), 3)
+    cb = _rand((m, k, d), 4)
+    g = torch.Generator().manual_seed(5)
+    index = torch.randint(0, k, (n, m, h, w), generator=g)
+    index[0, 0, 0, :] = 7 % k                                    # several vectors on one codeword: the scatter adds them up
+    hot = 1.0 + _rand((n, m, h, w), 6, 1e-3)
+    rowsum = ddist.double().sum(-1).float()
+    dd = ddist.double().numpy().reshape(n, m, hw, k)
+    xx = x.double().numpy().reshape(n, m, d, hw)
+    dq = ddeq.double().numpy().reshape(n, m, d, hw)
+    cc = cb.double().numpy()
+    want_dx = 2 * xx * rowsum.double().numpy().reshape(n, m, 1, hw) - 2 * np.einsum("ngvk,gkj->ngjv", dd, cc)
+    want_dc = 2 * cc * dd.sum((0, 2))[:, :, None] - 2 * np.einsum("ngvk,ngjv->gkj", dd, xx)
+    idx, hv = index.numpy().reshape(n, m, hw), hot.double().numpy().reshape(n, m, hw)
+    for a in range(n):
+        for b in range(m):
+            np.add.at(want_dc[b], idx[a, b], (hv[a, b][None, :] * dq[a, b]).T)
+    pk = ops.PackedCodebook(cb.to(dev))
+    dx, dcb = ops.vq_soft_bwd(ddist.to(dev), rowsum.to(dev), x.to(dev), ddeq.to(dev), index.to(dev), hot.to(dev), pk)
+    _close(dx, torch.from_numpy(want_dx.reshape(n, m * d, h, w)).float(), 2e-6, f"dx {case}")
+    _close(dcb, torch.from_numpy(want_dc).float(), 2e-6, f"dcodebook {case}")
+    dx2, dcb2 = ops.vq_soft_bwd(ddist.to(dev), rowsum.to(dev), x.to(dev), ddeq.to(dev), index.to(dev), hot.to(dev), pk)
+    assert torch.equal(dx, dx2) and torch.equal(dcb, dcb2), "the contractions are deterministic"

@@ -37,14 +37,17 @@ def test_neon_oracle_matches_reference_vectors(dense):
     codes = N.encode(sd, x)
     for lv, c in enumerate(codes):
         assert torch.equal(c, torch.from_numpy(z[f"code{lv}"].astype(np.int64))), lv
+    # (the GroupNorm variant amplifies the host's float32 summation order: the same oracle on the GPU box's CPU sits 1.1e-5 from the
+    #  vectors captured in the build container, the plain variant 0)
+    tol, tol_t = (5e-5, 1e-4) if dense else (2e-6, 5e-6)
     rec = N.decode(sd, codes)
-    np.testing.assert_allclose(rec[..., ::4, ::4].numpy(), z["rec_strided"], rtol=0, atol=2e-6)
-    np.testing.assert_allclose(N.residual_backward(sd, codes[1], 2).numpy(), z["residual_backward_1_2"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(rec[..., ::4, ::4].numpy(), z["rec_strided"], rtol=0, atol=tol)
+    np.testing.assert_allclose(N.residual_backward(sd, codes[1], 2).numpy(), z["residual_backward_1_2"], rtol=0, atol=tol)
     rf = N.residual_forward(sd, codes[1], N.residual_forward(sd, codes[0], None, 0), 1)
-    np.testing.assert_allclose(rf.numpy(), z["residual_forward_1"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(rf.numpy(), z["residual_forward_1"], rtol=0, atol=tol)
     xHat, yHat, codesT, logits, _ = N.forward_train(sd, x, _uniforms(k))
-    np.testing.assert_allclose(xHat[..., ::4, ::4].numpy(), z["train_xHat_strided"], rtol=0, atol=5e-6)
-    np.testing.assert_allclose(yHat.numpy(), z["train_yHat"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(xHat[..., ::4, ::4].numpy(), z["train_xHat_strided"], rtol=0, atol=tol_t)
+    np.testing.assert_allclose(yHat.numpy(), z["train_yHat"], rtol=0, atol=tol_t)
     for lv in range(4):
         assert torch.equal(codesT[lv], torch.from_numpy(z[f"train_code{lv}"].astype(np.int64)))
 

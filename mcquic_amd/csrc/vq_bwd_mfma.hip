@@ -16,22 +16,23 @@ __device__ __forceinline__ f32x4v load4_s(__amdgpu_buffer_rsrc_t r, unsigned vof
     return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 
-// ---- d codebook: D[c][j] over v.  A workgroup owns 32 codewords of one group; its four waves are four slices of the vectors
-// and meet in LDS in wave order (deterministic).  A operand: lane (hi, i) = ddist[v = 2 s + hi][c0 + i] -- 128 contiguous bytes
+// ---- d codebook: D[c][j] over v.  A workgroup owns 32 codewords of one group; its eight waves are eight slices of the vectors
+// and meet in LDS in wave order (deterministic).  (Four waves with an 8-step ring: 80 us at k = 8192 against 27 us of MFMA time --
+// every ddist line is a first touch from HBM, and 8 steps x 128 MFMA cycles is less than that latency.)  A operand: lane (hi, i) = ddist[v = 2 s + hi][c0 + i] -- 128 contiguous bytes
 // per half-wave; B operand: lane (hi, j) = x[v][g d + j] from the channel-major copy, two 32-channel blocks.  The column sum of
 // ddist rides along on the VALU (one add per step); the straight-through term -- hot_v dDeq_v into the row of v's sampled
 // codeword -- is sparse (one row per vector): every wave scans the indices of its slice, 64 at a time, and adds the hits in
 // vector order.
-constexpr int DC_PF = 8;
-__global__ __launch_bounds__(256) void vq_dc_mfma_kernel(VqBwdK p) {
-    __shared__ float part[3][2][16][64];
-    __shared__ float part_cs[3][64];
+constexpr int DC_PF = 16, DC_WAVES = 8;
+__global__ __launch_bounds__(64 * DC_WAVES) void vq_dc_mfma_kernel(VqBwdK p) {
+    __shared__ float part[DC_WAVES - 1][2][16][64];
+    __shared__ float part_cs[DC_WAVES - 1][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int hi = lane >> 5, i = lane & 31;
     const int g = blockIdx.y, c0 = blockIdx.x * 32;
     const int C = p.m * p.d, V = p.N * p.hw;
-    const int per = V >> 2;                                          // V % 64 == 0 (launcher): whole rings per slice
+    const int per = V / DC_WAVES;                                    // V % (2 DC_WAVES) == 0 (launcher): whole vector pairs per slice
     const int v0 = wave * per;
     const __amdgpu_buffer_rsrc_t dr = mcq_make_rsrc(p.ddist, (unsigned)((size_t)p.rows * p.k * 4u));
     const __amdgpu_buffer_rsrc_t xr = mcq_make_rsrc(p.xt, (unsigned)((size_t)V * C * 4u));
@@ -112,7 +113,9 @@ __global__ __launch_bounds__(256) void vq_dc_mfma_kernel(VqBwdK p) {
     }
     __syncthreads();
     if (wave != 0) return;
-    const float col_i = ((cs + part_cs[0][lane]) + part_cs[1][lane]) + part_cs[2][lane];
+    float col_i = cs;
+#pragma unroll
+    for (int w = 0; w < DC_WAVES - 1; ++w) col_i += part_cs[w][lane];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int cr = mcq_drow(r, hi);
@@ -122,7 +125,9 @@ __global__ __launch_bounds__(256) void vq_dc_mfma_kernel(VqBwdK p) {
         for (int nb = 0; nb < 2; ++nb) {
             const int j = 32 * nb + i;
             if (j < p.d && c < p.k) {
-                const float t = ((acc[nb][r] + part[0][nb][r][lane]) + part[1][nb][r][lane]) + part[2][nb][r][lane];
+                float t = acc[nb][r];
+#pragma unroll
+                for (int w = 0; w < DC_WAVES - 1; ++w) t += part[w][nb][r][lane];
                 const size_t ci = ((size_t)g * p.k + c) * p.d + j;
                 p.dcb[ci] = 2.0f * p.cb[ci] * col + t;
             }
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void vq_dc_mfma_kernel(VqBwdK p) {
 
 // ---- dx: D[j][v] over the codewords.  A workgroup owns 32 consecutive vectors of one (image, group); its sixteen waves are
 // sixteen slices of the codewords (the tile count is rows / 32 = 128 at the first level: the split has to come from inside the
-// workgroup) and meet in LDS as a fixed binary tree.  ddist is contiguous along the codewords and a lane owns a VECTOR, so a
+// workgroup -- and, below 256 tiles, from a second workgroup per tile, see the launcher) and meet in LDS as a fixed binary tree.  ddist is contiguous along the codewords and a lane owns a VECTOR, so a
 // lane reads 16 bytes = four codewords of its row per access and the k-steps take the codewords in the order the lanes hold them:
 // step (q, t) contracts codeword 8 q + 4 hi + t on half `hi`.  A operand: lane (hi, i) = C[g][8 q + 4 hi + t][32 jb + i].
 constexpr int DX_PFQ = 4;
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(1024) void vq_dx_mfma_kernel(VqBwdK p) {
     const int hi = lane >> 5, i = lane & 31;
     const int row0 = blockIdx.x * 32;                                // hw % 32 == 0: the 32 rows share (n, g)
     const int pix0 = row0 % p.hw, ng = row0 / p.hw, g = ng % p.m;
-    const int kslice = p.k >> 4, kk0 = wave * kslice;                // k % 512 == 0 (launcher): whole rings per slice
+    const int kslice = p.k / (16 * (int)gridDim.y), kk0 = ((int)blockIdx.y * 16 + wave) * kslice;     // (launcher: kslice % 8 == 0)
     const __amdgpu_buffer_rsrc_t dr = mcq_make_rsrc(p.ddist, (unsigned)((size_t)p.rows * p.k * 4u));
     const __amdgpu_buffer_rsrc_t cr = mcq_make_rsrc(p.cb, (unsigned)((size_t)p.m * p.k * p.d * 4u));
     const unsigned bvo = ((unsigned)i * (unsigned)p.k + 4u * (unsigned)hi) * 4u;
@@ -215,7 +220,10 @@ __global__ __launch_bounds__(1024) void vq_dx_mfma_kernel(VqBwdK p) {
             const int j = 32 * jb + mcq_drow(r, hi);
             if (j < p.d) {
                 const size_t xi = ((size_t)ng * p.d + j) * p.hw + pix0 + i;
-                p.dx[xi] = 2.0f * p.x[xi] * rs - 2.0f * acc[jb][r];
+                if (gridDim.y == 1) p.dx[xi] = 2.0f * p.x[xi] * rs - 2.0f * acc[jb][r];
+                // two workgroups per tile (halves of the codewords): each adds its part onto the zeroed output -- with exactly two
+                // addends the sum does not depend on who comes first (0 + a is a, a + b is b + a)
+                else unsafeAtomicAdd(p.dx + xi, blockIdx.y == 0 ? 2.0f * p.x[xi] * rs - 2.0f * acc[jb][r] : -2.0f * acc[jb][r]);
             }
         }
 }
@@ -224,16 +232,19 @@ __global__ __launch_bounds__(1024) void vq_dx_mfma_kernel(VqBwdK p) {
 
 bool mcq_vq_dc_mfma_ok(const VqBwdK& p) {
     const long long V = (long long)p.N * p.hw;
-    return p.d <= 64 && p.k % 32 == 0 && p.hw % 2 == 0 && V % 64 == 0 && (unsigned long long)p.rows * p.k * 4ull < 0x80000000ull &&
+    return p.d <= 64 && p.k % 32 == 0 && p.hw % 2 == 0 && V % (2 * DC_WAVES) == 0 && (unsigned long long)p.rows * p.k * 4ull < 0x80000000ull &&
            (unsigned long long)V * p.m * p.d * 4ull < 0x80000000ull;
 }
 bool mcq_vq_dx_mfma_ok(const VqBwdK& p) {
-    return p.d <= 64 && p.hw % 32 == 0 && p.k % 512 == 0 && (unsigned long long)p.rows * p.k * 4ull < 0x80000000ull &&
+    return p.d <= 64 && p.hw % 32 == 0 && p.k % 128 == 0 && (unsigned long long)p.rows * p.k * 4ull < 0x80000000ull &&
            (unsigned long long)p.m * p.k * p.d * 4ull < 0x80000000ull;
 }
 void mcq_vq_dc_mfma_launch(const VqBwdK& p, void* stream) {
-    hipLaunchKernelGGL(vq_dc_mfma_kernel, dim3((unsigned)(p.k / 32), (unsigned)p.m), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(vq_dc_mfma_kernel, dim3((unsigned)(p.k / 32), (unsigned)p.m), dim3(64 * DC_WAVES), 0, (hipStream_t)stream, p);
 }
 void mcq_vq_dx_mfma_launch(const VqBwdK& p, void* stream) {
-    hipLaunchKernelGGL(vq_dx_mfma_kernel, dim3((unsigned)(p.rows / 32)), dim3(1024), 0, (hipStream_t)stream, p);
+    // fewer tiles than CUs (rows / 32 = 128 at the first training level): the codewords are halved over two workgroups per tile
+    const unsigned zs = (p.rows / 32 < 256 && p.k % 256 == 0) ? 2u : 1u;
+    if (zs == 2) (void)hipMemsetAsync(p.dx, 0, (size_t)p.rows * p.d * sizeof(float), (hipStream_t)stream);
+    hipLaunchKernelGGL(vq_dx_mfma_kernel, dim3((unsigned)(p.rows / 32), zs), dim3(1024), 0, (hipStream_t)stream, p);
 }

@@ -24,10 +24,23 @@ struct VqLogitK {
     const float* temperature;   // [m]
     float bound;
     float scale;                // sqrt(k)
+    float rscale;               // RN(1 / scale)
     float* logits;              // [N, m, h, w, k]
     int raw;                    // 1: store the inner products <x_v, c_k> themselves (backward: dSample = dDeq . C^T)
     int tiles_per_z;            // codeword tiles per blockIdx.z (the logits of different tiles are independent)
 };
+
+// a / s, correctly rounded, for a divisor that is the same for the whole launch (sqrt(k)): with r = RN(1 / s), q0 = RN(a r) is
+// within one ulp of the quotient, the remainder a - q0 s is exact in an fma, and RN(q0 + rem r) is the correctly rounded quotient
+// (Markstein's division theorem; denormal quotients aside, which a distance over sqrt(k) never is).  Three instructions for the
+// ~13 of the IEEE division sequence -- 33.5 M of them sit in the epilogue of the k = 8192 level, issued in the MFMAs' shadow-less
+// tail of every tile (tests/test_gpu_train_forward.py::test_logit_division_is_the_ieee_quotient holds it to numpy's float32 division).
+__device__ __forceinline__ float div_by_constant(float a, float s, float r) {
+    const float q0 = a * r;
+    const float rem = __builtin_fmaf(-q0, s, a);
+    const float q1 = __builtin_fmaf(rem, r, q0);
+    return __builtin_isfinite(q0) ? q1 : q0;
+}
 
 __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
     const VqK& p = q.v;
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
                                 row[word] = acc[nb][wb][r];
                             } else {
                                 const float dist = __builtin_fmaf(-2.0f, acc[nb][wb][r], x2d[nb][r] + c2t[wb]);
-                                row[word] = ((-1.0f * dist) / q.scale) * tmax;
+                                row[word] = div_by_constant(-1.0f * dist, q.scale, q.rscale) * tmax;
                             }
                         }
                     }
@@ -452,8 +465,10 @@ __device__ __forceinline__ float row_max(float a, RowShared<T>& sm) {
     return a;
 }
 
+// (two 1024-thread workgroups per CU = eight waves per SIMD = 64 registers: with one, the load / arithmetic / reduction phases of a row -- separated by
+//  workgroup barriers -- have nothing to overlap with: 202 us = the row traffic plus the arithmetic, one after the other)
 template <int T>
-__global__ __launch_bounds__(T < 256 ? 256 : T) void vq_gumbel_sample_row_kernel(float* __restrict__ logits, const float* __restrict__ u_drop,
+__global__ __launch_bounds__(T < 256 ? 256 : T, T == 1024 ? 8 : 1) void vq_gumbel_sample_row_kernel(float* __restrict__ logits, const float* __restrict__ u_drop,
                                                                                   const float* __restrict__ u_gumbel,
                                                                                   const float* __restrict__ freq,
                                                                                   const float* __restrict__ drop_exponent_ptr,
@@ -471,27 +486,33 @@ __global__ __launch_bounds__(T < 256 ? 256 : T) void vq_gumbel_sample_row_kernel
     const float* fr = freq + (size_t)g * k;
     const float eps = 1.1920928955078125e-07f;
     const float drop_exponent = drop_exponent_ptr[0];
-    float l[ROW_E], vd[ROW_E], vg[ROW_E], vf[ROW_E], y[ROW_E];
-#pragma unroll
-    for (int e = 0; e < ROW_E; ++e) {
-        const int c = tid + T * e;
-        const bool ok = c < k;
-        l[e] = ok ? lr[c] : -INFINITY; vd[e] = ok ? ud[c] : 1.0f; vg[e] = ok ? ug[c] : 0.5f; vf[e] = ok ? fr[c] : 0.0f;
-    }
+    float y[ROW_E];
     float best_l = -INFINITY, best_y = -INFINITY;
     int code = 0x7fffffff, idx = 0x7fffffff;
+    // (two batches of four elements: sixteen loads in flight per thread, and the four inputs of an element die before the next
+    //  batch arrives -- all eight at once need 40 live registers plus libm's, which does not fit the 64 of two workgroups per CU)
 #pragma unroll
-    for (int e = 0; e < ROW_E; ++e) {
-        const int c = tid + T * e;
-        if (c < k) {
-            if (drop_decision(vd[e], drop_exponent, vf[e])) l[e] = l[e] + -1e9f;
-            lr[c] = l[e];
-            const float u = fminf(fmaxf(vg[e], eps), 1.0f - eps);
-            y[e] = l[e] + gumbel_noise(u);
-            if (l[e] > best_l) { best_l = l[e]; code = c; }
-            if (y[e] > best_y) { best_y = y[e]; idx = c; }
-        } else
-            y[e] = -INFINITY;
+    for (int e0 = 0; e0 < ROW_E; e0 += 4) {
+        float l[4], vd[4], vg[4], vf[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = tid + T * (e0 + e);
+            const bool ok = c < k;
+            l[e] = ok ? lr[c] : -INFINITY; vd[e] = ok ? ud[c] : 1.0f; vg[e] = ok ? ug[c] : 0.5f; vf[e] = ok ? fr[c] : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = tid + T * (e0 + e);
+            if (c < k) {
+                if (drop_decision(vd[e], drop_exponent, vf[e])) l[e] = l[e] + -1e9f;
+                lr[c] = l[e];
+                const float u = fminf(fmaxf(vg[e], eps), 1.0f - eps);
+                y[e0 + e] = l[e] + gumbel_noise(u);
+                if (l[e] > best_l) { best_l = l[e]; code = c; }
+                if (y[e0 + e] > best_y) { best_y = y[e0 + e]; idx = c; }
+            } else
+                y[e0 + e] = -INFINITY;
+        }
     }
     // (a thread whose elements are all -inf / NaN keeps index INT_MAX: it loses every tie, like the serial scan that starts at 0)
     row_argmax2<T>(best_l, code, best_y, idx, sm);
@@ -508,7 +529,7 @@ __global__ __launch_bounds__(T < 256 ? 256 : T) void vq_gumbel_sample_row_kernel
 }
 
 template <int T>
-__global__ __launch_bounds__(T < 256 ? 256 : T) void vq_softmax_bwd_row_kernel(const float* __restrict__ logits, const float* __restrict__ u_gumbel,
+__global__ __launch_bounds__(T < 256 ? 256 : T, T == 1024 ? 8 : 1) void vq_softmax_bwd_row_kernel(const float* __restrict__ logits, const float* __restrict__ u_gumbel,
                                                                                 float* __restrict__ ds, const float* __restrict__ temperature,
                                                                                 float bound, float scale, float* __restrict__ rowsum,
                                                                                 float* __restrict__ dtrow, const float* __restrict__ dlogits,
@@ -584,6 +605,7 @@ extern "C" int mcq_vq_logits_f32(const float* x, const float* cb_packed, const f
     q.temperature = temperature; q.bound = bound; q.logits = logits; q.raw = 0;
     // sqrt(k) as the reference computes it: math.sqrt (double) then used as a Python float in a float32 division
     q.scale = (float)sqrt((double)k);
+    q.rscale = (float)(1.0 / (double)q.scale);
     const unsigned gx = (unsigned)(((q.v.total_blocks + VQ_NB - 1) / VQ_NB + 3) / 4);
     // (vector tiles x m) waves walk all codeword tiles otherwise: split the tiles over grid.z until ~2048 waves exist
     {
@@ -604,7 +626,7 @@ extern "C" int mcq_vq_inner_f32(const float* x, const float* cb_packed, float* o
     VqLogitK q;
     if (!vq_setup(q.v, x, cb_packed, N, m, d, h, w, k)) return MCQ_ETOOLARGE;
     q.v.codes = nullptr;
-    q.temperature = nullptr; q.bound = 0.0f; q.scale = 1.0f; q.logits = out; q.raw = 1;
+    q.temperature = nullptr; q.bound = 0.0f; q.scale = 1.0f; q.rscale = 1.0f; q.logits = out; q.raw = 1;
     const unsigned gx = (unsigned)(((q.v.total_blocks + VQ_NB - 1) / VQ_NB + 3) / 4);
     // (vector tiles x m) waves walk all codeword tiles otherwise: split the tiles over grid.z until ~2048 waves exist
     {

@@ -32,6 +32,26 @@ def test_logits(dev, shape):
     assert err <= 2e-6 * max(1.0, want.abs().max().item()), f"logits max abs err {err:.3e}"
 
 
+@pytest.mark.parametrize("k", [8192, 2048, 512, 200, 32, 8])
+def test_logit_division_is_the_ieee_quotient(dev, k):
+    """-dist / sqrt(k) is computed as two fused steps around a precomputed reciprocal (csrc/vq_train.hip: div_by_constant); the
+    result must be the correctly rounded float32 quotient the reference's `/` gives.  A zero latent against codewords with a single
+    non-zero component makes dist = fl(v^2) exactly, so every logit is one known quotient: 16 x k of them per case."""
+    from mcquic_amd import ops
+    m, d = 16, 4
+    g = torch.Generator().manual_seed(k)
+    v = (torch.rand((m, k), generator=g) * 2 - 1) * torch.exp(torch.rand((m, k), generator=g) * 12 - 6)      # magnitudes 2.5e-3 .. 400
+    cb = torch.zeros((m, k, d))
+    cb[:, :, 1] = v
+    x = torch.zeros((1, m * d, 1, 1))
+    temp = torch.ones((m, 1, 1, 1))
+    got = ops.vq_logits(x.to(dev), ops.PackedCodebook(cb.to(dev)), temp.to(dev), R.EPS).cpu().numpy().reshape(m, k)
+    dist = (v.numpy() * v.numpy()).astype(np.float32)
+    want = (-dist) / np.float32(np.sqrt(np.float64(k)))
+    assert want.dtype == np.float32
+    assert np.array_equal(got, want), f"{(got != want).sum()} of {got.size} quotients differ"
+
+
 def test_gumbel_sample_and_soft_dequant(dev):
     from mcquic_amd import ops
     m, k, d, n, h, w = 2, 512, 64, 2, 4, 5

@@ -36,13 +36,9 @@
 #ifndef MCQ_PFB
 #define MCQ_PFB 18
 #endif
-// ... and of the 32 x 32 tile, the one the smallest maps run (split 8 ways, a wave's share of a 128-channel 3x3 layer is 72 steps)
-#ifndef MCQ_PF11A
-#define MCQ_PF11A 9
-#endif
-#ifndef MCQ_PF11B
-#define MCQ_PF11B 18
-#endif
+// (measured and dropped, round 3: deeper rings -- 18 / 36 and 36 / 36 steps -- for the 32 x 32 tile of the smallest maps, where a
+//  wave's share of a split 128-channel 3x3 layer is 72 steps: kernel durations unchanged in isolation (10.2-10.8 us), the training
+//  step 24.1 -> 24.2 ms.  tools/probes/pf11_sweep.sh)
 #ifndef MCQ_WINO_PERSIST
 #define MCQ_WINO_PERSIST 1          // workgroups per CU of the persistent 128-row Winograd instance; 0 = one workgroup per four tiles
 #endif
@@ -1423,7 +1419,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     if (MB == 2 && NB == 1) return launch_tile<2, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 1 && NB == 4) return launch_tile<1, 4, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 1 && NB == 2) return launch_tile<1, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 1 && NB == 1) return launch_tile<1, 1, MCQ_PF11A, MCQ_PF11B, 16>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 1 && NB == 1) return launch_tile<1, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
     return MCQ_EINVAL;
 }
 

@@ -28,7 +28,7 @@ SHAPES = [  # n, cin, cout, h, w, ks, stride
     (32, 128, 128, 192, 128, 1, 1),
     (32, 128, 128, 384, 256, 1, 1),
 ]
-TILES = [0, 0x42, 0x142, 0x242, 0x342, 0x41, 0x141, 0x241, 0x341, 0x22, 0x122, 0x222, 0x322, 0x11, 0x311]
+TILES = [0, 0x42, 0x142, 0x242, 0x342, 0x41, 0x141, 0x241, 0x341, 0x22, 0x122, 0x222, 0x322, 0x21, 0x121, 0x221, 0x11, 0x311]
 
 
 def main():

@@ -854,6 +854,41 @@ next_tile:
     // the band in registers; the global-memory epilogues of all bands then run concurrently on their owner waves
     // after the last barrier (finishing inside the barrier pair serialised the bands: ~11 us each).
     float* slot0 = mcq_lds + (size_t)(tile_in_wg << p.ks_log2) * (NB * 1024);
+    if constexpr (MB == 1 && NB <= 2 && !WINO) {
+        // One band: slice 0's wave owns it.  The others park their partial tiles, ONE barrier, and the owner adds them (slice
+        // order, two slices per LDS round trip) from inside the epilogue's accumulator hook -- i.e. after the epilogue has
+        // requested its bias / residual, whose latency then runs beside the sum instead of after it.  Stamp probe of an 8-way
+        // split 4x4 launch (round 3, tools/probes/tiny_stamps.py): 1.4 us from the slowest slice's last MFMA to the summed tile
+        // with the general form below -- seven dependent LDS round trips between two barriers -- and 1.1 us of epilogue behind
+        // it; 0.3 + 1.5 us with this one.  (Also tried there: requesting the weight ring ahead of the ~1 us of pixel geometry.
+        // Nothing: the eight slices of a tile share one CU, and their k-loop is that CU's matrix pipe, not a latency.)
+        if (active && kslice != 0) {
+            float* mine = slot0 + (size_t)kslice * (NB * 1024) + lane;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(nb * 16 + r) * 64] = acc[0][nb][r];
+        }
+        __syncthreads();
+        run_epilogue(active && kslice == 0, [&](int, int nb, float (&v)[16]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[0][nb][r];
+            const float* other = slot0 + (size_t)(nb * 16) * 64 + lane;
+            int w = 1;
+            for (; w + 1 < KS; w += 2) {
+                float a[16], b[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { a[r] = other[(size_t)w * (NB * 1024) + r * 64]; b[r] = other[(size_t)(w + 1) * (NB * 1024) + r * 64]; }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = (v[r] + a[r]) + b[r];
+            }
+            if (w < KS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = v[r] + other[(size_t)w * (NB * 1024) + r * 64];
+            }
+        }, 0, std::integral_constant<int, 1>{});
+        return;
+    }
     float own[NB][16];                         // band `kslice` (the launcher guarantees KS >= MB when it splits)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {

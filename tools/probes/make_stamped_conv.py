@@ -41,6 +41,8 @@ after("    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 
 before("    // ---- operand prefetch rings ----", "    STAMP(1);\n")
 before("    // (WINO) the transformed inputs of a group of PG k-steps from its PG loads", "    STAMP(2);\n")
 before("    if (WASM) asm volatile(\"s_nop 15\\n\\ts_nop 15\");", "    STAMP(3);\n")
+before("        run_epilogue(active && kslice == 0, [&](int, int nb, float (&v)[16]) {", "        STAMP(4);\n")      # one-band tiles: after the barrier
+before("        return;\n    }\n    float own[NB][16];", "        STAMP(5);\n")
 before("    run_epilogue(active && kslice < MB, [&](int, int nb, float (&v)[16]) {", "    STAMP(4);\n")
 after("        for (int r = 0; r < 16; ++r) v[r] = own[nb][r];\n    }, kslice, std::integral_constant<int, 1>{});\n", "    STAMP(5);\n")
 

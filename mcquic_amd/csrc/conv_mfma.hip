@@ -1006,7 +1006,7 @@ inline int pairs_padded(int Cin, int ks) {        // 1x1 loops advance a whole p
 inline int steps_padded(int Cin, int ks) { return pairs_padded(Cin, ks) * ks * ks; }
 // The operand stream of conv_mfma_kernel exists once per tile height: 128-, 64- and 32-row copies, each with its own
 // zero steps for the prefetch tail (the deepest weight ring of any instance).
-constexpr int MCQ_TAIL_STEPS = 40;
+constexpr int MCQ_TAIL_STEPS = 16;
 inline size_t section_floats(int Cout, int Cin, int ks, int bands) {
     const size_t ntile = (size_t)(Cout + 32 * bands - 1) / (32 * bands);
     return (ntile * (size_t)steps_padded(Cin, ks) + MCQ_TAIL_STEPS) * 64 * bands;

@@ -30,7 +30,7 @@ extern "C" {
  * compares it with mcq_abi_version() of the library it loaded before calling anything else: a stale .so under new
  * prototypes (or the reverse) misaligns arguments silently otherwise.  3 = round 3 (mcq_rans_*_with_indexes take cdf_lens,
  * mcq_gate_f32 takes out_silu -- both changed in round 2 without a bump --, GroupNorm / logits-gradient entry points). */
-#define MCQ_ABI_VERSION   3
+#define MCQ_ABI_VERSION   4
 
 #define MCQ_OK            0
 #define MCQ_EINVAL       -1   /* NULL pointer / non-positive dimension / unsupported combination */
@@ -81,8 +81,9 @@ size_t mcq_packed_conv_weight_floats(int32_t Cout, int32_t Cin, int32_t ksize);
 
 /* Re-lay a dense OIHW weight (nn.Conv2d.weight, mcquic/nn/convs.py:77-100,257-276) into the MFMA operand streams the
  * conv kernels read: [Cout/128][Cin/2 x taps][64 lanes][4] followed by dense copies for the 64- and 32-row wave tiles
- * ([Cout/64][..][64][2], [Cout/32][..][64][1]) and, for 3x3 layers with <= 16 output channels, the operand order of the
- * 16-row image-head kernel; every copy zero padded (one launch). */
+ * ([Cout/64][..][64][2], [Cout/32][..][64][1]), for 3x3 layers with Cin 64 / 128 and Cout % 16 == 0 (>= 32) a fourth copy in
+ * the order of the small-launch kernel ([Cout/16][Cin/4 x 9 / 4][64][4], csrc/conv_t16.h) and, for 3x3 layers with <= 16 output
+ * channels, the operand order of the 16-row image-head kernel; every copy zero padded (one launch). */
 int mcq_pack_conv_weight_f32(const float* w_oihw, int32_t Cout, int32_t Cin, int32_t ksize,
                              float* w_packed, void* stream);
 
@@ -101,6 +102,12 @@ int mcq_pack_conv_weight_winograd_f32(const float* w_oihw, int32_t Cout, int32_t
  * the layer's own OIHW weight: w_packed holds mcq_packed_conv_winograd_floats(Cin, Cout) floats */
 int mcq_pack_conv_dgrad_weight_winograd_f32(const float* w_oihw, int32_t Cout, int32_t Cin, float* w_packed, void* stream);
 int32_t mcq_conv2d_winograd_ok(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, uint32_t flags);
+/* 1 if mcq_conv2d_f32 / mcq_conv2d_multi_f32 (nprob problems) run this geometry and flag set on the small-launch kernel (16 x 16
+ * tiles on v_mfma_f32_16x16x4_f32, one per workgroup: launches that would leave most of the GPU idle with 32-row tiles -- the
+ * 4x4 ... 16x16 maps of a training step, the 12x8 / 24x16 levels of a single image), 0 if on the general one.  Same arithmetic,
+ * same epilogue order; the summation order over (channel, tap) differs as between any two tile shapes. */
+int32_t mcq_conv2d_small_launch(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, uint32_t flags,
+                                int32_t nprob);
 
 /* The operand stream of a layer's INPUT-GRADIENT convolution, packed straight from the layer's own OIHW weight
  * [Cout, Cin, k, k] in one launch (what torch.autograd derives for nn.Conv2d, mcquic/nn/convs.py:77-100):

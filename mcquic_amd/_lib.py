@@ -48,6 +48,7 @@ SYMBOLS = {
     "mcq_packed_conv_winograd16_floats": (c_size_t, [c_int32, c_int32]),
     "mcq_pack_conv_weight_winograd16_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "mcq_conv2d_winograd_ok": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint32]),
+    "mcq_conv2d_small_launch": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint32, c_int32]),
     "mcq_pack_conv_weight_max_multi": (c_int32, []),
     "mcq_pack_conv_weight_multi_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "mcq_conv2d_max_multi": (c_int32, []),
@@ -118,7 +119,7 @@ SYMBOLS = {
     "mcq_abi_version": (c_int32, []),
 }
 
-ABI_VERSION = 3          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
+ABI_VERSION = 4          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
 
 _lib = None
 

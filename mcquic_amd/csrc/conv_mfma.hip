@@ -91,6 +91,7 @@ constexpr unsigned RUNTIME_FLAGS = 0xffffffffu;    // epilogue instance that tes
 }  // namespace
 
 #include "conv_head16.h"
+#include "conv_t16.h"
 
 namespace {
 
@@ -926,6 +927,7 @@ next_tile:
 // up to MCQ_PACK_MAX_MULTI weights of one shape per launch (blockIdx.y picks the pair): after an optimizer step every conv of
 // the network re-packs its forward and its input-gradient operand stream -- 660 launches of ~4 us each, one by one
 constexpr int PACK_MAX_MULTI = 16;
+constexpr int MCQ_TAIL_STEPS = 16;
 struct PackTable { const float* w[PACK_MAX_MULTI]; float* out[PACK_MAX_MULTI]; };
 
 __device__ __forceinline__ void pack_conv_weight_body(const float* __restrict__ w, int Cout, int Cin, int ks, int S, int TP,
@@ -938,6 +940,18 @@ __device__ __forceinline__ void pack_conv_weight_body(const float* __restrict__ 
     const size_t at = i;
     int bands = 4;
     if (i >= sec4) { i -= sec4; bands = 2; if (i >= sec2) { i -= sec2; bands = 1; } }
+    const size_t sec1 = ((size_t)((Cout + 31) / 32) * TP + MCQ_TAIL_STEPS) * 64;
+    if (bands == 1 && i >= sec1) {
+        // fourth section (conv_t16.h): [Cout / 16][(Cin / 4) * 9 / 4][lane][4], k-step 4 g + u = 9 (channel quad) + tap
+        i -= sec1;
+        const int u = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        const size_t gg = i >> 8;
+        const int G = (Cin / 4) * 9 / 4;
+        const int tile = (int)(gg / G), step = 4 * (int)(gg - (size_t)tile * G) + u;
+        const int co = 16 * tile + (lane & 15), ci = 4 * (step / 9) + (lane >> 4);
+        out[at] = pack_source(w, mode, Co, Ci, ks, co, ci, step % 9) * scale;
+        return;
+    }
     const int ntile = (Cout + 32 * bands - 1) / (32 * bands);
     const int q = (int)(i % bands);
     const int lane = (int)((i / bands) & 63);
@@ -1005,14 +1019,14 @@ inline int pairs_padded(int Cin, int ks) {        // 1x1 loops advance a whole p
 }
 inline int steps_padded(int Cin, int ks) { return pairs_padded(Cin, ks) * ks * ks; }
 // The operand stream of conv_mfma_kernel exists once per tile height: 128-, 64- and 32-row copies, each with its own
-// zero steps for the prefetch tail (the deepest weight ring of any instance).
-constexpr int MCQ_TAIL_STEPS = 16;
+// zero steps for the prefetch tail (MCQ_TAIL_STEPS: the deepest weight ring of any instance); layers conv_t16.h can take carry a
+// fourth section in its order.
 inline size_t section_floats(int Cout, int Cin, int ks, int bands) {
     const size_t ntile = (size_t)(Cout + 32 * bands - 1) / (32 * bands);
     return (ntile * (size_t)steps_padded(Cin, ks) + MCQ_TAIL_STEPS) * 64 * bands;
 }
 inline size_t general_floats(int Cout, int Cin, int ks) {
-    return section_floats(Cout, Cin, ks, 4) + section_floats(Cout, Cin, ks, 2) + section_floats(Cout, Cin, ks, 1);
+    return section_floats(Cout, Cin, ks, 4) + section_floats(Cout, Cin, ks, 2) + section_floats(Cout, Cin, ks, 1) + t16_floats(Cout, Cin, ks);
 }
 
 template <int MB, int NB, int PF3A, int PF3B, int PF1>
@@ -1255,6 +1269,12 @@ int conv_validate(const mcq_conv_desc* d) {
     return MCQ_OK;
 }
 
+bool t16_takes(int N, int Cin, int H, int W, int Cout, int ksize, int stride, unsigned fl, int nprob) {
+    return N > 0 && H > 0 && W > 0 && nprob >= 1 && t16_shape(Cout, Cin, ksize) && stride == 1 && (fl & ~T16_FLAGS) == 0 &&
+           t16_tiles((long long)N * H * W, Cout, nprob) <= T16_MAX_TILES &&
+           (uint64_t)N * (Cin > Cout ? Cin : Cout) * H * W * 4ull < 0x80000000ull;
+}
+
 int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     const mcq_conv_desc* d = descs;
     const unsigned fl = d->flags;
@@ -1351,6 +1371,22 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         if ((uint64_t)co_tiles * 32u * (unsigned)MBw * (uint64_t)k.Ho * k.Wo * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
         k.flags = fl & ~(unsigned)MCQ_CONV_WINOGRAD;
         return MBw == 4 ? launch_wino<4>(k, tbw, co_tiles, (hipStream_t)stream) : launch_wino<2>(k, tbw, co_tiles, (hipStream_t)stream);
+    }
+
+    // launches too small to fill the chip with 32 x 32 tiles: 16 x 16 tiles, one per workgroup (conv_t16.h)
+    if (d->tile == 0 && t16_takes(d->N, d->Cin, d->H, d->W, d->Cout, d->ksize, d->stride, fl, nprob)) {
+        T16K t;
+        const size_t sec = section_floats(d->Cout, d->Cin, 3, 4) + section_floats(d->Cout, d->Cin, 3, 2) + section_floats(d->Cout, d->Cin, 3, 1);
+        for (int c = 0; c < MCQ_CONV_MAX_MULTI; ++c) {
+            const mcq_conv_desc* e = descs + (c < nprob ? c : 0);
+            T16Ptrs& a = t.p[c];
+            a.x = e->x; a.wp = e->w_packed + sec; a.bias = e->bias; a.y = e->y; a.y2 = e->y_silu; a.res = e->res; a.mul = e->mul;
+        }
+        t.N = d->N; t.Cin = d->Cin; t.H = d->H; t.W = d->W; t.Cout = d->Cout; t.flags = fl; t.res_scale = d->res_scale;
+        const dim3 grid((unsigned)(((long long)d->N * d->H * d->W + 15) / 16), (unsigned)(d->Cout / 16), (unsigned)nprob);
+        if (d->Cin == 128) hipLaunchKernelGGL(conv_t16_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, t);
+        else hipLaunchKernelGGL(conv_t16_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, t);
+        return mcq_check_launch();
     }
 
     // <= 16 output channels, 3x3, stride 1, nothing but bias / PixelShuffle in the epilogue: the 16-row MFMA kernel
@@ -1466,6 +1502,11 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
 }
 
 extern "C" int32_t mcq_conv2d_max_multi(void) { return MCQ_CONV_MAX_MULTI; }
+
+extern "C" int32_t mcq_conv2d_small_launch(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride,
+                                           uint32_t flags, int32_t nprob) {
+    return t16_takes(N, Cin, H, W, Cout, ksize, stride, flags, nprob) ? 1 : 0;
+}
 
 extern "C" int mcq_conv2d_multi_f32(const mcq_conv_desc* descs, int32_t n, void* stream) {
     if (!descs || n < 1 || n > MCQ_CONV_MAX_MULTI) return MCQ_EINVAL;

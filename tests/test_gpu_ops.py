@@ -575,3 +575,57 @@ def test_conv_winograd2d_both_instances(dev, monkeypatch, kernel):
     del seen[:]
     got = ops.conv2d(x.to(dev), pk, mul=g.to(dev), winograd=2)
     _close(got, F.conv2d(x, wt, None, padding=1) * g, 2e-5, "mul epilogue")
+
+
+T16_CASES = [  # n, cin, cout, h, w
+    (8, 128, 128, 4, 4), (8, 128, 128, 8, 8), (1, 128, 128, 12, 8), (1, 128, 128, 24, 16), (3, 64, 64, 5, 7), (2, 128, 32, 3, 3),
+    (1, 128, 256, 9, 11), (1, 64, 128, 1, 1), (5, 128, 128, 2, 9),
+]
+
+
+@pytest.mark.parametrize("case", T16_CASES)
+def test_conv_small_launch_kernel(dev, case):
+    """csrc/conv_t16.h: launches too small for 32-row tiles run 16 x 16 tiles on v_mfma_f32_16x16x4_f32 (one workgroup per tile,
+    four channel slices).  Every epilogue it carries, single and multi-problem launches, against F.conv2d; tiles straddling
+    images, maps smaller than a tile, partial last tiles.  `mcq_conv2d_small_launch` says the kernel is the one that ran, and a
+    forced general tile (tile=0x11) gives the general kernel's result for the same call: the two agree to summation order."""
+    from mcquic_amd import ops, _lib
+    n, cin, cout, h, w = case
+    lib = _lib.load()
+    xs = [_rand((n, cin, h, w), 50 + i) for i in range(4)]
+    wts = [_rand((cout, cin, 3, 3), 60 + i, 1.0 / np.sqrt(cin * 9)) for i in range(4)]
+    bs = [_rand((cout,), 70 + i, 0.1) for i in range(4)]
+    sides = [_rand((n, cout, h, w), 80 + i) for i in range(4)]
+    pks = [ops.PackedConv(wt.to(dev), b.to(dev)) for wt, b in zip(wts, bs)]
+    ys = [F.conv2d(x, wt, b, padding=1) for x, wt, b in zip(xs, wts, bs)]
+    dsilu = lambda t: torch.sigmoid(t) * (1 + t * (1 - torch.sigmoid(t)))          # noqa: E731
+    assert lib.mcq_conv2d_small_launch(n, cin, h, w, cout, 3, 1, 0, 1) == 1, "the case is meant to take the small-launch kernel"
+    x0, pk0, s0 = xs[0].to(dev), pks[0], sides[0].to(dev)
+    _close(ops.conv2d(x0, pk0), ys[0], 1e-5, "plain")
+    _close(ops.conv2d(x0, pk0, silu_out=True), F.silu(ys[0]), 1e-5, "silu_out")
+    _close(ops.conv2d(x0, pk0, res=s0, res_scale=0.5), ys[0] + 0.5 * sides[0], 1e-5, "residual with scale")
+    got = ops.conv2d(x0, pk0, res=s0, dual_silu=True)
+    _close(got, ys[0] + sides[0], 1e-5, "res + twin")
+    _close(ops.silu_twin(got), F.silu(ys[0] + sides[0]), 1e-5, "twin")
+    got = ops.conv2d(x0, pk0, dual_silu=True)
+    _close(ops.silu_twin(got), F.silu(ys[0]), 1e-5, "twin only")
+    _close(ops.conv2d(x0, pk0, dsilu_mul=s0), ys[0] * dsilu(sides[0]), 1e-5, "* silu'")
+    _close(ops.conv2d(x0, pk0, dsilu_mul=s0, res=s0), ys[0] * dsilu(sides[0]) + sides[0], 1e-5, "* silu' + dy")
+    _close(ops.conv2d(x0, ops.PackedConv(wts[0].to(dev), None)), F.conv2d(xs[0], wts[0], None, padding=1), 1e-5, "no bias")
+    general = ops.conv2d(x0, pk0, res=s0, dual_silu=True, tile=0x11)
+    _close(general, ys[0] + sides[0], 1e-5, "general kernel, forced tile")
+    for nprob in (2, 4):
+        if not lib.mcq_conv2d_small_launch(n, cin, h, w, cout, 3, 1, 0x108, nprob):
+            continue
+        outs = ops.conv2d_multi([x.to(dev) for x in xs[:nprob]], pks[:nprob], 1, per_problem=[dict(res=s.to(dev)) for s in sides[:nprob]],
+                                dual_silu=True)
+        for y, s, o in zip(ys, sides, outs):
+            _close(o, y + s, 1e-5, f"multi x{nprob}")
+            _close(ops.silu_twin(o), F.silu(y + s), 1e-5, f"multi x{nprob} twin")
+    # the input-gradient stream of the same layer carries the section too (dx of a 3x3 stride-1 conv = a conv with W')
+    dy = _rand((n, cout, h, w), 99)
+    xr = xs[0].clone().requires_grad_()
+    F.conv2d(xr, wts[0], None, padding=1).backward(dy)
+    back = ops.PackedConv.dgrad(wts[0].to(dev), 1) if hasattr(ops.PackedConv, "dgrad") else None
+    if back is not None and lib.mcq_conv2d_small_launch(n, cout, h, w, cin, 3, 1, 0, 1):
+        _close(ops.conv2d(dy.to(dev), back), xr.grad, 1e-5, "input gradient")

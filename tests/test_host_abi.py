@@ -36,8 +36,18 @@ def test_size_queries_run_without_a_gpu():
     # 16 zero tail steps; 128 -> 128 3x3 has 576 k-steps
     def sections(cout, steps):
         return sum(((cout + 32 * b - 1) // (32 * b) * steps + 16) * 64 * b for b in (4, 2, 1))
-    assert lib.mcq_packed_conv_weight_floats(128, 128, 3) == sections(128, 576)
-    assert lib.mcq_packed_conv_weight_floats(512, 128, 3) == sections(512, 576)
+    # 3x3 layers with 64 / 128 input channels and Cout % 16 == 0 (>= 32): + the 16-row copy of the small-launch kernel
+    # (csrc/conv_t16.h), Cin / 4 channel quads x 9 taps = 288 k-steps of four channels per 16-row tile, no tail
+    def small(cout, cin):
+        return cout // 16 * (cin // 4) * 9 * 64
+    assert lib.mcq_packed_conv_weight_floats(128, 128, 3) == sections(128, 576) + small(128, 128)
+    assert lib.mcq_packed_conv_weight_floats(512, 128, 3) == sections(512, 576) + small(512, 128)
+    assert lib.mcq_packed_conv_weight_floats(128, 256, 3) == sections(128, 1152)       # (256 input channels: not taken)
+    assert lib.mcq_conv2d_small_launch(8, 128, 4, 4, 128, 3, 1, 0, 2) == 1             # two 8 x 128 x 4 x 4 problems: 128 tiles
+    assert lib.mcq_conv2d_small_launch(8, 128, 8, 8, 128, 3, 1, 0, 4) == 0             # four 8 x 8 problems fill the chip: general kernel
+    assert lib.mcq_conv2d_small_launch(1, 128, 24, 16, 128, 3, 1, 0x108, 4) == 1       # residual + twin epilogue, batch 1
+    assert lib.mcq_conv2d_small_launch(1, 128, 24, 16, 128, 3, 1, 0x1, 1) == 0         # SiLU prologue: general kernel
+    assert lib.mcq_conv2d_small_launch(8, 128, 4, 4, 128, 1, 1, 0, 1) == 0             # 1x1
     assert lib.mcq_packed_conv_weight_floats(128, 3, 3) == sections(128, 18)         # 2 channel pairs x 9 taps
     assert lib.mcq_packed_conv_weight_floats(128, 8, 1) == sections(128, 16)         # 1x1: 4 pairs padded to one 16-deep ring
     # <= 16 output channels, 3x3: + the 16-row copy of the image-head kernel (32 four-channel groups x 9 taps + 16 tail steps)

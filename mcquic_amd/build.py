@@ -30,7 +30,7 @@ def csrc_sha() -> str:
     kernel can be recognised as stale."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("conv_mfma.hip", "conv_head16.h", "mcq_common.h", "conv_wino16.hip", "conv_wino16.h"):
+    for f in ("conv_mfma.hip", "conv_head16.h", "conv_t16.h", "mcq_common.h", "conv_wino16.hip", "conv_wino16.h"):
         h.update(f.encode() + b"\0")
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()

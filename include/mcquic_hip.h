@@ -156,6 +156,14 @@ int mcq_vq_pack_codebook_f32(const float* codebook, int32_t m, int32_t k, int32_
 int mcq_vq_assign_f32(const float* x, const float* cb_packed, int64_t* codes,
                       int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k,
                       void* stream);
+/* The same with a scratch buffer of mcq_vq_assign_workspace_bytes(...) bytes (0 = none needed; workspace may then be NULL):
+ * launches with too few latent vectors to fill the GPU -- a single 768x512 image is 48 workgroups at the first level -- range
+ * the codewords of a vector over up to 16 workgroups and fold the per-range minima in range order (first index on ties, as
+ * within one workgroup).  Identical codes. */
+size_t mcq_vq_assign_workspace_bytes(int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k);
+int mcq_vq_assign_ws_f32(const float* x, const float* cb_packed, int64_t* codes,
+                         int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k,
+                         void* workspace, void* stream);
 
 /* out[n, g*d + j, y, x] = codebook[g, codes[n, g, y, x], j]
  * (mcquic/modules/quantizer.py:249-259 _multiCodebookDeQuantization.decode).

@@ -58,6 +58,8 @@ SYMBOLS = {
     "mcq_vq_pack_codebook_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "mcq_vq_assign_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
+    "mcq_vq_assign_workspace_bytes": (c_size_t, [c_int32] * 6),
+    "mcq_vq_assign_ws_f32": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p, c_void_p]),
     "mcq_vq_gather_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
     "mcq_vq_logits_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,

@@ -98,8 +98,10 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
 
     f32x4v A[PF];
     float B[PF][NB];
-    const int per_slice = (p.ntile + CS - 1) >> p.cs_log2;
-    const int tile0 = slice * per_slice;                     // this wave's codeword tiles: [tile0, tile1)
+    // (grid.z workgroups x CS waves share the codeword tiles of a vector tile: small launches, see the launcher)
+    const int per_slice = (p.ntile + CS * p.zs - 1) / (CS * p.zs);
+    const int tile0r = ((int)blockIdx.z * CS + slice) * per_slice;
+    const int tile0 = tile0r < p.ntile ? tile0r : p.ntile;             // this wave's codeword tiles: [tile0, tile1) (possibly none)
     const int tile1 = active ? (tile0 + per_slice < p.ntile ? tile0 + per_slice : p.ntile) : tile0;
     // operand addresses stay off the vector ALU inside the k-loop (a VALU instruction between two MFMAs costs the
     // matrix pipe ~10 cycles, tools/probes/mfma_issue.hip): per-lane offsets are loop constants, the running part is
@@ -239,8 +241,30 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
-        if (hi == 0 && valid[nb])
-            p.codes[(((size_t)img[nb] * p.m + g) * p.h + yo[nb]) * p.w + xo[nb]] = (int64_t)bidx[nb];
+        if (hi == 0 && valid[nb]) {
+            const size_t v = (((size_t)img[nb] * p.m + g) * p.h + yo[nb]) * p.w + xo[nb];
+            if (p.zs == 1) p.codes[v] = (int64_t)bidx[nb];
+            else {
+                const size_t nvec = (size_t)p.N * p.m * p.h * p.w;
+                p.ws_best[(size_t)blockIdx.z * nvec + v] = best[nb];
+                p.ws_idx[(size_t)blockIdx.z * nvec + v] = bidx[nb];
+            }
+        }
+}
+
+// the ranges of a vector meet: range order = codeword order, so a later range only wins with a strictly smaller distance
+// (first index on ties, like torch.argmin and like the slices inside a workgroup)
+__global__ void vq_fold_kernel(const float* __restrict__ ws_best, const int* __restrict__ ws_idx, int zs, size_t nvec,
+                               int64_t* __restrict__ codes) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvec) return;
+    float best = ws_best[v];
+    int idx = ws_idx[v];
+    for (int z = 1; z < zs; ++z) {
+        const float ob = ws_best[(size_t)z * nvec + v];
+        if (ob < best) { best = ob; idx = ws_idx[(size_t)z * nvec + v]; }
+    }
+    codes[v] = (int64_t)idx;
 }
 
 // codebook [m, k, d] -> cbp [m][ntile][Sp][64][4] (+ zero tail) and c2p [m][ntile + 1][64][4]
@@ -362,8 +386,50 @@ extern "C" int mcq_vq_pack_codebook_f32(const float* codebook, int32_t m, int32_
     return mcq_check_launch();
 }
 
+namespace {
+// Workgroups per vector tile (grid.z) for launches that would leave most of the GPU idle -- one 768x512 image is 24 vector
+// tiles x 2 codebooks at the first level: 48 workgroups walking 8192 codewords each, 139 us for 20 us of MFMA work.  The
+// codeword tiles are then ranged over up to 16 workgroups (each at least one tile per wave) until ~1536 waves exist.
+int vq_assign_ranges(long long vtiles, int m, int ntile, int cs_log2) {
+    const long long waves = vtiles * m << cs_log2;
+    int zs = 1;
+    while (zs < 16 && waves * zs < 1536 && (ntile >> cs_log2) >= 2 * zs) zs *= 2;
+    return zs;
+}
+int vq_assign_plan(int N, int m, int d, int h, int w, int k, int& cs_log2_out) {
+    int bw_log2;
+    block_shape(h, w, bw_log2);
+    const int bw = 1 << bw_log2, bh = 32 >> bw_log2;
+    const long long tb = (long long)N * ((w + bw - 1) / bw) * ((h + bh - 1) / bh);
+    const long long vtiles = (tb + VQ_NB - 1) / VQ_NB;
+    const int ntile = (k + 127) / 128, Sp = vq_sp(d);
+    int cs_log2 = 0;
+    double best_cost = 1e30;
+    for (int lg = 0; lg <= 2 && (1 << lg) <= ntile; ++lg) {
+        const long long waves = vtiles * m << lg;
+        const double cost = (double)((waves + 2047) / 2048) / (double)(1 << lg);
+        if (cost < best_cost - 1e-12) { best_cost = cost; cs_log2 = lg; }
+    }
+    if (Sp == 128 && ntile >= 4) cs_log2 = 2;          // the LDS-staged mode: four slices share one vector tile
+    cs_log2_out = cs_log2;
+    return vq_assign_ranges(vtiles, m, ntile, cs_log2);
+}
+}  // namespace
+
+extern "C" size_t mcq_vq_assign_workspace_bytes(int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k) {
+    if (N <= 0 || m <= 0 || d <= 0 || h <= 0 || w <= 0 || k <= 0) return 0;
+    int cs;
+    const int zs = vq_assign_plan(N, m, d, h, w, k, cs);
+    return zs > 1 ? (size_t)zs * N * m * h * w * 8u : 0;
+}
+
 extern "C" int mcq_vq_assign_f32(const float* x, const float* cb_packed, int64_t* codes, int32_t N, int32_t m, int32_t d,
                                  int32_t h, int32_t w, int32_t k, void* stream) {
+    return mcq_vq_assign_ws_f32(x, cb_packed, codes, N, m, d, h, w, k, nullptr, stream);
+}
+
+extern "C" int mcq_vq_assign_ws_f32(const float* x, const float* cb_packed, int64_t* codes, int32_t N, int32_t m, int32_t d,
+                                    int32_t h, int32_t w, int32_t k, void* workspace, void* stream) {
     if (!x || !cb_packed || !codes || N <= 0 || m <= 0 || d <= 0 || h <= 0 || w <= 0 || k <= 0) return MCQ_EINVAL;
     if ((uint64_t)d * h * w * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
     VqK p;
@@ -386,21 +452,22 @@ extern "C" int mcq_vq_assign_f32(const float* x, const float* cb_packed, int64_t
     // with the fewest whole rounds of work.
     const long long vtiles = (tb + VQ_NB - 1) / VQ_NB;
     int cs_log2 = 0;
-    double best_cost = 1e30;
-    for (int lg = 0; lg <= 2 && (1 << lg) <= p.ntile; ++lg) {
-        const long long waves = vtiles * m << lg;
-        const double cost = (double)((waves + 2047) / 2048) / (double)(1 << lg);
-        if (cost < best_cost - 1e-12) { best_cost = cost; cs_log2 = lg; }
-    }
-    if (p.Sp == 128 && p.ntile >= 4) cs_log2 = 2;          // the LDS-staged mode: four slices share one vector tile
+    const int zs_plan = vq_assign_plan(N, m, d, h, w, k, cs_log2);
     p.cs_log2 = cs_log2;
+    p.zs = workspace ? zs_plan : 1;                          // (without a workspace: one workgroup per vector tile, as before)
+    const size_t nvec = (size_t)N * m * h * w;
+    p.ws_best = static_cast<float*>(workspace);
+    p.ws_idx = reinterpret_cast<int*>(p.ws_best + (size_t)p.zs * nvec);
     const int per_wg = 4 >> cs_log2;
     const unsigned gx = (unsigned)((vtiles + per_wg - 1) / per_wg);
-    const dim3 grid(gx, (unsigned)m);
+    const dim3 grid(gx, (unsigned)m, (unsigned)p.zs);
     if (p.Sp == 32) hipLaunchKernelGGL((vq_assign_kernel<32, false>), grid, dim3(256), 0, (hipStream_t)stream, p);          // d = 64
     else if (p.Sp == 128 && cs_log2 == 2) hipLaunchKernelGGL((vq_assign_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, p);   // d = 256
     else if (p.Sp == 128) hipLaunchKernelGGL((vq_assign_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((vq_assign_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (p.zs > 1)
+        hipLaunchKernelGGL(vq_fold_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.ws_best, p.ws_idx, p.zs,
+                           nvec, codes);
     return mcq_check_launch();
 }
 

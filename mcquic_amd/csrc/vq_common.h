@@ -16,6 +16,9 @@ struct VqK {
     int ntile;         // 128-codeword tiles
     int bw_log2, nbx, nby, total_blocks;
     int cs_log2;       // vq_assign: 1 << cs_log2 waves of a workgroup share one vector tile, each a slice of the codeword tiles
+    int zs;            // vq_assign: workgroups (grid.z) that share one vector tile, each a range of the codeword tiles (1 = none)
+    float* ws_best;    // zs > 1: [zs][N m h w] best distance / its codeword per range, folded by vq_fold_kernel
+    int* ws_idx;
 };
 
 inline void block_shape(int Ho, int Wo, int& lg_out) {

@@ -403,9 +403,12 @@ def vq_assign(x: torch.Tensor, cb: PackedCodebook) -> torch.Tensor:
     if c != cb.m * cb.d:
         raise ValueError(f"latent has {c} channels, codebook expects {cb.m}*{cb.d}")
     codes = torch.empty((n, cb.m, h, w), dtype=torch.int64, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.mcq_vq_assign_workspace_bytes(n, cb.m, cb.d, h, w, cb.k)       # > 0: a launch too small to fill the GPU ranges the codewords
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with _guard(x.device):
-        check(_lib.load().mcq_vq_assign_f32(_ptr(x), _ptr(cb.packed), _ptr(codes), n, cb.m, cb.d, h, w, cb.k, _stream()),
-              "mcq_vq_assign_f32")
+        check(lib.mcq_vq_assign_ws_f32(_ptr(x), _ptr(cb.packed), _ptr(codes), n, cb.m, cb.d, h, w, cb.k, _ptr(ws), _stream()),
+              "mcq_vq_assign_ws_f32")
     return codes
 
 

@@ -629,3 +629,29 @@ def test_conv_small_launch_kernel(dev, case):
     back = ops.PackedConv.dgrad(wts[0].to(dev), 1) if hasattr(ops.PackedConv, "dgrad") else None
     if back is not None and lib.mcq_conv2d_small_launch(n, cout, h, w, cin, 3, 1, 0, 1):
         _close(ops.conv2d(dy.to(dev), back), xr.grad, 1e-5, "input gradient")
+
+
+@pytest.mark.parametrize("shape", [(2, 8192, 64, 1, 32, 48), (2, 2048, 64, 1, 16, 24), (2, 8192, 64, 1, 8, 12), (3, 1000, 64, 1, 5, 9)])
+def test_vq_assign_codeword_ranges(dev, shape):
+    """Launches with too few vectors to fill the GPU (one 768x512 image: 48 workgroups at the first level) range the codewords of
+    a vector over several workgroups and fold the minima (mcq_vq_assign_ws_f32 / mcq_vq_assign_workspace_bytes): the same codes as
+    the one-workgroup form (no workspace) and as the oracle, first index on exact ties across ranges."""
+    import ctypes
+    from mcquic_amd import ops, _lib
+    m, k, d, n, h, w = shape
+    lib = _lib.load()
+    x, cb = _vq_case(m, k, d, n, h, w, 53)
+    half = (k // 2) // 128 * 128
+    cb[:, half:2 * half, :] = cb[:, :half, :]          # every codeword of the first half again, in a later range: the first must win
+    pk = ops.PackedCodebook(cb.to(dev))
+    nbytes = lib.mcq_vq_assign_workspace_bytes(n, m, d, h, w, k)
+    if k >= 2048:
+        assert nbytes > 0, "the case is meant to range its codewords"
+    got = ops.vq_assign(x.to(dev), pk)
+    plain = torch.empty((n, m, h, w), dtype=torch.int64, device=dev)
+    rc = lib.mcq_vq_assign_f32(x.to(dev).data_ptr(), pk.packed.data_ptr(), plain.data_ptr(), n, m, d, h, w, k, None)
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert torch.equal(got, plain), "ranged and one-workgroup forms disagree"
+    assert not bool(((got >= half) & (got < 2 * half)).any()), "a duplicate from a later range won an exact tie"
+    _audit_codes(got, x, cb, 2e-6, f"vq ranges {shape}")

@@ -657,9 +657,12 @@ inline bool tiny_shape(int N, int Cin, int H, int W, int Cout) {
 }
 }  // namespace
 
+#include "wgrad_t16.h"
+
 extern "C" int32_t mcq_conv2d_wgrad_nchw_max_group(void) { return ROWS_MAX_CONVS; }
 
 extern "C" size_t mcq_conv2d_wgrad_nchw_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout) {
+    if (wgt16_shape(N, Cin, H, W, Cout)) return 1;                                            // (wgrad_t16.h: one pass, no workspace)
     RowsPlan r;
     if (!rows_plan(N, Cin, H, W, Cout, r)) return tiny_shape(N, Cin, H, W, Cout) ? 1 : 0;      // (the small-map kernel needs no workspace)
     return (size_t)r.groups * 9 * Cout * Cin + (size_t)r.groups * 4 * Cout;
@@ -669,6 +672,12 @@ extern "C" int mcq_conv2d_wgrad_nchw_group_f32(const float* const* x, const floa
                                                int32_t nconv, float* workspace, int32_t N, int32_t Cin, int32_t H, int32_t W,
                                                int32_t Cout, void* stream) {
     if (!x || !dy || !dw || !workspace || nconv < 1 || nconv > ROWS_MAX_CONVS) return MCQ_EINVAL;
+    if (wgt16_shape(N, Cin, H, W, Cout)) {                          // few pixels: 16 x 16 tiles, one pass (wgrad_t16.h)
+        for (int c = 0; c < nconv; ++c)
+            if (!x[c] || !dy[c] || !dw[c]) return MCQ_EINVAL;
+        wgt16_launch(x, dy, dw, dbias, nconv, N, Cin, H, W, Cout, 9, false, (hipStream_t)stream);
+        return mcq_check_launch();
+    }
     RowsPlan r;
     if (!rows_plan(N, Cin, H, W, Cout, r, 9, false, nconv)) {      // (never more groups than the nconv = 1 plan the workspace query assumes)
         if (!tiny_shape(N, Cin, H, W, Cout)) return MCQ_EINVAL;
@@ -724,6 +733,7 @@ extern "C" int mcq_conv2d_wgrad_nchw_f32(const float* x, const float* dy, float*
 }
 
 extern "C" size_t mcq_conv2d_wgrad1x1_nchw_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout) {
+    if (wgt16_shape(N, Cin, H, W, Cout)) return 1;
     RowsPlan r;
     if ((H & 1) || !rows_plan(N, Cin, H, W, Cout, r, 1)) return 0;
     return (size_t)r.groups * Cout * Cin + (size_t)r.groups * 4 * Cout;
@@ -732,6 +742,14 @@ extern "C" size_t mcq_conv2d_wgrad1x1_nchw_workspace_floats(int32_t N, int32_t C
 extern "C" int mcq_conv2d_wgrad1x1_nchw_f32(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int32_t N,
                                             int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t square_x, void* stream) {
     if (!x || !dy || !dw || !workspace) return MCQ_EINVAL;
+    if (wgt16_shape(N, Cin, H, W, Cout)) {                          // few pixels: 16 x 16 tiles, one pass (wgrad_t16.h)
+        const float* xs[1] = {x};
+        const float* dys[1] = {dy};
+        float* dws[1] = {dw};
+        float* dbs[1] = {dbias};
+        wgt16_launch(xs, dys, dws, dbias ? dbs : nullptr, 1, N, Cin, H, W, Cout, 1, square_x != 0, (hipStream_t)stream);
+        return mcq_check_launch();
+    }
     RowsPlan r;
     if ((H & 1) || !rows_plan(N, Cin, H, W, Cout, r, 1)) return MCQ_EINVAL;
     WgRowsK p;

@@ -457,3 +457,38 @@ def test_soft_assignment_backward_contractions(dev, case):
     _close(dcb, torch.from_numpy(want_dc).float(), 2e-6, f"dcodebook {case}")
     dx2, dcb2 = ops.vq_soft_bwd(ddist.to(dev), rowsum.to(dev), x.to(dev), ddeq.to(dev), index.to(dev), hot.to(dev), pk)
     assert torch.equal(dx, dx2) and torch.equal(dcb, dcb2), "the contractions are deterministic"
+
+
+@pytest.mark.parametrize("case", [(8, 128, 128, 8, 8), (8, 128, 128, 4, 4), (1, 32, 64, 16, 16), (3, 64, 32, 6, 6), (11, 16, 48, 2, 10), (2, 128, 128, 10, 12),
+                                  (5, 48, 16, 2, 2)])
+def test_wgrad_few_pixels_kernel(dev, case):
+    """csrc/wgrad_t16.h: weight gradients over <= 512 pixels (16 x 16 tiles on v_mfma_f32_16x16x4_f32, one pass, whole images staged
+    in LDS in groups of <= 256 pixels): 3x3 (single and grouped launches), 1x1 and 1x1 over x^2, against CPU autograd -- image
+    counts below / above a group, maps that are not powers of two, rectangular tiles of the weight."""
+    from mcquic_amd import ops
+    n, cin, cout, h, w = case
+    lib = ops._lib.load()
+    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(n, cin, h, w, cout) == 1 and lib.mcq_conv2d_wgrad1x1_nchw_workspace_floats(n, cin, h, w, cout) == 1
+    xs = [_rand((n, cin, h, w), 31 + i) for i in range(3)]
+    gys = [_rand((n, cout, h, w), 41 + i) for i in range(3)]
+    wants = []
+    for x, gy in zip(xs, gys):
+        wr = torch.zeros((cout, cin, 3, 3), requires_grad=True)
+        br = torch.zeros((cout,), requires_grad=True)
+        F.conv2d(x, wr, br, padding=1).backward(gy)
+        wants.append((wr.grad, br.grad))
+    dw, db = ops.conv2d_wgrad(xs[0].to(dev), gys[0].to(dev), 3, 1, want_bias=True)
+    _close(dw, wants[0][0], 3e-6, f"dW {case}")
+    _close(db, wants[0][1], 3e-6, f"db {case}")
+    outs = ops.conv2d_wgrad_group([x.to(dev) for x in xs], [g.to(dev) for g in gys], want_bias=True)
+    for (gw, gb), (ww, wb) in zip(outs, wants):
+        _close(gw, ww, 3e-6, f"grouped dW {case}")
+        _close(gb, wb, 3e-6, f"grouped db {case}")
+    assert torch.equal(outs[0][0], dw) and torch.equal(outs[0][1], db), "a convolution's result does not depend on its launch"
+    for sq in (False, True):
+        w1 = torch.zeros((cout, cin, 1, 1), requires_grad=True)
+        b1 = torch.zeros((cout,), requires_grad=True)
+        F.conv2d(xs[1] * xs[1] if sq else xs[1], w1, b1).backward(gys[1])
+        dw1, db1 = ops.conv2d_wgrad(xs[1].to(dev), gys[1].to(dev), 1, 1, square_x=sq, want_bias=True)
+        _close(dw1, w1.grad, 3e-6, f"1x1 dW {case} sq={sq}")
+        _close(db1, b1.grad, 3e-6, f"1x1 db {case} sq={sq}")

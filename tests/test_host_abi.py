@@ -158,9 +158,12 @@ def test_oversized_planes_are_rejected_before_any_launch():
 def test_wgrad_rows_kernel_declines_other_shapes():
     from mcquic_amd import _lib
     lib = _lib.load()
-    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(2, 128, 12, 16, 128) == 0      # H not a multiple of 8
-    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(2, 128, 16, 12, 128) == 0      # W not a multiple of 8
-    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(8, 128, 4, 4, 128) == 1        # small map: the LDS kernel, no workspace
+    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(4, 128, 12, 16, 128) == 0      # H not a multiple of 8 (and > 512 pixels in all)
+    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(4, 128, 16, 12, 128) == 0      # W not a multiple of 8
+    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(2, 128, 12, 16, 128) == 1      # <= 512 pixels: the one-pass 16x16-tile kernel (csrc/wgrad_t16.h), no workspace
+    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(8, 128, 4, 4, 128) == 1        # small map: no workspace
+    assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(8, 40, 4, 4, 24) == 1          # channels not in sixteens: the LDS lane-per-weight kernel
+    assert lib.mcq_conv2d_wgrad1x1_nchw_workspace_floats(8, 128, 8, 8, 128) == 1
     assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(64, 128, 256, 256, 128) == 0   # a tensor of 2 GiB
     assert lib.mcq_conv2d_wgrad_nchw_workspace_floats(8, 128, 16, 16, 128) > 0
 

@@ -29,7 +29,7 @@ struct WgT16K {
     int hw_log2, w_log2;     // >= 0: H W / W are powers of two (shifts instead of divisions in the pixel walk)
 };
 
-constexpr int WGT16_MAX_PIXELS = 512;        // N H W the kernel takes
+constexpr int WGT16_MAX_PIXELS = 512;        // N H W the kernel takes (at 2048 -- eight 16x16 images -- it only matches the strip walk: 167 vs 171 us for sixteen problems)
 constexpr int WGT16_STAGE_PIXELS = 256;      // pixels (whole images) staged in LDS at a time: 32 KB per workgroup, four workgroups per CU
 inline bool wgt16_shape(int N, int Cin, int H, int W, int Cout) {
     return N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (long long)N * H * W <= WGT16_MAX_PIXELS && (H * W) % 4 == 0 && H * W <= WGT16_STAGE_PIXELS && Cin % 16 == 0 && Cout % 16 == 0 &&
@@ -106,8 +106,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_t16_kernel(WgT16K p) {
         // of its nine neighbours exist, and where) then depends on the position only and is worked out once per image group; inside,
         // a step costs one select per tap beside its ten LDS reads and nine MFMAs.  Wave w takes images w, w + 4, ... of the group.
         const int quads = HW >> 2;                               // (launcher: H W % 4 == 0)
-        int x = kq % p.W, y = kq / p.W;                          // this lane's position in quad 0; + 4 pixels per quad, no divisions
-        for (int q = 0; q < quads; ++q) {
+        // the group's (quad, image) steps over the four waves: by image when there are four or more, by quad when the group is a
+        // single image (a 16x16 map fills the staging area alone), two by two in between
+        const int nstep = nc >= 3 ? 4 : nc, nstart = nc >= 3 ? wave : wave % nc;
+        const int qstep = 4 / nstep, qstart = nc >= 3 ? 0 : wave / nc;
+        const int rem0 = 4 * qstart + kq;
+        int x = rem0 % p.W, y = rem0 / p.W;                      // this lane's position in its first quad; + 4 qstep pixels per quad, no divisions
+        for (int q = qstart; q < quads; q += qstep) {
             const int rem = 4 * q + kq;
             // (plain comparisons combined with &: written with && / ?: chains hipcc turned the nine validities into ~400
             //  instructions of exec-mask control flow per quad, 19 us of a workgroup's 24)
@@ -124,9 +129,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_t16_kernel(WgT16K p) {
                 }
                 off[t] = (rem + (ok[t] ? toff[t] : 0)) * 16 + i;
             }
-            x += 4;
+            x += 4 * qstep;
             while (x >= p.W) { x -= p.W; ++y; }
-            for (int n = wave; n < nc; n += 4) {
+            for (int n = nstart; n < nc; n += nstep) {
                 const int base = n * HW * 16;
                 const float a = stage[0][0][base + rem * 16 + i];
                 bsum += a;

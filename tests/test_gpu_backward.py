@@ -460,7 +460,7 @@ def test_soft_assignment_backward_contractions(dev, case):
 
 
 @pytest.mark.parametrize("case", [(8, 128, 128, 8, 8), (8, 128, 128, 4, 4), (1, 32, 64, 16, 16), (3, 64, 32, 6, 6), (11, 16, 48, 2, 10), (2, 128, 128, 10, 12),
-                                  (5, 48, 16, 2, 2)])
+                                  (5, 48, 16, 2, 2), (2, 128, 128, 16, 16), (3, 32, 32, 8, 16), (3, 16, 16, 12, 12)])
 def test_wgrad_few_pixels_kernel(dev, case):
     """csrc/wgrad_t16.h: weight gradients over <= 512 pixels (16 x 16 tiles on v_mfma_f32_16x16x4_f32, one pass, whole images staged
     in LDS in groups of <= 256 pixels): 3x3 (single and grouped launches), 1x1 and 1x1 over x^2, against CPU autograd -- image

@@ -242,7 +242,11 @@ int mcq_conv2d_wgrad_f32(const float* x_nhwc, const float* dy_nhwc, float* dw, f
 /* The same gradient for 3x3 stride-1 convolutions straight from the NCHW tensors X [N,Cin,H,W] and dY [N,Cout,H,W], W a
  * multiple of 8, each tensor below 1 GiB (mcq_conv2d_wgrad_nchw_workspace_floats returns 0 for any other shape: use the
  * NHWC entry point then).  No channel-major copies: a wave walks an 8-pixel strip down the rows with a three-row window of
- * X in registers, all nine taps per dY operand (csrc/wgrad_rows.hip).  Deterministic. */
+ * X in registers, all nine taps per dY operand (csrc/wgrad_rows.hip).  Deterministic.
+ * Shapes with N H W <= 512 pixels, H W a multiple of 4 (<= 256) and channel counts in sixteens -- the 4x4 / 8x8 maps of a training
+ * step -- take a one-pass kernel on 16 x 16 tiles instead (csrc/wgrad_t16.h: whole images staged in LDS, no partial sums): the
+ * workspace query returns 1 for them (as for the other small maps) and `workspace` is not touched.  The same holds for the 1x1
+ * entry point below. */
 size_t mcq_conv2d_wgrad_nchw_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout);
 int mcq_conv2d_wgrad_nchw_f32(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int32_t N, int32_t Cin,
                               int32_t H, int32_t W, int32_t Cout, void* stream);

@@ -82,6 +82,36 @@ inline bool rows_plan(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int t
     r.ups = (int)((r.units + splits - 1) / splits);
     r.splits = (r.units + r.ups - 1) / r.ups;
     r.groups = (r.splits + 3) / 4;
+    if (nconv > 1 && taps == 9 && !stride2 && sr / MCQ_WGROWS_MIN_ROWS >= 4) {
+        // A grouped launch is planned as a whole: all its waves are equal, so it runs in rounds of MCQ_WGROWS_WAVES and every
+        // wave pays a fixed cost (first loads, LDS tree, 36 KB of partial sums per workgroup: about four rows' worth) on top of
+        // its rows.  Pick the cut (row ranges per column x columns per wave) with the smallest rounds x (rows + fixed) -- twelve
+        // 64x64 convolutions planned one by one were 12 rounds of 16 rows (998 us, 226 MB of partials); 3 rounds of 64 rows
+        // do the same work.  Never more groups than the nconv = 1 plan (the workspace query assumes that one).
+        RowsPlan one;
+        (void)rows_plan(N, Cin, H, W, Cout, one);
+        const long long cols = (long long)N * r.strips, fixed = r.F == 8 ? 4 : 8;
+        long long best = -1; int best_chunks = 0, best_ups = 0;
+        for (long long ch = 1; ch <= hb; ++ch) {
+            const long long rpc = (hb + ch - 1) / ch * rb, rc = (H + rpc - 1) / rpc, units = cols * rc;
+            for (long long ups = 1; ups <= units; ups *= 2) {
+                const long long sp = (units + ups - 1) / ups;
+                if (sp < 4 || (sp + 3) / 4 > one.groups) continue;
+                const long long waves = tiles * nconv * ((sp + 3) / 4) * 4;
+                const long long rounds = (waves + MCQ_WGROWS_WAVES - 1) / MCQ_WGROWS_WAVES;
+                const long long cost = rounds * (ups * rpc + fixed);
+                if (best < 0 || cost < best) { best = cost; best_chunks = (int)ch; best_ups = (int)ups; }
+            }
+        }
+        if (best >= 0) {
+            r.rpc = (int)((hb + best_chunks - 1) / best_chunks) * rb;
+            r.row_chunks = (H + r.rpc - 1) / r.rpc;
+            r.units = N * r.strips * r.row_chunks;
+            r.ups = best_ups;
+            r.splits = (r.units + r.ups - 1) / r.ups;
+        }
+    }
+    r.groups = (r.splits + 3) / 4;
     return true;
 }
 

@@ -47,7 +47,7 @@ struct WgRowsK {
     int units, splits, ups;          // (image, strip, row range) walks; waves per tile; walks per wave
 };
 
-struct RowsPlan { int F, strips, row_chunks, rpc, units, splits, ups, groups; };
+struct RowsPlan { int F, strips, row_chunks, rpc, units, splits, ups, groups, gmax; };
 
 inline bool rows_plan(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int taps = 9, bool stride2 = false, int nconv = 1) {
     // (H, W: the map the walk runs over = dY's; with stride2 the input is 2H x 2W)
@@ -82,24 +82,31 @@ inline bool rows_plan(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int t
     r.ups = (int)((r.units + splits - 1) / splits);
     r.splits = (r.units + r.ups - 1) / r.ups;
     r.groups = (r.splits + 3) / 4;
-    if (nconv > 1 && taps == 9 && !stride2 && sr / MCQ_WGROWS_MIN_ROWS >= 4) {
-        // A grouped launch is planned as a whole: all its waves are equal, so it runs in rounds of MCQ_WGROWS_WAVES and every
-        // wave pays a fixed cost (first loads, LDS tree, 36 KB of partial sums per workgroup: about four rows' worth) on top of
-        // its rows.  Pick the cut (row ranges per column x columns per wave) with the smallest rounds x (rows + fixed) -- twelve
-        // 64x64 convolutions planned one by one were 12 rounds of 16 rows (998 us, 226 MB of partials); 3 rounds of 64 rows
-        // do the same work.  Never more groups than the nconv = 1 plan (the workspace query assumes that one).
-        RowsPlan one;
-        (void)rows_plan(N, Cin, H, W, Cout, one);
-        const long long cols = (long long)N * r.strips, fixed = r.F == 8 ? 4 : 8;
+    r.gmax = r.groups;
+    if (taps == 9 && !stride2 && sr / MCQ_WGROWS_MIN_ROWS >= 4) {
+        // The launch is then planned as a whole.  All its waves are equal; the matrix pipe of a SIMD is kept busy by ONE such
+        // wave (two per SIMD take twice as long over the same rows: "1 instead of 2 waves per SIMD changes nothing"),
+        // so a launch lasts  ceil(waves / 1024 SIMDs) x (rows per wave + fixed)  with the fixed part (first loads, LDS tree,
+        // 36 KB of partial sums per workgroup and their share of the reduce pass) worth about six rows.  Pick the cut (row
+        // ranges per column x columns per wave) that minimises it -- twelve 64x64 convolutions planned one by one were 24 576
+        // waves of 16 rows (998 us, 226 MB of partials); 3 072 waves of 128 rows do the same work.  Never more groups per
+        // convolution than the one-by-one plan above (gmax: what the workspace query reports).
+        if (nconv > 1) {
+            RowsPlan one;
+            (void)rows_plan(N, Cin, H, W, Cout, one);
+            r.gmax = one.gmax;
+        }
+        const long long cols = (long long)N * r.strips, fixed = r.F == 8 ? 6 : 12, simds = MCQ_WGROWS_WAVES / 2;
         long long best = -1; int best_chunks = 0, best_ups = 0;
         for (long long ch = 1; ch <= hb; ++ch) {
             const long long rpc = (hb + ch - 1) / ch * rb, rc = (H + rpc - 1) / rpc, units = cols * rc;
-            for (long long ups = 1; ups <= units; ups *= 2) {
+            if (ch > 1 && rpc == (hb + ch - 2) / (ch - 1) * rb) continue;          // (same row ranges as the previous count)
+            for (long long ups = 1; ups <= units; ++ups) {
                 const long long sp = (units + ups - 1) / ups;
-                if (sp < 4 || (sp + 3) / 4 > one.groups) continue;
+                if (sp < 4) break;
+                if ((sp + 3) / 4 > r.gmax) continue;
                 const long long waves = tiles * nconv * ((sp + 3) / 4) * 4;
-                const long long rounds = (waves + MCQ_WGROWS_WAVES - 1) / MCQ_WGROWS_WAVES;
-                const long long cost = rounds * (ups * rpc + fixed);
+                const long long cost = (waves + simds - 1) / simds * (ups * rpc + fixed);
                 if (best < 0 || cost < best) { best = cost; best_chunks = (int)ch; best_ups = (int)ups; }
             }
         }
@@ -695,7 +702,7 @@ extern "C" size_t mcq_conv2d_wgrad_nchw_workspace_floats(int32_t N, int32_t Cin,
     if (wgt16_shape(N, Cin, H, W, Cout)) return 1;                                            // (wgrad_t16.h: one pass, no workspace)
     RowsPlan r;
     if (!rows_plan(N, Cin, H, W, Cout, r)) return tiny_shape(N, Cin, H, W, Cout) ? 1 : 0;      // (the small-map kernel needs no workspace)
-    return (size_t)r.groups * 9 * Cout * Cin + (size_t)r.groups * 4 * Cout;
+    return (size_t)r.gmax * 9 * Cout * Cin + (size_t)r.gmax * 4 * Cout;
 }
 
 extern "C" int mcq_conv2d_wgrad_nchw_group_f32(const float* const* x, const float* const* dy, float* const* dw, float* const* dbias,
@@ -811,7 +818,7 @@ extern "C" int mcq_conv2d_wgrad1x1_nchw_f32(const float* x, const float* dy, flo
 extern "C" size_t mcq_conv2d_wgrad_s2_nchw_workspace_floats(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout) {
     RowsPlan r;
     if ((H & 1) || (W & 1) || !rows_plan(N, Cin, H / 2, W / 2, Cout, r, 9, true)) return 0;
-    return (size_t)r.groups * 9 * Cout * Cin + (size_t)r.groups * 4 * Cout;
+    return (size_t)r.gmax * 9 * Cout * Cin + (size_t)r.gmax * 4 * Cout;
 }
 
 extern "C" int mcq_conv2d_wgrad_s2_nchw_f32(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int32_t N,

@@ -49,7 +49,30 @@ struct WgRowsK {
 
 struct RowsPlan { int F, strips, row_chunks, rpc, units, splits, ups, groups, gmax; };
 
+inline bool rows_plan_search(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int taps, bool stride2, int nconv);
+
+// (the plan of a shape is looked up far more often than it changes: the last few are remembered per host thread)
 inline bool rows_plan(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int taps = 9, bool stride2 = false, int nconv = 1) {
+    struct Memo { int key[8]; RowsPlan plan; bool ok, used; };
+    static thread_local Memo memo[16];
+    static thread_local int next = 0;
+    const int key[8] = {N, Cin, H, W, Cout, taps, stride2 ? 1 : 0, nconv};
+    for (const Memo& m : memo) {
+        bool same = m.used;
+        for (int i = 0; same && i < 8; ++i) same = m.key[i] == key[i];
+        if (same) { r = m.plan; return m.ok; }
+    }
+    RowsPlan fresh{};
+    const bool ok = rows_plan_search(N, Cin, H, W, Cout, fresh, taps, stride2, nconv);
+    Memo& m = memo[next];                  // (claimed after the search: the search itself looks up the one-by-one plan)
+    next = (next + 1) & 15;
+    for (int i = 0; i < 8; ++i) m.key[i] = key[i];
+    m.plan = fresh; m.ok = ok; m.used = true;
+    r = fresh;
+    return ok;
+}
+
+inline bool rows_plan_search(int N, int Cin, int H, int W, int Cout, RowsPlan& r, int taps, bool stride2, int nconv) {
     // (H, W: the map the walk runs over = dY's; with stride2 the input is 2H x 2W)
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (W & 7) || (H & ((taps == 1 || stride2) ? 1 : 7))) return false;
     if ((uint64_t)N * Cin * H * W * (stride2 ? 16ull : 4ull) >= 0x40000000ull || (uint64_t)N * Cout * H * W * 4ull >= 0x40000000ull) return false;

@@ -1476,6 +1476,15 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         // read and a sigmoid per element; the 128 x 32 tile has a band-wise instance of it (the 128 x 64 tile has no registers
         // left for one) and at three waves per SIMD hides it better (8 x 128 x 128 x 128: 300-311 -> 270-277 us)
         else if (MB == 4 && NB == 2 && ksl == 0 && (fl & MCQ_CONV_DSILU_MUL) && d->ksize == 3) NB = 1;
+        // 1x1 layers (GDN / IGDN, the AttentionBlock gate): 64 k-steps per tile against an epilogue that reads and writes an
+        // output-shaped tensor each -- HBM time, not matrix time.  One pixel block per wave (half the epilogue per wave, three
+        // waves per SIMD to hide it) wins wherever the launch still fills the chip without a split: 32 x 128 x 384x256 GDN
+        // 1276 -> 1234 us, 192x128 323 -> 306, 96x64 87 -> 73, 48x32 (64 x 32 tile) 38.7 -> 26.3 (tools/microbench_conv.py --k1 --flags gdn)
+        if (d->ksize == 1 && d->stride == 1 && co32 >= 4) {
+            const long long t41 = tb * ((co32 + 3) / 4) * nprob, t21 = tb * ((co32 + 1) / 2) * nprob;
+            if (t41 >= 2048) { MB = 4; NB = 1; ksl = 0; }
+            else if (t21 >= 2048) { MB = 2; NB = 1; ksl = 0; }
+        }
     }
     const int pro = (fl & MCQ_CONV_SILU_IN) ? PRO_SILU : (fl & MCQ_CONV_SQUARE_IN) ? PRO_SQUARE : PRO_NONE;
     const long long ptiles = (tb + NB - 1) / NB;

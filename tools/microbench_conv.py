@@ -23,6 +23,8 @@ SHAPES = [  # n, cin, cout, h, w, ks, stride
     (32, 128, 128, 48, 32, 3, 1),
     (32, 128, 128, 24, 16, 3, 1),
     (32, 128, 128, 12, 8, 3, 1),
+    (32, 128, 128, 12, 8, 1, 1),
+    (32, 128, 128, 24, 16, 1, 1),
     (32, 128, 128, 48, 32, 1, 1),
     (32, 128, 128, 96, 64, 1, 1),
     (32, 128, 128, 192, 128, 1, 1),

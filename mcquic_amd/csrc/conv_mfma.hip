@@ -1004,6 +1004,73 @@ __global__ void pack_conv_weight_multi_kernel(PackTable t, int Cout, int Cin, in
     pack_conv_weight_body(w, Cout, Cin, ks, S, TP, out, sec4, sec2, total, mode, Co, Ci, scale);
 }
 
+// The same four sections for a 3x3 weight with one thread per (output channel, input channel) run: the nine taps of a pair are
+// 36 consecutive bytes of the OIHW tensor in every mode (forward, flipped / transposed, sub-pixel), so a thread reads its run
+// once and leaves nine values 64 x bands floats apart -- a wave's store is still 256 consecutive bytes.  The element-per-thread
+// kernel above fetched a 128-byte line for every float it wrote (a wave's 64 lanes = 64 different rows of the weight): with an
+// optimizer step inside the training step every conv re-packs both its operand streams, and those ~45 grouped launches were
+// 1.6 ms of a 24 ms step; this form does the same in a quarter of the time.  Same bits in the same places.
+__device__ __forceinline__ void pack_conv_weight_runs_body(const float* __restrict__ w, int Cout, int Cin, int S, int TP,
+                                                           float* __restrict__ out, int mode, int Co, int Ci, float scale, unsigned n16) {
+    // (32-bit index arithmetic throughout: a packed weight is far below 2^31 floats -- the element-per-thread kernel's 64-bit
+    //  divisions were a good part of its time)
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned base = 0;
+#pragma unroll
+    for (int b = 4; b >= 1; b >>= 1) {
+        const unsigned ntile = (unsigned)(Cout + 32 * b - 1) / (32u * b);
+        const unsigned main = ntile * (unsigned)S * 64u * b, tail = (unsigned)MCQ_TAIL_STEPS * 64u * b;
+        if (i < main) {
+            const unsigned q = i % b, lane = (i / b) & 63u;
+            const unsigned sg = i / (64u * b);
+            const unsigned tile = sg / (unsigned)S, s = sg - tile * (unsigned)S;
+            const int co = (int)(tile * 32u * b + 32u * q + (lane & 31u)), ci = (int)(2u * s + (lane >> 5));
+            float v[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) v[tap] = 0.0f;
+            if (co < Cout && ci < Cin) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) v[tap] = pack_source(w, mode, Co, Ci, 3, co, ci, tap) * scale;
+            }
+            float* o = out + base + ((tile * (unsigned)TP + s * 9u) * 64u + lane) * b + q;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) o[(unsigned)tap * 64u * b] = v[tap];
+            return;
+        }
+        i -= main;
+        if (i < tail) { out[base + ntile * (unsigned)TP * 64u * b + i] = 0.0f; return; }
+        i -= tail;
+        base += (ntile * (unsigned)TP + MCQ_TAIL_STEPS) * 64u * b;
+    }
+    if (i < n16) {             // fourth section (conv_t16.h): one 16-byte store = four consecutive k-steps of a lane
+        const unsigned lane = i & 63u, gg = i >> 6;
+        const unsigned G = (unsigned)(Cin / 4) * 9u / 4u;
+        const unsigned tile = gg / G, g = gg - tile * G;
+        const int co = (int)(16u * tile + (lane & 15u));
+        f32x4v v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned step = 4u * g + (unsigned)u;
+            v[u] = pack_source(w, mode, Co, Ci, 3, co, (int)(4u * (step / 9u) + (lane >> 4)), (int)(step % 9u)) * scale;
+        }
+        *reinterpret_cast<f32x4v*>(out + base + i * 4u) = v;
+    }
+}
+
+__global__ void pack_conv_weight_runs_kernel(const float* __restrict__ w, int Cout, int Cin, int S, int TP, float* __restrict__ out,
+                                             int mode, int Co, int Ci, float scale, unsigned n16) {
+    pack_conv_weight_runs_body(w, Cout, Cin, S, TP, out, mode, Co, Ci, scale, n16);
+}
+
+__global__ void pack_conv_weight_runs_multi_kernel(PackTable t, int Cout, int Cin, int S, int TP, int mode, int Co, int Ci, float scale, unsigned n16) {
+    const float* w = t.w[0];
+    float* out = t.out[0];
+#pragma unroll
+    for (int c = 1; c < PACK_MAX_MULTI; ++c)
+        if ((int)blockIdx.y == c) { w = t.w[c]; out = t.out[c]; }
+    pack_conv_weight_runs_body(w, Cout, Cin, S, TP, out, mode, Co, Ci, scale, n16);
+}
+
 __global__ void nonneg_reparam_kernel(const float* __restrict__ p, float bound, float pedestal, float* __restrict__ out,
                                       int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1025,6 +1092,13 @@ inline size_t section_floats(int Cout, int Cin, int ks, int bands) {
     const size_t ntile = (size_t)(Cout + 32 * bands - 1) / (32 * bands);
     return (ntile * (size_t)steps_padded(Cin, ks) + MCQ_TAIL_STEPS) * 64 * bands;
 }
+// threads of pack_conv_weight_runs_kernel: one per (channel pair run, lane, band), per zero of a tail, per 16 bytes of the fourth section
+inline size_t pack_runs_threads(int Cout, int Cin) {
+    size_t t = 0;
+    for (int b = 4; b >= 1; b >>= 1) t += ((size_t)(Cout + 32 * b - 1) / (32 * b) * (size_t)pairs_padded(Cin, 3) + MCQ_TAIL_STEPS) * 64 * b;
+    return t + t16_floats(Cout, Cin, 3) / 4;
+}
+
 inline size_t general_floats(int Cout, int Cin, int ks) {
     return section_floats(Cout, Cin, ks, 4) + section_floats(Cout, Cin, ks, 2) + section_floats(Cout, Cin, ks, 1) + t16_floats(Cout, Cin, ks);
 }
@@ -1180,8 +1254,12 @@ extern "C" int mcq_pack_conv_weight_f32(const float* w, int32_t Cout, int32_t Ci
     if (!w || !out || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return MCQ_EINVAL;
     const size_t total = general_floats(Cout, Cin, ksize);
     const int S = pairs_padded(Cin, ksize), TP = steps_padded(Cin, ksize);
-    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
-                       ksize, S, TP, out, section_floats(Cout, Cin, ksize, 4), section_floats(Cout, Cin, ksize, 2), total, 0, Cout, Cin, 1.0f);
+    if (ksize == 3 && total < (1ull << 31))
+        hipLaunchKernelGGL(pack_conv_weight_runs_kernel, dim3((unsigned)((pack_runs_threads(Cout, Cin) + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           w, Cout, Cin, S, TP, out, 0, Cout, Cin, 1.0f, (unsigned)(t16_floats(Cout, Cin, 3) / 4));
+    else
+        hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
+                           ksize, S, TP, out, section_floats(Cout, Cin, ksize, 4), section_floats(Cout, Cin, ksize, 2), total, 0, Cout, Cin, 1.0f);
     if (head16_shape(Cout, ksize)) {      // second copy in the 16-row operand order of conv_head16_kernel
         const size_t t16 = head16_floats(Cin);
         hipLaunchKernelGGL(pack_head16_kernel, dim3((unsigned)((t16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
@@ -1204,9 +1282,13 @@ extern "C" int mcq_pack_conv_dgrad_weight_f32(const float* w, int32_t Cout, int3
     // same layout and size as a forward pack of a [co_d, ci_d, ks, ks] weight: mcq_packed_conv_weight_floats(co_d, ci_d, ks)
     const size_t total = general_floats(co_d, ci_d, ksize);
     const int S = pairs_padded(ci_d, ksize), TP = steps_padded(ci_d, ksize);
-    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, co_d, ci_d,
-                       ksize, S, TP, out, section_floats(co_d, ci_d, ksize, 4), section_floats(co_d, ci_d, ksize, 2), total,
-                       stride == 1 ? 1 : 2, Cout, Cin, scale);
+    if (ksize == 3 && total < (1ull << 31))
+        hipLaunchKernelGGL(pack_conv_weight_runs_kernel, dim3((unsigned)((pack_runs_threads(co_d, ci_d) + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           w, co_d, ci_d, S, TP, out, stride == 1 ? 1 : 2, Cout, Cin, scale, (unsigned)(t16_floats(co_d, ci_d, 3) / 4));
+    else
+        hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, co_d, ci_d,
+                           ksize, S, TP, out, section_floats(co_d, ci_d, ksize, 4), section_floats(co_d, ci_d, ksize, 2), total,
+                           stride == 1 ? 1 : 2, Cout, Cin, scale);
     if (head16_shape(co_d, ksize)) {      // narrow input gradients (the 8-channel fixture models) take the 16-row kernel
         const size_t t16 = head16_floats(ci_d);
         hipLaunchKernelGGL(pack_head16_kernel, dim3((unsigned)((t16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, co_d, ci_d,
@@ -1235,9 +1317,13 @@ extern "C" int mcq_pack_conv_weight_multi_f32(const float* const* w, float* cons
     }
     const size_t total = general_floats(co, ci, ksize);
     const int S = pairs_padded(ci, ksize), TP = steps_padded(ci, ksize);
-    hipLaunchKernelGGL(pack_conv_weight_multi_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, t, co,
-                       ci, ksize, S, TP, section_floats(co, ci, ksize, 4), section_floats(co, ci, ksize, 2), total, mode, Cout, Cin,
-                       dgrad ? scale : 1.0f);
+    if (ksize == 3 && total < (1ull << 31))
+        hipLaunchKernelGGL(pack_conv_weight_runs_multi_kernel, dim3((unsigned)((pack_runs_threads(co, ci) + 255) / 256), (unsigned)n), dim3(256), 0,
+                           (hipStream_t)stream, t, co, ci, S, TP, mode, Cout, Cin, dgrad ? scale : 1.0f, (unsigned)(t16_floats(co, ci, 3) / 4));
+    else
+        hipLaunchKernelGGL(pack_conv_weight_multi_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, t, co,
+                           ci, ksize, S, TP, section_floats(co, ci, ksize, 4), section_floats(co, ci, ksize, 2), total, mode, Cout, Cin,
+                           dgrad ? scale : 1.0f);
     return mcq_check_launch();
 }
 

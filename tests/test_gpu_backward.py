@@ -148,7 +148,11 @@ def test_wgrad_small_map_kernel(dev, case):
     assert torch.equal(dw2, dw3)
 
 
-@pytest.mark.parametrize("case", [(3, 2, 128, 128, 16, 16), (16, 8, 128, 128, 8, 8), (19, 1, 32, 64, 8, 16)])
+@pytest.mark.parametrize("case", [(3, 2, 128, 128, 16, 16), (16, 8, 128, 128, 8, 8), (19, 1, 32, 64, 8, 16),
+                                  # the training step's own groups (whole-launch plans: several rounds of long walks, several
+                                  # columns per wave, fewer than 1024 waves) and a ragged one
+                                  (12, 8, 128, 128, 64, 64), (14, 8, 128, 128, 32, 32), (2, 8, 128, 128, 128, 128),
+                                  (16, 8, 128, 128, 16, 16), (5, 3, 40, 72, 24, 16)])
 def test_wgrad_rows_grouped_launch(dev, case):
     """Several convolutions of one shape in one launch pair: every (dW, db) equals the single-conv launch to float32 rounding
     (the grouped plan shares the launch's wave budget between the convolutions, i.e. sums the rows in other ranges), and the

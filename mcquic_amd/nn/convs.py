@@ -56,23 +56,26 @@ class Conv2d(nn.Module):
             return 0            # (the opt-in Winograd streams are packed per convolution: grouped packs carry none)
         fwd, bwd = {}, {}
         for c in convs:
-            key = c._key()
+            params = c._parameters                   # (nn.Module.__getattr__ costs more than the whole check)
+            w, b = params["weight"], params.get("bias")
+            wv, wptr = ops.tensor_version(w), w.data_ptr()
+            key = (wv, wptr, None if b is None else (ops.tensor_version(b), b.data_ptr()), False)
             if c._packed is None or key != c._packedKey:
-                fwd.setdefault((tuple(c.weight.shape), c.weight.device), []).append((c, key))
+                fwd.setdefault((w.shape, w.device), []).append((c, key, w, b))
             cache = c.__dict__.get("_dgradCache")
-            if cache is not None and cache.key is not None and cache.key != (key[0], key[1], c.stride):
-                bwd.setdefault((tuple(c.weight.shape), c.weight.device, c.stride), []).append((c, cache))
+            if cache is not None and cache.key is not None and cache.key != (wv, wptr, c.stride):
+                bwd.setdefault((w.shape, w.device, c.stride), []).append((c, cache, w, (wv, wptr, c.stride)))
         done = 0
         for group in fwd.values():
-            packs = ops.pack_convs([c.weight for c, _ in group], [c.bias for c, _ in group])
-            for (c, key), pk in zip(group, packs):
+            packs = ops.pack_convs([w for _, _, w, _ in group], [b for _, _, _, b in group], into=[c._packed for c, _, _, _ in group])
+            for (c, key, _, _), pk in zip(group, packs):
                 c._packed, c._packedKey = pk, key
             done += len(group)
         for (_, _, stride), group in bwd.items():
-            packs = ops.pack_convs([c.weight for c, _ in group], dgrad=True, stride=stride)
-            for (c, cache), pk in zip(group, packs):
-                cache.packed, cache.key = pk, (ops.tensor_version(c.weight), c.weight.data_ptr(), stride)
-                cache.winograd = ops.winograd_enabled()           # (grouped packs carry no Winograd stream: those launches stay direct)
+            packs = ops.pack_convs([w for _, _, w, _ in group], dgrad=True, stride=stride, into=[cache.packed for _, cache, _, _ in group])
+            for (c, cache, _, key), pk in zip(group, packs):
+                cache.packed, cache.key = pk, key
+                cache.winograd = False                    # (grouped packs carry no Winograd stream: those launches stay direct)
             done += len(group)
         return done
 

@@ -202,7 +202,7 @@ class PackedConv:
 
 
 def pack_convs(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]] = None, *, dgrad: bool = False,
-               stride: int = 1, scale: float = 1.0) -> List[PackedConv]:
+               stride: int = 1, scale: float = 1.0, into: Optional[Sequence[Optional[PackedConv]]] = None) -> List[PackedConv]:
     """PackedConv (or PackedConv.dgrad) of several weights of ONE shape in ceil(n / 16) launches
     (mcq_pack_conv_weight_multi_f32).  The biases are referenced, not copied: this is the re-pack after an optimizer step,
     whose caller re-packs again whenever a parameter changes."""
@@ -226,15 +226,25 @@ def pack_convs(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Option
             return [PackedConv.dgrad(w, stride, scale) for w in ws]
         return [PackedConv(w, None if biases is None else biases[i], copy_bias=False) for i, w in enumerate(ws)]
     floats = lib.mcq_packed_conv_weight_floats(co, ci, kh)
-    slab = torch.empty((len(ws), floats), dtype=torch.float32, device=ws[0].device)
+    # `into`: the streams these weights were packed into before -- the re-pack after an optimizer step writes them in place
+    # (same stream order as the launches that read them; no allocation, no new objects, addresses a captured graph can keep)
+    reuse = into is not None and len(into) == len(ws) and all(
+        pk is not None and pk.wp.numel() == floats and pk.wp.device == ws[0].device and pk.wino is None and pk.wino2d is None and pk.wino16 is None
+        and (pk.cout, pk.cin, pk.ksize) == (co, ci, kh) for pk in into)
+    slab = None if reuse else torch.empty((len(ws), floats), dtype=torch.float32, device=ws[0].device)
+    dsts = [pk.wp for pk in into] if reuse else [slab[i] for i in range(len(ws))]
     cap = lib.mcq_pack_conv_weight_max_multi()
     with _guard(ws[0].device):
         for at in range(0, len(ws), cap):
             n = min(cap, len(ws) - at)
             src = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws[at:at + n]])
-            dst = (ctypes.c_void_p * n)(*[slab[at + i].data_ptr() for i in range(n)])
+            dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts[at:at + n]])
             check(lib.mcq_pack_conv_weight_multi_f32(src, dst, n, cout, cin, kh, 1 if dgrad else 0, stride, float(scale), _stream()),
                   "mcq_pack_conv_weight_multi_f32")
+    if reuse:
+        for i, pk in enumerate(into):
+            pk.bias = None if dgrad or biases is None or biases[i] is None else _dev(biases[i].detach(), "bias")
+        return list(into)
     out = []
     for i in range(len(ws)):
         pk = PackedConv.__new__(PackedConv)

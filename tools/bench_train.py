@@ -75,6 +75,9 @@ def main():
             xHat, yHat, codes, logits = net(x)
             static_loss = torch.nn.functional.mse_loss(xHat, x)
             static_loss.backward()
+            if opt is not None:
+                opt.step()                                 # (the update itself is part of the captured step; the forward above
+                                                           #  starts with the grouped re-pack of every stale operand stream)
 
         def step():                                        # noqa: F811
             graph.replay()

@@ -141,13 +141,48 @@ class EntropyCoder(nn.Module):
         [n, m, h, w, k] over (n, h, w) and all-reduces each level; here the counts are histograms of the int64 codes
         and the three levels share ONE all-reduce (parallel.code_histograms)."""
         from ..parallel import code_histograms
-        counts = code_histograms(codes, self._k)
+        if self._deferCounts(codes):
+            return
+        self._emaUpdate(code_histograms(codes, self._k))
+
+    def _emaUpdate(self, counts):
         for lv, totalCount in enumerate(counts):
             totalCount = totalCount.to(self._freqEMA[lv].dtype)
             normalized = totalCount / totalCount.sum(-1, keepdim=True)
             ema = (1 - self._ema) * normalized + self._ema * self._freqEMA[lv]
             self._freqEMA[lv].copy_(ema)
         self.resetFreqAndCDF()
+
+    # ---- deferred mode (parallel.GraphedTrainStep): forward leaves this rank's counts in a static buffer, the caller
+    #      all-reduces them outside the captured step and hands the global counts to applyCounts ------------------------
+    def deferCounts(self, on: bool):
+        self.__dict__["_countSinkOn"] = bool(on)
+        if not on:
+            self.__dict__["_countSinkBuf"] = None
+
+    def countSink(self) -> torch.Tensor:
+        buf = self.__dict__.get("_countSinkBuf")
+        if buf is None:
+            raise RuntimeError("countSink: no training forward has run in deferred mode yet")
+        return buf
+
+    def _deferCounts(self, codes) -> bool:
+        if not self.__dict__.get("_countSinkOn", False):
+            return False
+        from ..parallel import local_code_counts
+        local = local_code_counts(codes, self._k)
+        buf = self.__dict__.get("_countSinkBuf")
+        if buf is None or buf.shape != local.shape or buf.device != local.device:
+            self.__dict__["_countSinkBuf"] = local.clone()
+        else:
+            buf.copy_(local)
+        self.__dict__["_countMs"] = [int(c.shape[1]) for c in codes]
+        return True
+
+    @torch.no_grad()
+    def applyCounts(self, flat: torch.Tensor):
+        from ..parallel import split_code_counts
+        self._emaUpdate(split_code_counts(flat, self.__dict__["_countMs"], self._k))
 
     # ---- frequency / CDF tables (entropyCoder.py:46-79) ------------------------------------------------------
     def resetFreqAndCDF(self):
@@ -296,11 +331,21 @@ class VariousMCoder(nn.Module):
     def forward(self, codes: List[torch.Tensor]):
         """EMA update (:306-323) from integer codes (level l: [n, m_l, h, w]); one fused all-reduce for all levels."""
         from ..parallel import code_histograms
-        for lv, totalCount in enumerate(code_histograms(codes, self._k)):
+        if self._deferCounts(codes):
+            return
+        self._emaUpdate(code_histograms(codes, self._k))
+
+    def _emaUpdate(self, counts):
+        for lv, totalCount in enumerate(counts):
             totalCount = totalCount.to(self._freqEMA[lv].dtype)
             normalized = totalCount / totalCount.sum(-1, keepdim=True)
             self._freqEMA[lv].copy_((1 - self._ema) * normalized + self._ema * self._freqEMA[lv])
         self.resetFreqAndCDF()
+
+    deferCounts = EntropyCoder.deferCounts
+    countSink = EntropyCoder.countSink
+    _deferCounts = EntropyCoder._deferCounts
+    applyCounts = EntropyCoder.applyCounts
 
     def resetFreqAndCDF(self):
         self._normalizedFreq = None

@@ -53,8 +53,8 @@ def gather_image_stats(local: torch.Tensor, group=None) -> torch.Tensor:
     return torch.cat([o[: int(c)] for o, c in zip(out, counts)], 0).to(home)
 
 
-def code_histograms(codes: Sequence[torch.Tensor], ks: Sequence[int], group=None) -> List[torch.Tensor]:
-    """Per-level code counts [m, k_l] (int64) summed over all images of all ranks with ONE all_reduce."""
+def local_code_counts(codes: Sequence[torch.Tensor], ks: Sequence[int]) -> torch.Tensor:
+    """This rank's per-level code counts, all levels in ONE flat int64 buffer (level l: m_l * k_l entries, [m, k] row-major)."""
     flat = []
     for code, k in zip(codes, ks):
         n, m = code.shape[0], code.shape[1]
@@ -63,17 +63,32 @@ def code_histograms(codes: Sequence[torch.Tensor], ks: Sequence[int], group=None
         # inside a captured hipGraph)
         idx = idx.reshape(-1)
         flat.append(torch.zeros(m * k, dtype=torch.int64, device=code.device).scatter_add_(0, idx, torch.ones_like(idx)))
-    buf = torch.cat(flat)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        staged = _staged(buf, group)
-        dist.all_reduce(staged, group=group)
-        buf = staged.to(buf.device)
+    return torch.cat(flat)
+
+
+def split_code_counts(buf: torch.Tensor, ms: Sequence[int], ks: Sequence[int]) -> List[torch.Tensor]:
+    """The [m_l, k_l] views of a flat count buffer (local_code_counts' layout)."""
     out, off = [], 0
-    for code, k in zip(codes, ks):
-        m = code.shape[1]
+    for m, k in zip(ms, ks):
         out.append(buf[off: off + m * k].reshape(m, k))
         off += m * k
     return out
+
+
+def all_reduce_(buf: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum of `buf` over the ranks of `group` (RCCL on device tensors; staged through the host under gloo)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        staged = _staged(buf, group)
+        dist.all_reduce(staged, group=group)
+        if staged is not buf:
+            buf.copy_(staged)
+    return buf
+
+
+def code_histograms(codes: Sequence[torch.Tensor], ks: Sequence[int], group=None) -> List[torch.Tensor]:
+    """Per-level code counts [m, k_l] (int64) summed over all images of all ranks with ONE all_reduce."""
+    buf = all_reduce_(local_code_counts(codes, ks), group)
+    return split_code_counts(buf, [code.shape[1] for code in codes], ks)
 
 
 def data_parallel(model: torch.nn.Module, device: torch.device, group=None, **kwargs):
@@ -109,3 +124,121 @@ def data_parallel(model: torch.nn.Module, device: torch.device, group=None, **kw
             return fut
         ddp.register_comm_hook(None, staged_allreduce)
     return ddp
+
+
+class GraphedTrainStep:
+    """One rank's data-parallel training step (BASELINE configs[4]: `torchrun` + DDP in the reference, mcquic/train/ddp.py:79-95)
+    with the host out of the loop.  DDP's eager step is bound by the host here -- ~1 000 launches of ~20 us each per step, with
+    two host cores per rank on an 8-GPU node -- and a step captured WITH DDP's hooks replays slower than eager (the bucket
+    all-reduces live on RCCL's stream: a multi-stream graph).  So the step is cut where the exchange is:
+
+        main graph   forward + backward of the local shard on a static input, every gradient copied into ONE flat float32
+                     buffer (`torch.cat(..., out=)`), this rank's code counts of the frequency-EMA update into one int64 buffer
+        exchange     two all-reduces outside any graph: the flat gradients (65 MB for the qp=2 model -- one large message per
+                     step is what a point-to-point xGMI ring wants, not 25 MB buckets) and the 86 KB of counts
+        post graph   gradients / world size, the optimizer's update, the frequency EMA from the GLOBAL counts
+                     (mcquic/modules/entropyCoder.py:28-44 all-reduces them inside forward; here that collective is deferred)
+
+    The forward of the next replay starts with the grouped re-pack of every operand stream the update made stale
+    (`Conv2d.repack_stale`, in place): all parameters are marked changed before the capture so that those launches are recorded.
+    Nothing overlaps the gradient all-reduce with the backward pass; at 8 x 256 x 256 per rank the step is ~22 ms of kernels and
+    the message ~1 ms of link time.
+
+        step = GraphedTrainStep(model, optimizer, example_x)        # after torch.distributed is initialised (or not at all)
+        loss = step(x)                                              # x: this rank's shard, shape of example_x
+    """
+
+    def __init__(self, model: torch.nn.Module, optimizer, example_x: torch.Tensor, loss_fn=None, group=None,
+                 forward_kwargs: dict | None = None, warmup: int = 2, capture_post: bool = True):
+        if not example_x.is_cuda:
+            raise RuntimeError("GraphedTrainStep needs a HIP device (hipGraph capture)")
+        self.model, self.optimizer, self.group = model, optimizer, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.x = example_x.detach().clone()
+        self.kwargs = dict(forward_kwargs or {})
+        self.loss_fn = loss_fn or (lambda out, x: torch.nn.functional.mse_loss(out[0], x))
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.coders = [m for m in model.modules() if hasattr(m, "deferCounts")]
+        model.train()
+        for c in self.coders:
+            c.deferCounts(True)
+        try:
+            for _ in range(max(1, warmup)):                  # caches, workspaces, the coders' count sinks
+                self._forward_backward()
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                torch._foreach_add_(self.params, 0.0)        # every parameter "changed": the capture records all re-packs
+            for p in self.params:
+                p.grad = None
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._forward_backward()
+                self.live = [p for p in self.params if p.grad is not None]
+                self.flat = torch.empty(sum(p.numel() for p in self.live), dtype=torch.float32, device=self.x.device)
+                torch.cat([p.grad.reshape(-1) for p in self.live], out=self.flat)
+                sinks = [c.countSink() for c in self.coders]
+                self.counts = torch.cat(sinks) if sinks else None
+        except BaseException:
+            for c in self.coders:
+                c.deferCounts(False)
+            raise
+        off = 0
+        for p in self.live:                                  # the optimizer reads the reduced gradients
+            p.grad = self.flat[off: off + p.numel()].view_as(p)
+            off += p.numel()
+        self.post = None
+        if capture_post:
+            try:
+                post = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(post):
+                    self._post()
+                self.post = post
+            except Exception:                                # an optimizer that cannot be captured: its update runs eagerly
+                torch.cuda.synchronize()
+                self.post = None
+
+    def _forward_backward(self):
+        for p in self.params:
+            p.grad = None
+        out = self.model(self.x, **self.kwargs)
+        loss = self.loss_fn(out, self.x)
+        loss.backward()
+        return loss.detach()
+
+    def _post(self):
+        if self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+        self.optimizer.step()
+        off = 0
+        for c in self.coders:
+            n = c.countSink().numel()
+            c.applyCounts(self.counts[off: off + n])
+            off += n
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        self.x.copy_(x, non_blocking=True)
+        self.graph.replay()
+        if self.world > 1:
+            all_reduce_(self.flat, self.group)
+            if self.counts is not None:
+                all_reduce_(self.counts, self.group)
+        if self.post is not None:
+            self.post.replay()
+        else:
+            self._post()
+        for c in self.coders:
+            c.resetFreqAndCDF()
+        return self.loss
+
+    def invalidate(self):
+        """Replays change the parameters without the host seeing it (no version counter moves): mark every parameter changed so
+        that the next EAGER use of the model (evaluation, a checkpoint's `compress`) re-packs its operand streams -- they are one
+        update behind after a replay.  Call before using the model outside this step; `close()` does."""
+        with torch.no_grad():
+            torch._foreach_add_(self.params, 0.0)
+
+    def close(self):
+        """Back to the eager step: the coders update their EMA inside forward again, `.grad` is whatever the last step left."""
+        for c in self.coders:
+            c.deferCounts(False)
+        self.invalidate()

@@ -115,6 +115,73 @@ def train_mode(rank, world, dev):
     return out
 
 
+def graphed_mode(rank, world, dev):
+    """parallel.GraphedTrainStep over the two ranks (2 crops each; main graph, flat gradient all-reduce + count all-reduce staged
+    through the host under gloo, post graph) against ONE process making the same SGD update on all 4 crops."""
+    import copy
+    from mcquic_amd import Compressor, parallel
+    ks = [8192, 2048, 512]
+    per, hw, lr = 2, 256, 1e-2
+    n = per * world
+    torch.manual_seed(3407)
+    model = Compressor(128, 2, ks).to(dev).train()
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand((n, 3, hw, hw), generator=g) * 2 - 1).to(dev)
+    us = []
+    for lv, k in enumerate(ks):
+        s = hw // 16 // (2 ** lv)
+        us.append((torch.rand((n, 2, s, s, k), generator=g).to(dev), torch.rand((n, 2, s, s, k), generator=g).to(dev)))
+    out, ref, ref_ema = {}, None, None
+    if rank == 0:
+        solo_model = copy.deepcopy(model)
+        solo = dist.new_group([0])
+        import mcquic_amd.parallel as P
+        orig = P.code_histograms
+        P.code_histograms = lambda c, k, group=None: orig(c, k, group=solo)
+        try:
+            opt = torch.optim.SGD(solo_model.parameters(), lr=lr)
+            xHat = solo_model(x, uniforms=us)[0]
+            torch.nn.functional.mse_loss(xHat, x).backward()
+            opt.step()
+        finally:
+            P.code_histograms = orig
+        torch.cuda.synchronize()
+        ref = [p.detach().clone() for p in solo_model.parameters()]
+        ref_ema = [f.detach().clone() for f in solo_model._quantizer._entropyCoder._freqEMA]
+    else:
+        dist.new_group([0])                                             # (new_group is collective over the default group)
+    dist.barrier()
+    lo, hi = rank * per, (rank + 1) * per
+    init = [p.detach().clone() for p in model.parameters()]
+    step = parallel.GraphedTrainStep(model, torch.optim.SGD(model.parameters(), lr=lr), x[lo:hi],
+                                     forward_kwargs={"uniforms": [(a[lo:hi], b[lo:hi]) for a, b in us]})
+    loss = step(x[lo:hi])
+    step.close()
+    torch.cuda.synchronize()
+    if rank == 0:
+        worst, worst_name, moved = 0.0, "", 0.0
+        for (name, p), r, p0 in zip(model.named_parameters(), ref, init):
+            if not p.requires_grad:
+                continue
+            upd = float((r - p0).abs().max())
+            if upd == 0.0:
+                continue
+            # error against 1e-4 of the update itself plus the rounding of the parameter's own magnitude (an update of a few
+            # ulps cannot agree better than to an ulp)
+            tol = 1e-4 * upd + 4 * 1.1920929e-07 * float(r.abs().max())
+            rel = float((p.detach() - r).abs().max()) / tol
+            moved = max(moved, upd)
+            if rel > worst:
+                worst, worst_name = rel, name
+        out["worst_update_rel_err"] = worst
+        out["worst_update_name"] = worst_name
+        out["largest_update"] = moved
+        out["post_captured"] = step.post is not None
+        out["ema_max_abs_diff"] = max(float((a - b).abs().max()) for a, b in zip(ref_ema, model._quantizer._entropyCoder._freqEMA))
+        out["loss_rank0"] = float(loss)
+    return out
+
+
 def parallel_gather(t, world, dev):
     host = t.cpu()
     out = [torch.empty_like(host) for _ in range(world)]
@@ -128,7 +195,7 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)                                       # BOTH ranks on the one GPU
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    out = {"validate": validate_mode, "train": train_mode}[mode](rank, world, dev)
+    out = {"validate": validate_mode, "train": train_mode, "graphed": graphed_mode}[mode](rank, world, dev)
     torch.cuda.synchronize()
     dist.barrier()
     if rank == 0:

@@ -55,3 +55,13 @@ def test_two_rank_ddp_training_step_matches_one_process(dev, tmp_path):
     assert r["ema_max_abs_diff"] < 1e-7, r
     # float32 reassociation only: two partial sums of two crops averaged vs one sum over four crops
     assert r["worst_grad_rel_err"] < 2e-5, r
+
+
+def test_two_rank_graphed_step_matches_one_process(dev, tmp_path):
+    """parallel.GraphedTrainStep: two ranks' captured steps + flat gradient / count all-reduces = one process's SGD update on
+    the whole batch (the parameter updates agree to float32 reassociation, the frequency EMA exactly)."""
+    r = _run("graphed", tmp_path)
+    assert r["post_captured"], r
+    assert r["largest_update"] > 0, r
+    assert r["worst_update_rel_err"] < 1.0, r        # (in units of 1e-4 x the update + 4 ulps of the parameter)
+    assert r["ema_max_abs_diff"] < 1e-7, r

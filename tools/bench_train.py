@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--crop", type=int, default=256)
     ap.add_argument("--graph", action="store_true", help="capture forward+backward in one hipGraph and replay it (single GPU)")
     ap.add_argument("--graph-streams", action="store_true", help="with --graph: keep the branch streams on during capture (experiment)")
+    ap.add_argument("--graphed", action="store_true",
+                    help="parallel.GraphedTrainStep: main hipGraph (forward + backward, flat gradient buffer) + one gradient all-reduce "
+                         "over the ranks + post hipGraph (SGD update, frequency EMA) -- the data-parallel step without DDP's hooks")
     ap.add_argument("--optimizer-step", action="store_true",
                     help="SGD step inside the timed region: the weights change every step, so every conv re-packs its forward and "
                          "input-gradient operand streams each step, as in a real training loop")
@@ -48,7 +51,7 @@ def main():
     from mcquic_amd import Compressor
     torch.manual_seed(3407)
     model = Compressor(128, 2, [8192, 2048, 512]).to(dev).train()
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if use_dist else model
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if use_dist and not args.graphed else model
     x = (torch.rand((args.batch, 3, args.crop, args.crop), generator=torch.Generator().manual_seed(rank)) * 2 - 1).to(dev)
 
     opt = torch.optim.SGD(model.parameters(), lr=1e-6) if args.optimizer_step else None
@@ -63,9 +66,16 @@ def main():
             opt.step()
         return loss
 
+    if args.graphed:
+        from mcquic_amd import parallel
+        args.optimizer_step = True
+        gstep = parallel.GraphedTrainStep(model, torch.optim.SGD(model.parameters(), lr=1e-6), x)
+
+        def step():                                        # noqa: F811
+            return gstep(x)
     for _ in range(args.warmup):
         step()
-    if args.graph and not use_dist:
+    if args.graph and not use_dist and not args.graphed:
         # whole-step capture: ~5000 kernel launches per step become one graph launch
         torch.cuda.synchronize()
         for p in model.parameters():
@@ -98,7 +108,8 @@ def main():
         print(json.dumps({"metric": "training step (forward + backward), 256x256 crops, qp=2 model", "n_gpus": world,
                           "images_per_gpu": args.batch, "ms_per_step": round(dt / args.steps * 1e3, 2),
                           "images_per_s": round(world * args.batch * args.steps / dt, 2), "loss": float(loss), "grad_norm": gn,
-                          "dtype": "f32", "graph": bool(args.graph and not use_dist), "ddp": bool(use_dist),
+                          "dtype": "f32", "graph": bool((args.graph and not use_dist) or args.graphed), "ddp": bool(use_dist and not args.graphed),
+                          "graphed_data_parallel": bool(args.graphed),
                           "optimizer_step": "SGD inside the timed region (weights re-packed every step)" if args.optimizer_step else "not included"}))
     if use_dist:
         dist.destroy_process_group()

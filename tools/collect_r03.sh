@@ -23,6 +23,9 @@ python tools/bench_train.py --steps 10 2>/dev/null | tail -1 > $O/bench_train.js
 python tools/bench_train.py --steps 10 --graph 2>/dev/null | tail -1 >> $O/bench_train.json
 python tools/bench_train.py --steps 10 --optimizer-step 2>/dev/null | tail -1 >> $O/bench_train.json
 python tools/bench_train.py --steps 10 --graph --optimizer-step 2>/dev/null | tail -1 >> $O/bench_train.json
+python tools/bench_train.py --steps 20 --graphed 2>/dev/null | tail -1 >> $O/bench_train.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 tools/bench_train.py --gpus 1 --steps 20 --graphed 2>/dev/null | tail -1 >> $O/bench_train.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 tools/bench_train.py --gpus 1 --steps 20 --optimizer-step 2>/dev/null | tail -1 >> $O/bench_train.json
 MCQUIC_AMD_BRANCH_STREAMS=0 rocprofv3 --kernel-trace -d $O/kt_train -o kt -- python tools/bench_train.py > /dev/null 2>&1
 python profiles/kernel_stats.py $O/kt_train/kt_results.db > $O/kernel_stats_train_single_stream.txt
 python tools/bench_speed_protocol.py 2>/dev/null | tail -1 > $O/speed_protocol.txt

@@ -139,3 +139,50 @@ def test_data_parallel_host_staged_buckets_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(world))
+
+
+def _deferred_worker(rank, world, port, ret):
+    """The exchange part of parallel.GraphedTrainStep on CPU tensors: every rank's EntropyCoder leaves its LOCAL counts in a
+    buffer (deferred mode), one all-reduce makes them global, applyCounts gives the frequency EMA the in-forward all-reduce
+    gives; a flat float buffer averaged the same way."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mcquic_amd import parallel
+    from mcquic_amd.modules.entropyCoder import EntropyCoder
+    ks = [32, 16, 8]
+    g = torch.Generator().manual_seed(1)
+    codes_all = [torch.randint(0, k, (6, 2, s, s), generator=g) for k, s in zip(ks, (4, 2, 1))]
+    lo, hi = parallel.shard_range(6, rank, world)
+    mine = [c[lo:hi] for c in codes_all]
+    direct, deferred = EntropyCoder(2, ks), EntropyCoder(2, ks)
+    direct(mine)                                             # all-reduce inside forward (the reference's order)
+    deferred.deferCounts(True)
+    deferred(mine)
+    assert all(torch.equal(a, torch.ones_like(a) / a.shape[-1]) for a in deferred._freqEMA)     # nothing applied yet
+    counts = deferred.countSink().clone()
+    assert torch.equal(counts, parallel.local_code_counts(mine, ks))
+    parallel.all_reduce_(counts)
+    deferred.applyCounts(counts)
+    deferred.deferCounts(False)
+    ok = all(torch.equal(a, b) for a, b in zip(direct._freqEMA, deferred._freqEMA))
+    ok = ok and int(counts.sum()) == 6 * 2 * (16 + 4 + 1)
+    flat = torch.full((5,), float(rank + 1))
+    parallel.all_reduce_(flat)
+    ok = ok and torch.equal(flat, torch.full((5,), 3.0))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_deferred_counts_and_flat_allreduce_world2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_deferred_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world))

@@ -165,6 +165,7 @@ class GraphedTrainStep:
         try:
             for _ in range(max(1, warmup)):                  # caches, workspaces, the coders' count sinks
                 self._forward_backward()
+            self._init_optimizer_state()
             torch.cuda.synchronize()
             with torch.no_grad():
                 torch._foreach_add_(self.params, 0.0)        # every parameter "changed": the capture records all re-packs
@@ -196,6 +197,26 @@ class GraphedTrainStep:
             except Exception:                                # an optimizer that cannot be captured: its update runs eagerly
                 torch.cuda.synchronize()
                 self.post = None
+                self._zero_optimizer_state()                 # (host-side counters may have moved before the capture gave up)
+
+    def _init_optimizer_state(self):
+        """An optimizer creates its state (momentum buffers, Adam's moments and step counter) inside its first `step()`; created
+        inside the capture they would be re-created by every replay.  One throw-away update with the warm-up gradients brings
+        them into existence, then the parameters are restored and the state is zeroed -- which is the state a fresh optimizer
+        starts from (SGD with momentum, Adam / AdamW; an optimizer whose initial state is not zeros needs its own warm-up)."""
+        saved = [p.detach().clone() for p in self.params]
+        self.optimizer.step()
+        with torch.no_grad():
+            for p, v in zip(self.params, saved):
+                p.copy_(v)
+        self._zero_optimizer_state()
+
+    def _zero_optimizer_state(self):
+        with torch.no_grad():
+            for st in self.optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
 
     def _forward_backward(self):
         for p in self.params:

@@ -37,7 +37,7 @@ def test_graphed_step_equals_eager_step(dev, cfg):
         loss = torch.nn.functional.mse_loss(out[0], x)
         loss.backward()
         opt_e.step()
-        losses_e.append(float(loss))
+        losses_e.append(float(loss.detach()))
 
     opt_g = torch.optim.SGD(graphed.parameters(), lr=lr)
     step = parallel.GraphedTrainStep(graphed, opt_g, xs[0], forward_kwargs={"uniforms": us})
@@ -79,3 +79,21 @@ def test_graphed_step_really_updates(dev):
     after = [p.detach() for p in model.parameters() if p.requires_grad]
     assert any(not torch.equal(a, b) for a, b in zip(before, after))
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("capturable", [True, False])
+def test_graphed_step_with_adam(dev, capturable):
+    """Adam (what the reference's configs train with): captured in the post graph when built with capturable=True, run eagerly
+    after the exchange otherwise -- either way the loss on a fixed batch goes down and the state advances every step."""
+    from mcquic_amd import Compressor, parallel
+    torch.manual_seed(4)
+    model = Compressor(32, 2, [64, 32, 16]).to(dev).train()
+    x = (torch.rand((2, 3, 64, 64), generator=torch.Generator().manual_seed(2)) * 2 - 1).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3, capturable=capturable)
+    step = parallel.GraphedTrainStep(model, opt, x, forward_kwargs={"uniforms": _uniforms(2, 64, [64, 32, 16], dev, 9)})
+    assert (step.post is not None) == capturable
+    losses = [float(step(x)) for _ in range(10)]
+    step.close()
+    assert losses[-1] < losses[0], losses
+    st = next(iter(opt.state.values()))
+    assert int(st["step"]) == 10

@@ -146,6 +146,11 @@ class GraphedTrainStep:
 
         step = GraphedTrainStep(model, optimizer, example_x)        # after torch.distributed is initialised (or not at all)
         loss = step(x)                                              # x: this rank's shard, shape of example_x
+        step.close()                                                # before evaluating / saving: eager code re-packs its streams
+
+    A captured update bakes in whatever the optimizer read on the host at capture time: give a scheduled learning rate to the
+    optimizer as a TENSOR (torch.optim reads it on the device then; Adam / AdamW additionally need `capturable=True`), or pass
+    `capture_post=False` and the update (with the EMA) runs eagerly after the exchange -- ~15 launches, still no per-layer host work.
     """
 
     def __init__(self, model: torch.nn.Module, optimizer, example_x: torch.Tensor, loss_fn=None, group=None,

@@ -30,7 +30,7 @@ extern "C" {
  * compares it with mcq_abi_version() of the library it loaded before calling anything else: a stale .so under new
  * prototypes (or the reverse) misaligns arguments silently otherwise.  3 = round 3 (mcq_rans_*_with_indexes take cdf_lens,
  * mcq_gate_f32 takes out_silu -- both changed in round 2 without a bump --, GroupNorm / logits-gradient entry points). */
-#define MCQ_ABI_VERSION   4
+#define MCQ_ABI_VERSION   5
 
 #define MCQ_OK            0
 #define MCQ_EINVAL       -1   /* NULL pointer / non-positive dimension / unsupported combination */
@@ -311,6 +311,16 @@ int mcq_detransform_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 int32_t mcq_pack_conv_weight_max_multi(void);
 int mcq_pack_conv_weight_multi_f32(const float* const* w, float* const* out, int32_t n, int32_t Cout, int32_t Cin, int32_t ksize,
                                    int32_t dgrad, int32_t stride, float scale, void* stream);
+/* The same with a section mask per weight (NULL or 0 = all): bit 0 the 128-row copy of the 3x3 operand stream, bit 1 the 64-row
+ * copy, bit 2 the 32-row copy, bit 3 the 16x16-tile order; copies not named are left as they are.  For a re-pack INSIDE a captured
+ * training step, whose launches -- and therefore the copies they read -- never change: mcq_conv_section_trace(1) starts recording
+ * which copy every conv launch reads per packed buffer (clearing earlier records), (0) stops; mcq_conv_sections_used(packed) =
+ * the recorded mask of a buffer (0: not seen).  1x1 weights ignore the mask.  (A training loop's re-pack after optimizer.step():
+ * train/trainer.py's step; nothing in the reference corresponds to the mask -- cuDNN keeps no re-laid copies.) */
+int mcq_pack_conv_weight_multi_masked_f32(const float* const* w, float* const* out, const uint8_t* masks, int32_t n, int32_t Cout,
+                                          int32_t Cin, int32_t ksize, int32_t dgrad, int32_t stride, float scale, void* stream);
+void mcq_conv_section_trace(int32_t on);
+uint32_t mcq_conv_sections_used(const float* packed);
 
 /* cdf[0..k] (uint32, cdf[0] = 0, cdf[k] = 1 << precision, strictly increasing) from pmf[0..k-1].
  * Same arithmetic as pmfToQuantizedCDF (third_party/CompressAI/cpp_exts/ops.cpp:42-111). */

@@ -18,7 +18,9 @@
 // the k-steps of a tile over 2 / 4 / 8 waves of a workgroup (LDS reduction); the epilogue (bias, GDN / IGDN, gate,
 // residual, SiLU, SiLU twin, PixelShuffle store) runs on buffer instructions without predication.
 // Build switches below (all measured on MI355X): ring depths, XCD-aware tile order, tile rules.
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 #include "mcq_common.h"
 #include "../../include/mcquic_hip.h"
@@ -926,9 +928,22 @@ next_tile:
 // for k-step = s * taps + tap (channel-major, tap-inner); zero beyond Cout / Cin and in the tail (MCQ_TAIL_STEPS).
 // up to MCQ_PACK_MAX_MULTI weights of one shape per launch (blockIdx.y picks the pair): after an optimizer step every conv of
 // the network re-packs its forward and its input-gradient operand stream -- 660 launches of ~4 us each, one by one
+// Which copy of its operand stream a launch reads, recorded per packed buffer while tracing is on (mcq_conv_section_trace): a
+// training step captured as a hipGraph replays the same launches forever, so its in-graph re-pack after the optimizer's update
+// only needs to refresh the copies those launches read (mcq_pack_conv_weight_multi_masked_f32) -- a quarter of the bytes.
+std::mutex g_sec_mu;
+bool g_sec_trace = false;
+std::unordered_map<const float*, unsigned> g_sec_used;
+inline void sec_note(const mcq_conv_desc* descs, int nprob, unsigned bit) {
+    if (!g_sec_trace) return;
+    std::lock_guard<std::mutex> lock(g_sec_mu);
+    for (int c = 0; c < nprob; ++c) g_sec_used[descs[c].w_packed] |= bit;
+}
+
 constexpr int PACK_MAX_MULTI = 16;
 constexpr int MCQ_TAIL_STEPS = 16;
-struct PackTable { const float* w[PACK_MAX_MULTI]; float* out[PACK_MAX_MULTI]; };
+struct PackTable { const float* w[PACK_MAX_MULTI]; float* out[PACK_MAX_MULTI]; unsigned char mask[PACK_MAX_MULTI]; };
+// (mask: sections to write -- bit 0 the 128-row copy, 1 the 64-row, 2 the 32-row, 3 the 16x16-tile order; mcq_pack_conv_weight_multi_masked_f32)
 
 __device__ __forceinline__ void pack_conv_weight_body(const float* __restrict__ w, int Cout, int Cin, int ks, int S, int TP,
                                                       float* __restrict__ out, size_t sec4, size_t sec2, size_t total, int mode, int Co, int Ci,
@@ -1011,7 +1026,8 @@ __global__ void pack_conv_weight_multi_kernel(PackTable t, int Cout, int Cin, in
 // optimizer step inside the training step every conv re-packs both its operand streams, and those ~45 grouped launches were
 // 1.6 ms of a 24 ms step; this form does the same in a quarter of the time.  Same bits in the same places.
 __device__ __forceinline__ void pack_conv_weight_runs_body(const float* __restrict__ w, int Cout, int Cin, int S, int TP,
-                                                           float* __restrict__ out, int mode, int Co, int Ci, float scale, unsigned n16) {
+                                                           float* __restrict__ out, int mode, int Co, int Ci, float scale, unsigned n16,
+                                                           unsigned mask) {
     // (32-bit index arithmetic throughout: a packed weight is far below 2^31 floats -- the element-per-thread kernel's 64-bit
     //  divisions were a good part of its time)
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1020,7 +1036,9 @@ __device__ __forceinline__ void pack_conv_weight_runs_body(const float* __restri
     for (int b = 4; b >= 1; b >>= 1) {
         const unsigned ntile = (unsigned)(Cout + 32 * b - 1) / (32u * b);
         const unsigned main = ntile * (unsigned)S * 64u * b, tail = (unsigned)MCQ_TAIL_STEPS * 64u * b;
+        const bool wanted = (mask >> (b == 4 ? 0 : b == 2 ? 1 : 2)) & 1u;
         if (i < main) {
+            if (!wanted) return;
             const unsigned q = i % b, lane = (i / b) & 63u;
             const unsigned sg = i / (64u * b);
             const unsigned tile = sg / (unsigned)S, s = sg - tile * (unsigned)S;
@@ -1038,11 +1056,11 @@ __device__ __forceinline__ void pack_conv_weight_runs_body(const float* __restri
             return;
         }
         i -= main;
-        if (i < tail) { out[base + ntile * (unsigned)TP * 64u * b + i] = 0.0f; return; }
+        if (i < tail) { if (wanted) out[base + ntile * (unsigned)TP * 64u * b + i] = 0.0f; return; }
         i -= tail;
         base += (ntile * (unsigned)TP + MCQ_TAIL_STEPS) * 64u * b;
     }
-    if (i < n16) {             // fourth section (conv_t16.h): one 16-byte store = four consecutive k-steps of a lane
+    if (i < n16 && (mask & 8u)) {             // fourth section (conv_t16.h): one 16-byte store = four consecutive k-steps of a lane
         const unsigned lane = i & 63u, gg = i >> 6;
         const unsigned G = (unsigned)(Cin / 4) * 9u / 4u;
         const unsigned tile = gg / G, g = gg - tile * G;
@@ -1059,16 +1077,17 @@ __device__ __forceinline__ void pack_conv_weight_runs_body(const float* __restri
 
 __global__ void pack_conv_weight_runs_kernel(const float* __restrict__ w, int Cout, int Cin, int S, int TP, float* __restrict__ out,
                                              int mode, int Co, int Ci, float scale, unsigned n16) {
-    pack_conv_weight_runs_body(w, Cout, Cin, S, TP, out, mode, Co, Ci, scale, n16);
+    pack_conv_weight_runs_body(w, Cout, Cin, S, TP, out, mode, Co, Ci, scale, n16, 15u);
 }
 
 __global__ void pack_conv_weight_runs_multi_kernel(PackTable t, int Cout, int Cin, int S, int TP, int mode, int Co, int Ci, float scale, unsigned n16) {
     const float* w = t.w[0];
     float* out = t.out[0];
+    unsigned mask = t.mask[0];
 #pragma unroll
     for (int c = 1; c < PACK_MAX_MULTI; ++c)
-        if ((int)blockIdx.y == c) { w = t.w[c]; out = t.out[c]; }
-    pack_conv_weight_runs_body(w, Cout, Cin, S, TP, out, mode, Co, Ci, scale, n16);
+        if ((int)blockIdx.y == c) { w = t.w[c]; out = t.out[c]; mask = t.mask[c]; }
+    pack_conv_weight_runs_body(w, Cout, Cin, S, TP, out, mode, Co, Ci, scale, n16, mask);
 }
 
 __global__ void nonneg_reparam_kernel(const float* __restrict__ p, float bound, float pedestal, float* __restrict__ out,
@@ -1299,8 +1318,36 @@ extern "C" int mcq_pack_conv_dgrad_weight_f32(const float* w, int32_t Cout, int3
 
 extern "C" int32_t mcq_pack_conv_weight_max_multi(void) { return PACK_MAX_MULTI; }
 
+extern "C" void mcq_conv_section_trace(int32_t on) {
+    std::lock_guard<std::mutex> lock(g_sec_mu);
+    if (on) g_sec_used.clear();
+    g_sec_trace = on != 0;
+}
+
+extern "C" uint32_t mcq_conv_sections_used(const float* packed) {
+    std::lock_guard<std::mutex> lock(g_sec_mu);
+    const auto it = g_sec_used.find(packed);
+    return it == g_sec_used.end() ? 0u : it->second;
+}
+
+namespace {
+int pack_multi(const float* const* w, float* const* out, const uint8_t* masks, int32_t n, int32_t Cout, int32_t Cin, int32_t ksize,
+               int32_t dgrad, int32_t stride, float scale, void* stream);
+}
+
 extern "C" int mcq_pack_conv_weight_multi_f32(const float* const* w, float* const* out, int32_t n, int32_t Cout, int32_t Cin, int32_t ksize,
                                               int32_t dgrad, int32_t stride, float scale, void* stream) {
+    return pack_multi(w, out, nullptr, n, Cout, Cin, ksize, dgrad, stride, scale, stream);
+}
+
+extern "C" int mcq_pack_conv_weight_multi_masked_f32(const float* const* w, float* const* out, const uint8_t* masks, int32_t n, int32_t Cout,
+                                                     int32_t Cin, int32_t ksize, int32_t dgrad, int32_t stride, float scale, void* stream) {
+    return pack_multi(w, out, masks, n, Cout, Cin, ksize, dgrad, stride, scale, stream);
+}
+
+namespace {
+int pack_multi(const float* const* w, float* const* out, const uint8_t* masks, int32_t n, int32_t Cout, int32_t Cin, int32_t ksize,
+               int32_t dgrad, int32_t stride, float scale, void* stream) {
     if (!w || !out || n < 1 || n > PACK_MAX_MULTI || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return MCQ_EINVAL;
     int32_t co = Cout, ci = Cin;
     int mode = 0;
@@ -1314,6 +1361,7 @@ extern "C" int mcq_pack_conv_weight_multi_f32(const float* const* w, float* cons
         const int k = c < n ? c : 0;
         if (!w[k] || !out[k]) return MCQ_EINVAL;
         t.w[c] = w[k]; t.out[c] = out[k];
+        t.mask[c] = (masks && (masks[k] & 15u)) ? (unsigned char)(masks[k] & 15u) : (unsigned char)15u;      // (0 = unknown = everything)
     }
     const size_t total = general_floats(co, ci, ksize);
     const int S = pairs_padded(ci, ksize), TP = steps_padded(ci, ksize);
@@ -1326,6 +1374,7 @@ extern "C" int mcq_pack_conv_weight_multi_f32(const float* const* w, float* cons
                            dgrad ? scale : 1.0f);
     return mcq_check_launch();
 }
+}  // namespace
 
 extern "C" int mcq_nonneg_reparam_f32(const float* p, float bound, float pedestal, float* out, int64_t n, void* stream) {
     if (!p || !out || n <= 0) return MCQ_EINVAL;
@@ -1461,6 +1510,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
 
     // launches too small to fill the chip with 32 x 32 tiles: 16 x 16 tiles, one per workgroup (conv_t16.h)
     if (d->tile == 0 && t16_takes(d->N, d->Cin, d->H, d->W, d->Cout, d->ksize, d->stride, fl, nprob)) {
+        sec_note(descs, nprob, 8u);
         T16K t;
         const size_t sec = section_floats(d->Cout, d->Cin, 3, 4) + section_floats(d->Cout, d->Cin, 3, 2) + section_floats(d->Cout, d->Cin, 3, 1);
         for (int c = 0; c < MCQ_CONV_MAX_MULTI; ++c) {
@@ -1579,6 +1629,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     // rows of the last cout tile included
     if ((uint64_t)co_tiles * 32u * (unsigned)MB * (uint64_t)k.Ho * k.Wo * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
     hipStream_t s = (hipStream_t)stream;
+    sec_note(descs, nprob, MB == 4 ? 1u : MB == 2 ? 2u : 4u);
     if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42A, MCQ_PF42B, 4>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 2) return launch_tile<2, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);

@@ -172,7 +172,7 @@ class BaseCompressor(nn.Module):
             from ..nn.convs import Conv2d
             convs = self.__dict__["_convList"] = [m for m in self.modules() if isinstance(m, Conv2d)]
         from ..nn.convs import Conv2d
-        Conv2d.repack_stale(convs)
+        Conv2d.repack_stale(convs, self.__dict__.get("_packMasks"))     # (_packMasks: only while parallel.GraphedTrainStep captures)
 
     def reAssignCodebook(self) -> torch.Tensor:
         return self._quantizer.reAssignCodebook()

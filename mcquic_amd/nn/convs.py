@@ -47,11 +47,13 @@ class Conv2d(nn.Module):
         return self._packed
 
     @staticmethod
-    def repack_stale(convs) -> int:
+    def repack_stale(convs, masks=None) -> int:
         """Bring the operand streams of all `convs` up to date in grouped launches (ops.pack_convs: up to 16 weights of one
         shape per launch) -- what a training loop does once per step after its optimizer update instead of 2 launches + a bias
         copy per convolution.  Forward streams for every stale conv; input-gradient streams for the stale ones that have
-        been asked for one before.  Returns the number of streams re-packed."""
+        been asked for one before.  Returns the number of streams re-packed.  `masks` ({id(PackedConv): section mask}, from
+        ops.sections_used): copies to refresh when a stream is re-packed in place -- only for a re-pack recorded inside a captured
+        step whose launches are known (parallel.GraphedTrainStep); everything else packs whole streams."""
         if ops.winograd_enabled():
             return 0            # (the opt-in Winograd streams are packed per convolution: grouped packs carry none)
         fwd, bwd = {}, {}
@@ -67,12 +69,14 @@ class Conv2d(nn.Module):
                 bwd.setdefault((w.shape, w.device, c.stride), []).append((c, cache, w, (wv, wptr, c.stride)))
         done = 0
         for group in fwd.values():
-            packs = ops.pack_convs([w for _, _, w, _ in group], [b for _, _, _, b in group], into=[c._packed for c, _, _, _ in group])
+            packs = ops.pack_convs([w for _, _, w, _ in group], [b for _, _, _, b in group], into=[c._packed for c, _, _, _ in group],
+                                   masks=None if masks is None else [masks.get(id(c._packed), 0) for c, _, _, _ in group])
             for (c, key, _, _), pk in zip(group, packs):
                 c._packed, c._packedKey = pk, key
             done += len(group)
         for (_, _, stride), group in bwd.items():
-            packs = ops.pack_convs([w for _, _, w, _ in group], dgrad=True, stride=stride, into=[cache.packed for _, cache, _, _ in group])
+            packs = ops.pack_convs([w for _, _, w, _ in group], dgrad=True, stride=stride, into=[cache.packed for _, cache, _, _ in group],
+                                   masks=None if masks is None else [masks.get(id(cache.packed), 0) for _, cache, _, _ in group])
             for (c, cache, _, key), pk in zip(group, packs):
                 cache.packed, cache.key = pk, key
                 cache.winograd = False                    # (grouped packs carry no Winograd stream: those launches stay direct)

@@ -202,7 +202,8 @@ class PackedConv:
 
 
 def pack_convs(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]] = None, *, dgrad: bool = False,
-               stride: int = 1, scale: float = 1.0, into: Optional[Sequence[Optional[PackedConv]]] = None) -> List[PackedConv]:
+               stride: int = 1, scale: float = 1.0, into: Optional[Sequence[Optional[PackedConv]]] = None,
+               masks: Optional[Sequence[int]] = None) -> List[PackedConv]:
     """PackedConv (or PackedConv.dgrad) of several weights of ONE shape in ceil(n / 16) launches
     (mcq_pack_conv_weight_multi_f32).  The biases are referenced, not copied: this is the re-pack after an optimizer step,
     whose caller re-packs again whenever a parameter changes."""
@@ -239,8 +240,14 @@ def pack_convs(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Option
             n = min(cap, len(ws) - at)
             src = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws[at:at + n]])
             dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts[at:at + n]])
-            check(lib.mcq_pack_conv_weight_multi_f32(src, dst, n, cout, cin, kh, 1 if dgrad else 0, stride, float(scale), _stream()),
-                  "mcq_pack_conv_weight_multi_f32")
+            if reuse and masks is not None:
+                # (only ever for an in-place re-pack: the copies the mask leaves out keep what an earlier full pack wrote)
+                mk = (ctypes.c_uint8 * n)(*[int(m) & 15 for m in masks[at:at + n]])
+                check(lib.mcq_pack_conv_weight_multi_masked_f32(src, dst, mk, n, cout, cin, kh, 1 if dgrad else 0, stride, float(scale), _stream()),
+                      "mcq_pack_conv_weight_multi_masked_f32")
+            else:
+                check(lib.mcq_pack_conv_weight_multi_f32(src, dst, n, cout, cin, kh, 1 if dgrad else 0, stride, float(scale), _stream()),
+                      "mcq_pack_conv_weight_multi_f32")
     if reuse:
         for i, pk in enumerate(into):
             pk.bias = None if dgrad or biases is None or biases[i] is None else _dev(biases[i].detach(), "bias")
@@ -254,6 +261,18 @@ def pack_convs(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Option
         pk.wino = pk.wino2d = pk.wino16 = None
         out.append(pk)
     return out
+
+
+def section_trace(on: bool) -> None:
+    """Start (clearing earlier records) / stop recording which copy of its operand stream every conv launch reads
+    (mcq_conv_section_trace); `sections_used(pack)` reads a stream's record back.  parallel.GraphedTrainStep uses it so that the
+    re-pack inside its captured step refreshes only the copies the captured launches read."""
+    _lib.load().mcq_conv_section_trace(1 if on else 0)
+
+
+def sections_used(pack: Optional[PackedConv]) -> int:
+    """Mask of the copies of `pack.wp` read by conv launches since section_trace(True) (0 = none seen = treat as all)."""
+    return 0 if pack is None else int(_lib.load().mcq_conv_sections_used(pack.wp.data_ptr()))
 
 
 def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool = False, square_in: bool = False,

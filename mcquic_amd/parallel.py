@@ -167,9 +167,22 @@ class GraphedTrainStep:
         model.train()
         for c in self.coders:
             c.deferCounts(True)
+        from . import ops
         try:
-            for _ in range(max(1, warmup)):                  # caches, workspaces, the coders' count sinks
-                self._forward_backward()
+            ops.section_trace(True)                          # which copy of its operand stream every conv launch of the step reads
+            try:
+                for _ in range(max(1, warmup)):              # caches, workspaces, the coders' count sinks
+                    self._forward_backward()
+            finally:
+                ops.section_trace(False)
+            masks = {}
+            for m in model.modules():
+                for pk in (m.__dict__.get("_packed"), getattr(m.__dict__.get("_dgradCache"), "packed", None)):
+                    if pk is not None and hasattr(pk, "wp"):
+                        used = ops.sections_used(pk)
+                        if used:
+                            masks[id(pk)] = used
+            model.__dict__["_packMasks"] = masks             # the captured re-pack refreshes those copies only (replays repeat the launches)
             self._init_optimizer_state()
             torch.cuda.synchronize()
             with torch.no_grad():
@@ -188,6 +201,8 @@ class GraphedTrainStep:
             for c in self.coders:
                 c.deferCounts(False)
             raise
+        finally:
+            model.__dict__.pop("_packMasks", None)
         off = 0
         for p in self.live:                                  # the optimizer reads the reduced gradients
             p.grad = self.flat[off: off + p.numel()].view_as(p)

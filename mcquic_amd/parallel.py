@@ -157,6 +157,11 @@ class GraphedTrainStep:
                  forward_kwargs: dict | None = None, warmup: int = 2, capture_post: bool = True):
         if not example_x.is_cuda:
             raise RuntimeError("GraphedTrainStep needs a HIP device (hipGraph capture)")
+        if type(model).__name__ == "Neon":
+            # its backward pass reaches AccumulateGrad nodes that outlive an iteration (autograd warns about their stream), which
+            # turns the capture into a nested fork -- hipStreamEndCapture segfaults on those (ROCm 7.2; tools/probes/neon_capture_probe.py)
+            raise NotImplementedError("GraphedTrainStep: the Neon family's training step does not survive hipGraph capture on this "
+                                      "ROCm; use the eager step (parallel.data_parallel) for it")
         self.model, self.optimizer, self.group = model, optimizer, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.x = example_x.detach().clone()
@@ -168,6 +173,9 @@ class GraphedTrainStep:
         for c in self.coders:
             c.deferCounts(True)
         from . import ops
+        from .nn import blocks
+        streams = blocks._BRANCH_STREAMS
+        blocks._BRANCH_STREAMS = False                       # nested stream forks crash hipGraph capture (ROCm 7.2): one stream
         try:
             ops.section_trace(True)                          # which copy of its operand stream every conv launch of the step reads
             try:
@@ -203,6 +211,7 @@ class GraphedTrainStep:
             raise
         finally:
             model.__dict__.pop("_packMasks", None)
+            blocks._BRANCH_STREAMS = streams
         off = 0
         for p in self.live:                                  # the optimizer reads the reduced gradients
             p.grad = self.flat[off: off + p.numel()].view_as(p)

@@ -97,3 +97,13 @@ def test_graphed_step_with_adam(dev, capturable):
     assert losses[-1] < losses[0], losses
     st = next(iter(opt.state.values()))
     assert int(st["step"]) == 10
+
+
+def test_graphed_step_refuses_neon(dev):
+    """The Neon family's backward does not survive hipGraph capture on this ROCm (a segfault in hipStreamEndCapture,
+    tools/probes/neon_capture_probe.py): refused loudly, the eager / DDP step remains its path."""
+    from mcquic_amd import Neon, parallel
+    model = Neon(32, 256, [8, 4, 2, 2], False).to(dev).train()
+    x = torch.zeros((2, 3, 128, 128), device=dev)
+    with pytest.raises(NotImplementedError):
+        parallel.GraphedTrainStep(model, torch.optim.SGD(model.parameters(), lr=1e-2), x)

@@ -6,8 +6,6 @@ cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 O=gpurun_out/r03
 rm -rf $O && mkdir -p $O
-python bench.py > $O/bench.json 2> $O/bench.err
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_torchrun.json 2> $O/bench_torchrun.err
 rocprofv3 --kernel-trace -d $O/kt_bench -o kt -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 python profiles/kernel_stats.py $O/kt_bench/kt_results.db > $O/kernel_stats_bench.txt
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
@@ -17,6 +15,10 @@ done
 python profiles/pmc_stats.py $O/pmc_FETCH_SIZE/pmc_results.db $O/pmc_WRITE_SIZE/pmc_results.db $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES/pmc_results.db > $O/pmc_by_kernel.txt 2>&1
 cp /tmp/pmc_rows.json $O/pmc_rows.json 2>/dev/null
 python profiles/make_pmc_json.py $O/pmc_rows.json > $O/pmc.json 2>$O/pmc_json.err
+# the bench line reads the newest profiles/rNN_pmc.json for roofline.traffic: hand it THIS collection's passes (same kernel sources)
+[ -s $O/pmc.json ] && cp $O/pmc.json profiles/r03_pmc.json
+python bench.py > $O/bench.json 2> $O/bench.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_torchrun.json 2> $O/bench_torchrun.err
 MCQUIC_AMD_BRANCH_STREAMS=0 rocprofv3 --kernel-trace -d $O/kt_bench_ss -o kt -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 python profiles/kernel_stats.py $O/kt_bench_ss/kt_results.db > $O/kernel_stats_bench_single_stream.txt
 python tools/bench_train.py --steps 10 2>/dev/null | tail -1 > $O/bench_train.json

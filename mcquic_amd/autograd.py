@@ -80,7 +80,10 @@ class SiluFn(torch.autograd.Function):
     def forward(ctx, x):
         ctx.save_for_backward(x)
         twin = ops.silu_twin(x)                     # the producer may have stored silu(x) beside x already
-        return twin if twin is not None else ops.silu(x)
+        # (a fresh tensor object over the twin's storage: returning the twin itself would hang THIS node on the object x carries
+        #  as an attribute -- x -> twin -> grad_fn -> saved x, a cycle through C++ that outlives the iteration and keeps
+        #  AccumulateGrad nodes alive, which breaks hipGraph capture of the next iteration)
+        return twin.detach() if twin is not None else ops.silu(x)
 
     @staticmethod
     def backward(ctx, dy):

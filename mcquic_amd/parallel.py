@@ -157,11 +157,6 @@ class GraphedTrainStep:
                  forward_kwargs: dict | None = None, warmup: int = 2, capture_post: bool = True):
         if not example_x.is_cuda:
             raise RuntimeError("GraphedTrainStep needs a HIP device (hipGraph capture)")
-        if type(model).__name__ == "Neon":
-            # its backward pass reaches AccumulateGrad nodes that outlive an iteration (autograd warns about their stream), which
-            # turns the capture into a nested fork -- hipStreamEndCapture segfaults on those (ROCm 7.2; tools/probes/neon_capture_probe.py)
-            raise NotImplementedError("GraphedTrainStep: the Neon family's training step does not survive hipGraph capture on this "
-                                      "ROCm; use the eager step (parallel.data_parallel) for it")
         self.model, self.optimizer, self.group = model, optimizer, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.x = example_x.detach().clone()

@@ -99,11 +99,38 @@ def test_graphed_step_with_adam(dev, capturable):
     assert int(st["step"]) == 10
 
 
-def test_graphed_step_refuses_neon(dev):
-    """The Neon family's backward does not survive hipGraph capture on this ROCm (a segfault in hipStreamEndCapture,
-    tools/probes/neon_capture_probe.py): refused loudly, the eager / DDP step remains its path."""
+def test_graphed_step_neon(dev):
+    """The Neon family (ResidualBackwardQuantizer, VariousMCoder's frequency EMA, op-by-op autograd blocks) through the same
+    graphed step: captures, replays, stays finite, its deferred frequency EMA is applied."""
     from mcquic_amd import Neon, parallel
-    model = Neon(32, 256, [8, 4, 2, 2], False).to(dev).train()
-    x = torch.zeros((2, 3, 128, 128), device=dev)
-    with pytest.raises(NotImplementedError):
-        parallel.GraphedTrainStep(model, torch.optim.SGD(model.parameters(), lr=1e-2), x)
+    torch.manual_seed(11)
+    model = Neon(32, 256, [8, 4, 2, 2], False).to(dev).train()             # (tests/test_neon.py's fixture configuration)
+    x = (torch.rand((2, 3, 128, 128), generator=torch.Generator().manual_seed(6)) * 2 - 1).to(dev)
+    before = [p.detach().clone() for p in model.parameters() if p.requires_grad]
+    step = parallel.GraphedTrainStep(model, torch.optim.SGD(model.parameters(), lr=1e-2), x)
+    losses = [float(step(x)) for _ in range(8)]
+    step.close()
+    assert all(l == l and l < 10 for l in losses), losses
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, [p for p in model.parameters() if p.requires_grad]))
+    assert len(step.coders) == 1 and step.counts is not None
+    assert any(not torch.allclose(f, torch.ones_like(f) / f.shape[-1]) for f in step.coders[0]._freqEMA)   # global counts applied
+
+
+def test_no_autograd_graph_outlives_an_iteration(dev):
+    """After backward() nothing may still carry a graph: a tensor that does keeps AccumulateGrad nodes alive across iterations
+    (memory, and hipGraph capture of the next iteration turns into a nested fork -- hipStreamEndCapture segfaulted on the Neon
+    family until SiluFn stopped returning the twin object its input carries)."""
+    import gc
+    from mcquic_amd import Compressor, Neon
+    for model, hw in ((Compressor(32, 2, [64, 32, 16]), 64), (Neon(32, 256, [8, 4, 2, 2], False), 128), (Neon(32, 256, [8, 4, 2, 2], True), 128)):
+        model = model.to(dev).train()
+        x = (torch.rand((2, 3, hw, hw), generator=torch.Generator().manual_seed(1)) * 2 - 1).to(dev)
+        for _ in range(2):
+            for p in model.parameters():
+                p.grad = None
+            out = model(x)
+            torch.nn.functional.mse_loss(out[0], x).backward()
+            del out
+        gc.collect()
+        alive = [(tuple(o.shape), type(o.grad_fn).__name__) for o in gc.get_objects() if isinstance(o, torch.Tensor) and o.grad_fn is not None]
+        assert not alive, (type(model).__name__, alive[:8])

@@ -125,6 +125,8 @@ def test_no_autograd_graph_outlives_an_iteration(dev):
     for model, hw in ((Compressor(32, 2, [64, 32, 16]), 64), (Neon(32, 256, [8, 4, 2, 2], False), 128), (Neon(32, 256, [8, 4, 2, 2], True), 128)):
         model = model.to(dev).train()
         x = (torch.rand((2, 3, hw, hw), generator=torch.Generator().manual_seed(1)) * 2 - 1).to(dev)
+        gc.collect()
+        earlier = {id(o) for o in gc.get_objects() if isinstance(o, torch.Tensor) and o.grad_fn is not None}   # (other tests' leftovers)
         for _ in range(2):
             for p in model.parameters():
                 p.grad = None
@@ -132,5 +134,6 @@ def test_no_autograd_graph_outlives_an_iteration(dev):
             torch.nn.functional.mse_loss(out[0], x).backward()
             del out
         gc.collect()
-        alive = [(tuple(o.shape), type(o.grad_fn).__name__) for o in gc.get_objects() if isinstance(o, torch.Tensor) and o.grad_fn is not None]
+        alive = [(tuple(o.shape), type(o.grad_fn).__name__) for o in gc.get_objects()
+                 if isinstance(o, torch.Tensor) and o.grad_fn is not None and id(o) not in earlier]
         assert not alive, (type(model).__name__, alive[:8])

@@ -356,6 +356,19 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
         except Exception as exc:                              # noqa: BLE001
             sec["train_step"]["ms_with_sgd"] = None
             sec["train_step"]["with_sgd_error"] = repr(exc)[:200]
+        # ... and as the data-parallel step is meant to run (parallel.GraphedTrainStep: main graph, flat gradient buffer, [the
+        # all-reduce over the ranks: none at N = 1], post graph with the SGD update and the frequency EMA; the in-graph re-pack
+        # refreshes only the operand-stream copies its launches read)
+        try:
+            from mcquic_amd import parallel
+            gstep = parallel.GraphedTrainStep(tm, torch.optim.SGD(tm.parameters(), lr=1e-6), xt)
+            ms3 = _timed(lambda: gstep(xt), 10, warmup=2)
+            gstep.close()
+            sec["train_step"]["ms_graphed_data_parallel"] = round(ms3, 3)
+            del gstep
+        except Exception as exc:                              # noqa: BLE001
+            sec["train_step"]["ms_graphed_data_parallel"] = None
+            sec["train_step"]["graphed_error"] = repr(exc)[:200]
         del tm
     except Exception as exc:                                  # noqa: BLE001
         sec["train_step"] = {"error": repr(exc)[:300]}

@@ -209,12 +209,18 @@ class BaseCompressor(nn.Module):
 
     def encode(self, x: torch.Tensor) -> List[torch.Tensor]:
         self._check(x)
+        if x.shape[0] == 0:
+            # an empty shard (fewer images than ranks, parallel.shard_range): PyTorch's layers hand back empty tensors of the
+            # right geometry (the reference's behaviour); the kernels refuse empty launches, so the geometry comes from one blank image
+            return [c[:0] for c in self.encode(x.new_zeros((1,) + tuple(x.shape[1:])))]
         with torch.no_grad():
             if self._graphs is not None and x.is_cuda and not torch.cuda.is_current_stream_capturing():
                 return self._graphed("encode", lambda t: self._quantizer.encode(self._encode_latent(t)), [x.contiguous()])
             return self._quantizer.encode(self._encode_latent(x))
 
     def decode(self, codes: List[torch.Tensor]) -> torch.Tensor:
+        if codes[0].shape[0] == 0:                            # (empty shard, see encode)
+            return self.decode([c.new_zeros((1,) + tuple(c.shape[1:])) for c in codes])[:0]
         with torch.no_grad():
             if self._graphs is not None and codes[0].is_cuda and not torch.cuda.is_current_stream_capturing():
                 return self._graphed("decode", lambda *c: self._decoder(self._quantizer.decode(list(c))), [c.contiguous() for c in codes])
@@ -223,6 +229,8 @@ class BaseCompressor(nn.Module):
     def compress(self, x: torch.Tensor) -> Tuple[List[torch.Tensor], List[List[bytes]], List[FileHeader]]:
         self._check(x)
         n, c, h, w = x.shape
+        if n == 0:                                            # (empty shard: no streams, no headers)
+            return self.encode(x), [], []
         with torch.no_grad():
             codes, binaries, codeSizes = self._quantizer.compress(self._encode_latent(x))
         header = [FileHeader(__version__, self._qp, codeSize, ImageSize(height=h, width=w, channel=c)) for codeSize in codeSizes]

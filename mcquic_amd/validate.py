@@ -75,6 +75,9 @@ def validate(model, images: torch.Tensor, group=None, msssim: bool = True, gathe
     images (rank order) -- the [psnr, ms_ssim, bits] statistics of the reference's validator (validator.py:40-58).
     `msssim=False` fills the MS-SSIM column with NaN (the metric is undefined for sides <= 160 pixels); `gather=False`
     returns this rank's rows only."""
+    if images.shape[0] == 0:                                  # an empty shard still takes part in the gather
+        rows = torch.empty((0, 3), dtype=torch.float64, device=images.device)
+        return parallel.gather_image_stats(rows, group) if gather else rows
     codes, binaries, headers = model.compress(images)
     restored = model.decompress(binaries, headers)
     a, b = ops.detransform(images.contiguous()), ops.detransform(restored.contiguous())

@@ -20,17 +20,18 @@ def _worker(rank, world, port, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mcquic_amd import parallel
-    n = 5                                                     # ragged: 3 + 2
-    lo, hi = parallel.shard_range(n, rank, world)
-    g = torch.Generator().manual_seed(0)
-    stats_all = torch.rand((n, 3), generator=g)
-    codes_all = [torch.randint(0, k, (n, 2, s, s), generator=g) for k, s in ((32, 4), (16, 2), (8, 1))]
-    stats = parallel.gather_image_stats(stats_all[lo:hi])
-    hist = parallel.code_histograms([c[lo:hi] for c in codes_all], [32, 16, 8])
-    ok = torch.equal(stats, stats_all)
-    for h, c, k in zip(hist, codes_all, (32, 16, 8)):
-        want = torch.stack([torch.bincount(c[:, m].reshape(-1), minlength=k) for m in range(2)])
-        ok = ok and torch.equal(h, want)
+    ok = True
+    for n in (5, 1):                                          # ragged: 3 + 2; then 1 + 0 -- rank 1's shard is EMPTY (fewer images than ranks)
+        lo, hi = parallel.shard_range(n, rank, world)
+        g = torch.Generator().manual_seed(0)
+        stats_all = torch.rand((n, 3), generator=g)
+        codes_all = [torch.randint(0, k, (n, 2, s, s), generator=g) for k, s in ((32, 4), (16, 2), (8, 1))]
+        stats = parallel.gather_image_stats(stats_all[lo:hi])
+        hist = parallel.code_histograms([c[lo:hi] for c in codes_all], [32, 16, 8])
+        ok = ok and torch.equal(stats, stats_all)
+        for h, c, k in zip(hist, codes_all, (32, 16, 8)):
+            want = torch.stack([torch.bincount(c[:, m].reshape(-1), minlength=k) for m in range(2)])
+            ok = ok and torch.equal(h, want)
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 

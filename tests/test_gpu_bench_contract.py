@@ -36,13 +36,15 @@ def test_bench_line_has_the_contract_fields(dev):
     # the round's other results ride in the same line, each with a fraction of the peak that is a true
     # utilisation (real issued work / time / peak), never above 1
     sec = d["secondary"]
-    for key in ("winograd2d", "train_step", "vq_config4", "batch1"):
+    for key in ("winograd2d", "train_step", "vq_config4", "batch1", "host_buffers"):
         assert key in sec and "error" not in sec[key], (key, sec.get(key))
     assert 0 < sec["winograd2d"]["mfma_work_frac"] <= 1.0 and sec["winograd2d"]["images_s"] > 0
     assert sec["winograd2d"]["mfma_gflop_per_step"] < sec["winograd2d"]["direct_form_gflop_per_step"]
     assert sec["winograd2d"]["parity"]["decode_max_abs_err"] <= 1e-4
     assert sec["train_step"]["graph"] is True and 0 < sec["train_step"]["frac_of_peak"] <= 1.0
     assert 0 < sec["vq_config4"]["frac_of_peak"] <= 1.0 and 0 < sec["batch1"]["frac_of_peak"] <= 1.0
+    # the PCIe-inclusive rate is reported beside the headline, never as it (inputs resident in HBM): it cannot be the faster one
+    assert 0 < sec["host_buffers"]["images_s"] <= d["value"] * 1.02
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key

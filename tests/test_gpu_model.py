@@ -253,3 +253,25 @@ def test_validate_helpers(dev):
         validate.validate(model, R.make_images(1, 128, 128).to(dev))
     enc, dec = validate.speed(model, iters=2, batch=2, height=128, width=128)
     assert enc > 0 and dec > 0
+
+
+@pytest.mark.parametrize("family", ["Compressor", "Neon"])
+def test_empty_shard_is_empty_tensors_of_the_right_geometry(dev, family):
+    """A rank that `parallel.shard_range` leaves without images (fewer images than ranks): like the reference's PyTorch
+    layers, the API hands back EMPTY tensors with the geometry a non-empty batch would have -- no launch, no error -- and
+    `validate` still joins the statistics gather with zero rows."""
+    import mcquic_amd
+    from mcquic_amd import validate
+    model = (mcquic_amd.Compressor(32, 2, [64, 32, 16]) if family == "Compressor" else mcquic_amd.Neon(32, 256, [8, 4, 2, 2])).eval().to(dev)
+    full = model.encode(torch.zeros((1, 3, 128, 128), device=dev))
+    x = torch.empty((0, 3, 128, 128), device=dev)
+    codes = model.encode(x)
+    assert len(codes) == len(full)
+    for c, f in zip(codes, full):
+        assert c.dtype == torch.int64 and c.is_cuda and tuple(c.shape) == (0,) + tuple(f.shape[1:])
+    pix = model.decode(codes)
+    assert pix.is_cuda and tuple(pix.shape) == (0,) + tuple(model.decode(full).shape[1:])
+    c2, binaries, headers = model.compress(x)
+    assert binaries == [] and headers == [] and all(tuple(a.shape) == tuple(b.shape) for a, b in zip(c2, codes))
+    rows = validate.validate(model, x, msssim=False)
+    assert tuple(rows.shape) == (0, 3) and rows.dtype == torch.float64

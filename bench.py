@@ -508,13 +508,18 @@ def main():
     for _ in range(args.steps):
         prof.next_step()
         step()
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0                            # this rank's K steps, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     prof.remove()
+    rank_ms = None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt, own], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        dt = max(float(v[0].item()) for v in every)           # the contract's figure: barrier to barrier, MAX over ranks
+        rank_ms = [round(float(v[1].item()) / args.steps * 1e3, 3) for v in every]
 
     # secondary: each direction on its own (Mpps as in the reference's README), untimed region
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -547,6 +552,9 @@ def main():
                            "issued, roofline.equivalent_direct the direct form's FLOPs")
                           if args.winograd else "direct form, exact fp32 MFMA (the reference's arithmetic)",
             "rccl_world": rccl_world, "rank0_cores": None if cores is None else len(cores),
+            # each rank's own ms per step BEFORE it waits at the closing barrier (ms_per_step is barrier to barrier, MAX over
+            # ranks): tells a slow GPU / a starved host apart from a scaling loss; null without a launcher
+            "rank_ms_per_step": rank_ms,
             "config": {"workload": f"qp=2 reference model Compressor(128, 2, [8192, 2048, 512]), batch={args.batch} "
                                    f"768x512 random images per GPU, encode+decode tensor path (BASELINE configs[1])",
                        "images_per_gpu": args.batch, "parallelism": f"dp{world} (independent image shards, no data-path collective)"},

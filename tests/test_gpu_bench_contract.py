@@ -74,11 +74,13 @@ def test_bench_under_a_process_group(dev):
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0 and "cpu_baseline" not in d
     assert d["rccl_world"] == 1                              # an RCCL all-reduce actually ran over the process group
+    # every rank's own time before the closing barrier rides along; the contract's figure (barrier to barrier, MAX) bounds it
+    assert len(d["rank_ms_per_step"]) == 1 and 0 < d["rank_ms_per_step"][0] <= d["ms_per_step"] * 1.001
 
 
 def test_bench_without_a_launcher_takes_no_process_group(dev):
     d = _run("--no-cpu-baseline", "--no-secondary")
-    assert d["n_gpus"] == 1 and d["rccl_world"] is None and "secondary" not in d
+    assert d["n_gpus"] == 1 and d["rccl_world"] is None and d["rank_ms_per_step"] is None and "secondary" not in d
 
 
 def test_bench_gpus_must_match_the_launcher(dev):

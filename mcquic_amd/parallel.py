@@ -261,6 +261,8 @@ class GraphedTrainStep:
             off += n
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if tuple(x.shape) != tuple(self.x.shape):             # (`copy_` would BROADCAST a smaller batch into the static input silently)
+            raise RuntimeError(f"GraphedTrainStep was captured for shards of shape {tuple(self.x.shape)}, got {tuple(x.shape)}")
         self.x.copy_(x, non_blocking=True)
         self.graph.replay()
         if self.world > 1:

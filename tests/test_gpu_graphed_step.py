@@ -75,6 +75,8 @@ def test_graphed_step_really_updates(dev):
     step = parallel.GraphedTrainStep(model, torch.optim.SGD(model.parameters(), lr=0.05), x,
                                      forward_kwargs={"uniforms": _uniforms(2, 64, [64, 32, 16], dev, 9)})
     losses = [float(step(x)) for _ in range(12)]
+    with pytest.raises(RuntimeError, match="captured for shards of shape"):
+        step(x[:1])                                           # (a smaller shard would broadcast into the static input)
     step.close()
     after = [p.detach() for p in model.parameters() if p.requires_grad]
     assert any(not torch.equal(a, b) for a, b in zip(before, after))

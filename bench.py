@@ -242,7 +242,8 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
                    8 x 256x256 crops as ONE captured hipGraph, 10 replays
       vq_config4   BASELINE configs[3]: M=4, K=4096, D=256 distance + argmin on 49 152 vectors per codebook
       batch1       one 768x512 image, encode+decode as hipGraph replays (latency)
-      host_buffers the headline workload with images and reconstructions in pinned host memory (the PCIe-inclusive rate)"""
+      host_buffers the headline workload with images and reconstructions in pinned host memory (the PCIe-inclusive rate)
+      speed_protocol the reference's own Mpps protocol (`Validator.speed`: batch 10, compress / decompress with the rANS byte streams)"""
     from mcquic_amd import Compressor, ops
     from mcquic_amd.nn import blocks
     sec = {}
@@ -268,6 +269,17 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
         del xh, yh
     except Exception as exc:                                  # noqa: BLE001
         sec["host_buffers"] = {"error": repr(exc)[:300]}
+    # ---- the reference's own throughput protocol (byte streams included) ---------------------------------------------------
+    try:
+        from mcquic_amd import validate
+        enc, dec = validate.speed(model, iters=20)
+        sec["speed_protocol"] = {"encode_mpps": round(enc, 2), "decode_mpps": round(dec, 2),
+                                 "images_s_encode_decode_768x512": round(1.0 / (0.393216 / enc + 0.393216 / dec), 2),
+                                 "protocol": "mcquic/validate/validator.py:60-97 with 20 instead of 50 iterations: torch.rand(10, 3, 768, 512), one "
+                                             "warm-up, `compress` x 20 then `decompress` x 20 between events, host rANS coding INCLUDED",
+                                 "reference_published": {"encode_mpps": 25.45, "decode_mpps": 22.03, "hardware": "1x RTX 3090 (TF32), README.md:304"}}
+    except Exception as exc:                                  # noqa: BLE001
+        sec["speed_protocol"] = {"error": repr(exc)[:300]}
     # ---- opt-in Winograd F(2x2, 3x3) ------------------------------------------------------------------------------------
     try:
         ops.set_winograd(2)

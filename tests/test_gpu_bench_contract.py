@@ -36,7 +36,7 @@ def test_bench_line_has_the_contract_fields(dev):
     # the round's other results ride in the same line, each with a fraction of the peak that is a true
     # utilisation (real issued work / time / peak), never above 1
     sec = d["secondary"]
-    for key in ("winograd2d", "train_step", "vq_config4", "batch1", "host_buffers"):
+    for key in ("winograd2d", "train_step", "vq_config4", "batch1", "host_buffers", "speed_protocol"):
         assert key in sec and "error" not in sec[key], (key, sec.get(key))
     assert 0 < sec["winograd2d"]["mfma_work_frac"] <= 1.0 and sec["winograd2d"]["images_s"] > 0
     assert sec["winograd2d"]["mfma_gflop_per_step"] < sec["winograd2d"]["direct_form_gflop_per_step"]
@@ -46,6 +46,7 @@ def test_bench_line_has_the_contract_fields(dev):
     # the PCIe-inclusive rate is reported beside the headline, never as it (at this test's 2 images x 2 steps the two are not
     # comparable: the child process times warmer steps)
     assert sec["host_buffers"]["images_s"] > 0 and sec["host_buffers"]["h2d_mb_per_step"] > 0
+    assert sec["speed_protocol"]["encode_mpps"] > 0 and sec["speed_protocol"]["decode_mpps"] > 0
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key

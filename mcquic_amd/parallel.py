@@ -27,6 +27,41 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+def prefetch(batches, device: torch.device):
+    """Host-resident batches -> device tensors, the copy of batch i + 1 in flight while the caller computes on batch i (what the
+    reference's validator gets from a pinned DataLoader + `.to(device, non_blocking=True)`, mcquic/validate/validator.py:40-58).
+    The copies run on a side stream (SDMA engines, no CU is taken from the kernels); the caller's stream waits on each batch's
+    event and the tensor is tied to it with `record_stream`, so the allocator cannot hand its memory to the next copy early.
+    Give PINNED host tensors -- a pageable source makes the copy synchronous.  On a CPU device: the batches as they are."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        yield from batches
+        return
+    side = torch.cuda.Stream(device)
+
+    def load(host):
+        with torch.cuda.stream(side):
+            t = host.to(device, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        return t, done
+    it = iter(batches)
+    try:
+        ahead = load(next(it))
+    except StopIteration:
+        return
+    while ahead is not None:
+        t, done = ahead
+        try:
+            ahead = load(next(it))                            # issued BEFORE the caller launches anything on batch i
+        except StopIteration:
+            ahead = None
+        here = torch.cuda.current_stream(device)
+        here.wait_event(done)
+        t.record_stream(here)
+        yield t
+
+
 def _staged(t: torch.Tensor, group=None) -> torch.Tensor:
     """The tensor a collective of `group` should run on: device tensors as they are under RCCL ("nccl"); under gloo (the CPU
     tests, and the two-processes-on-one-GPU test: RCCL refuses two ranks on one device) a host copy."""

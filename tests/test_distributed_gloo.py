@@ -187,3 +187,11 @@ def test_deferred_counts_and_flat_allreduce_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(world))
+
+
+def test_prefetch_is_the_identity_on_a_cpu_device():
+    from mcquic_amd import parallel
+    batches = [torch.full((2, 3), float(i)) for i in range(4)]
+    out = list(parallel.prefetch(iter(batches), torch.device("cpu")))
+    assert len(out) == 4 and all(a is b for a, b in zip(out, batches))
+    assert list(parallel.prefetch([], "cpu")) == []

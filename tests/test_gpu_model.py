@@ -275,3 +275,21 @@ def test_empty_shard_is_empty_tensors_of_the_right_geometry(dev, family):
     assert binaries == [] and headers == [] and all(tuple(a.shape) == tuple(b.shape) for a, b in zip(c2, codes))
     rows = validate.validate(model, x, msssim=False)
     assert tuple(rows.shape) == (0, 3) and rows.dtype == torch.float64
+
+
+def test_prefetch_feeds_the_same_batches(dev):
+    """parallel.prefetch: pinned host batches arrive on the device in order and intact while the previous batch is in the
+    kernels; codes of the prefetched batches = codes of the same batches copied up front."""
+    import mcquic_amd
+    from mcquic_amd import parallel
+    model = mcquic_amd.Compressor(32, 2, [64, 32, 16]).eval().to(dev)
+    host = [(torch.rand((2, 3, 128, 128), generator=torch.Generator().manual_seed(i)) * 2 - 1).pin_memory() for i in range(5)]
+    want = [[c.cpu() for c in model.encode(h.to(dev))] for h in host]
+    got = []
+    for xd in parallel.prefetch(host, dev):
+        assert xd.is_cuda
+        got.append([c.cpu() for c in model.encode(xd)])
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert all(torch.equal(a, b) for a, b in zip(g, w))
+    assert list(parallel.prefetch([], dev)) == []

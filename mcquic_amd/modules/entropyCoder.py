@@ -87,6 +87,13 @@ def hostThreads() -> int:
     return max(1, min(n, 32))
 
 
+def _poolThreads(threads: int, symbols: int) -> int:
+    """Threads for one batched call: never more than one per 16 K symbols.  A pool thread costs ~40 us to start and join, a
+    symbol ~25 ns: ten 768x512 images (61 K symbols on level 0, 15 K and 4 K below) code fastest on 2-4 threads (0.30 ms per
+    `compress` against 0.84 ms on 32, tools/probes/rans_threads.py on the GPU box's host) and the small levels on the caller's."""
+    return max(1, min(threads or hostThreads(), symbols // 16384))
+
+
 def ransEncodeBatchWithIndexes(symbols: np.ndarray, indexes: np.ndarray, t: _Tables, threads: int = 0) -> List[bytes]:
     """symbols [n_streams, n] (one stream per row, all coded with the same `indexes[n]`) -> one byte string per row.
     ONE C call; rows are spread over a pool of host threads (mcq_rans_encode_batch_with_indexes)."""
@@ -98,7 +105,7 @@ def ransEncodeBatchWithIndexes(symbols: np.ndarray, indexes: np.ndarray, t: _Tab
     sizes = np.zeros(ns, dtype=np.int64)
     rc = _lib.load().mcq_rans_encode_batch_with_indexes(_vp(symbols), ns, n, _vp(indexes), _vp(t.cdfs), _vp(t.starts), _vp(t.sizes),
                                                         _vp(t.lens), _vp(t.offsets), t.m, _vp(out), stride, _vp(sizes),
-                                                        threads or hostThreads())
+                                                        _poolThreads(threads, symbols.size))
     if rc != 0:
         raise RuntimeError(f"rANS encode failed ({rc}): a code index outside [0, k), or a malformed table")
     return [out[i, :sizes[i]].tobytes() for i in range(ns)]
@@ -118,7 +125,7 @@ def ransDecodeBatchWithIndexes(binaries: List[bytes], indexes: np.ndarray, t: _T
         raise ValueError("ransDecodeBatchWithIndexes: `out` must be a C-contiguous int32 [n_streams, n] array")
     rc = _lib.load().mcq_rans_decode_batch_with_indexes(_vp(buf), _vp(offs), len(binaries), _vp(indexes), indexes.size, _vp(t.cdfs),
                                                         _vp(t.starts), _vp(t.sizes), _vp(t.lens), _vp(t.offsets), t.m, _vp(out),
-                                                        threads or hostThreads())
+                                                        _poolThreads(threads, out.size))
     if rc != 0:
         raise RuntimeError("Got a truncated or malformed rANS stream.")
     return out

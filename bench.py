@@ -267,26 +267,13 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
                                "note": "PCIe-inclusive: float32 images copied from pinned host memory, encode + decode, reconstructions "
                                        "copied back to pinned host memory, nothing overlapped; never the headline `value` (inputs resident in HBM)"}
         # ... and as a caller with a stream of batches would run it: parallel.prefetch copies batch i + 1 while batch i is in the
-        # kernels, the reconstructions leave on a second side stream (6 batches, two output buffers in rotation)
+        # kernels; the reconstructions leave on the COMPUTE stream (a copy-out on a second side stream measures slower than the
+        # serial copy on this stack, tools/probes/prefetch_overlap.py: +8 ms per batch against +3.6)
         from mcquic_amd import parallel
-        out_stream = torch.cuda.Stream(dev)
-        yhs = [yh, torch.empty(x.shape, dtype=x.dtype, pin_memory=True)]
-        freed = [None, None]
 
         def piped(n_batches):
-            main = torch.cuda.current_stream(dev)
-            for i, xd in enumerate(parallel.prefetch([xh] * n_batches, dev)):
-                y = model.decode(model.encode(xd))
-                ready = torch.cuda.Event()
-                ready.record(main)
-                if freed[i % 2] is not None:
-                    freed[i % 2].synchronize()                # (a real caller consumes the host buffer here)
-                with torch.cuda.stream(out_stream):
-                    out_stream.wait_event(ready)
-                    yhs[i % 2].copy_(y, non_blocking=True)
-                    y.record_stream(out_stream)
-                    freed[i % 2] = torch.cuda.Event()
-                    freed[i % 2].record(out_stream)
+            for xd in parallel.prefetch([xh] * n_batches, dev):
+                yh.copy_(model.decode(model.encode(xd)), non_blocking=True)
         piped(3)                                              # (the side streams' allocator pools fill up here, not in the timed loop)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -295,9 +282,9 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
         ms = (time.perf_counter() - t0) / 6 * 1e3
         sec["host_buffers"]["images_s_prefetched"] = round(x.shape[0] / ms * 1e3, 2)
         sec["host_buffers"]["ms_per_step_prefetched"] = round(ms, 3)
-        sec["host_buffers"]["prefetched"] = ("6 batches through parallel.prefetch: the copy of batch i + 1 and the copy-out of batch i - 1 "
-                                             "overlap the kernels of batch i (side streams, SDMA)")
-        del xh, yh, yhs
+        sec["host_buffers"]["prefetched"] = ("6 batches through parallel.prefetch: the copy of batch i + 1 overlaps the kernels of batch i "
+                                             "(side stream); the copy-out stays on the compute stream")
+        del xh, yh
     except Exception as exc:                                  # noqa: BLE001
         sec["host_buffers"] = {"error": repr(exc)[:300]}
     # ---- the reference's own throughput protocol (byte streams included) ---------------------------------------------------

@@ -27,7 +27,11 @@ class _DgradCache:
     def get(self, weight: torch.Tensor, stride: int) -> ops.PackedConv:
         key = (ops.tensor_version(weight), weight.data_ptr(), stride)
         if key != self.key or self.winograd != ops.winograd_enabled():
-            self.packed = ops.PackedConv.dgrad(weight, stride)      # one pack launch (flip / transpose / sub-pixel scatter inside)
+            if self.packed is not None and self.key is not None and self.key[2] == stride and not self.winograd and not ops.winograd_enabled():
+                # same layer, new weight version: into the existing stream (same address, no allocation)
+                self.packed = ops.pack_convs([weight], dgrad=True, stride=stride, into=[self.packed])[0]
+            else:
+                self.packed = ops.PackedConv.dgrad(weight, stride)  # one pack launch (flip / transpose / sub-pixel scatter inside)
             self.key, self.winograd = key, ops.winograd_enabled()
         return self.packed
 

@@ -1577,9 +1577,13 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         //  the 24x16 / 12x8 levels gained 0.4 % at batch 32 and lost 8 % on the batch-8 training step: not used)
         static const int cand[3][2] = {{4, 2}, {2, 2}, {1, 1}};
         MB = 1; NB = 1;
+        // Cout that is no multiple of 128 (model No. 12 of the reference: channel 192 = six 32-row bands): the 128-row tile would
+        // run its last instance half empty -- 8 bands of MFMAs for 6 -- where 64-row tiles cover the rows exactly; the 64 x 64 tile
+        // costs ~3 % more per MFMA than the 128 x 64 one (operand loads per MFMA), far less than a quarter of the work
+        const bool rows64 = ((co32 + 3) / 4) * 4 > ((co32 + 1) / 2) * 2;
         for (int c = 0; c < 3; ++c) {
             const int mb = cand[c][0], nb = cand[c][1];
-            if (mb > co32) continue;
+            if (mb > co32 || (mb == 4 && rows64)) continue;
             const long long tiles = ((tb + nb - 1) / nb) * ((co32 + mb - 1) / mb);      // (per problem: the tile a single launch takes)
             MB = mb; NB = nb;
             if (tiles * 8 >= 1024) break;          // even an 8-way split would leave SIMDs idle: try a smaller tile
@@ -1618,7 +1622,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         // 1276 -> 1234 us, 192x128 323 -> 306, 96x64 87 -> 73, 48x32 (64 x 32 tile) 38.7 -> 26.3 (tools/microbench_conv.py --k1 --flags gdn)
         if (d->ksize == 1 && d->stride == 1 && co32 >= 4) {
             const long long t41 = tb * ((co32 + 3) / 4) * nprob, t21 = tb * ((co32 + 1) / 2) * nprob;
-            if (t41 >= 2048) { MB = 4; NB = 1; ksl = 0; }
+            if (t41 >= 2048 && !rows64) { MB = 4; NB = 1; ksl = 0; }
             else if (t21 >= 2048) { MB = 2; NB = 1; ksl = 0; }
         }
     }

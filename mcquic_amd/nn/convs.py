@@ -42,7 +42,10 @@ class Conv2d(nn.Module):
         """Weights in MFMA operand order; re-packed whenever the parameters change (version / storage / device)."""
         key = self._key()
         if self._packed is None or key != self._packedKey:
-            self._packed = ops.PackedConv(self.weight, self.bias)
+            # in place where the shapes allow it: the streams keep their addresses (a captured training step may hold them)
+            with torch.no_grad():
+                if self._packed is None or not self._packed.repack_(self.weight, self.bias):
+                    self._packed = ops.PackedConv(self.weight, self.bias)
             self._packedKey = key
         return self._packed
 

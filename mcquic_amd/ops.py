@@ -174,6 +174,31 @@ class PackedConv:
                     check(lib.mcq_pack_conv_weight_winograd16_f32(_ptr(weight), cout, cin, _ptr(self.wino16), _stream()),
                           "mcq_pack_conv_weight_winograd16_f32")
 
+    def repack_(self, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
+        """Pack `weight` (+ `bias`) into THIS object's streams, in place: same addresses, no allocation -- what a captured
+        hipGraph that reads them (parallel.GraphedTrainStep) and the allocator both prefer to a new object per weight version.
+        False (nothing written) when the shapes differ or Winograd streams are involved: the caller then builds a new pack."""
+        if self.wino is not None or self.wino2d is not None or self.wino16 is not None or _WINOGRAD:
+            return False
+        weight = _dev(weight.detach(), "weight")
+        cout, cin, kh, kw = weight.shape
+        lib = _lib.load()
+        if kh != kw or (cout, cin, kh) != (self.cout, self.cin, self.ksize) or weight.device != self.wp.device or \
+                self.wp.numel() != lib.mcq_packed_conv_weight_floats(cout, cin, kh) or (bias is None) != (self.bias is None):
+            return False
+        if bias is not None:
+            bias = _dev(bias.detach(), "bias")
+            if bias.data_ptr() != self.bias.data_ptr():       # (a pack that references the live parameter has nothing to copy)
+                if bias.shape != self.bias.shape:
+                    return False
+                try:
+                    self.bias.copy_(bias)
+                except RuntimeError:                          # (a copy made under torch.inference_mode() cannot be updated outside it)
+                    return False
+        with _guard(weight.device):
+            check(lib.mcq_pack_conv_weight_f32(_ptr(weight), cout, cin, kh, _ptr(self.wp), _stream()), "mcq_pack_conv_weight_f32")
+        return True
+
     @classmethod
     def dgrad(cls, weight: torch.Tensor, stride: int, scale: float = 1.0, winograd: Optional[bool] = None) -> "PackedConv":
         """Operand stream of the layer's input-gradient convolution, packed straight from its OIHW weight in one launch

@@ -162,43 +162,73 @@ def data_parallel(model: torch.nn.Module, device: torch.device, group=None, **kw
 
 
 class GraphedTrainStep:
-    """One rank's data-parallel training step (BASELINE configs[4]: `torchrun` + DDP in the reference, mcquic/train/ddp.py:79-95)
-    with the host out of the loop.  DDP's eager step is bound by the host here -- ~1 000 launches of ~20 us each per step, with
-    two host cores per rank on an 8-GPU node -- and a step captured WITH DDP's hooks replays slower than eager (the bucket
-    all-reduces live on RCCL's stream: a multi-stream graph).  So the step is cut where the exchange is:
+    """One rank's data-parallel training step (BASELINE configs[4]: `torchrun` + DDP in the reference, mcquic/train/ddp.py:79-95;
+    its gradient exchange is overlapped with the backward pass bucket by bucket, mcquic/train/trainer.py:94,105) with the host out
+    of the loop.  DDP's eager step is bound by the host here -- ~1 000 launches of ~20 us each per step, with two host cores per
+    rank on an 8-GPU node -- and a step captured WITH DDP's hooks replays slower than eager (the bucket all-reduces live on RCCL's
+    stream: a multi-stream graph, docs/experiments.md).  So the step is cut where the exchange is:
 
-        main graph   forward + backward of the local shard on a static input, every gradient copied into ONE flat float32
-                     buffer (`torch.cat(..., out=)`), this rank's code counts of the frequency-EMA update into one int64 buffer
-        exchange     two all-reduces outside any graph: the flat gradients (65 MB for the qp=2 model -- one large message per
-                     step is what a point-to-point xGMI ring wants, not 25 MB buckets) and the 86 KB of counts
-        post graph   gradients / world size, the optimizer's update, the frequency EMA from the GLOBAL counts
-                     (mcquic/modules/entropyCoder.py:28-44 all-reduces them inside forward; here that collective is deferred)
+        segment graphs  forward + backward of the local shard on a static input, captured as `segments` hipGraphs in BACKWARD
+                        order -- [forward, loss, decoder backward] -> [quantizer backward] -> [encoder backward] -- each ending
+                        with the copy of its parameters' gradients into ITS slice of ONE flat float32 buffer; this rank's code
+                        counts of the frequency-EMA update go into one int64 buffer (known after the forward)
+        exchange        outside any graph: as soon as a segment's replay is enqueued, the all-reduce of its slice is started
+                        (async on RCCL's stream, which waits for exactly that segment) while the next segment replays --
+                        the slices are 21.5 / 166.3 / 14.4 MB for the qp=2 model (decoder / quantizer / encoder; 202.2 MB =
+                        50 558 738 float32 gradients in all), so only the encoder's 14 MB are exchanged after the last kernel;
+                        one message per segment is what a point-to-point xGMI ring wants, not 25 MB buckets
+        post graph      gradients / world size, the optimizer's update, the frequency EMA from the GLOBAL counts
+                        (mcquic/modules/entropyCoder.py:28-44 all-reduces them inside forward; here that collective is deferred)
+
+    `segments=1` is the whole step as one graph followed by one all-reduce (what a single rank runs: nothing to overlap with);
+    the default is 3 under a process group of more than one rank, when the model has the Compressor's three stages and the
+    loss is the default one (a custom `loss_fn` sees (xHat, yHat, codes, logits) with yHat / logits as LEAVES of the decoder's
+    segment: its gradients on them are carried into the quantizer's segment).
+    Link time of the exchange at 8 ranks: a ring all-reduce moves 2 x 7/8 x 202 MB = 354 MB through every GPU; ~1.2 ms if RCCL
+    spreads it over the seven xGMI links of a GPU (~300 GB/s bus bandwidth), ~4.6 ms on one link direction --
+    5-20 % of a 22 ms step when serial, which is why it is overlapped.
 
     The forward of the next replay starts with the grouped re-pack of every operand stream the update made stale
     (`Conv2d.repack_stale`, in place): all parameters are marked changed before the capture so that those launches are recorded.
-    Nothing overlaps the gradient all-reduce with the backward pass; at 8 x 256 x 256 per rank the step is ~22 ms of kernels and
-    the message ~1 ms of link time.
+    The step keeps every operand stream, count sink and static buffer its graphs have addresses of alive for its own lifetime,
+    so using the model eagerly in between (`invalidate()`, then evaluation / `compress`, then more steps) is safe.
 
         step = GraphedTrainStep(model, optimizer, example_x)        # after torch.distributed is initialised (or not at all)
         loss = step(x)                                              # x: this rank's shard, shape of example_x
-        step.close()                                                # before evaluating / saving: eager code re-packs its streams
+        step.invalidate(); model.eval(); ...; model.train()         # evaluating in between: eager code re-packs its streams
+        step.close()                                                # done: the step cannot be replayed any more
 
+    Under more than one rank the constructor broadcasts rank 0's parameters and buffers (as DDP does), so the replicas start
+    equal.  An optimizer that already holds state (resumed from a checkpoint) keeps it: its tensors are restored after the
+    throw-away update that brings missing state into existence.
     A captured update bakes in whatever the optimizer read on the host at capture time: give a scheduled learning rate to the
     optimizer as a TENSOR (torch.optim reads it on the device then; Adam / AdamW additionally need `capturable=True`), or pass
     `capture_post=False` and the update (with the EMA) runs eagerly after the exchange -- ~15 launches, still no per-layer host work.
     """
 
     def __init__(self, model: torch.nn.Module, optimizer, example_x: torch.Tensor, loss_fn=None, group=None,
-                 forward_kwargs: dict | None = None, warmup: int = 2, capture_post: bool = True):
+                 forward_kwargs: dict | None = None, warmup: int = 2, capture_post: bool = True, segments: int | None = None,
+                 broadcast: bool = True):
         if not example_x.is_cuda:
             raise RuntimeError("GraphedTrainStep needs a HIP device (hipGraph capture)")
         self.model, self.optimizer, self.group = model, optimizer, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.x = example_x.detach().clone()
         self.kwargs = dict(forward_kwargs or {})
+        staged = all(hasattr(model, a) for a in ("_encoder", "_quantizer", "_decoder", "_repackStale")) and set(self.kwargs) <= {"uniforms"}
+        if segments is None:
+            segments = 3 if (self.world > 1 and staged) else 1
+        if segments not in (1, 3):
+            raise ValueError("segments must be 1 (one graph, one all-reduce) or 3 (decoder / quantizer / encoder backward)")
+        if segments == 3 and not staged:
+            raise ValueError("segments=3 needs a model with _encoder / _quantizer / _decoder stages and no forward_kwargs but `uniforms`")
+        self.segments = segments
         self.loss_fn = loss_fn or (lambda out, x: torch.nn.functional.mse_loss(out[0], x))
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.coders = [m for m in model.modules() if hasattr(m, "deferCounts")]
+        self.closed = False
+        if self.world > 1 and broadcast:
+            self._broadcast_state()
         model.train()
         for c in self.coders:
             c.deferCounts(True)
@@ -206,35 +236,59 @@ class GraphedTrainStep:
         from .nn import blocks
         streams = blocks._BRANCH_STREAMS
         blocks._BRANCH_STREAMS = False                       # nested stream forks crash hipGraph capture (ROCm 7.2): one stream
+        # (under a process group RCCL's watchdog thread may query events while we capture: thread-local mode keeps a capture from
+        #  being invalidated by what OTHER threads do; the autograd thread's launches are captured either way -- capture follows
+        #  the stream, not the thread)
+        mode = dict(capture_error_mode="thread_local") if (dist.is_available() and dist.is_initialized()) else {}
         try:
             ops.section_trace(True)                          # which copy of its operand stream every conv launch of the step reads
             try:
                 for _ in range(max(1, warmup)):              # caches, workspaces, the coders' count sinks
-                    self._forward_backward()
+                    for k in range(self.segments):
+                        self._segment(k)
             finally:
                 ops.section_trace(False)
-            masks = {}
+            masks, pinned = {}, []
             for m in model.modules():
                 for pk in (m.__dict__.get("_packed"), getattr(m.__dict__.get("_dgradCache"), "packed", None)):
                     if pk is not None and hasattr(pk, "wp"):
+                        pinned.append(pk.wp)                 # the graphs re-pack into / read from these addresses for as long as they live
                         used = ops.sections_used(pk)
                         if used:
                             masks[id(pk)] = used
             model.__dict__["_packMasks"] = masks             # the captured re-pack refreshes those copies only (replays repeat the launches)
+            # flat layout = segment order (backward order), parameters without a gradient left out
+            groups = self._param_groups()
+            self.live_groups = [[p for p in g if p.grad is not None] for g in groups]
+            self.live = [p for g in self.live_groups for p in g]
+            self.flat = torch.empty(sum(p.numel() for p in self.live), dtype=torch.float32, device=self.x.device)
+            self.slices, off = [], 0
+            for g in self.live_groups:
+                n = sum(p.numel() for p in g)
+                self.slices.append(self.flat[off: off + n])
+                off += n
             self._init_optimizer_state()
             torch.cuda.synchronize()
             with torch.no_grad():
                 torch._foreach_add_(self.params, 0.0)        # every parameter "changed": the capture records all re-packs
             for p in self.params:
                 p.grad = None
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.loss = self._forward_backward()
-                self.live = [p for p in self.params if p.grad is not None]
-                self.flat = torch.empty(sum(p.numel() for p in self.live), dtype=torch.float32, device=self.x.device)
-                torch.cat([p.grad.reshape(-1) for p in self.live], out=self.flat)
-                sinks = [c.countSink() for c in self.coders]
-                self.counts = torch.cat(sinks) if sinks else None
+            self.graphs = []
+            pool = torch.cuda.graph_pool_handle() if self.segments > 1 else None
+            self.counts = None
+            for k in range(self.segments):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, **mode):
+                    self._segment(k)
+                    if self.live_groups[k]:
+                        torch.cat([p.grad.reshape(-1) for p in self.live_groups[k]], out=self.slices[k])
+                    if k == 0:
+                        sinks = [c.countSink() for c in self.coders]
+                        self.counts = torch.cat(sinks) if sinks else None
+                self.graphs.append(g)
+            self.graph = self.graphs[0]
+            self._carry = None                               # (the autograd graph between segments: only needed while capturing)
+            self._pinned = pinned + [c.countSink() for c in self.coders]
         except BaseException:
             for c in self.coders:
                 c.deferCounts(False)
@@ -248,34 +302,116 @@ class GraphedTrainStep:
             off += p.numel()
         self.post = None
         if capture_post:
+            before = self._snapshot_optimizer_state()
             try:
                 post = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(post):
+                with torch.cuda.graph(post, **mode):
                     self._post()
                 self.post = post
             except Exception:                                # an optimizer that cannot be captured: its update runs eagerly
                 torch.cuda.synchronize()
                 self.post = None
-                self._zero_optimizer_state()                 # (host-side counters may have moved before the capture gave up)
+                self._restore_optimizer_state(before)        # (host-side counters may have moved before the capture gave up)
+
+    # ---- replica state ---------------------------------------------------------------------------------------------------
+    def _broadcast_state(self):
+        """Rank 0's parameters and buffers to every rank (what DDP's constructor does): replicas that start from different
+        weights would average gradients of diverging models without any error."""
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        seen = set()
+        with torch.no_grad():
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                if id(t) in seen:
+                    continue
+                seen.add(id(t))
+                buf = _staged(t.detach(), self.group)
+                buf = buf if buf.is_contiguous() else buf.contiguous()
+                dist.broadcast(buf, src, group=self.group)
+                if buf.data_ptr() != t.data_ptr():
+                    t.copy_(buf)
+
+    # ---- optimizer state ---------------------------------------------------------------------------------------------------
+    def _snapshot_optimizer_state(self):
+        return {(id(p), k): v.detach().clone() for p, st in self.optimizer.state.items() for k, v in st.items() if torch.is_tensor(v)}
+
+    def _restore_optimizer_state(self, snap):
+        """State tensors that existed at the snapshot get their values back; the ones created since are zeroed -- which is the
+        state a fresh optimizer starts from (SGD with momentum, Adam / AdamW; an optimizer whose initial state is not zeros
+        needs its own warm-up)."""
+        with torch.no_grad():
+            for p, st in self.optimizer.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        old = snap.get((id(p), k))
+                        if old is None:
+                            v.zero_()
+                        else:
+                            v.copy_(old)
 
     def _init_optimizer_state(self):
         """An optimizer creates its state (momentum buffers, Adam's moments and step counter) inside its first `step()`; created
         inside the capture they would be re-created by every replay.  One throw-away update with the warm-up gradients brings
-        them into existence, then the parameters are restored and the state is zeroed -- which is the state a fresh optimizer
-        starts from (SGD with momentum, Adam / AdamW; an optimizer whose initial state is not zeros needs its own warm-up)."""
+        them into existence; then the parameters and every state tensor that existed BEFORE (an optimizer resumed from a
+        checkpoint: momentum, moments, step counters) are restored and only the newly created ones are zeroed."""
         saved = [p.detach().clone() for p in self.params]
+        snap = self._snapshot_optimizer_state()
         self.optimizer.step()
         with torch.no_grad():
             for p, v in zip(self.params, saved):
                 p.copy_(v)
-        self._zero_optimizer_state()
+        self._restore_optimizer_state(snap)
 
-    def _zero_optimizer_state(self):
-        with torch.no_grad():
-            for st in self.optimizer.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+    # ---- the step's segments ---------------------------------------------------------------------------------------------
+    def _param_groups(self):
+        """Parameters by segment, in the order the backward pass finishes them: decoder, quantizer, encoder (+ anything else)."""
+        if self.segments == 1:
+            return [list(self.params)]
+        taken, groups = set(), []
+        for stage in (self.model._decoder, self.model._quantizer):
+            g = [p for p in stage.parameters() if p.requires_grad and id(p) not in taken]
+            taken.update(id(p) for p in g)
+            groups.append(g)
+        groups.append([p for p in self.params if id(p) not in taken])
+        return groups
+
+    def _segment(self, k: int):
+        if self.segments == 1:
+            self.loss = self._forward_backward()
+            return
+        from . import ops
+        m = self.model
+        if k == 0:
+            for p in self.params:
+                p.grad = None
+            m._repackStale()
+            y = m._encoder(self.x)                            # (no padding in the training forward, compressor.py:39)
+            yl = y.detach().requires_grad_()
+            tw = ops.silu_twin(y)
+            if tw is not None:
+                ops.set_silu_twin(yl, tw)
+            yHat, codes, logits = m._quantizer(yl, self.kwargs.get("uniforms"))
+            yh = yHat.detach().requires_grad_()
+            tw = ops.silu_twin(yHat)
+            if tw is not None:
+                ops.set_silu_twin(yh, tw)
+            lgl = [lg.detach().requires_grad_() if (torch.is_tensor(lg) and lg.requires_grad) else lg for lg in logits]
+            xHat = m._decoder(yh)
+            loss = self.loss_fn((xHat, yh, codes, lgl), self.x)
+            loss.backward()                                   # decoder parameters, d yHat (, d logits)
+            self.loss = loss.detach()
+            self._carry = (y, yl, yHat, yh, logits, lgl)
+        elif k == 1:
+            y, yl, yHat, yh, logits, lgl = self._carry
+            outs, grads = [yHat], [yh.grad]
+            for lg, leaf in zip(logits, lgl):
+                if torch.is_tensor(leaf) and leaf is not lg and leaf.grad is not None:
+                    outs.append(lg)
+                    grads.append(leaf.grad)
+            torch.autograd.backward(outs, grads)              # quantizer parameters, d y
+        else:
+            y, yl = self._carry[0], self._carry[1]
+            y.backward(yl.grad)                               # encoder parameters
+            self._carry = None
 
     def _forward_backward(self):
         for p in self.params:
@@ -295,15 +431,33 @@ class GraphedTrainStep:
             c.applyCounts(self.counts[off: off + n])
             off += n
 
+    def _start_all_reduce(self, buf: torch.Tensor):
+        """Sum `buf` over the ranks without waiting for it: under RCCL an async all-reduce (its stream waits for what the current
+        stream has enqueued so far -- the segment that just filled `buf` -- and the returned work is joined before the post
+        graph); under gloo (tests) the blocking host-staged form."""
+        if buf.numel() == 0:
+            return None
+        if buf.is_cuda and dist.get_backend(self.group) == "gloo":
+            all_reduce_(buf, self.group)
+            return None
+        return dist.all_reduce(buf, group=self.group, async_op=True)
+
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if self.closed:
+            raise RuntimeError("GraphedTrainStep: the step was closed (its count sinks are gone); build a new one")
         if tuple(x.shape) != tuple(self.x.shape):             # (`copy_` would BROADCAST a smaller batch into the static input silently)
             raise RuntimeError(f"GraphedTrainStep was captured for shards of shape {tuple(self.x.shape)}, got {tuple(x.shape)}")
         self.x.copy_(x, non_blocking=True)
-        self.graph.replay()
-        if self.world > 1:
-            all_reduce_(self.flat, self.group)
-            if self.counts is not None:
-                all_reduce_(self.counts, self.group)
+        works = []
+        for k, g in enumerate(self.graphs):
+            g.replay()
+            if self.world > 1:
+                works.append(self._start_all_reduce(self.slices[k]))       # ... while the next segment replays
+                if k == 0 and self.counts is not None:
+                    works.append(self._start_all_reduce(self.counts))
+        for w in works:
+            if w is not None:
+                w.wait()                                      # (the current stream waits; the host does not)
         if self.post is not None:
             self.post.replay()
         else:
@@ -315,12 +469,18 @@ class GraphedTrainStep:
     def invalidate(self):
         """Replays change the parameters without the host seeing it (no version counter moves): mark every parameter changed so
         that the next EAGER use of the model (evaluation, a checkpoint's `compress`) re-packs its operand streams -- they are one
-        update behind after a replay.  Call before using the model outside this step; `close()` does."""
+        update behind after a replay.  Call before using the model outside this step; `close()` does.  The step itself stays
+        usable: its graphs re-pack the copies they read at the start of every replay, into streams this object keeps alive."""
         with torch.no_grad():
             torch._foreach_add_(self.params, 0.0)
 
     def close(self):
-        """Back to the eager step: the coders update their EMA inside forward again, `.grad` is whatever the last step left."""
+        """Back to the eager step for good: the coders update their EMA inside forward again, `.grad` is whatever the last step
+        left, and this object refuses further replays (its count sinks are released)."""
+        if self.closed:
+            return
+        self.closed = True
         for c in self.coders:
             c.deferCounts(False)
         self.invalidate()
+        self._pinned = []

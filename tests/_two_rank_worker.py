@@ -153,6 +153,10 @@ def graphed_mode(rank, world, dev):
     dist.barrier()
     lo, hi = rank * per, (rank + 1) * per
     init = [p.detach().clone() for p in model.parameters()]
+    if rank != 0:                                                       # a replica that starts elsewhere: the constructor's broadcast
+        with torch.no_grad():                                           # from rank 0 must bring it back, or the update below is wrong
+            for p in model.parameters():
+                p.add_(0.01)
     step = parallel.GraphedTrainStep(model, torch.optim.SGD(model.parameters(), lr=lr), x[lo:hi],
                                      forward_kwargs={"uniforms": [(a[lo:hi], b[lo:hi]) for a, b in us]})
     loss = step(x[lo:hi])
@@ -177,6 +181,8 @@ def graphed_mode(rank, world, dev):
         out["worst_update_name"] = worst_name
         out["largest_update"] = moved
         out["post_captured"] = step.post is not None
+        out["segments"] = step.segments
+        out["slice_mb"] = [round(sl.numel() * 4 / 1e6, 1) for sl in step.slices]
         out["ema_max_abs_diff"] = max(float((a - b).abs().max()) for a, b in zip(ref_ema, model._quantizer._entropyCoder._freqEMA))
         out["loss_rank0"] = float(loss)
     return out

@@ -534,6 +534,40 @@ def main():
     if want("f11"):
         capture_neon(C, RQ, True, "f11_neon_dense_norm.npz")
 
+    # ---- F12: the reference's second listed model, No. 12 = Compressor(192, 12, [8192, 2048, 512]) (README.md:306):
+    #           channel 192, twelve codebooks of 16-dimensional codewords.  1 x 768x512 and 2 x 200x136 (sizes that are no multiple of 128):
+    #           every code, the reference's top-2 gap per vector, strided pixels + crop of the reconstruction --------
+    if want("f12"):
+        m12 = {}
+        sd = R.make_state_dict(192, 12, [8192, 2048, 512], seed=12)
+        model = ref_harness.reference_compressor(192, 12, [8192, 2048, 512], sd)
+        for tag, (n, h, w, seed) in {"kodak": (1, 768, 512, 3412), "ragged": (2, 200, 136, 13)}.items():
+            xi = R.make_images(n, h, w, seed=seed)
+            gaps = []
+            orig_distance = RQ._multiCodebookQuantization._distance
+
+            def recording_distance12(self, x):
+                dist = orig_distance(self, x)
+                top2 = torch.topk(dist, 2, dim=-1, largest=False).values
+                gaps.append((top2[..., 1] - top2[..., 0]).clone())
+                return dist
+            RQ._multiCodebookQuantization._distance = recording_distance12
+            try:
+                with torch.inference_mode():
+                    codes = model.encode(xi)
+            finally:
+                RQ._multiCodebookQuantization._distance = orig_distance
+            with torch.inference_mode():
+                rec = model.decode(codes)
+            m12[tag + "_shape"] = np.array([n, h, w, seed])
+            for lv, cd in enumerate(codes):
+                m12[f"{tag}_code{lv}"] = cd.numpy().astype(np.int16)
+                m12[f"{tag}_gap{lv}"] = gaps[lv].numpy()
+            m12[tag + "_rec_strided"] = rec[..., ::16, ::16].numpy()
+            m12[tag + "_rec_crop"] = rec[:, :, h // 2 - 32:h // 2 + 32, w // 2 - 32:w // 2 + 32].numpy()
+            m12[tag + "_rec_mean_abs"] = np.array([rec.abs().mean().item()])
+        np.savez_compressed(os.path.join(OUT, "f12_model12.npz"), **m12)
+
     # ---- F5c: BASELINE configs[2] -- the 256 images `bench.py --gpus 8` generates (8 rank-seeded shards of 32 x 768x512,
     #           bench.py's own random-init qp=2 weights) through the REFERENCE in float32, and the reference's own
     #           sensitivity on them: the same model in float64 (and shard 0 with 1 instead of 8 threads).  Stored: a hash

@@ -5,8 +5,16 @@ import torch
 import torch.nn.functional as F
 
 from oracle import mcquic_ref as R
+from _record import record
 
 pytestmark = pytest.mark.gpu
+
+# Worst relative gradient error (per parameter tensor, against its largest entry) allowed per case = 4x what the round-4 GPU run
+# measured (profiles/r04_gradient_errors.json); the cases not yet measured keep the old blanket bar.
+GRAD_BARS = {
+    "full_training_step[8-32-2x128]": 2e-3, "full_training_step[128-512-1x128]": 2e-3, "full_training_step[128-8192-8x256]": 2e-3,
+    "logits_gradient[8-32-2x128]": 2e-3, "logits_gradient[128-512-1x128]": 2e-3,
+}
 
 
 def _rand(shape, seed, scale=1.0):
@@ -276,7 +284,59 @@ def test_full_training_step_gradients(dev, cfg):
         rel = (got - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
         if rel > worst[1]:
             worst = (name, rel)
-    assert worst[1] < 2e-3, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"
+    bar = GRAD_BARS[f"full_training_step[{ch}-{ks[0]}-{n}x{hw}]"]
+    record(f"full_training_step[{ch}-{ks[0]}-{n}x{hw}]", worst_rel_grad_err=worst[1], at=worst[0], bar=bar)
+    assert worst[1] < bar, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"
+
+
+@pytest.mark.parametrize("cfg", [(8, 2, [32, 16, 8], 2, 128), (128, 2, [512, 64, 16], 1, 128)])
+def test_training_step_gradients_against_float64(dev, cfg):
+    """The same step with the oracle in FLOAT64 as the truth: the HIP path (exact-fp32 MFMA contractions, v_log_f32 / v_exp_f32
+    and Markstein division in the soft assignment, csrc/vq_train.hip) must sit as close to it as the float32 CPU path does --
+    per parameter, error relative to the tensor's largest gradient; the discrete decisions (codes, random drop, hard sample) of
+    the float64 run must be the float32 run's, or the comparison is meaningless (then the case is skipped, not failed)."""
+    from mcquic_amd import Compressor
+    ch, m, ks, n, hw = cfg
+    sd, x, us = _train_setup(ch, m, ks, n, hw, 21)
+
+    def leaves(dtype):
+        leaf = {k: ((v.to(dtype) if v.is_floating_point() else v).clone().requires_grad_()
+                    if v.is_floating_point() and "reparam" not in k and "_bound" not in k and "_freqEMA" not in k
+                    else (v.to(dtype) if v.is_floating_point() else v)) for k, v in sd.items()}
+        for lv in range(len(ks)):
+            cb = leaf[f"_quantizer._encoders.{lv}._quantizer._codebook"]
+            leaf[f"_quantizer._encoders.{lv}._dequantizer._codebook"] = cb
+            leaf[f"_quantizer._decoders.{lv}._dequantizer._codebook"] = cb
+        return leaf
+    G = torch.rand((n, 3, hw, hw), generator=torch.Generator().manual_seed(5)) - 0.5
+    l32, l64 = leaves(torch.float32), leaves(torch.float64)
+    o32 = R.forward_train(l32, x, us)
+    (o32[0] * G).sum().backward()
+    o64 = R.forward_train(l64, x.double(), [(a.double(), b.double()) for a, b in us])
+    (o64[0] * G.double()).sum().backward()
+    if not all(torch.equal(a, b) for a, b in zip(o32[2], o64[2])):
+        pytest.skip("the float64 run takes other discrete decisions than the float32 run on this seed")
+    model = Compressor(ch, m, ks)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    out = model(x.to(dev), uniforms=[(a.to(dev), b.to(dev)) for a, b in us])
+    (out[0] * G.to(dev)).sum().backward()
+    worst_gpu, worst_cpu = ("", 0.0), ("", 0.0)
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        truth = l64[name].grad
+        scale = max(truth.abs().max().item(), 1e-6)
+        eg = (p.grad.detach().cpu().double() - truth).abs().max().item() / scale
+        ec = (l32[name].grad.double() - truth).abs().max().item() / scale
+        if eg > worst_gpu[1]:
+            worst_gpu = (name, eg)
+        if ec > worst_cpu[1]:
+            worst_cpu = (name, ec)
+    record(f"training_step_vs_float64[{ch}-{ks[0]}-{n}x{hw}]", hip_worst_rel_err=worst_gpu[1], hip_at=worst_gpu[0],
+           cpu_f32_worst_rel_err=worst_cpu[1], cpu_at=worst_cpu[0])
+    assert worst_gpu[1] <= max(4.0 * worst_cpu[1], 2e-5), (f"HIP gradients are {worst_gpu[1]:.3e} from the float64 truth at {worst_gpu[0]}; "
+                                                          f"the float32 CPU path is {worst_cpu[1]:.3e} ({worst_cpu[0]})")
 
 
 @pytest.mark.parametrize("cfg", [(8, 2, [32, 16, 8], 2, 128), (128, 2, [512, 64, 16], 1, 128)])
@@ -313,7 +373,9 @@ def test_logits_carry_their_gradient(dev, cfg):
         rel = (got - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
         if rel > worst[1]:
             worst = (name, rel)
-    assert worst[1] < 2e-3, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"
+    bar = GRAD_BARS[f"logits_gradient[{ch}-{ks[0]}-{n}x{hw}]"]
+    record(f"logits_gradient[{ch}-{ks[0]}-{n}x{hw}]", worst_rel_grad_err=worst[1], at=worst[0], bar=bar)
+    assert worst[1] < bar, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"
     # the logits term alone (no gradient on xHat at all): the quantizer-side parameters still receive theirs
     for p in model.parameters():
         p.grad = None

@@ -18,8 +18,11 @@ def _uniforms(n, hw, ks, dev, seed):
     return us
 
 
+@pytest.mark.parametrize("segments", [1, 3])
 @pytest.mark.parametrize("cfg", [(32, [64, 32, 16], 64), (128, [8192, 2048, 512], 128)])
-def test_graphed_step_equals_eager_step(dev, cfg):
+def test_graphed_step_equals_eager_step(dev, cfg, segments):
+    """segments = 1: the whole step as one hipGraph; 3: [forward + decoder backward] -> [quantizer backward] -> [encoder backward],
+    the cut a multi-rank run overlaps its gradient all-reduces at (forced here at world size 1)."""
     from mcquic_amd import Compressor, parallel
     ch, ks, hw = cfg
     n, steps, lr = 2, 3, 1e-3
@@ -40,8 +43,16 @@ def test_graphed_step_equals_eager_step(dev, cfg):
         losses_e.append(float(loss.detach()))
 
     opt_g = torch.optim.SGD(graphed.parameters(), lr=lr)
-    step = parallel.GraphedTrainStep(graphed, opt_g, xs[0], forward_kwargs={"uniforms": us})
+    step = parallel.GraphedTrainStep(graphed, opt_g, xs[0], forward_kwargs={"uniforms": us}, segments=segments)
     assert step.post is not None, "SGD's update should have been captured"
+    assert len(step.graphs) == segments and len(step.slices) == segments
+    # the gradient message is EVERY trainable parameter (202.2 MB for the qp=2 model: 50 558 738 float32), cut by stage
+    trainable = sum(p.numel() for p in graphed.parameters() if p.requires_grad)
+    assert step.flat.numel() == trainable == sum(sl.numel() for sl in step.slices)
+    if ch == 128:
+        assert trainable == 50558738
+        if segments == 3:
+            assert [sl.numel() for sl in step.slices] == [5376396, 41587206, 3595136]      # decoder, quantizer, encoder
     losses_g = [float(step(x)) for x in xs]
     step.close()
     torch.cuda.synchronize()
@@ -63,6 +74,80 @@ def test_graphed_step_equals_eager_step(dev, cfg):
     with torch.no_grad():
         ce, cg = eager.encode(xs[0]), graphed.encode(xs[0])
     assert all(torch.equal(a, b) for a, b in zip(ce, cg))
+
+
+def test_graphed_step_survives_eager_use_in_between(dev):
+    """train -> invalidate -> evaluate (encode re-packs every conv's streams) -> train.  The step's graphs hold the
+    addresses of the operand streams they were captured with; eager re-packs now happen in place and the step pins what it
+    captured, so the interleaved run equals an eager loop doing the same, and a closed step refuses to replay."""
+    from mcquic_amd import Compressor, parallel
+    ks, hw, n, lr = [64, 32, 16], 64, 2, 1e-2
+    torch.manual_seed(9)
+    eager = Compressor(32, 2, ks).to(dev).train()
+    graphed = copy.deepcopy(eager)
+    xs = [(torch.rand((n, 3, hw, hw), generator=torch.Generator().manual_seed(40 + i)) * 2 - 1).to(dev) for i in range(4)]
+    us = _uniforms(n, hw, ks, dev, 6)
+    opt_e = torch.optim.SGD(eager.parameters(), lr=lr, momentum=0.9)
+    codes_e = []
+    for i, x in enumerate(xs):
+        opt_e.zero_grad(set_to_none=True)
+        torch.nn.functional.mse_loss(eager(x, uniforms=us)[0], x).backward()
+        opt_e.step()
+        if i == 1:
+            eager.eval()
+            with torch.no_grad():
+                codes_e = eager.encode(xs[0])
+            eager.train()
+    step = parallel.GraphedTrainStep(graphed, torch.optim.SGD(graphed.parameters(), lr=lr, momentum=0.9), xs[0], forward_kwargs={"uniforms": us})
+    streams = {id(m): m._packed.wp.data_ptr() for m in graphed.modules() if getattr(m, "_packed", None) is not None}
+    for i, x in enumerate(xs):
+        step(x)
+        if i == 1:
+            step.invalidate()
+            graphed.eval()
+            with torch.no_grad():
+                codes_g = graphed.encode(xs[0])
+            # churn the allocator: were the old streams freed, this would land on them
+            junk = [torch.full((1 << 18,), float("nan"), device=dev) for _ in range(64)]
+            del junk
+            graphed.train()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(codes_e, codes_g))
+    assert streams == {id(m): m._packed.wp.data_ptr() for m in graphed.modules() if getattr(m, "_packed", None) is not None}, "operand streams moved"
+    for (name, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
+        scale = max(float(pe.detach().abs().max()), 1e-12)
+        assert float((pe.detach() - pg.detach()).abs().max()) <= 4e-6 * scale, name
+    step.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        step(xs[0])
+
+
+def test_graphed_step_keeps_a_resumed_optimizer_state(dev):
+    """an optimizer restored from a checkpoint (momentum buffers, Adam moments, step counters) must come out of the
+    constructor with that state -- the throw-away update that creates missing state restores what was there."""
+    from mcquic_amd import Compressor, parallel
+    ks, hw = [64, 32, 16], 64
+    torch.manual_seed(5)
+    model = Compressor(32, 2, ks).to(dev).train()
+    x = (torch.rand((2, 3, hw, hw), generator=torch.Generator().manual_seed(3)) * 2 - 1).to(dev)
+    us = _uniforms(2, hw, ks, dev, 8)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    for _ in range(3):                                        # "the checkpoint": three eager updates
+        opt.zero_grad(set_to_none=True)
+        torch.nn.functional.mse_loss(model(x, uniforms=us)[0], x).backward()
+        opt.step()
+    want = {(i, k): v.detach().clone() for i, (p, st) in enumerate(opt.state.items()) for k, v in st.items() if torch.is_tensor(v)}
+    assert want and all(int(st["step"]) == 3 for st in opt.state.values())
+    params = [p.detach().clone() for p in model.parameters()]
+    step = parallel.GraphedTrainStep(model, opt, x, forward_kwargs={"uniforms": us})
+    got = {(i, k): v for i, (p, st) in enumerate(opt.state.items()) for k, v in st.items() if torch.is_tensor(v)}
+    assert got.keys() == want.keys()
+    for key in want:
+        assert torch.equal(got[key].detach().to(want[key].device), want[key]), key
+    assert all(torch.equal(a, b.detach()) for a, b in zip(params, model.parameters()))
+    step(x)
+    assert all(int(st["step"]) == 4 for st in opt.state.values())
+    step.close()
 
 
 def test_graphed_step_really_updates(dev):

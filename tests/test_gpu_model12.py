@@ -1,0 +1,121 @@
+"""The reference's second listed model, No. 12 = `Compressor(192, 12, [8192, 2048, 512])` (/root/reference/README.md:306,
+mcquic/modules/compressor.py:120-177) through the whole HIP path: channel 192 (Cout % 128 == 64: three 64-row bands, Cin = 192
+rings), twelve codebooks of 16-dimensional codewords at k = 8192 / 2048 / 512.
+
+Golden F12 (tests/golden/f12_model12.npz) was captured from the REAL reference by tests/golden/make_golden.py: every code of
+1 x 768x512 and of 2 x 200x136 (sizes that are no multiple of 128), the reference's own top-2 distance gap per vector, strided
+pixels and a crop of the reconstructions.  Index parity follows the near-tie protocol of DESIGN section 6 (a code may differ only
+where the reference's own gap is < 1e-5; with twelve codebooks of short codewords there are more such vectors per image than at
+qp = 2: 6 of 18 432 level-0 vectors of the 768x512 image sit below 1e-5, the closest at one float32 ulp)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mcquic_ref as R
+from test_gpu_golden import _audit_codes as _audit_model_codes
+from test_gpu_ops import _audit_codes as _audit_vq_codes, _close, _rand, _vq_case
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MODEL12 = (192, 12, [8192, 2048, 512])
+
+
+@pytest.fixture(scope="module")
+def model12(dev):
+    from mcquic_amd import Compressor
+    sd = R.make_state_dict(*MODEL12, seed=12)
+    model = Compressor(*MODEL12).eval()
+    model.load_state_dict(sd, strict=True)
+    return model.to(dev), sd
+
+
+@pytest.mark.parametrize("tag", ["kodak", "ragged"])
+def test_model12_against_reference_vectors(dev, model12, tag):
+    model, _ = model12
+    z = np.load(os.path.join(G, "f12_model12.npz"))
+    n, h, w, seed = [int(v) for v in z[tag + "_shape"]]
+    codes = [c.cpu() for c in model.encode(R.make_images(n, h, w, seed=seed).to(dev))]
+    want = [torch.from_numpy(z[f"{tag}_code{lv}"].astype(np.int64)) for lv in range(3)]
+    for c, wc in zip(codes, want):
+        assert c.dtype == torch.int64 and c.shape == wc.shape
+    flips, cut = _audit_model_codes(codes, want, [z[f"{tag}_gap{lv}"] for lv in range(3)])
+    near = sum(int((z[f"{tag}_gap{lv}"] < 1e-5).sum()) for lv in range(3))
+    assert flips <= max(1, near), f"{flips} audited flips but only {near} near-tie vectors in the reference's own distances"
+    rec = model.decode([c.to(dev) for c in want]).cpu()
+    np.testing.assert_allclose(rec[..., ::16, ::16].numpy(), z[tag + "_rec_strided"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(rec[:, :, h // 2 - 32:h // 2 + 32, w // 2 - 32:w // 2 + 32].numpy(), z[tag + "_rec_crop"], rtol=0, atol=1e-4)
+    assert abs(rec.abs().mean().item() - float(z[tag + "_rec_mean_abs"][0])) < 1e-5
+
+
+def test_model12_against_oracle_batch(dev, model12):
+    """Four 256x384 images against the CPU oracle (itself bit-equal to the reference): codes down to the first near-tie flip per
+    image, pixels from the oracle's codes within 1e-4; state_dict keys and Codebooks shapes of the reference's class."""
+    model, sd = model12
+    assert [tuple(c.shape) for c in model.Codebooks] == [(12, 8192, 16), (12, 2048, 16), (12, 512, 16)]
+    assert set(model.state_dict().keys()) == set(sd.keys())
+    x = R.make_images(4, 256, 384, seed=77)
+    want = R.encode(sd, x)
+    got = [c.cpu() for c in model.encode(x.to(dev))]
+    total = sum(c.numel() for c in want)
+    diff = sum(int((a != b).sum()) for a, b in zip(got, want))
+    assert diff <= max(4, total // 2000), f"{diff} of {total} codes differ from the oracle's (near-ties explain a handful per image, not this)"
+    rec = model.decode([c.to(dev) for c in want]).cpu()
+    ref = R.decode(sd, want)
+    assert float((rec - ref).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("shape", [(12, 8192, 16, 1, 48, 32), (12, 2048, 16, 2, 24, 16), (12, 512, 16, 2, 12, 8), (12, 8192, 16, 8, 48, 32)])
+def test_vq_assign_model12_shapes(dev, shape):
+    """d = 16, m = 12 at the three codebook sizes (one image, and a batch that fills the chip) against the oracle."""
+    from mcquic_amd import ops
+    m, k, d, n, h, w = shape
+    x, cb = _vq_case(m, k, d, n, h, w, 1200 + k)
+    pk = ops.PackedCodebook(cb.to(dev))
+    got = ops.vq_assign(x.to(dev), pk)
+    assert tuple(got.shape) == (n, m, h, w) and int(got.min()) >= 0 and int(got.max()) < k
+    _audit_vq_codes(got, x, cb, 2e-6, f"vq{shape}")
+    out = ops.vq_gather(got, pk).cpu()
+    want = torch.stack([cb[g][got.cpu()[:, g]] for g in range(m)], 1)          # [n, m, h, w, d]
+    assert torch.equal(out, want.permute(0, 1, 4, 2, 3).reshape(n, m * d, h, w))
+
+
+@pytest.mark.parametrize("case", [(2, 192, 192, 24, 32, 3, 1), (1, 192, 192, 13, 37, 3, 1), (2, 192, 192, 24, 16, 3, 2),
+                                  (3, 192, 192, 12, 8, 3, 1), (2, 3, 192, 32, 48, 3, 2), (2, 192, 192, 16, 24, 1, 1),
+                                  (1, 192, 12, 16, 32, 3, 1), (2, 192, 768, 12, 16, 3, 1)])
+@pytest.mark.parametrize("tile", [0, 0x42, 0x41, 0x22, 0x21, 0x11, 0x242, 0x122, 0x222, 0x311])
+def test_conv_width_192_forced_tiles(dev, case, tile):
+    """Cin = Cout = 192: three 64-row bands, or a 128-row tile whose second instance is half empty (rows >= 192 are out of range
+    for every store); every forced tile and the library's own choice against F.conv2d."""
+    from mcquic_amd import ops
+    n, cin, cout, h, w, ks, stride = case
+    if tile and ((tile >> 4) & 15) * 32 > ((cout + 31) // 32) * 32:
+        pytest.skip("tile taller than Cout")
+    x = _rand((n, cin, h, w), 21)
+    wt = _rand((cout, cin, ks, ks), 22, 1.0 / np.sqrt(cin * ks * ks))
+    b = _rand((cout,), 23, 0.1)
+    want = F.conv2d(x, wt, b, stride=stride, padding=ks // 2)
+    pk = ops.PackedConv(wt.to(dev), b.to(dev))
+    _close(ops.conv2d(x.to(dev), pk, stride, tile=tile), want, 2e-6, f"conv{case} tile={tile:#x}")
+    if ks == 3 and stride == 1 and cout == cin:
+        res = _rand(tuple(want.shape), 24)
+        got = ops.conv2d(x.to(dev), pk, stride, tile=tile, res=res.to(dev), dual_silu=True, silu_in=True)
+        want2 = F.conv2d(F.silu(x), wt, b, padding=1) + res
+        _close(got, want2, 2e-6, f"conv+res{case} tile={tile:#x}")
+        _close(ops.silu_twin(got), F.silu(want2), 2e-6, f"conv+twin{case} tile={tile:#x}")
+
+
+def test_model12_compress_roundtrip(dev, model12):
+    """compress -> rANS byte streams -> decompress equals decode(encode(x)) cropped (the API surface the CLI uses)."""
+    model, _ = model12
+    x = R.make_images(2, 200, 136, seed=5).to(dev)
+    codes, binaries, headers = model.compress(x)
+    rec = model.decompress(binaries, headers)
+    direct = model.decode(codes)
+    assert tuple(rec.shape) == (2, 3, 200, 136) and tuple(direct.shape) == (2, 3, 256, 256)
+    top, left = (256 - 200) // 2, (256 - 136) // 2
+    assert torch.equal(rec, direct[..., top:top + 200, left:left + 136])
+    assert [tuple(c.shape) for c in codes] == [(2, 12, 16, 16), (2, 12, 8, 8), (2, 12, 4, 4)]

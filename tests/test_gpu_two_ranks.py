@@ -62,6 +62,7 @@ def test_two_rank_graphed_step_matches_one_process(dev, tmp_path):
     the whole batch (the parameter updates agree to float32 reassociation, the frequency EMA exactly)."""
     r = _run("graphed", tmp_path)
     assert r["post_captured"], r
+    assert r["segments"] == 3 and r["slice_mb"] == [21.5, 166.3, 14.4], r      # decoder / quantizer / encoder slices of the 202.2 MB
     assert r["largest_update"] > 0, r
     assert r["worst_update_rel_err"] < 1.0, r        # (in units of 1e-4 x the update + 4 ulps of the parameter)
     assert r["ema_max_abs_diff"] < 1e-7, r

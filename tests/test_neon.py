@@ -13,6 +13,7 @@ from oracle import neon_ref as N
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f10_neon.npz")
 G_DENSE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f11_neon_dense_norm.npz")     # denseNorm=True
 CFG = (32, 256, [8, 4, 2, 2])
+NEON_GRAD_BAR = {False: 2e-3, True: 2e-3}      # denseNorm -> worst relative gradient error allowed (4x the measured value once measured)
 DENSE = pytest.mark.parametrize("dense", [False, True], ids=["plain", "denseNorm"])
 
 
@@ -168,4 +169,7 @@ def test_neon_training_forward_and_gradients(dev, dense):
         rel = (p.grad.detach().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-3 * scale, 1e-6)
         if rel > worst[1]:
             worst = (name, rel)
-    assert worst[1] < 2e-3, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"
+    from _record import record
+    bar = NEON_GRAD_BAR[bool(dense)]
+    record(f"neon_training_step[denseNorm={bool(dense)}]", worst_rel_grad_err=worst[1], at=worst[0], bar=bar)
+    assert worst[1] < bar, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"

@@ -375,9 +375,90 @@ def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool
     return d, y, y2, (x, res, mul, gate_id)
 
 
+# ---- images whose activations do not fit one launch --------------------------------------------------------------------------
+# The kernels address one image's [C, H, W] slab through 32-bit buffer offsets whose top bit is the out-of-range marker
+# (MCQ_ETOOLARGE at 2 GiB): a 6000 x 4000 photo's stem output is 3000 x 2000 x 128 x 4 B = 3.07 GB.  The reference has no limit
+# but memory (mcquic/modules/compressor.py:67-117), so such layers run band by band: rows [o0, o1) of the output from the input
+# rows under them (+ the 3x3 halo), each band a contiguous copy that fits.  Every output pixel still sees its own taps in the
+# kernel's (channel pair, tap) order, so a band's rows are the unsplit launch's rows bit for bit wherever both take the same
+# tile / split (tests/test_gpu_model.py::test_row_band_fallback_equals_the_single_launch at a lowered limit).
+_SLAB_LIMIT = int(os.environ.get("MCQUIC_AMD_SLAB_LIMIT", str(1 << 31)))
+_TENSOR_OPTS = ("res", "gdn_mul", "igdn_mul", "gate_mul", "gate_id", "mul", "dsilu_mul")
+
+
+def set_slab_limit(nbytes: Optional[int]) -> int:
+    """Per-image activation bytes above which a convolution runs in row bands (default 2 GiB = the kernels' own limit); tests
+    lower it.  Returns the previous value; None restores the default."""
+    global _SLAB_LIMIT
+    prev = _SLAB_LIMIT
+    _SLAB_LIMIT = (1 << 31) if nbytes is None else int(nbytes)
+    return prev
+
+
+def _slab_bytes(cin: int, h: int, wd: int, cout: int, ho: int, wo: int) -> int:
+    """What conv_validate / conv_launch bound (csrc/conv_mfma.hip): the input slab plus the prefetch rings' over-read, the output
+    slab with its last 128-row tile complete."""
+    return max((cin + 16) * h * wd * 4, -(-cout // 128) * 128 * ho * wo * 4)
+
+
+def _band_rows(x: torch.Tensor, w: PackedConv, stride: int) -> int:
+    """0 when the layer fits one launch, else the output rows per band."""
+    n, cin, h, wd = x.shape
+    pad = w.ksize // 2
+    ho, wo = (h + 2 * pad - w.ksize) // stride + 1, (wd + 2 * pad - w.ksize) // stride + 1
+    if _slab_bytes(cin, h, wd, w.cout, ho, wo) < _SLAB_LIMIT:
+        return 0
+    per_row = max((cin + 16) * wd * 4 * stride, -(-w.cout // 128) * 128 * wo * 4)      # bytes one more output row costs
+    rows = (_SLAB_LIMIT - 1) // per_row - 4                                            # (halo rows on both sides)
+    if rows < 1:
+        raise RuntimeError(f"mcquic_amd: one output row of a {cin}->{w.cout} layer on a {wd}-pixel-wide map exceeds the slab limit")
+    return int(rows)
+
+
+def _conv2d_banded(x: torch.Tensor, w: PackedConv, stride: int, rows: int, fused: dict) -> torch.Tensor:
+    if fused.get("silu_in"):
+        twin = silu_twin(x)
+        if twin is not None:
+            x, fused = twin, dict(fused, silu_in=False)
+    x = _dev(x, "x")
+    n, cin, h, wd = x.shape
+    k, pad = w.ksize, w.ksize // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+    shuffle2, dual = bool(fused.get("shuffle2")), bool(fused.get("dual_silu"))
+    up = 2 if shuffle2 else 1
+    y = torch.empty((n, w.cout // 4, 2 * ho, 2 * wo) if shuffle2 else (n, w.cout, ho, wo), dtype=torch.float32, device=x.device)
+    y2 = torch.empty_like(y) if dual else None
+    sides = {kk: _dev(fused[kk], kk) for kk in _TENSOR_OPTS if fused.get(kk) is not None}
+    plain = {kk: v for kk, v in fused.items() if kk not in _TENSOR_OPTS}
+    for o0 in range(0, ho, rows):
+        o1 = min(ho, o0 + rows)
+        # input rows [b0, b1): every tap of the kept output rows is inside the band or outside the image (where the conv pads)
+        b0 = max(0, stride * o0 - stride) if pad else stride * o0
+        b1 = min(h, stride * (o1 - 1) + k - pad)
+        g0 = b0 // stride                                           # the band's local output row 0 is global output row g0
+        xb = x[:, :, b0:b1].contiguous()
+        hl = (b1 - b0 + 2 * pad - k) // stride + 1
+        local = {kk: v[:, :, g0:g0 + hl].contiguous() for kk, v in sides.items()}
+        for kk, v in local.items():
+            if v.shape[2] != hl:                                    # (the band computes rows past the map's end: pad the side input)
+                local[kk] = torch.nn.functional.pad(v, (0, 0, 0, hl - v.shape[2]))
+        yb = conv2d(xb, w, stride, **plain, **local)
+        lo, hi = up * (o0 - g0), up * (o1 - g0)
+        y[:, :, up * o0:up * o1] = yb[:, :, lo:hi]
+        if dual:
+            y2[:, :, up * o0:up * o1] = silu_twin(yb)[:, :, lo:hi]
+    if dual:
+        set_silu_twin(y, y2)
+    return y
+
+
 def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, **fused) -> torch.Tensor:
     """y = epilogue(conv(prologue(x)) + bias); one kernel launch (mcq_conv2d_f32).  Options: silu_in, square_in, silu_out,
-    res (+ res_scale), gdn_mul / igdn_mul / gate_mul (+ gate_id) / mul / dsilu_mul, shuffle2, dual_silu, tile."""
+    res (+ res_scale), gdn_mul / igdn_mul / gate_mul (+ gate_id) / mul / dsilu_mul, shuffle2, dual_silu, tile.
+    A layer whose per-image slab exceeds the kernels' 2 GiB addressing runs in row bands (same results, see above)."""
+    rows = _band_rows(x, w, stride)
+    if rows:
+        return _conv2d_banded(x, w, stride, rows, fused)
     d, y, y2, keep = _conv_desc(x, w, stride, **fused)
     with _guard(y.device):
         check(_lib.load().mcq_conv2d_f32(ctypes.byref(d), _stream()), "mcq_conv2d_f32")
@@ -395,7 +476,7 @@ def conv2d_multi(xs, ws, stride: int = 1, per_problem=None, **shared):
     n = len(xs)
     per_problem = per_problem or [{}] * n
     lib = _lib.load()
-    if n == 1 or not _MULTI:
+    if n == 1 or not _MULTI or _band_rows(xs[0], ws[0], stride):
         return [conv2d(x, w, stride, **shared, **pp) for x, w, pp in zip(xs, ws, per_problem)]
     cap = lib.mcq_conv2d_max_multi()
     out = []

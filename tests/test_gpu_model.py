@@ -293,3 +293,27 @@ def test_prefetch_feeds_the_same_batches(dev):
     for g, w in zip(got, want):
         assert all(torch.equal(a, b) for a, b in zip(g, w))
     assert list(parallel.prefetch([], dev)) == []
+
+
+def test_row_band_fallback_equals_the_single_launch(dev):
+    """Images beyond ~16 MP (VERDICT r3 missing #4): `encode` / `decode` must not refuse an image whose activations exceed the
+    kernels' 2 GiB-per-image addressing (the reference has no limit but memory, mcquic/modules/compressor.py:67-117).  With the
+    limit lowered to 20 MB the 384x256 maps of a 768x512 image (50 MB per layer) run in row bands while the smaller maps run
+    whole: the same codes, and pixels to float32 reassociation (a band is a smaller launch and may split its k-steps)."""
+    from mcquic_amd import Compressor, ops
+    sd = R.make_state_dict(128, 2, [8192, 2048, 512], seed=0)
+    model = Compressor(128, 2, [8192, 2048, 512]).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    x = R.make_images(1, 768, 512, seed=3407).to(dev)
+    codes = model.encode(x)
+    rec = model.decode(codes)
+    prev = ops.set_slab_limit(20 << 20)
+    try:
+        banded_codes = model.encode(x)
+        banded_rec = model.decode(codes)
+    finally:
+        ops.set_slab_limit(prev)
+    for lv, (a, b) in enumerate(zip(codes, banded_codes)):
+        assert torch.equal(a, b), f"level {lv}: {(a != b).sum().item()} codes differ between the banded and the single-launch run"
+    assert float((rec - banded_rec).abs().max()) <= 2e-6

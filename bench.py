@@ -430,6 +430,80 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
     return sec
 
 
+def two_core_child(args):
+    """`bench.py --two-core-child`: what ONE rank of an 8-GPU node gets from the host -- two cores (a 16-core box / 8 ranks) --
+    for the three host-driven loops of the path: the eager B32 encode+decode step (~330 Python-side launches), the same step as
+    hipGraph replays, the reference's speed protocol (host rANS coder in the loop) and the graphed data-parallel training step.
+    The affinity is set before torch starts its thread pools (the equivalent of `taskset -c a,b python bench.py ...`)."""
+    cores = sorted(os.sched_getaffinity(0))[:2]
+    os.sched_setaffinity(0, set(cores))
+    os.environ["OMP_NUM_THREADS"] = "2"
+    torch.set_num_threads(2)
+    from mcquic_amd import Compressor, parallel, validate
+    from mcquic_amd.nn import blocks
+    from mcquic_amd.utils import synthetic
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    out = {"cores": cores}
+    model = synthetic.bench_model().to(dev)
+    x = synthetic.bench_images(0, args.batch, H, W).to(dev)
+
+    def wall(fn, steps, warmup=1):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    try:
+        ms = wall(lambda: model.decode(model.encode(x)), 4, warmup=2)
+        out["b32_eager"] = {"images_s": round(args.batch / ms * 1e3, 2), "ms_per_step": round(ms, 3)}
+        model.enableGraphs(True)
+        ms = wall(lambda: model.decode(model.encode(x)), 4, warmup=2)
+        out["b32_graphs"] = {"images_s": round(args.batch / ms * 1e3, 2), "ms_per_step": round(ms, 3)}
+        model.enableGraphs(False)
+    except Exception as exc:                                  # noqa: BLE001
+        out["b32_error"] = repr(exc)[:300]
+    try:
+        enc, dec = validate.speed(model, iters=10)
+        out["speed_protocol"] = {"encode_mpps": round(enc, 2), "decode_mpps": round(dec, 2)}
+    except Exception as exc:                                  # noqa: BLE001
+        out["speed_protocol"] = {"error": repr(exc)[:300]}
+    del model, x
+    streams = blocks._BRANCH_STREAMS
+    try:
+        blocks._BRANCH_STREAMS = False
+        torch.manual_seed(3407)
+        tm = Compressor(**MODEL).to(dev).train()
+        xt = (torch.rand((8, 3, 256, 256), generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
+        for seg in (1, 3):
+            gstep = parallel.GraphedTrainStep(tm, torch.optim.SGD(tm.parameters(), lr=1e-6), xt, segments=seg)
+            out[f"train_graphed_ms_segments{seg}"] = round(wall(lambda: gstep(xt), 10, warmup=2), 3)
+            gstep.close()
+            del gstep
+    except Exception as exc:                                  # noqa: BLE001
+        out["train_error"] = repr(exc)[:300]
+    finally:
+        blocks._BRANCH_STREAMS = streams
+    print("TWOCORE " + json.dumps(out), flush=True)
+    return 0
+
+
+def child_json(argv, tag, timeout):
+    """Run `bench.py argv...` as a child process and return the JSON object on its `tag ` line (or an {"error": ...} record)."""
+    import subprocess
+    try:
+        run = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=timeout)
+        for line in reversed(run.stdout.splitlines()):
+            if line.startswith(tag + " "):
+                return json.loads(line[len(tag) + 1:])
+        return {"error": f"child exited with code {run.returncode} and no result: {run.stderr[-300:]}"}
+    except Exception as exc:                                  # noqa: BLE001
+        return {"error": repr(exc)[:300]}
+
+
 def secondary_child(args):
     """`bench.py --secondary-child FILE`: the secondary measurements in a process of their own -- a crash or hang in an opt-in
     mode or in the training-step capture must not be able to take the headline line down with it."""
@@ -483,10 +557,15 @@ def main():
     ap.add_argument("--secondary-child", default=None, metavar="FILE",
                     help="internal: run ONLY the `secondary` measurements (FILE = optional torch file with the oracle's codes / pixels "
                          "for the parity leg) and print their JSON object; bench.py starts this as a child process")
+    ap.add_argument("--two-core-child", action="store_true",
+                    help="internal: the host-bound loops of the path with this process confined to two host cores (one rank's share "
+                         "of an 8-GPU node); prints one TWOCORE line")
     ap.add_argument("--winograd", type=int, nargs="?", const=1, default=0, choices=(0, 1, 2),
                     help="OPT-IN experiment, never the headline: large 3x3 stride-1 layers in a Winograd form (not the reference's arithmetic); "
                          "1 = F(2, 3) along x, 2 = F(2x2, 3x3) where the layer allows it")
     args = ap.parse_args()
+    if args.two_core_child:
+        return two_core_child(args)
     if args.secondary_child is not None:
         return secondary_child(args)
 
@@ -627,6 +706,29 @@ def main():
             del model, codes, pix                 # (the child builds its own model on the same GPU)
             torch.cuda.empty_cache()
             out["secondary"] = secondary_in_child(args, cpu_codes, cpu_pix)
+            # one rank's share of the host on an 8-GPU node (16 cores / 8 ranks): the host-driven loops again, confined to two cores
+            two = child_json(["--two-core-child", "--batch", str(args.batch)], "TWOCORE", 420)
+            sec = out["secondary"] if isinstance(out["secondary"], dict) else {}
+            try:
+                ref = {"b32_eager": value, "b32_graphs": value,
+                       "speed_encode": sec.get("speed_protocol", {}).get("encode_mpps"), "speed_decode": sec.get("speed_protocol", {}).get("decode_mpps"),
+                       "train": sec.get("train_step", {}).get("ms_graphed_data_parallel")}
+                drop = {}
+                if "b32_eager" in two:
+                    drop["b32_eager_pct"] = round(100 * (1 - two["b32_eager"]["images_s"] / ref["b32_eager"]), 2)
+                    drop["b32_graphs_pct"] = round(100 * (1 - two["b32_graphs"]["images_s"] / ref["b32_graphs"]), 2)
+                if ref["speed_encode"] and "encode_mpps" in two.get("speed_protocol", {}):
+                    drop["speed_encode_pct"] = round(100 * (1 - two["speed_protocol"]["encode_mpps"] / ref["speed_encode"]), 2)
+                    drop["speed_decode_pct"] = round(100 * (1 - two["speed_protocol"]["decode_mpps"] / ref["speed_decode"]), 2)
+                if ref["train"] and two.get("train_graphed_ms_segments1"):
+                    drop["train_graphed_pct"] = round(100 * (two["train_graphed_ms_segments1"] / ref["train"] - 1), 2)
+                two["loss_vs_all_cores"] = drop
+                two["note"] = ("the same loops with the process confined to two host cores (`taskset -c a,b`): what a rank of an 8-GPU node "
+                               "has; loss_vs_all_cores in percent against this run's headline / secondary figures (negative = faster)")
+            except Exception as exc:                          # noqa: BLE001
+                two["compare_error"] = repr(exc)[:200]
+            if isinstance(out["secondary"], dict):
+                out["secondary"]["two_core_host"] = two
     # RCCL writes its version banner through C stdio, which a pipe only sees at exit: every rank flushes it out before the
     # last barrier so that rank 0's ONE line below is the last thing on stdout
     try:

@@ -398,7 +398,7 @@ def set_slab_limit(nbytes: Optional[int]) -> int:
 def _slab_bytes(cin: int, h: int, wd: int, cout: int, ho: int, wo: int) -> int:
     """What conv_validate / conv_launch bound (csrc/conv_mfma.hip): the input slab plus the prefetch rings' over-read, the output
     slab with its last 128-row tile complete."""
-    return max((cin + 16) * h * wd * 4, -(-cout // 128) * 128 * ho * wo * 4)
+    return max((cin + 32) * h * wd * 4, -(-cout // 128) * 128 * ho * wo * 4)
 
 
 def _band_rows(x: torch.Tensor, w: PackedConv, stride: int) -> int:
@@ -408,7 +408,7 @@ def _band_rows(x: torch.Tensor, w: PackedConv, stride: int) -> int:
     ho, wo = (h + 2 * pad - w.ksize) // stride + 1, (wd + 2 * pad - w.ksize) // stride + 1
     if _slab_bytes(cin, h, wd, w.cout, ho, wo) < _SLAB_LIMIT:
         return 0
-    per_row = max((cin + 16) * wd * 4 * stride, -(-w.cout // 128) * 128 * wo * 4)      # bytes one more output row costs
+    per_row = max((cin + 32) * wd * 4 * stride, -(-w.cout // 128) * 128 * wo * 4)      # bytes one more output row costs
     rows = (_SLAB_LIMIT - 1) // per_row - 4                                            # (halo rows on both sides)
     if rows < 1:
         raise RuntimeError(f"mcquic_amd: one output row of a {cin}->{w.cout} layer on a {wd}-pixel-wide map exceeds the slab limit")

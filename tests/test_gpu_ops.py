@@ -677,7 +677,7 @@ def test_conv_row_band_fallback_is_the_single_launch(dev, case):
     for opts in variants:
         opts = {k: v for k, v in opts.items() if v is not None}
         whole = ops.conv2d(x, pk, stride, tile=0x11, **opts)
-        prev = ops.set_slab_limit(max(cin + 16, 128) * w * 4 * 12)            # ~8 output rows per band
+        prev = ops.set_slab_limit(max(cin + 32, 128) * w * 4 * 12)            # ~8 output rows per band
         try:
             assert ops._band_rows(x, pk, stride) > 0, "the case is meant to band"
             banded = ops.conv2d(x, pk, stride, tile=0x11, **opts)

@@ -10,10 +10,12 @@ from _record import record
 pytestmark = pytest.mark.gpu
 
 # Worst relative gradient error (per parameter tensor, against its largest entry) allowed per case = 4x what the round-4 GPU run
-# measured (profiles/r04_gradient_errors.json); the cases not yet measured keep the old blanket bar.
+# measured (profiles/r04_gradient_errors.json, written by tests/_record.py).
+# measured (MI355X, round 4): 2.6e-6 / 6.1e-6 / 3.6e-6 for the three training steps, 3.9e-6 / 2.4e-6 with the logits term; against
+# the oracle in float64 the HIP gradients are 1.7e-6 / 2.8e-6 off where the float32 CPU path is 2.4e-6 / 3.5e-6.
 GRAD_BARS = {
-    "full_training_step[8-32-2x128]": 2e-3, "full_training_step[128-512-1x128]": 2e-3, "full_training_step[128-8192-8x256]": 2e-3,
-    "logits_gradient[8-32-2x128]": 2e-3, "logits_gradient[128-512-1x128]": 2e-3,
+    "full_training_step[8-32-2x128]": 1.1e-5, "full_training_step[128-512-1x128]": 2.5e-5, "full_training_step[128-8192-8x256]": 1.5e-5,
+    "logits_gradient[8-32-2x128]": 1.6e-5, "logits_gradient[128-512-1x128]": 1.0e-5,
 }
 
 

@@ -113,7 +113,8 @@ def test_graphed_step_survives_eager_use_in_between(dev):
             graphed.train()
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(codes_e, codes_g))
-    assert streams == {id(m): m._packed.wp.data_ptr() for m in graphed.modules() if getattr(m, "_packed", None) is not None}, "operand streams moved"
+    now = {id(m): m._packed.wp.data_ptr() for m in graphed.modules() if getattr(m, "_packed", None) is not None}
+    assert len(streams) > 100 and all(now[k] == v for k, v in streams.items()), "operand streams moved"     # (eval packs a few layers more)
     for (name, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
         scale = max(float(pe.detach().abs().max()), 1e-12)
         assert float((pe.detach() - pg.detach()).abs().max()) <= 4e-6 * scale, name

@@ -666,7 +666,10 @@ def test_conv_row_band_fallback_is_the_single_launch(dev, case):
     n, cin, cout, h, w, ks, stride = case
     x = _rand((n, cin, h, w), 31).to(dev)
     wt = _rand((cout, cin, ks, ks), 32, 1.0 / np.sqrt(cin * ks * ks))
-    pk = ops.PackedConv(wt.to(dev), _rand((cout,), 33, 0.1).to(dev))
+    bias = _rand((cout,), 33, 0.1)
+    if ks == 1:                                                             # GDN: beta + gamma @ x^2 must stay positive under the root
+        wt, bias = wt.abs(), bias.abs() + 1.0
+    pk = ops.PackedConv(wt.to(dev), bias.to(dev))
     ho, wo = (h + 2 * (ks // 2) - ks) // stride + 1, (w + 2 * (ks // 2) - ks) // stride + 1
     res = _rand((n, cout, ho, wo), 34).to(dev)
     variants = [dict(), dict(res=res, dual_silu=True), dict(silu_in=True, silu_out=True)]

@@ -13,7 +13,10 @@ from oracle import neon_ref as N
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f10_neon.npz")
 G_DENSE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f11_neon_dense_norm.npz")     # denseNorm=True
 CFG = (32, 256, [8, 4, 2, 2])
-NEON_GRAD_BAR = {False: 2e-3, True: 2e-3}      # denseNorm -> worst relative gradient error allowed (4x the measured value once measured)
+# denseNorm -> worst relative gradient error allowed = 4x the measured value (profiles/r04_gradient_errors.json: 3.6e-6 plain; with
+# denseNorm 4.2e-4, all of it at a conv bias in front of a one-channel-per-group GroupNorm whose gradient is structurally ZERO --
+# both sides hold rounding noise there and the error is taken against 1e-3 of the model's largest gradient, see below)
+NEON_GRAD_BAR = {False: 1.5e-5, True: 1.7e-3}
 DENSE = pytest.mark.parametrize("dense", [False, True], ids=["plain", "denseNorm"])
 
 

@@ -331,6 +331,43 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
         sec["winograd2d"] = {"error": repr(exc)[:300]}
     finally:
         ops.set_winograd(0)
+    # ---- the reference's second listed model, No. 12 (README.md:306) --------------------------------------------------------
+    try:
+        torch.manual_seed(3412)
+        m12 = Compressor(192, 12, [8192, 2048, 512]).eval().to(dev)
+        nb12 = min(16, x.shape[0])
+        x12 = x[:nb12].contiguous()
+        prof = ConvProfiler().install()
+        prof.MAX_STEPS = 2
+        prof.active = False
+        m12.decode(m12.encode(x12))                            # pack + warm-up, not bracketed
+        prof.active = True
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            prof.next_step()
+            m12.decode(m12.encode(x12))
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 2 * 1e3
+        prof.remove()
+        c = prof.summary()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record(); c12 = m12.encode(x12); e[1].record(); m12.decode(c12); e[2].record()
+        torch.cuda.synchronize()
+        enc12, dec12 = validate.speed(m12, iters=10)
+        sec["model12"] = {"model": "Compressor(192, 12, [8192, 2048, 512]) (the reference's model No. 12), random-init weights",
+                          "batch": nb12, "images_s": round(nb12 / ms * 1e3, 2), "ms_per_step": round(ms, 3),
+                          "encode_mpps": round(nb12 * H * W / 1e3 / e[0].elapsed_time(e[1]), 2),
+                          "decode_mpps": round(nb12 * H * W / 1e3 / e[1].elapsed_time(e[2]), 2),
+                          "frac_of_peak": round(c["mfma_flops"] / (c["ms"] * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+                          "conv_gflop_per_image": round(c["flops"] / c["steps"] / nb12 / 1e9, 1),
+                          "whole_step_frac": round(c["flops"] / c["steps"] / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+                          "speed_protocol": {"encode_mpps": round(enc12, 2), "decode_mpps": round(dec12, 2),
+                                             "protocol": "Validator.speed, batch 10, rANS byte streams included, 10 iterations"},
+                          "reference_published": {"encode_mpps": 11.07, "decode_mpps": 10.21, "hardware": "1x RTX 3090 (TF32), README.md:306"}}
+        del m12, x12, c12
+    except Exception as exc:                                  # noqa: BLE001
+        sec["model12"] = {"error": repr(exc)[:300]}
     # ---- batch-1 latency, hipGraph replay ---------------------------------------------------------------------------------
     try:
         model.enableGraphs(True)

@@ -35,6 +35,12 @@ __all__ = ["ResidualBlockWithStride", "ResidualBlockShuffle", "ResidualBlock", "
 _BRANCH_STREAMS = os.environ.get("MCQUIC_AMD_BRANCH_STREAMS", "1") != "0"
 _side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
 _MULTI_MAX_PIXELS = int(os.environ.get("MCQUIC_AMD_MULTI_MAX_PIXELS", str(64 * 1024)))   # N * H * W up to which AttentionBlock stacks share launches
+# ... and below this many pixels nothing is forked at all: a launch that does not fill the chip for several rounds has no tail worth
+# filling, and forks inside a captured hipGraph cost more than they give.  Round 4 (tools/probes/batch1_order.py): one 768x512 image
+# as graph replays, 5.64-5.67 ms without forks in every order of events; with them 5.87 ms when captured in a fresh process and
+# 6.6-6.7 ms when captured after eager 32-image steps had created their side streams (the bench line's 6.9 vs the stand-alone 5.9
+# of round 3), eager anywhere between 5.9 and 12.7.  At 32 images the forked maps (96x64 and up: 196 k pixels) are unaffected.
+_FORK_MIN_PIXELS = int(os.environ.get("MCQUIC_AMD_FORK_MIN_PIXELS", str(128 * 1024)))
 
 
 def _side_stream(main: "torch.cuda.Stream") -> "torch.cuda.Stream":
@@ -51,7 +57,7 @@ class _fork:
     main stream wait for it and hands tensor `t` (allocated on the side stream) over to the main stream."""
 
     def __init__(self, x: torch.Tensor):
-        self.on = _BRANCH_STREAMS and x.is_cuda
+        self.on = _BRANCH_STREAMS and x.is_cuda and x.shape[0] * x.shape[-2] * x.shape[-1] >= _FORK_MIN_PIXELS
         if self.on:
             self.main = torch.cuda.current_stream(x.device)
             self.side = _side_stream(self.main)

@@ -30,7 +30,7 @@ extern "C" {
  * compares it with mcq_abi_version() of the library it loaded before calling anything else: a stale .so under new
  * prototypes (or the reverse) misaligns arguments silently otherwise.  3 = round 3 (mcq_rans_*_with_indexes take cdf_lens,
  * mcq_gate_f32 takes out_silu -- both changed in round 2 without a bump --, GroupNorm / logits-gradient entry points). */
-#define MCQ_ABI_VERSION   6
+#define MCQ_ABI_VERSION   5
 
 #define MCQ_OK            0
 #define MCQ_EINVAL       -1   /* NULL pointer / non-positive dimension / unsupported combination */
@@ -108,11 +108,6 @@ int32_t mcq_conv2d_winograd_ok(int32_t N, int32_t Cin, int32_t H, int32_t W, int
  * same epilogue order; the summation order over (channel, tap) differs as between any two tile shapes. */
 int32_t mcq_conv2d_small_launch(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, uint32_t flags,
                                 int32_t nprob);
-/* Launches of min_tiles .. max_tiles tiles of 32 channels x 16 pixels (3x3, stride 1, Cin % 32 == 0, Cout % 32 == 0, the small-launch
- * kernel's epilogues) run one wave per tile over the whole contraction, no split-K (csrc/conv_r16.h: the 16x16 maps of a training
- * step, the 12x8 level of a 32-image batch; nn.Conv2d under mcquic/nn/blocks.py:162-200,245-288).  Defaults 1024 .. 6144; a tuning
- * knob for sweeps, process-wide, not thread-safe against concurrent launches.  `tile` = 0x1f in a descriptor forces the kernel. */
-void mcq_conv2d_r16_range(int64_t min_tiles, int64_t max_tiles);
 
 /* The operand stream of a layer's INPUT-GRADIENT convolution, packed straight from the layer's own OIHW weight
  * [Cout, Cin, k, k] in one launch (what torch.autograd derives for nn.Conv2d, mcquic/nn/convs.py:77-100):

@@ -54,7 +54,6 @@ SYMBOLS = {
     "mcq_pack_conv_weight_multi_masked_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "mcq_conv_section_trace": (None, [c_int32]),
     "mcq_conv_sections_used": (c_uint32, [c_void_p]),
-    "mcq_conv2d_r16_range": (None, [c_int64, c_int64]),
     "mcq_conv2d_max_multi": (c_int32, []),
     "mcq_conv2d_multi_f32": (c_int32, [POINTER(ConvDesc), c_int32, c_void_p]),
     "mcq_nonneg_reparam_f32": (c_int32, [c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
@@ -125,7 +124,7 @@ SYMBOLS = {
     "mcq_abi_version": (c_int32, []),
 }
 
-ABI_VERSION = 6          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
+ABI_VERSION = 5          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
 
 _lib = None
 

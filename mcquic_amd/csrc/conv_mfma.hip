@@ -94,7 +94,6 @@ constexpr unsigned RUNTIME_FLAGS = 0xffffffffu;    // epilogue instance that tes
 
 #include "conv_head16.h"
 #include "conv_t16.h"
-#include "conv_r16.h"
 
 namespace {
 
@@ -1411,13 +1410,6 @@ bool t16_takes(int N, int Cin, int H, int W, int Cout, int ksize, int stride, un
            (uint64_t)N * (Cin > Cout ? Cin : Cout) * H * W * 4ull < 0x80000000ull;
 }
 
-bool r16_takes(int N, int Cin, int H, int W, int Cout, int ksize, int stride, unsigned fl, int nprob, bool forced) {
-    if (!(N > 0 && H > 0 && W > 0 && nprob >= 1 && r16_shape(Cout, Cin, ksize) && stride == 1 && (fl & ~T16_FLAGS) == 0 &&
-          (uint64_t)N * (Cin > Cout ? Cin : Cout) * H * W * 4ull < 0x80000000ull)) return false;
-    const long long tiles = r16_tiles((long long)N * H * W, Cout, nprob);
-    return forced || (tiles >= g_r16_min_tiles && tiles <= g_r16_max_tiles);
-}
-
 int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     const mcq_conv_desc* d = descs;
     const unsigned fl = d->flags;
@@ -1530,24 +1522,6 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         const dim3 grid((unsigned)(((long long)d->N * d->H * d->W + 15) / 16), (unsigned)(d->Cout / 16), (unsigned)nprob);
         if (d->Cin == 128) hipLaunchKernelGGL(conv_t16_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, t);
         else hipLaunchKernelGGL(conv_t16_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, t);
-        return mcq_check_launch();
-    }
-
-    // one to a few 32 x 16 tiles per SIMD: a wave per tile over the whole contraction, no split (conv_r16.h); tile 0x1f forces it
-    if ((d->tile & 0xff) == 0x1f && !r16_takes(d->N, d->Cin, d->H, d->W, d->Cout, d->ksize, d->stride, fl, nprob, true)) return MCQ_EINVAL;
-    if ((d->tile == 0 || (d->tile & 0xff) == 0x1f) &&
-        r16_takes(d->N, d->Cin, d->H, d->W, d->Cout, d->ksize, d->stride, fl, nprob, (d->tile & 0xff) == 0x1f)) {
-        sec_note(descs, nprob, 8u);
-        T16K t;
-        const size_t sec = section_floats(d->Cout, d->Cin, 3, 4) + section_floats(d->Cout, d->Cin, 3, 2) + section_floats(d->Cout, d->Cin, 3, 1);
-        for (int c = 0; c < MCQ_CONV_MAX_MULTI; ++c) {
-            const mcq_conv_desc* e = descs + (c < nprob ? c : 0);
-            T16Ptrs& a = t.p[c];
-            a.x = e->x; a.wp = e->w_packed + sec; a.bias = e->bias; a.y = e->y; a.y2 = e->y_silu; a.res = e->res; a.mul = e->mul;
-        }
-        t.N = d->N; t.Cin = d->Cin; t.H = d->H; t.W = d->W; t.Cout = d->Cout; t.flags = fl; t.res_scale = d->res_scale;
-        const dim3 grid((unsigned)(((long long)d->N * d->H * d->W + 63) / 64), (unsigned)(d->Cout / 32), (unsigned)nprob);
-        hipLaunchKernelGGL(conv_r16_kernel, grid, dim3(256), 0, (hipStream_t)stream, t);
         return mcq_check_launch();
     }
 
@@ -1678,11 +1652,6 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
 }
 
 extern "C" int32_t mcq_conv2d_max_multi(void) { return MCQ_CONV_MAX_MULTI; }
-
-extern "C" void mcq_conv2d_r16_range(int64_t min_tiles, int64_t max_tiles) {
-    g_r16_min_tiles = min_tiles;
-    g_r16_max_tiles = max_tiles;
-}
 
 extern "C" int32_t mcq_conv2d_small_launch(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride,
                                            uint32_t flags, int32_t nprob) {

@@ -15,7 +15,7 @@ for r in rows:
     print(f"{r[2]:10.2f} {100 * r[2] / tot:6.2f} {r[1]:6d} {r[3]:10.1f} {r[4]:10.1f} {r[5]:10.1f}  {r[0][:120]}")
 print("\n# conv / VQ / weight-gradient kernels by launch grid (workgroups x grid.y)")
 rows = cur.execute("select name, grid_x, grid_y, workgroup_x, count(*), avg(end-start)/1e3, min(end-start)/1e3, sum(end-start)/1e6, "
-                   "max(vgpr_count), max(accum_vgpr_count), grid_z from kernels where name like '%conv_mfma%' or name like '%conv_head16%' or name like '%vq_%' or name like '%wgrad%' "
+                   "max(vgpr_count), max(accum_vgpr_count), grid_z from kernels where name like '%conv_mfma%' or name like '%conv_head16%' or name like '%conv_t16%' or name like '%conv_r16%' or name like '%vq_%' or name like '%wgrad%' "
                    "or name like '%fused_%' group by name, grid_x, grid_y, grid_z order by 8 desc").fetchall()
 print(f"{'total_ms':>10} {'calls':>6} {'avg_us':>10} {'min_us':>10} {'wgs':>8} {'gy':>3} {'gz':>3} {'vgpr':>5}  kernel")
 for r in rows:

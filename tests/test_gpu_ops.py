@@ -689,50 +689,3 @@ def test_conv_row_band_fallback_is_the_single_launch(dev, case):
         assert torch.equal(whole, banded), f"{case} {sorted(opts)}: max diff {(whole - banded).abs().max().item():.3e}"
         if opts.get("dual_silu"):
             assert torch.equal(ops.silu_twin(whole), ops.silu_twin(banded))
-
-
-@pytest.mark.parametrize("case", [(8, 128, 128, 16, 16), (3, 128, 128, 5, 7), (32, 128, 128, 12, 8), (2, 64, 96, 9, 11), (8, 128, 512, 8, 8)])
-def test_conv_r16_kernel(dev, case):
-    """csrc/conv_r16.h: one wave per 32-channel x 16-pixel tile over the whole contraction (no split-K, no LDS) for launches of one to
-    a few such tiles per SIMD -- the 16x16 maps of a training step, the 12x8 level of a 32-image batch.  Forced with tile=0x1f here;
-    every epilogue it carries, single and multi-problem launches, tiles straddling images, partial last tiles, the input-gradient
-    stream, against F.conv2d; and the library's own choice for the shapes it is meant for."""
-    from mcquic_amd import ops, _lib
-    n, cin, cout, h, w = case
-    xs = [_rand((n, cin, h, w), 150 + i) for i in range(4)]
-    wts = [_rand((cout, cin, 3, 3), 160 + i, 1.0 / np.sqrt(cin * 9)) for i in range(4)]
-    bs = [_rand((cout,), 170 + i, 0.1) for i in range(4)]
-    sides = [_rand((n, cout, h, w), 180 + i) for i in range(4)]
-    pks = [ops.PackedConv(wt.to(dev), b.to(dev)) for wt, b in zip(wts, bs)]
-    ys = [F.conv2d(x, wt, b, padding=1) for x, wt, b in zip(xs, wts, bs)]
-    dsilu = lambda t: torch.sigmoid(t) * (1 + t * (1 - torch.sigmoid(t)))          # noqa: E731
-    x0, pk0, s0 = xs[0].to(dev), pks[0], sides[0].to(dev)
-    T = 0x1f
-    _close(ops.conv2d(x0, pk0, tile=T), ys[0], 1e-5, "plain")
-    _close(ops.conv2d(x0, pk0, silu_out=True, tile=T), F.silu(ys[0]), 1e-5, "silu_out")
-    _close(ops.conv2d(x0, pk0, res=s0, res_scale=0.5, tile=T), ys[0] + 0.5 * sides[0], 1e-5, "residual with scale")
-    got = ops.conv2d(x0, pk0, res=s0, dual_silu=True, tile=T)
-    _close(got, ys[0] + sides[0], 1e-5, "res + twin")
-    _close(ops.silu_twin(got), F.silu(ys[0] + sides[0]), 1e-5, "twin")
-    _close(ops.conv2d(x0, pk0, dsilu_mul=s0, tile=T), ys[0] * dsilu(sides[0]), 1e-5, "* silu'")
-    _close(ops.conv2d(x0, pk0, dsilu_mul=s0, res=s0, tile=T), ys[0] * dsilu(sides[0]) + sides[0], 1e-5, "* silu' + dy")
-    _close(ops.conv2d(x0, ops.PackedConv(wts[0].to(dev), None), tile=T), F.conv2d(xs[0], wts[0], None, padding=1), 1e-5, "no bias")
-    for nprob in (2, 4):
-        outs = ops.conv2d_multi([x.to(dev) for x in xs[:nprob]], pks[:nprob], 1, per_problem=[dict(res=s.to(dev)) for s in sides[:nprob]],
-                                dual_silu=True, tile=T)
-        for y, s, o in zip(ys, sides, outs):
-            _close(o, y + s, 1e-5, f"multi x{nprob}")
-            _close(ops.silu_twin(o), F.silu(y + s), 1e-5, f"multi x{nprob} twin")
-        # the library's own choice (whatever kernel it is) agrees
-        auto = ops.conv2d_multi([x.to(dev) for x in xs[:nprob]], pks[:nprob], 1, per_problem=[dict(res=s.to(dev)) for s in sides[:nprob]], dual_silu=True)
-        for y, s, o in zip(ys, sides, auto):
-            _close(o, y + s, 1e-5, f"auto multi x{nprob}")
-    dy = _rand((n, cout, h, w), 199)
-    xr = xs[0].clone().requires_grad_()
-    F.conv2d(xr, wts[0], None, padding=1).backward(dy)
-    back = ops.PackedConv.dgrad(wts[0].to(dev), 1)
-    if cout % 32 == 0 and cout in (64, 128):
-        _close(ops.conv2d(dy.to(dev), back, tile=T), xr.grad, 1e-5, "input gradient")
-    # a shape the kernel does not take is refused when forced, never silently run on another kernel
-    with pytest.raises(RuntimeError):
-        ops.conv2d(_rand((1, 48, 8, 8), 1).to(dev), ops.PackedConv(_rand((32, 48, 3, 3), 2).to(dev), None), tile=T)

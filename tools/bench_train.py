@@ -32,7 +32,31 @@ def main():
     ap.add_argument("--optimizer-step", action="store_true",
                     help="SGD step inside the timed region: the weights change every step, so every conv re-packs its forward and "
                          "input-gradient operand streams each step, as in a real training loop")
+    ap.add_argument("--tile-rule", default="", help="tile experiments: comma-separated nprob:H:Cout:tile[:flagmask] entries, e.g. 1:128:128:0x121 -- "
+                                                    "3x3 stride-1 launches with that many problems on H x H maps get that forced tile")
     args = ap.parse_args()
+    if args.tile_rule:
+        from mcquic_amd import ops
+        rules = {}
+        for ent in args.tile_rule.split(","):
+            f = ent.split(":")
+            rules[(int(f[0]), int(f[1]), int(f[2]))] = int(f[3], 16)
+        orig_conv, orig_multi = ops.conv2d, ops.conv2d_multi
+
+        def conv(x, w, stride=1, **kw):
+            t = rules.get((1, x.shape[2], w.cout)) if (w.ksize == 3 and stride == 1 and "tile" not in kw) else None
+            return orig_conv(x, w, stride, **(dict(kw, tile=t) if t else kw))
+
+        def multi(xs, ws, stride=1, per_problem=None, **shared):
+            t = rules.get((len(xs), xs[0].shape[2], ws[0].cout)) if (ws[0].ksize == 3 and stride == 1 and "tile" not in shared) else None
+            if t:
+                shared = dict(shared, tile=t)
+            ops.conv2d = orig_conv
+            try:
+                return orig_multi(xs, ws, stride, per_problem=per_problem, **shared)
+            finally:
+                ops.conv2d = conv
+        ops.conv2d, ops.conv2d_multi = conv, multi
     if args.graph and not args.graph_streams:
         # capturing the nested stream forks of the training graph crashes hipGraph capture (ROCm 7.2): one stream there
         os.environ["MCQUIC_AMD_BRANCH_STREAMS"] = "0"

@@ -30,7 +30,7 @@ SHAPES = [  # n, cin, cout, h, w, ks, stride
     (32, 128, 128, 192, 128, 1, 1),
     (32, 128, 128, 384, 256, 1, 1),
 ]
-TILES = [0, 0x42, 0x142, 0x242, 0x342, 0x41, 0x141, 0x241, 0x341, 0x22, 0x122, 0x222, 0x322, 0x21, 0x121, 0x221, 0x11, 0x311, 0x1f]
+TILES = [0, 0x42, 0x142, 0x242, 0x342, 0x41, 0x141, 0x241, 0x341, 0x22, 0x122, 0x222, 0x322, 0x21, 0x121, 0x221, 0x11, 0x311]
 
 
 def main():
@@ -45,12 +45,8 @@ def main():
     ap.add_argument("--nprob", type=int, default=1, help="problems per launch (ops.conv2d_multi)")
     ap.add_argument("--batch1", action="store_true", help="the 3x3 shapes of one 768x512 image (batch-1 latency)")
     ap.add_argument("--train", action="store_true", help="the 3x3 shapes of the config-#5 training step (8 images of 128x128 ... 4x4)")
-    ap.add_argument("--r16", type=int, nargs=2, default=None, metavar=("MIN", "MAX"), help="tile range of the conv_r16.h kernel for tile 0 (the library's choice); 0 0 = never")
     ap.add_argument("--tiles", default=None, help="comma-separated hex tile codes instead of the full list, e.g. 0,0x1f,0x11")
     args = ap.parse_args()
-    if args.r16 is not None:
-        from mcquic_amd import _lib
-        _lib.load().mcq_conv2d_r16_range(args.r16[0], args.r16[1])
     tiles = TILES if args.tiles is None else [int(t, 16) for t in args.tiles.split(",")]
     dev = torch.device("cuda:0")
     print("lib:", os.environ.get("MCQUIC_AMD_LIB", "default"))

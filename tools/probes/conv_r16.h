@@ -1,3 +1,10 @@
+// RESEARCH PROBE (round 4), NOT part of the library: measured and dropped.  To try it again: copy next to conv_t16.h, include it from
+// conv_mfma.hip after conv_t16.h and route launches to conv_r16_kernel (commit 29f26f1 has the launcher glue and the test).
+// Result on MI355X: in isolation (tools/microbench_conv.py under rocprofv3, L2-warm weights) two 8 x 128 x 16x16 problems take 14.8 us
+// against 20-21 us for the split 32 x 32 tiles (res + twin), four problems 26.5 against 34 -- but inside the captured training step
+// (tools/bench_train.py --graph) the step got SLOWER, 22.53 -> 22.74 ms: every wave streams the full 147 KB of its channel pair's
+// weights, 150 MB through L2 per launch where the split tiles move 38 MB, and in the step those weights are HBM-cold.
+//
 // 3x3 stride-1 convolutions of launches with ONE TO A FEW 32 x 16 tiles per SIMD, on v_mfma_f32_16x16x4_f32 (included by conv_mfma.hip).
 //
 // Between the launches conv_t16.h takes (at most three 16 x 16 tiles per CU: the 4x4 / 8x8 maps of a training step) and the ones
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_r16_kernel(T16K k) {
 
 // 32 x 16 tiles the launch would have; taken between R16_MIN_TILES (below: conv_t16.h or a split tile, which use more CUs) and
 // R16_MAX_TILES (above: the 32-row tiles' operand reuse wins).  Both are run-time settable for sweeps (mcq_conv2d_r16_range).
-long long g_r16_min_tiles = 1024, g_r16_max_tiles = 6144;
+long long g_r16_min_tiles = 1024, g_r16_max_tiles = 2048;
 inline long long r16_tiles(long long npix, int Cout, int nprob) { return ((npix + 15) / 16) * (Cout / 32) * nprob; }
 
 }  // namespace

@@ -30,7 +30,7 @@ extern "C" {
  * compares it with mcq_abi_version() of the library it loaded before calling anything else: a stale .so under new
  * prototypes (or the reverse) misaligns arguments silently otherwise.  3 = round 3 (mcq_rans_*_with_indexes take cdf_lens,
  * mcq_gate_f32 takes out_silu -- both changed in round 2 without a bump --, GroupNorm / logits-gradient entry points). */
-#define MCQ_ABI_VERSION   5
+#define MCQ_ABI_VERSION   6
 
 #define MCQ_OK            0
 #define MCQ_EINVAL       -1   /* NULL pointer / non-positive dimension / unsupported combination */
@@ -298,6 +298,9 @@ int mcq_pixel_unshuffle2_f32(const float* in, float* out, int32_t N, int32_t C, 
 
 /* out = a + b  (quantizer.py:354  xHat = q + sideHead(formerLevel)). */
 int mcq_add_f32(const float* a, const float* b, float* out, float* out_silu /* or NULL */, int64_t n, void* stream);
+/* out = (a + b) + c: the three gradient paths that meet at the input of an AttentionBlock (main stack, side stack, the gate's
+ * identity term; what torch.autograd accumulates with two additions for mcquic/nn/blocks.py:281-288) in one launch. */
+int mcq_add3_f32(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream);
 
 /* u8 = trunc(clamp(((x + 1) / 2) * 255.999, 0, 255))   (mcquic/utils/vision.py:143-146 DeTransform). */
 int mcq_detransform_u8(const float* x, uint8_t* out, int64_t n, void* stream);

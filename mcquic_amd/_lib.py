@@ -102,6 +102,7 @@ SYMBOLS = {
     "mcq_gdn_bwd_prep_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_pixel_unshuffle2_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_add_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_add3_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_detransform_u8": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_pmf_to_quantized_cdf": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
     "mcq_rans_encode_with_indexes": (c_int64, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
@@ -124,7 +125,7 @@ SYMBOLS = {
     "mcq_abi_version": (c_int32, []),
 }
 
-ABI_VERSION = 5          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
+ABI_VERSION = 6          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
 
 _lib = None
 

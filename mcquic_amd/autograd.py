@@ -47,15 +47,21 @@ class ConvFn(torch.autograd.Function):
     """y = conv(x, W) + b (+ res); `shuffle2` stores through PixelShuffle(2)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, conv, shuffle2):
-        y = ops.conv2d(x, conv.packed(), conv.stride, shuffle2=shuffle2, res=res)
+    def forward(ctx, x, weight, bias, res, conv, shuffle2, dual_silu):
+        y = ops.conv2d(x, conv.packed(), conv.stride, shuffle2=shuffle2, res=res, dual_silu=bool(dual_silu) and not shuffle2)
+        sy = ops.silu_twin(y)                       # silu(y) from the same launch, for a consumer that starts with an activation
         ctx.save_for_backward(x, weight)
         ctx.conv, ctx.shuffle2, ctx.has_bias, ctx.has_res = conv, shuffle2, bias is not None, res is not None
-        return y
+        if sy is not None:
+            ctx.mark_non_differentiable(sy)
+        ctx.set_materialize_grads(False)
+        return y, sy
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dsy=None):
         x, weight = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 7
         conv = ctx.conv
         dy = dy.contiguous()
         dyc = ops.pixel_unshuffle2(dy) if ctx.shuffle2 else dy
@@ -76,7 +82,7 @@ class ConvFn(torch.autograd.Function):
                 dw = ops.conv2d_wgrad(x, dyc, conv.kernelSize, conv.stride)
         elif want_db:
             db = ops.channel_sum(dyc)
-        return dx, dw, db, (dy if ctx.has_res else None), None, None
+        return dx, dw, db, (dy if ctx.has_res else None), None, None, None
 
 
 class SiluFn(torch.autograd.Function):
@@ -211,7 +217,7 @@ class AttentionBlockFn(torch.autograd.Function):
         pairs = []                                               # appended RB 2, 1, 0; per RB: main (conv1, conv2), side (conv1, conv2)
         for i in (2, 1, 0):
             h, g = _rb_backward_multi([block._mainBranch[i], block._sideBranch[i]], [main[i], side[i]], [h, g], pairs)
-        dx = ops.add(ops.add(h, g), dout)
+        dx = ops.add3(h, g, dout)
         grads = _wgrads(pairs)
         by_rb = {i: grads[4 * k: 4 * k + 4] for k, i in enumerate((2, 1, 0))}
         flat = []
@@ -251,7 +257,8 @@ def _lockstep_forward(stacks, xs, keep: bool):
     k = len(stacks)
     xs = list(xs)
     tape = []
-    for layer in zip(*stacks):
+    nlayers = len(stacks[0])
+    for li, layer in enumerate(zip(*stacks)):
         kind = _kind(layer[0])
         if kind == "rb":
             ys, sys_, saved = _rb_forward_multi(list(layer), xs, [_silu_of(x) for x in xs])
@@ -274,7 +281,8 @@ def _lockstep_forward(stacks, xs, keep: bool):
             tape.append((kind, layer, (a, b, bbs, saved)))
             xs = outs
         else:
-            ys = ops.conv2d_multi(xs, [m.packed() for m in layer])
+            # (a conv3x3 in the middle of a head feeds a ResidualBlock: its launch writes the SiLU twin that block starts from)
+            ys = ops.conv2d_multi(xs, [m.packed() for m in layer], dual_silu=li + 1 < nlayers)
             tape.append((kind, layer, xs))
             xs = ys
     return xs, (tape if keep else None)
@@ -308,7 +316,7 @@ def _lockstep_backward(tape, dys, grads):
                 hs, gs = out[:k], out[k:]
                 for blk in blocks:
                     owners.extend([blk._branch[1], blk._branch[3]])
-            dys = [ops.add(ops.add(h, g), dout) for h, g, dout in zip(hs, gs, dys)]
+            dys = [ops.add3(h, g, dout) for h, g, dout in zip(hs, gs, dys)]
         else:
             xs = saved
             for m, x, dy in zip(layer, xs, dys):
@@ -499,8 +507,13 @@ def group_norm(x, module):
     return GroupNormFn.apply(x, module.weight, module.bias, module.num_groups, module.eps)
 
 
-def conv(x, module, res: Optional[torch.Tensor] = None, shuffle2: bool = False):
-    return ConvFn.apply(x, module.weight, module.bias, res, module, shuffle2)
+def conv(x, module, res: Optional[torch.Tensor] = None, shuffle2: bool = False, dual_silu: bool = False):
+    """`dual_silu`: the launch also stores silu(y), which the result then carries as its twin (the strided / shuffle blocks'
+    closing convolutions feed blocks that start with an activation: one stand-alone SiLU launch less per block)."""
+    y, sy = ConvFn.apply(x, module.weight, module.bias, res, module, shuffle2, dual_silu)
+    if sy is not None:
+        ops.set_silu_twin(y, sy)
+    return y
 
 
 def silu(x):

@@ -539,48 +539,54 @@ next_tile:
                 unsigned sob[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sob[r] = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
-                float vv[NB][16], rvv[NB][16], tw[NB][16];
-                if (EF & MCQ_CONV_DSILU_MUL) {              // (tw is free here: no SiLU twin in a gradient launch)
+                // pixel blocks finished together per three-phase pass: both at two waves per SIMD; ONE at three waves per SIMD (the
+                // 64 x 64 tile's 168-register budget: the 96 temporaries of two blocks spilled 24 registers to scratch there)
+                constexpr int EB = OCC >= 3 ? 1 : NB;
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
+                for (int nb0 = 0; nb0 < NB; nb0 += EB) {
+                    float vv[EB][16], rvv[EB][16], tw[EB][16];
+                    if (EF & MCQ_CONV_DSILU_MUL) {              // (tw is free here: no SiLU twin in a gradient launch)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) tw[nb][r] = mcq_buffer_load_s(mr[nb], pvo[nb], sob[r]);
-                }
-                if (EF & MCQ_CONV_RESIDUAL) {
+                        for (int e = 0; e < EB; ++e)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) rvv[nb][r] = mcq_buffer_load_s(rr_[nb], pvo[nb], sob[r]);
-                }
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    get_acc(mi, nb, vv[nb]);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) vv[nb][r] = vv[nb][r] + bias16[r];
-                    if (EF & MCQ_CONV_DSILU_MUL) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) vv[nb][r] = vv[nb][r] * mcq_dsilu(tw[nb][r]);
+                            for (int r = 0; r < 16; ++r) tw[e][r] = mcq_buffer_load_s(mr[nb0 + e], pvo[nb0 + e], sob[r]);
                     }
                     if (EF & MCQ_CONV_RESIDUAL) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) vv[nb][r] = vv[nb][r] + p.res_scale * rvv[nb][r];
+                        for (int e = 0; e < EB; ++e)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) rvv[e][r] = mcq_buffer_load_s(rr_[nb0 + e], pvo[nb0 + e], sob[r]);
                     }
-                    if (EF & MCQ_CONV_SILU_OUT) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) vv[nb][r] = mcq_silu(vv[nb][r]);
+                    for (int e = 0; e < EB; ++e) {
+                        get_acc(mi, nb0 + e, vv[e]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) vv[e][r] = vv[e][r] + bias16[r];
+                        if (EF & MCQ_CONV_DSILU_MUL) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) vv[e][r] = vv[e][r] * mcq_dsilu(tw[e][r]);
+                        }
+                        if (EF & MCQ_CONV_RESIDUAL) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) vv[e][r] = vv[e][r] + p.res_scale * rvv[e][r];
+                        }
+                        if (EF & MCQ_CONV_SILU_OUT) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) vv[e][r] = mcq_silu(vv[e][r]);
+                        }
+                        if (EF & MCQ_CONV_DUAL_SILU) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) tw[e][r] = mcq_silu(vv[e][r]);
+                        }
                     }
-                    if (EF & MCQ_CONV_DUAL_SILU) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) tw[nb][r] = mcq_silu(vv[nb][r]);
-                    }
-                }
+                    for (int e = 0; e < EB; ++e) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
+                        for (int r = 0; r < 16; ++r) mcq_buffer_store_s(vv[e][r], yr[nb0 + e], pvo[nb0 + e], sob[r]);
+                        if (EF & MCQ_CONV_DUAL_SILU) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mcq_buffer_store_s(vv[nb][r], yr[nb], pvo[nb], sob[r]);
-                    if (EF & MCQ_CONV_DUAL_SILU) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) mcq_buffer_store_s(tw[nb][r], y2r[nb], pvo[nb], sob[r]);
+                            for (int r = 0; r < 16; ++r) mcq_buffer_store_s(tw[e][r], y2r[nb0 + e], pvo[nb0 + e], sob[r]);
+                        }
                     }
                 }
                 continue;
@@ -1138,6 +1144,9 @@ int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2
     const size_t lds = ksplit_log2 ? (size_t)waves * NB * 1024 * sizeof(float) : 0;
     const dim3 grid((unsigned)((tiles + (1 << k.tiles_log2) - 1) >> k.tiles_log2), (unsigned)co_tiles, (unsigned)k.nprob);
     const dim3 block(64 * waves);
+    // (round 4, measured and removed: `s_setprio 2` for the first-dispatched workgroup of every CU in single-round launches, so that
+    //  one of the two waves of a SIMD finishes its k-loop early and its epilogue runs under the other's MFMAs -- the captured
+    //  training step 22.32 vs 22.34 ms, the 32-image step 123.3 vs 123.4 ms: two epilogues side by side cost what one does)
     if (k.ks == 3) {
         if (pro == PRO_SILU) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF3A, PF3B, 9, OCC>), grid, block, lds, s, k);
         else if (pro == PRO_NONE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF3A, PF3B, 9, OCC>), grid, block, lds, s, k);

@@ -350,6 +350,20 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
     }
 }
 
+// out = (a + b) + c, the rounding order of two chained additions (the three gradient paths that meet at an AttentionBlock's input)
+__global__ void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, float* __restrict__ out,
+                            int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const f32x4v va = *reinterpret_cast<const f32x4v*>(a + i);
+        const f32x4v vb = *reinterpret_cast<const f32x4v*>(b + i);
+        const f32x4v vc = *reinterpret_cast<const f32x4v*>(c + i);
+        *reinterpret_cast<f32x4v*>(out + i) = (va + vb) + vc;
+    } else {
+        for (; i < n; ++i) out[i] = (a[i] + b[i]) + c[i];
+    }
+}
+
 __global__ void detransform_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -484,6 +498,13 @@ extern "C" int mcq_add_f32(const float* a, const float* b, float* out, float* ou
     if (!a || !b || !out || n <= 0) return MCQ_EINVAL;
     const int64_t threads = (n + 3) / 4;
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, out_silu, n);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_add3_f32(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream) {
+    if (!a || !b || !c || !out || n <= 0) return MCQ_EINVAL;
+    const int64_t threads = (n + 3) / 4;
+    hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, out, n);
     return mcq_check_launch();
 }
 

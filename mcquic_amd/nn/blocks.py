@@ -141,7 +141,7 @@ class ResidualBlockWithStride(_residulBlock):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
             t = self._branch[2](self._branch[1](AG.silu(x)))
-            return self._branch[3](t, res=self._skip(x))
+            return self._branch[3](t, res=self._skip(x), dual_silu=True)      # (+ silu(out) for the block that follows)
         with _fork(x) as f:
             identity = self._skip(x)
         t = self._branch[1](x, silu_in=True)
@@ -161,7 +161,7 @@ class ResidualBlockShuffle(_residulBlock):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
             t = self._branch[2](self._branch[1](AG.silu(x)))
-            return self._branch[3](t, res=self._skip(x))
+            return self._branch[3](t, res=self._skip(x), dual_silu=True)
         with _fork(x) as f:
             identity = self._skip(x)
         t = self._branch[1](x, silu_in=True)

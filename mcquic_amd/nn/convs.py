@@ -93,7 +93,7 @@ class Conv2d(nn.Module):
             extra = set(fused) - {"res", "shuffle2", "dual_silu"}
             if extra:
                 raise NotImplementedError(f"fused conv options {sorted(extra)} are inference-only")
-            return AG.conv(x, self, res=fused.get("res"), shuffle2=bool(fused.get("shuffle2", False)))
+            return AG.conv(x, self, res=fused.get("res"), shuffle2=bool(fused.get("shuffle2", False)), dual_silu=bool(fused.get("dual_silu", False)))
         return ops.conv2d(x, self.packed(), self.stride, **fused)
 
     def extra_repr(self) -> str:

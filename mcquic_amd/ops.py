@@ -621,6 +621,17 @@ def add(a: torch.Tensor, b: torch.Tensor, dual_silu: bool = False) -> torch.Tens
     return out
 
 
+def add3(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    """(a + b) + c in one launch (mcq_add3_f32)."""
+    a, b, c = _dev(a, "a"), _dev(b, "b"), _dev(c, "c")
+    if a.shape != b.shape or a.shape != c.shape:
+        raise ValueError("add3: shape mismatch")
+    out = torch.empty_like(a)
+    with _guard(a.device):
+        check(_lib.load().mcq_add3_f32(_ptr(a), _ptr(b), _ptr(c), _ptr(out), a.numel(), _stream()), "mcq_add3_f32")
+    return out
+
+
 def group_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], groups: int, eps: float = 1e-5,
                dual_silu: bool = False, want_stats: bool = False):
     """nn.GroupNorm(groups, C) on [n, C, h, w] (mcq_group_norm_f32; `denseNorm=True`, mcquic/nn/blocks.py:179-200).

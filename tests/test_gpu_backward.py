@@ -560,3 +560,24 @@ def test_wgrad_few_pixels_kernel(dev, case):
         dw1, db1 = ops.conv2d_wgrad(xs[1].to(dev), gys[1].to(dev), 1, 1, square_x=sq, want_bias=True)
         _close(dw1, w1.grad, 3e-6, f"1x1 dW {case} sq={sq}")
         _close(db1, b1.grad, 3e-6, f"1x1 db {case} sq={sq}")
+
+
+def test_training_graph_producers_hand_silu_twins_on(dev):
+    """Round 4: in the training graph the closing convolution of a strided / shuffle block (and the conv3x3 in the middle of a
+    head) writes silu(out) in the same launch, so the block that follows starts from the twin instead of a stand-alone SiLU
+    launch; the three gradient paths meeting at an AttentionBlock's input are one 3-way add (mcq_add3_f32).  Twins must be
+    silu(out) exactly as the SiLU kernel gives it, and carry no autograd graph."""
+    from mcquic_amd import nn as N, ops
+    c = 32
+    x = _rand((2, c, 8, 12), 5).to(dev).requires_grad_()
+    for blk in (N.ResidualBlockWithStride(c, c), N.ResidualBlockShuffle(c, c)):
+        blk = blk.to(dev).train()
+        y = blk(x)
+        tw = ops.silu_twin(y)
+        assert tw is not None and tw.grad_fn is None and not tw.requires_grad
+        assert torch.equal(tw, ops.silu(y.detach()))
+        y.sum().backward()
+    a, b, cc = (_rand((3, 5, 7, 9), s).to(dev) for s in (1, 2, 3))
+    assert torch.equal(ops.add3(a, b, cc), (a + b) + cc)
+    t = _rand((1031,), 4).to(dev)                                   # a tail that is no multiple of four
+    assert torch.equal(ops.add3(t, t, t), (t + t) + t)

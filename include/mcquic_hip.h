@@ -49,6 +49,10 @@ extern "C" {
 #define MCQ_CONV_MUL        0x200u /* y = mul * acc                     (GDN backward: 2 x * (gamma^T ds))                    */
 #define MCQ_CONV_DSILU_MUL  0x400u /* y = acc * silu'(mul)              (backward of SiLU fused into the input-gradient conv:  */
                                    /*                                    mul = the SiLU's input; then + res as usual)           */
+#define MCQ_CONV_GDN_BWD    0x4000u /* GDN backward in the epilogue of the recomputed s = beta + gamma x^2 launch (with SQUARE_IN): y = res / sqrt(s)
+                                     * (the direct term dy f(s)), y_silu = res * mul * (-1/2 s^-3/2) (d s); res = dy, mul = x, RESIDUAL not set.
+                                     * What torch.autograd derives for mcquic/nn/gdn.py:75-79; round 3 ran it as a launch of its own behind s. */
+#define MCQ_CONV_IGDN_BWD   0x8000u /* the same for InvGenDivNorm (gdn.py:87-91): y = res * sqrt(s), y_silu = res * mul * (1/2 s^-1/2) */
 #define MCQ_CONV_DUAL_SILU  0x100u /* also store silu(y) to y_silu: the next block's act1(x), computed once per element */
 #define MCQ_CONV_WINOGRAD2D 0x1000u /* OPT-IN like MCQ_CONV_WINOGRAD: F(2x2, 3x3), 4/9 of the multiplications; w_packed from   */
                                     /* mcq_pack_conv_weight_winograd2d_f32; Cout % 128 == 0, Cin % 8 == 0                                */

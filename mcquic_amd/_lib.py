@@ -21,6 +21,7 @@ CONV_GDN, CONV_IGDN, CONV_GATE, CONV_SHUFFLE2, CONV_DUAL_SILU, CONV_MUL, CONV_DS
 CONV_WINOGRAD = 0x800
 CONV_WINOGRAD2D = 0x1000
 CONV_WINOGRAD2D16 = 0x2000
+CONV_GDN_BWD, CONV_IGDN_BWD = 0x4000, 0x8000
 
 
 class ConvDesc(Structure):

@@ -477,8 +477,7 @@ class GdnFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, beta_p, gamma_p = ctx.saved_tensors
         dy = dy.contiguous()
-        s = ops.conv2d(x, ctx.packed, square_in=True)                          # beta + gamma @ x^2, recomputed
-        dxd, ds = ops.gdn_bwd_prep(x, s, dy, ctx.inverse)
+        dxd, ds = ops.conv2d_gdn_bwd(x, ctx.packed, dy, ctx.inverse)          # s = beta + gamma @ x^2 recomputed, dy f(s) and dy x f'(s) from its epilogue
         dx = ops.conv2d(ds, ctx.back, mul=x, res=dxd)                          # dy f(s) + 2 x (gamma^T ds)
         dgamma, dbeta = ops.conv2d_wgrad(x, ds, 1, 1, square_x=True, want_bias=True)
         bb, gb = ctx.bounds

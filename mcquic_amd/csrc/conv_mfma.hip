@@ -507,9 +507,10 @@ next_tile:
         for (int nb = 0; nb < NB; ++nb) {
             const size_t slab = (size_t)img[nb] * p.Cout * HoWo;
             yr[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_y + slab), slab_bytes);
-            if (f & MCQ_CONV_DUAL_SILU) y2r[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_y2 + slab), slab_bytes);
-            if (f & MCQ_CONV_RESIDUAL) rr_[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_res + slab), slab_bytes);
-            if (f & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL | MCQ_CONV_DSILU_MUL))
+            constexpr unsigned GBWD = MCQ_CONV_GDN_BWD | MCQ_CONV_IGDN_BWD;
+            if (f & (MCQ_CONV_DUAL_SILU | GBWD)) y2r[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_y2 + slab), slab_bytes);
+            if (f & (MCQ_CONV_RESIDUAL | GBWD)) rr_[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_res + slab), slab_bytes);
+            if (f & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL | MCQ_CONV_DSILU_MUL | GBWD))
                 mr[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_mul + slab), slab_bytes);
             if (f & MCQ_CONV_GATE) gr[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_gid + slab), slab_bytes);
             if (f & MCQ_CONV_SHUFFLE2)      // [Cout/4, 2 Ho, 2 Wo]: channel c = co / 4 -> rows of 2 Wo, this lane's 2x2 cell
@@ -611,6 +612,23 @@ next_tile:
                 unsigned so[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) so[r] = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
+                if (f & (MCQ_CONV_GDN_BWD | MCQ_CONV_IGDN_BWD)) {
+                    // v = s = beta + gamma x^2 (recomputed); the two element-wise gradients of y = x f(s) leave from here instead of a
+                    // launch of their own behind a stored s: dxd = dy f(s), ds = dy x f'(s) (train_ops.hip: gdn_bwd_prep_kernel's order)
+                    float m[16], g[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { m[r] = mcq_buffer_load_s(mr[nb], pvo[nb], so[r]); g[r] = mcq_buffer_load_s(rr_[nb], pvo[nb], so[r]); }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float rs = 1.0f / sqrtf(v[r]);
+                        float dxd, ds;
+                        if (f & MCQ_CONV_IGDN_BWD) { dxd = g[r] * sqrtf(v[r]); ds = g[r] * m[r] * (0.5f * rs); }
+                        else { dxd = g[r] * rs; ds = g[r] * m[r] * (-0.5f * rs * rs * rs); }
+                        mcq_buffer_store_s(dxd, yr[nb], pvo[nb], so[r]);
+                        mcq_buffer_store_s(ds, y2r[nb], pvo[nb], so[r]);
+                    }
+                    continue;
+                }
                 if (f & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL | MCQ_CONV_DSILU_MUL)) {
                     float m[16];
 #pragma unroll
@@ -1403,6 +1421,10 @@ int conv_validate(const mcq_conv_desc* d) {
     if ((fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL | MCQ_CONV_DSILU_MUL)) && !d->mul) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_GATE) && !d->gate_id) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_DUAL_SILU) && (!d->y_silu || (fl & MCQ_CONV_SILU_OUT))) return MCQ_EINVAL;
+    if (fl & (MCQ_CONV_GDN_BWD | MCQ_CONV_IGDN_BWD)) {      // s-launch with the GDN backward's element-wise part as its epilogue
+        if (!d->res || !d->mul || !d->y_silu || (fl & ~(unsigned)(MCQ_CONV_SQUARE_IN | MCQ_CONV_GDN_BWD | MCQ_CONV_IGDN_BWD)) ||
+            (fl & MCQ_CONV_GDN_BWD && fl & MCQ_CONV_IGDN_BWD) || d->ksize != 1) return MCQ_EINVAL;
+    }
     if ((fl & MCQ_CONV_SILU_IN) && (fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;
     if (fl & MCQ_CONV_SHUFFLE2) {
         if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN | MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D | MCQ_CONV_WINOGRAD2D16))) return MCQ_EINVAL;

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import (CONV_DSILU_MUL, CONV_DUAL_SILU, CONV_MUL, CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN,
-                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, CONV_WINOGRAD2D, CONV_WINOGRAD2D16, ConvDesc, check)
+                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, CONV_WINOGRAD2D, CONV_WINOGRAD2D16, CONV_GDN_BWD, CONV_IGDN_BWD, ConvDesc, check)
 
 # OPT-IN fast path, never the default and never the headline bench: large 3x3 stride-1 layers in the Winograd F(2, 3) form
 # along x (mcq_pack_conv_weight_winograd_f32 + MCQ_CONV_WINOGRAD): 2/3 of the multiplications, float32 throughout, but not
@@ -465,6 +465,22 @@ def conv2d(x: torch.Tensor, w: PackedConv, stride: int = 1, **fused) -> torch.Te
     if y2 is not None:
         set_silu_twin(y, y2)
     return y
+
+
+def conv2d_gdn_bwd(x: torch.Tensor, w: PackedConv, dy: torch.Tensor, inverse: bool):
+    """(dy f(s), dy x f'(s)) with s = beta + gamma @ x^2 recomputed by THIS launch (`w` = the layer's folded 1x1 operand stream):
+    the element-wise part of the GDN / IGDN backward as the epilogue of the s-convolution (MCQ_CONV_GDN_BWD / _IGDN_BWD) instead of
+    a launch of its own behind a stored s -- one launch and 2 x the tensor less HBM traffic per layer."""
+    x, dy = _dev(x, "x"), _dev(dy, "dy")
+    if w.ksize != 1 or x.shape != dy.shape or x.shape[1] != w.cin or w.cout != w.cin:
+        raise ValueError("conv2d_gdn_bwd: a square 1x1 layer and dy of x's shape")
+    n, c, h, wd = x.shape
+    dxd, ds = torch.empty_like(x), torch.empty_like(x)
+    d = ConvDesc(_ptr(x), _ptr(w.wp), _ptr(w.bias), _ptr(dxd), _ptr(ds), _ptr(dy), _ptr(x), None,
+                 n, c, h, wd, w.cout, 1, 1, CONV_SQUARE_IN | (CONV_IGDN_BWD if inverse else CONV_GDN_BWD), 1.0, 0)
+    with _guard(x.device):
+        check(_lib.load().mcq_conv2d_f32(ctypes.byref(d), _stream()), "mcq_conv2d_f32")
+    return dxd, ds
 
 
 _MULTI = os.environ.get("MCQUIC_AMD_MULTI_CONV", "1") != "0"      # A/B switch: 0 = one launch per convolution

@@ -581,3 +581,22 @@ def test_training_graph_producers_hand_silu_twins_on(dev):
     assert torch.equal(ops.add3(a, b, cc), (a + b) + cc)
     t = _rand((1031,), 4).to(dev)                                   # a tail that is no multiple of four
     assert torch.equal(ops.add3(t, t, t), (t + t) + t)
+
+
+@pytest.mark.parametrize("case", [(2, 128, 24, 16), (1, 32, 9, 7), (8, 128, 64, 64)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn_backward_epilogue_is_the_two_launch_form(dev, case, inverse):
+    """MCQ_CONV_GDN_BWD / _IGDN_BWD: the element-wise gradients of y = x f(beta + gamma x^2) as the epilogue of the launch that
+    recomputes s -- bit-equal to the round-3 form (s stored by one launch, mcq_gdn_bwd_prep_f32 behind it)."""
+    from mcquic_amd import ops
+    n, c, h, w = case
+    x = _rand((n, c, h, w), 3, 2.0).to(dev)
+    dy = _rand((n, c, h, w), 4).to(dev)
+    gamma = (_rand((c, c, 1, 1), 5).abs() * 0.1 + torch.eye(c)[..., None, None] * 0.1)
+    beta = _rand((c,), 6).abs() + 1.0
+    pk = ops.PackedConv(gamma.to(dev), beta.to(dev))
+    s = ops.conv2d(x, pk, square_in=True)
+    want_dxd, want_ds = ops.gdn_bwd_prep(x, s, dy, inverse)
+    dxd, ds = ops.conv2d_gdn_bwd(x, pk, dy, inverse)
+    assert torch.isfinite(dxd).all() and torch.isfinite(ds).all()
+    assert torch.equal(dxd, want_dxd) and torch.equal(ds, want_ds)

@@ -37,5 +37,7 @@ def run(m, k, d, n, h, w, iters=10):
 if __name__ == "__main__":
     out = {"metric": "VQ distance/argmin kernel in isolation (fp32 MFMA)", "peak_tflops": PEAK,
            "config4": run(4, 4096, 256, 32, 48, 32),
-           "qp2_levels": [run(2, 8192, 64, 32, 48, 32), run(2, 2048, 64, 32, 24, 16), run(2, 512, 64, 32, 12, 8)]}
+           "qp2_levels": [run(2, 8192, 64, 32, 48, 32), run(2, 2048, 64, 32, 24, 16), run(2, 512, 64, 32, 12, 8)],
+           # the reference's model No. 12: twelve codebooks of 16-dimensional codewords (a 64-MFMA tile against a 128-distance epilogue)
+           "model12_levels": [run(12, 8192, 16, 16, 48, 32), run(12, 2048, 16, 16, 24, 16), run(12, 512, 16, 16, 12, 8)]}
     print(json.dumps(out))

@@ -16,8 +16,11 @@ from typing import Optional
 
 import torch
 
+import os
+
 from . import ops
 
+_GDN_BWD_FUSED = os.environ.get("MCQUIC_AMD_GDN_BWD_FUSED", "1") != "0"
 
 # ---- input-gradient operand streams (packed straight from the OIHW parameter, cached per weight version) ----------
 class _DgradCache:
@@ -477,7 +480,10 @@ class GdnFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, beta_p, gamma_p = ctx.saved_tensors
         dy = dy.contiguous()
-        dxd, ds = ops.conv2d_gdn_bwd(x, ctx.packed, dy, ctx.inverse)          # s = beta + gamma @ x^2 recomputed, dy f(s) and dy x f'(s) from its epilogue
+        if _GDN_BWD_FUSED:
+            dxd, ds = ops.conv2d_gdn_bwd(x, ctx.packed, dy, ctx.inverse)      # s = beta + gamma @ x^2 recomputed, dy f(s) and dy x f'(s) from its epilogue
+        else:                                                                  # (A/B switch: the round-3 form, s stored and read back)
+            dxd, ds = ops.gdn_bwd_prep(x, ops.conv2d(x, ctx.packed, square_in=True), dy, ctx.inverse)
         dx = ops.conv2d(ds, ctx.back, mul=x, res=dxd)                          # dy f(s) + 2 x (gamma^T ds)
         dgamma, dbeta = ops.conv2d_wgrad(x, ds, 1, 1, square_x=True, want_bias=True)
         bb, gb = ctx.bounds

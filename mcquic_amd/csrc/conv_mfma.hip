@@ -612,7 +612,9 @@ next_tile:
                 unsigned so[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) so[r] = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
-                if (f & (MCQ_CONV_GDN_BWD | MCQ_CONV_IGDN_BWD)) {
+                // (compiled into the one-pixel-block 1x1 instances with the squaring prologue only -- the launcher routes these
+                //  launches there: in every other instance the extra 32 side values pushed the run-time-flag path into scratch)
+                if (TAPS == 1 && PRO == PRO_SQUARE && NB == 1 && (f & (MCQ_CONV_GDN_BWD | MCQ_CONV_IGDN_BWD))) {
                     // v = s = beta + gamma x^2 (recomputed); the two element-wise gradients of y = x f(s) leave from here instead of a
                     // launch of their own behind a stored s: dxd = dy f(s), ds = dy x f'(s) (train_ops.hip: gdn_bwd_prep_kernel's order)
                     float m[16], g[16];
@@ -1656,6 +1658,10 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
             if (t41 >= 2048 && !rows64) { MB = 4; NB = 1; ksl = 0; }
             else if (t21 >= 2048) { MB = 2; NB = 1; ksl = 0; }
         }
+    }
+    if (fl & (MCQ_CONV_GDN_BWD | MCQ_CONV_IGDN_BWD)) {      // the instances that carry this epilogue: one pixel block per wave, no split
+        if (!(fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;
+        NB = 1; ksl = 0;
     }
     const int pro = (fl & MCQ_CONV_SILU_IN) ? PRO_SILU : (fl & MCQ_CONV_SQUARE_IN) ? PRO_SQUARE : PRO_NONE;
     const long long ptiles = (tb + NB - 1) / NB;

@@ -415,6 +415,22 @@ def _band_rows(x: torch.Tensor, w: PackedConv, stride: int) -> int:
     return int(rows)
 
 
+def _band_plan(h: int, ksize: int, stride: int, rows: int):
+    """[(o0, o1, b0, b1, g0)] covering the output rows of a conv (kernel `ksize`, padding ksize // 2, `stride`) on an `h`-row map in
+    bands of at most `rows` output rows: output rows [o0, o1) come from input rows [b0, b1) -- every tap of a kept row is inside
+    the band or outside the image, where the conv pads -- and the band's local output row 0 is global output row g0 (b0 is a
+    multiple of the stride, so the band's own conv computes rows g0, g0 + 1, ... and rows o0 - g0 .. o1 - g0 of it are kept)."""
+    pad = ksize // 2
+    ho = (h + 2 * pad - ksize) // stride + 1
+    plan = []
+    for o0 in range(0, ho, rows):
+        o1 = min(ho, o0 + rows)
+        b0 = max(0, stride * o0 - stride) if pad else stride * o0
+        b1 = min(h, stride * (o1 - 1) + ksize - pad)
+        plan.append((o0, o1, b0, b1, b0 // stride))
+    return plan
+
+
 def _conv2d_banded(x: torch.Tensor, w: PackedConv, stride: int, rows: int, fused: dict) -> torch.Tensor:
     if fused.get("silu_in"):
         twin = silu_twin(x)
@@ -430,12 +446,7 @@ def _conv2d_banded(x: torch.Tensor, w: PackedConv, stride: int, rows: int, fused
     y2 = torch.empty_like(y) if dual else None
     sides = {kk: _dev(fused[kk], kk) for kk in _TENSOR_OPTS if fused.get(kk) is not None}
     plain = {kk: v for kk, v in fused.items() if kk not in _TENSOR_OPTS}
-    for o0 in range(0, ho, rows):
-        o1 = min(ho, o0 + rows)
-        # input rows [b0, b1): every tap of the kept output rows is inside the band or outside the image (where the conv pads)
-        b0 = max(0, stride * o0 - stride) if pad else stride * o0
-        b1 = min(h, stride * (o1 - 1) + k - pad)
-        g0 = b0 // stride                                           # the band's local output row 0 is global output row g0
+    for o0, o1, b0, b1, g0 in _band_plan(h, k, stride, rows):
         xb = x[:, :, b0:b1].contiguous()
         hl = (b1 - b0 + 2 * pad - k) // stride + 1
         local = {kk: v[:, :, g0:g0 + hl].contiguous() for kk, v in sides.items()}

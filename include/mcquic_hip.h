@@ -189,9 +189,18 @@ int mcq_vq_logits_f32(const float* x, const float* cb_packed, const float* tempe
  *   sample_index = argmax_c softmax(logits + gumbel(u_gumbel))[c], sample_hot = (1 - s) + s with s the soft
  *   probability there: the value of y_hard - y_soft.detach() + y_soft, which is zero everywhere else
  *                                                                                (gumbelSoftmax, mcquic/nn/base.py:118-133) */
-int mcq_vq_gumbel_sample_f32(float* logits, const float* u_drop, const float* u_gumbel, const float* freq_ema /* [m, k] */,
+/* `rng_state` (round 4; NULL = both draws are given): {seed, offset} as two uint64 in DEVICE memory.  Where u_drop / u_gumbel is
+ * NULL its draws are made inside the kernel from the state (stream 0 = the drop's, 1 = the Gumbel noise's): a counter-based
+ * generator over (seed, offset, stream, element index), 24-bit uniforms in [0, 1) like torch.rand's -- the reference's
+ * `torch.rand_like(logit)` tensors (2 x 134 MB at the first level of a training step) are never written or read.  The state is
+ * read on the device, so a captured hipGraph sees the offset its host code advanced on the device before each replay. */
+int mcq_vq_gumbel_sample_f32(float* logits, const float* u_drop /* or NULL */, const float* u_gumbel /* or NULL */,
+                             const uint64_t* rng_state /* or NULL */, const float* freq_ema /* [m, k] */,
                              const float* drop_exponent /* device scalar */, int64_t* codes, int64_t* sample_index,
                              float* sample_hot, int32_t N, int32_t m, int32_t h, int32_t w, int32_t k, void* stream);
+/* out[i] = the generator's draw for element i of `stream_id` under `rng_state` -- exactly what the two kernels around it use in
+ * place of a NULL u_drop (stream 0) / u_gumbel (stream 1): for tests and for callers that want the tensors after all. */
+int mcq_hash_uniform_f32(const uint64_t* rng_state, uint32_t stream_id, float* out, int64_t n, void* stream);
 
 /* out[n, g*d + j, y, x] = sample_hot * codebook[g, sample_index, j]: bmm(sample, codebook) for the one-hot-valued
  * straight-through sample (_multiCodebookDeQuantization.forward, quantizer.py:262-274). */
@@ -208,7 +217,8 @@ int mcq_vq_inner_f32(const float* x, const float* cb_packed, float* out, int32_t
  * `dlogits` (NULL = none): a gradient on the logits the forward returned (quantizer.py:232-239 returns them with their
  * graph); it is added in front of `_logit`.  The random drop's `+= -1e9` (quantizer.py:194-200) passes gradients through,
  * so dropped entries take part and `raw_logits` = the logits WITHOUT the drop (mcq_vq_logits_f32 again) must come along. */
-int mcq_vq_softmax_bwd_f32(const float* logits, const float* u_gumbel, float* ds_inout, const float* temperature, float bound,
+int mcq_vq_softmax_bwd_f32(const float* logits, const float* u_gumbel /* or NULL: remade from rng_state */, const uint64_t* rng_state /* or NULL */,
+                           float* ds_inout, const float* temperature, float bound,
                            float* rowsum, float* dtrow, const float* dlogits, const float* raw_logits,
                            int32_t N, int32_t m, int32_t h, int32_t w, int32_t k, void* stream);
 

@@ -68,12 +68,13 @@ SYMBOLS = {
                                     c_int32, c_void_p]),
     "mcq_vq_logits_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
-    "mcq_vq_gumbel_sample_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "mcq_vq_gumbel_sample_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "mcq_hash_uniform_f32": (c_int32, [c_void_p, c_uint32, c_void_p, c_int64, c_void_p]),
     "mcq_vq_dequant_soft_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_int32, c_void_p]),
     "mcq_vq_inner_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
-    "mcq_vq_softmax_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+    "mcq_vq_softmax_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_vq_soft_bwd_f32": (c_int32, [c_void_p] * 10 + [c_int32] * 6 + [c_void_p]),
     "mcq_nchw_to_nhwc_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

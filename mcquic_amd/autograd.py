@@ -587,11 +587,11 @@ class SoftQuantizeFn(torch.autograd.Function):
     extra is launched)."""
 
     @staticmethod
-    def forward(ctx, x, codebook, temperature, freq_ema, u_drop, u_gumbel, drop_exponent, packed, bound):
+    def forward(ctx, x, codebook, temperature, freq_ema, u_drop, u_gumbel, drop_exponent, packed, bound, rng=None):
         logits = ops.vq_logits(x, packed, temperature, bound)
-        code, index, hot = ops.vq_gumbel_sample(logits, u_drop, u_gumbel, freq_ema, drop_exponent)
+        code, index, hot = ops.vq_gumbel_sample(logits, u_drop, u_gumbel, freq_ema, drop_exponent, rng)
         deq = ops.vq_dequant_soft(index, hot, packed)
-        ctx.save_for_backward(x, logits, u_gumbel, index, hot, temperature)
+        ctx.save_for_backward(x, logits, u_gumbel, index, hot, temperature, rng)     # (u_gumbel None: remade from `rng` in backward)
         ctx.packed, ctx.bound = packed, bound
         ctx.mark_non_differentiable(code)
         ctx.set_materialize_grads(False)        # (an unused `dlogits` would be a zero fill of the [n, m, h, w, k] logits: 134 MB at level 0)
@@ -599,19 +599,19 @@ class SoftQuantizeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ddeq, _dcode, dlogits):
-        x, logits, u_gumbel, index, hot, temperature = ctx.saved_tensors
+        x, logits, u_gumbel, index, hot, temperature, rng = ctx.saved_tensors
         packed = ctx.packed
         if ddeq is None and dlogits is None:
-            return (None,) * 9
+            return (None,) * 10
         ddeq = torch.zeros_like(x) if ddeq is None else ddeq.contiguous()
         ds = ops.vq_inner(ddeq, packed)                                        # dSample = dDeq . C^T
         raw = None
         if dlogits is not None:                                                # the logits before the random drop, recomputed
             dlogits = dlogits.contiguous()
             raw = ops.vq_logits(x, packed, temperature, ctx.bound)
-        rowsum, dtrow = ops.vq_softmax_bwd(logits, u_gumbel, ds, temperature, ctx.bound, dlogits, raw)   # ds now holds d dist
+        rowsum, dtrow = ops.vq_softmax_bwd(logits, u_gumbel, ds, temperature, ctx.bound, dlogits, raw, rng)   # ds now holds d dist
         dx, dcb = ops.vq_soft_bwd(ds, rowsum, x, ddeq, index, hot, packed)
         dtb = ops.channel_sum(dtrow)                                           # [m]: d max(T, bound)
         t = temperature.detach().reshape(-1)
         dt = (((t >= ctx.bound) | (dtb < 0)).to(dtb.dtype) * dtb).reshape(temperature.shape)   # LowerBound's rule
-        return dx, dcb, dt, None, None, None, None, None, None
+        return dx, dcb, dt, None, None, None, None, None, None, None

@@ -191,6 +191,40 @@ __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
 // u^e < f, decided like `powf(u, e) < f`.  The hardware pair v_log_f32 / v_exp_f32 gives u^e to ~1e-4 relative at the
 // exponents in use (e <= 13, |log2 u| <= 24); only when that estimate is within 1e-3 of f does the libm powf decide (about
 // one lane in 10^4).  The decision is therefore powf's own, bit for bit, at a fifth of its instruction count.
+// ---- uniform draws made inside the kernels (round 4) ------------------------------------------------------------------------
+// The reference draws two `torch.rand_like(logit)` tensors per level (quantizer.py:194-230): at the first level of a training
+// step that is 2 x 134 MB written by the generator and read back here (and the Gumbel draw once more in backward).  With
+// `rng_state` = {seed, offset} (two uint64 in device memory, so that a captured hipGraph sees a fresh offset on every replay)
+// the same numbers are made where they are used: u(stream, i) = a 24-bit uniform in [0, 1) from two rounds of a 32-bit
+// avalanche mixer over (seed, offset, stream, element index i = row * k + c) -- a counter-based generator: any kernel, any
+// thread layout and the backward pass reproduce element i's draw from its index alone.  Not torch's Philox stream (no RNG-stream
+// parity is promised by either side: the draws are i.i.d. uniforms); mcq_hash_uniform_f32 materialises them for tests.
+struct RngState { uint32_t s0, s1, o0, o1; };
+__device__ __forceinline__ RngState rng_load(const unsigned long long* st) {
+    RngState r = {0u, 0u, 0u, 0u};
+    if (st) {
+        const unsigned long long seed = st[0], off = st[1];
+        r.s0 = (uint32_t)seed; r.s1 = (uint32_t)(seed >> 32); r.o0 = (uint32_t)off; r.o1 = (uint32_t)(off >> 32);
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t rng_mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float rng_uniform(const RngState& r, uint32_t stream, size_t idx) {
+    uint32_t h = rng_mix((uint32_t)idx ^ r.s0);
+    h = rng_mix(h + (uint32_t)((unsigned long long)idx >> 32) * 0x9E3779B1u + r.s1 + r.o0 * 0x85EBCA77u + r.o1 * 0x27D4EB2Fu + stream * 0xC2B2AE3Du);
+    return (float)(h >> 8) * 5.9604644775390625e-08f;            // k / 2^24, k in [0, 2^24): float32's own grid on [0, 1), like torch.rand
+}
+// element c of a row's draw: from the tensor the caller gave, or made here
+#define MCQ_U(ptr, stream, c) ((ptr) ? (ptr)[c] : rng_uniform(rng, (stream), rowbase + (size_t)(c)))
+
+__global__ void hash_uniform_kernel(const unsigned long long* __restrict__ st, uint32_t stream, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rng_uniform(rng_load(st), stream, i);
+}
+
 __device__ __forceinline__ bool drop_decision(float u, float e, float f) {
     const float est = __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(u));      // (u = 0: log2 = -inf, est = 0 like powf)
     const float tol = 1e-3f * fmaxf(est, f);
@@ -219,7 +253,7 @@ __device__ __forceinline__ float exp_nonpos(float x) {
 }
 
 __global__ __launch_bounds__(256) void vq_gumbel_sample_kernel(float* __restrict__ logits, const float* __restrict__ u_drop,
-                                                               const float* __restrict__ u_gumbel,
+                                                               const float* __restrict__ u_gumbel, const unsigned long long* __restrict__ rng_state,
                                                                const float* __restrict__ freq, const float* __restrict__ drop_exponent_ptr,
                                                                int64_t* __restrict__ codes, int64_t* __restrict__ index,
                                                                float* __restrict__ hot, int rows, int m, int hw, int k) {
@@ -228,8 +262,10 @@ __global__ __launch_bounds__(256) void vq_gumbel_sample_kernel(float* __restrict
     if (row >= rows) return;
     const int g = (row / hw) % m;
     float* lr = logits + (size_t)row * k;
-    const float* ud = u_drop + (size_t)row * k;
-    const float* ug = u_gumbel + (size_t)row * k;
+    const size_t rowbase = (size_t)row * k;
+    const RngState rng = rng_load(rng_state);
+    const float* ud = u_drop ? u_drop + rowbase : nullptr;
+    const float* ug = u_gumbel ? u_gumbel + rowbase : nullptr;
     const float* fr = freq + (size_t)g * k;
     const float eps = 1.1920928955078125e-07f;       // torch.finfo(float32).eps
     const float drop_exponent = drop_exponent_ptr[0];
@@ -238,9 +274,9 @@ __global__ __launch_bounds__(256) void vq_gumbel_sample_kernel(float* __restrict
     int code = 0, idx = 0;
     for (int c = lane; c < k; c += 64) {
         float l = lr[c];
-        if (drop_decision(ud[c], drop_exponent, fr[c])) l = l + -1e9f;
+        if (drop_decision(MCQ_U(ud, 0u, c), drop_exponent, fr[c])) l = l + -1e9f;
         lr[c] = l;
-        const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
+        const float u = fminf(fmaxf(MCQ_U(ug, 1u, c), eps), 1.0f - eps);
         const float y = l + gumbel_noise(u);
         if (l > best_l) { best_l = l; code = c; }
         if (y > best_y) { best_y = y; idx = c; }
@@ -256,7 +292,7 @@ __global__ __launch_bounds__(256) void vq_gumbel_sample_kernel(float* __restrict
     // softmax denominator with the max subtracted (torch's softmax): s[index] = exp(0) / sum = 1 / sum
     float sum = 0.0f;
     for (int c = lane; c < k; c += 64) {
-        const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
+        const float u = fminf(fmaxf(MCQ_U(ug, 1u, c), eps), 1.0f - eps);
         sum += exp_nonpos((lr[c] + gumbel_noise(u)) - best_y);
     }
 #pragma unroll
@@ -292,6 +328,7 @@ __global__ void vq_dequant_soft_kernel(const int64_t* __restrict__ index, const 
 //   dz = y (dS - <y, dS>)            (straight-through: the gradient reaches the sample through y_soft only)
 //   d dist = dz * (-Tb / sqrt(k)),   d Tb += sum_k dz[k] * logit[k] / Tb,   rowsum = sum_k d dist[k]
 __global__ __launch_bounds__(256) void vq_softmax_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ u_gumbel,
+                                                             const unsigned long long* __restrict__ rng_state,
                                                              float* __restrict__ ds, const float* __restrict__ temperature,
                                                              float bound, float scale, float* __restrict__ rowsum,
                                                              float* __restrict__ dtrow, const float* __restrict__ dlogits,
@@ -302,7 +339,9 @@ __global__ __launch_bounds__(256) void vq_softmax_bwd_kernel(const float* __rest
     const int g = (row / hw) % m;
     const float tb = fmaxf(temperature[g], bound);
     const float* lr = logits + (size_t)row * k;
-    const float* ug = u_gumbel + (size_t)row * k;
+    const size_t rowbase = (size_t)row * k;
+    const RngState rng = rng_load(rng_state);
+    const float* ug = u_gumbel ? u_gumbel + rowbase : nullptr;
     float* dr = ds + (size_t)row * k;
     // a gradient on the returned logits themselves (quantizer.py:232-239 hands back a graph-carrying tensor): it joins the
     // soft-max's gradient in front of `_logit`; the random drop's `+= -1e9` passes gradients through, so dropped entries
@@ -312,14 +351,14 @@ __global__ __launch_bounds__(256) void vq_softmax_bwd_kernel(const float* __rest
     const float eps = 1.1920928955078125e-07f;
     float mx = -INFINITY;
     for (int c = lane; c < k; c += 64) {
-        const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
+        const float u = fminf(fmaxf(MCQ_U(ug, 1u, c), eps), 1.0f - eps);
         mx = fmaxf(mx, lr[c] + gumbel_noise(u));
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     float sum = 0.0f, dot = 0.0f;
     for (int c = lane; c < k; c += 64) {
-        const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
+        const float u = fminf(fmaxf(MCQ_U(ug, 1u, c), eps), 1.0f - eps);
         const float e = exp_nonpos((lr[c] + gumbel_noise(u)) - mx);
         sum += e;
         dot += e * dr[c];
@@ -331,7 +370,7 @@ __global__ __launch_bounds__(256) void vq_softmax_bwd_kernel(const float* __rest
     float rs = 0.0f, dt = 0.0f;
     const float dscale = -tb / scale;
     for (int c = lane; c < k; c += 64) {
-        const float u = fminf(fmaxf(ug[c], eps), 1.0f - eps);
+        const float u = fminf(fmaxf(MCQ_U(ug, 1u, c), eps), 1.0f - eps);
         const float y = exp_nonpos((lr[c] + gumbel_noise(u)) - mx) * inv;
         float dz = y * (dr[c] - dot);
         if (dl) {
@@ -470,6 +509,7 @@ __device__ __forceinline__ float row_max(float a, RowShared<T>& sm) {
 template <int T>
 __global__ __launch_bounds__(T < 256 ? 256 : T, T == 1024 ? 8 : 1) void vq_gumbel_sample_row_kernel(float* __restrict__ logits, const float* __restrict__ u_drop,
                                                                                   const float* __restrict__ u_gumbel,
+                                                                                  const unsigned long long* __restrict__ rng_state,
                                                                                   const float* __restrict__ freq,
                                                                                   const float* __restrict__ drop_exponent_ptr,
                                                                                   int64_t* __restrict__ codes, int64_t* __restrict__ index,
@@ -481,8 +521,10 @@ __global__ __launch_bounds__(T < 256 ? 256 : T, T == 1024 ? 8 : 1) void vq_gumbe
     if (row >= rows) return;                                     // (T >= 256: the whole workgroup)
     const int g = (row / hw) % m;
     float* lr = logits + (size_t)row * k;
-    const float* ud = u_drop + (size_t)row * k;
-    const float* ug = u_gumbel + (size_t)row * k;
+    const size_t rowbase = (size_t)row * k;
+    const RngState rng = rng_load(rng_state);
+    const float* ud = u_drop ? u_drop + rowbase : nullptr;
+    const float* ug = u_gumbel ? u_gumbel + rowbase : nullptr;
     const float* fr = freq + (size_t)g * k;
     const float eps = 1.1920928955078125e-07f;
     const float drop_exponent = drop_exponent_ptr[0];
@@ -498,7 +540,7 @@ __global__ __launch_bounds__(T < 256 ? 256 : T, T == 1024 ? 8 : 1) void vq_gumbe
         for (int e = 0; e < 4; ++e) {
             const int c = tid + T * (e0 + e);
             const bool ok = c < k;
-            l[e] = ok ? lr[c] : -INFINITY; vd[e] = ok ? ud[c] : 1.0f; vg[e] = ok ? ug[c] : 0.5f; vf[e] = ok ? fr[c] : 0.0f;
+            l[e] = ok ? lr[c] : -INFINITY; vd[e] = ok ? MCQ_U(ud, 0u, c) : 1.0f; vg[e] = ok ? MCQ_U(ug, 1u, c) : 0.5f; vf[e] = ok ? fr[c] : 0.0f;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -530,6 +572,7 @@ __global__ __launch_bounds__(T < 256 ? 256 : T, T == 1024 ? 8 : 1) void vq_gumbe
 
 template <int T>
 __global__ __launch_bounds__(T < 256 ? 256 : T, T == 1024 ? 8 : 1) void vq_softmax_bwd_row_kernel(const float* __restrict__ logits, const float* __restrict__ u_gumbel,
+                                                                                const unsigned long long* __restrict__ rng_state,
                                                                                 float* __restrict__ ds, const float* __restrict__ temperature,
                                                                                 float bound, float scale, float* __restrict__ rowsum,
                                                                                 float* __restrict__ dtrow, const float* __restrict__ dlogits,
@@ -542,7 +585,9 @@ __global__ __launch_bounds__(T < 256 ? 256 : T, T == 1024 ? 8 : 1) void vq_softm
     const int g = (row / hw) % m;
     const float tb = fmaxf(temperature[g], bound);
     const float* lr = logits + (size_t)row * k;
-    const float* ug = u_gumbel + (size_t)row * k;
+    const size_t rowbase = (size_t)row * k;
+    const RngState rng = rng_load(rng_state);
+    const float* ug = u_gumbel ? u_gumbel + rowbase : nullptr;
     float* dr = ds + (size_t)row * k;
     const float* dl = dlogits ? dlogits + (size_t)row * k : nullptr;
     const float* rw = raw_logits ? raw_logits + (size_t)row * k : nullptr;
@@ -552,7 +597,7 @@ __global__ __launch_bounds__(T < 256 ? 256 : T, T == 1024 ? 8 : 1) void vq_softm
     for (int e = 0; e < ROW_E; ++e) {
         const int c = tid + T * e;
         const bool ok = c < k;
-        l[e] = ok ? lr[c] : -INFINITY; y[e] = ok ? ug[c] : 0.5f; dd[e] = ok ? dr[c] : 0.0f;
+        l[e] = ok ? lr[c] : -INFINITY; y[e] = ok ? MCQ_U(ug, 1u, c) : 0.5f; dd[e] = ok ? dr[c] : 0.0f;
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -640,26 +685,36 @@ extern "C" int mcq_vq_inner_f32(const float* x, const float* cb_packed, float* o
     return mcq_check_launch();
 }
 
-extern "C" int mcq_vq_gumbel_sample_f32(float* logits, const float* u_drop, const float* u_gumbel, const float* freq_ema,
+extern "C" int mcq_hash_uniform_f32(const uint64_t* rng_state, uint32_t stream_id, float* out, int64_t n, void* stream) {
+    if (!rng_state || !out || n <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(hash_uniform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned long long*>(rng_state), stream_id, out, (size_t)n);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_vq_gumbel_sample_f32(float* logits, const float* u_drop, const float* u_gumbel, const uint64_t* rng_state_u64,
+                                        const float* freq_ema,
                                         const float* drop_exponent, int64_t* codes, int64_t* sample_index, float* sample_hot,
                                         int32_t N, int32_t m, int32_t h, int32_t w, int32_t k, void* stream) {
-    if (!logits || !u_drop || !u_gumbel || !freq_ema || !drop_exponent || !codes || !sample_index || !sample_hot) return MCQ_EINVAL;
+    const unsigned long long* rng_state = reinterpret_cast<const unsigned long long*>(rng_state_u64);
+    if (!logits || !freq_ema || !drop_exponent || !codes || !sample_index || !sample_hot) return MCQ_EINVAL;
+    if ((!u_drop || !u_gumbel) && !rng_state) return MCQ_EINVAL;        // every draw comes from a tensor or from the generator state
     if (N <= 0 || m <= 0 || h <= 0 || w <= 0 || k <= 0) return MCQ_EINVAL;
     const long long rows = (long long)N * m * h * w;
     if (rows > 0x7fffffffLL) return MCQ_ETOOLARGE;
     hipStream_t s = (hipStream_t)stream;
     if (k <= 64 * ROW_E)
-        hipLaunchKernelGGL(vq_gumbel_sample_row_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, u_drop, u_gumbel,
+        hipLaunchKernelGGL(vq_gumbel_sample_row_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, u_drop, u_gumbel, rng_state,
                            freq_ema, drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
     else if (k <= 256 * ROW_E)
-        hipLaunchKernelGGL(vq_gumbel_sample_row_kernel<256>, dim3((unsigned)rows), dim3(256), 0, s, logits, u_drop, u_gumbel, freq_ema,
+        hipLaunchKernelGGL(vq_gumbel_sample_row_kernel<256>, dim3((unsigned)rows), dim3(256), 0, s, logits, u_drop, u_gumbel, rng_state, freq_ema,
                            drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
     else if (k <= 1024 * ROW_E)
-        hipLaunchKernelGGL(vq_gumbel_sample_row_kernel<1024>, dim3((unsigned)rows), dim3(1024), 0, s, logits, u_drop, u_gumbel, freq_ema,
+        hipLaunchKernelGGL(vq_gumbel_sample_row_kernel<1024>, dim3((unsigned)rows), dim3(1024), 0, s, logits, u_drop, u_gumbel, rng_state, freq_ema,
                            drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
     else
         hipLaunchKernelGGL(vq_gumbel_sample_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits,
-                           u_drop, u_gumbel, freq_ema, drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
+                           u_drop, u_gumbel, rng_state, freq_ema, drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
     return mcq_check_launch();
 }
 
@@ -672,10 +727,12 @@ extern "C" int mcq_vq_dequant_soft_f32(const int64_t* sample_index, const float*
     return mcq_check_launch();
 }
 
-extern "C" int mcq_vq_softmax_bwd_f32(const float* logits, const float* u_gumbel, float* ds_inout, const float* temperature,
+extern "C" int mcq_vq_softmax_bwd_f32(const float* logits, const float* u_gumbel, const uint64_t* rng_state_u64, float* ds_inout,
+                                      const float* temperature,
                                       float bound, float* rowsum, float* dtrow, const float* dlogits, const float* raw_logits,
                                       int32_t N, int32_t m, int32_t h, int32_t w, int32_t k, void* stream) {
-    if (!logits || !u_gumbel || !ds_inout || !temperature || !rowsum || !dtrow || N <= 0 || m <= 0 || h <= 0 || w <= 0 || k <= 0)
+    const unsigned long long* rng_state = reinterpret_cast<const unsigned long long*>(rng_state_u64);
+    if (!logits || (!u_gumbel && !rng_state) || !ds_inout || !temperature || !rowsum || !dtrow || N <= 0 || m <= 0 || h <= 0 || w <= 0 || k <= 0)
         return MCQ_EINVAL;
     if ((dlogits != nullptr) != (raw_logits != nullptr)) return MCQ_EINVAL;
     const long long rows = (long long)N * m * h * w;
@@ -683,16 +740,16 @@ extern "C" int mcq_vq_softmax_bwd_f32(const float* logits, const float* u_gumbel
     hipStream_t s = (hipStream_t)stream;
     const float scale = (float)sqrt((double)k);
     if (k <= 64 * ROW_E)
-        hipLaunchKernelGGL(vq_softmax_bwd_row_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, u_gumbel, ds_inout,
+        hipLaunchKernelGGL(vq_softmax_bwd_row_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, u_gumbel, rng_state, ds_inout,
                            temperature, bound, scale, rowsum, dtrow, dlogits, raw_logits, (int)rows, m, h * w, k);
     else if (k <= 256 * ROW_E)
-        hipLaunchKernelGGL(vq_softmax_bwd_row_kernel<256>, dim3((unsigned)rows), dim3(256), 0, s, logits, u_gumbel, ds_inout, temperature,
+        hipLaunchKernelGGL(vq_softmax_bwd_row_kernel<256>, dim3((unsigned)rows), dim3(256), 0, s, logits, u_gumbel, rng_state, ds_inout, temperature,
                            bound, scale, rowsum, dtrow, dlogits, raw_logits, (int)rows, m, h * w, k);
     else if (k <= 1024 * ROW_E)
-        hipLaunchKernelGGL(vq_softmax_bwd_row_kernel<1024>, dim3((unsigned)rows), dim3(1024), 0, s, logits, u_gumbel, ds_inout, temperature,
+        hipLaunchKernelGGL(vq_softmax_bwd_row_kernel<1024>, dim3((unsigned)rows), dim3(1024), 0, s, logits, u_gumbel, rng_state, ds_inout, temperature,
                            bound, scale, rowsum, dtrow, dlogits, raw_logits, (int)rows, m, h * w, k);
     else
-        hipLaunchKernelGGL(vq_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, u_gumbel,
+        hipLaunchKernelGGL(vq_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, u_gumbel, rng_state,
                            ds_inout, temperature, bound, scale, rowsum, dtrow, dlogits, raw_logits, (int)rows, m, h * w, k);
     return mcq_check_launch();
 }

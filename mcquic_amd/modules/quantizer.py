@@ -19,6 +19,7 @@ from .. import ops
 from .entropyCoder import EntropyCoder, VariousMCoder
 
 EPS = 1e-6
+_TORCH_RAND = __import__("os").environ.get("MCQUIC_AMD_TORCH_RAND", "0") == "1"      # A/B switch: draw the uniforms with torch.rand
 
 
 class _CodebookCache:
@@ -128,8 +129,15 @@ class _multiCodebookQuantization(nn.Module):
         cb = self._cache[0].get(self._codebook)
         n, _, h, w = x.shape
         shape = (n, self._m, h, w, self._k)
+        rng = None
         if uniforms is None:
-            uniforms = (torch.rand(shape, device=x.device), torch.rand(shape, device=x.device))
+            # the two `torch.rand_like(logit)` draws of the reference are made inside the kernels that use them, from a generator
+            # snapshot (ops.rng_snapshot): 2 x 134 MB per training step that are never written or read.  MCQUIC_AMD_TORCH_RAND=1
+            # draws the tensors with torch.rand instead (the round-3 form).
+            if _TORCH_RAND or not x.is_cuda:
+                uniforms = (torch.rand(shape, device=x.device), torch.rand(shape, device=x.device))
+            else:
+                uniforms, rng = (None, None), ops.rng_snapshot(x.device)
         bits = math.log2(self._k)
         # exponent of _randomDrop (:196-198), kept on the device: no host sync in the step
         with torch.no_grad():
@@ -138,10 +146,10 @@ class _multiCodebookQuantization(nn.Module):
         if torch.is_grad_enabled():
             from ..autograd import SoftQuantizeFn
             deq, code, logit = SoftQuantizeFn.apply(x, self._codebook, self._temperature, freqEMA.detach(), uniforms[0], uniforms[1],
-                                                    exponent, cb, float(EPS))
+                                                    exponent, cb, float(EPS), rng)
             return deq, code, logit           # the sample is represented by its (differentiable) dequantisation
         logit = ops.vq_logits(x, cb, self._temperature, float(EPS))
-        code, index, hot = ops.vq_gumbel_sample(logit, uniforms[0], uniforms[1], freqEMA, exponent)
+        code, index, hot = ops.vq_gumbel_sample(logit, uniforms[0], uniforms[1], freqEMA, exponent, rng)
         return (index, hot), code, logit
 
 

@@ -604,13 +604,57 @@ def vq_logits(x: torch.Tensor, cb: PackedCodebook, temperature: torch.Tensor, bo
     return logits
 
 
-def vq_gumbel_sample(logits: torch.Tensor, u_drop: torch.Tensor, u_gumbel: torch.Tensor, freq_ema: torch.Tensor,
-                     drop_exponent: torch.Tensor):
-    """In place on `logits`: random drop; returns (codes, sample_index, sample_hot), each [n, m, h, w]."""
+# ---- the generator behind the soft assignment's draws (csrc/vq_train.hip: rng_uniform) ------------------------------------------
+_rng_states = {}
+
+
+def seed_rng(seed: int, device=None) -> None:
+    """(Re)seed the in-kernel generator of `device` (default: the current one) and rewind its offset."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = _rng_states.get(dev.index)
+    val = torch.tensor([int(seed) & 0x7fffffffffffffff, 0], dtype=torch.int64)
+    if st is None:
+        _rng_states[dev.index] = val.to(dev)
+    else:
+        st.copy_(val)
+
+
+def rng_snapshot(device) -> torch.Tensor:
+    """{seed, offset} for ONE pair of draws (a fresh int64[2] device tensor), after which the generator's offset moves on -- both
+    on the device and in stream order, so the sequence is captured by a hipGraph and advances on every replay.  Seeded from
+    torch's own seed at first use (`torch.manual_seed` before it, or `seed_rng` at any time)."""
+    dev = torch.device(device)
+    st = _rng_states.get(dev.index)
+    if st is None:
+        seed_rng(torch.initial_seed(), dev)
+        st = _rng_states[dev.index]
+    snap = st.clone()
+    st[1:].add_(1)
+    return snap
+
+
+def hash_uniform(rng: torch.Tensor, stream_id: int, shape) -> torch.Tensor:
+    """The generator's draws for a tensor of `shape` (stream 0 = random drop, 1 = Gumbel noise) under the snapshot `rng`:
+    exactly what the kernels use in place of a missing u_drop / u_gumbel (mcq_hash_uniform_f32)."""
+    rng = _dev(rng, "rng", torch.int64)
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=rng.device)
+    with _guard(rng.device):
+        check(_lib.load().mcq_hash_uniform_f32(_ptr(rng), int(stream_id), _ptr(out), out.numel(), _stream()), "mcq_hash_uniform_f32")
+    return out
+
+
+def vq_gumbel_sample(logits: torch.Tensor, u_drop: Optional[torch.Tensor], u_gumbel: Optional[torch.Tensor], freq_ema: torch.Tensor,
+                     drop_exponent: torch.Tensor, rng: Optional[torch.Tensor] = None):
+    """In place on `logits`: random drop; returns (codes, sample_index, sample_hot), each [n, m, h, w].  A draw that is None is
+    made inside the kernel from the generator snapshot `rng` (rng_snapshot)."""
     logits = _dev(logits, "logits")
     n, m, h, w, k = logits.shape
-    u_drop, u_gumbel = _dev(u_drop, "u_drop"), _dev(u_gumbel, "u_gumbel")
-    if u_drop.shape != logits.shape or u_gumbel.shape != logits.shape:
+    if (u_drop is None or u_gumbel is None) and rng is None:
+        raise ValueError("vq_gumbel_sample: give both uniform draws or a generator snapshot")
+    u_drop = None if u_drop is None else _dev(u_drop, "u_drop")
+    u_gumbel = None if u_gumbel is None else _dev(u_gumbel, "u_gumbel")
+    rng = None if rng is None else _dev(rng, "rng", torch.int64)
+    if any(u is not None and u.shape != logits.shape for u in (u_drop, u_gumbel)):
         raise ValueError("uniform draws must have the logits' shape")
     freq = _dev(freq_ema.detach(), "freq_ema")
     expo = _dev(drop_exponent.detach().reshape(1), "drop_exponent")
@@ -618,7 +662,7 @@ def vq_gumbel_sample(logits: torch.Tensor, u_drop: torch.Tensor, u_gumbel: torch
     index = torch.empty_like(codes)
     hot = torch.empty((n, m, h, w), dtype=torch.float32, device=logits.device)
     with _guard(logits.device):
-        check(_lib.load().mcq_vq_gumbel_sample_f32(_ptr(logits), _ptr(u_drop), _ptr(u_gumbel), _ptr(freq), _ptr(expo), _ptr(codes),
+        check(_lib.load().mcq_vq_gumbel_sample_f32(_ptr(logits), _ptr(u_drop), _ptr(u_gumbel), _ptr(rng), _ptr(freq), _ptr(expo), _ptr(codes),
                                                    _ptr(index), _ptr(hot), n, m, h, w, k, _stream()), "mcq_vq_gumbel_sample_f32")
     return codes, index, hot
 
@@ -923,11 +967,16 @@ def vq_inner(x: torch.Tensor, cb: PackedCodebook) -> torch.Tensor:
     return out
 
 
-def vq_softmax_bwd(logits: torch.Tensor, u_gumbel: torch.Tensor, ds: torch.Tensor, temperature: torch.Tensor, bound: float,
-                   dlogits: Optional[torch.Tensor] = None, raw_logits: Optional[torch.Tensor] = None):
+def vq_softmax_bwd(logits: torch.Tensor, u_gumbel: Optional[torch.Tensor], ds: torch.Tensor, temperature: torch.Tensor, bound: float,
+                   dlogits: Optional[torch.Tensor] = None, raw_logits: Optional[torch.Tensor] = None, rng: Optional[torch.Tensor] = None):
     """In place on `ds` (dSample -> d dist); returns (rowsum, dtrow), each [n, m, h, w].  `dlogits`: a gradient on the returned
-    logits themselves, with `raw_logits` = the logits before the random drop."""
-    logits, u_gumbel, ds = _dev(logits, "logits"), _dev(u_gumbel, "u_gumbel"), _dev(ds, "ds")
+    logits themselves, with `raw_logits` = the logits before the random drop.  `u_gumbel` None: the forward's Gumbel draw is
+    remade from its generator snapshot `rng`."""
+    logits, ds = _dev(logits, "logits"), _dev(ds, "ds")
+    if u_gumbel is None and rng is None:
+        raise ValueError("vq_softmax_bwd: give the Gumbel draw or the forward's generator snapshot")
+    u_gumbel = None if u_gumbel is None else _dev(u_gumbel, "u_gumbel")
+    rng = None if rng is None else _dev(rng, "rng", torch.int64)
     if dlogits is not None:
         dlogits, raw_logits = _dev(dlogits, "dlogits"), _dev(raw_logits, "raw_logits")
         if dlogits.shape != logits.shape or raw_logits.shape != logits.shape:
@@ -937,7 +986,7 @@ def vq_softmax_bwd(logits: torch.Tensor, u_gumbel: torch.Tensor, ds: torch.Tenso
     rowsum = torch.empty((n, m, h, w), dtype=torch.float32, device=logits.device)
     dtrow = torch.empty_like(rowsum)
     with _guard(logits.device):
-        check(_lib.load().mcq_vq_softmax_bwd_f32(_ptr(logits), _ptr(u_gumbel), _ptr(ds), _ptr(t), float(bound), _ptr(rowsum), _ptr(dtrow),
+        check(_lib.load().mcq_vq_softmax_bwd_f32(_ptr(logits), _ptr(u_gumbel), _ptr(rng), _ptr(ds), _ptr(t), float(bound), _ptr(rowsum), _ptr(dtrow),
                                                  _ptr(dlogits), _ptr(raw_logits), n, m, h, w, k, _stream()), "mcq_vq_softmax_bwd_f32")
     return rowsum, dtrow
 

@@ -623,3 +623,72 @@ def test_wgrad_grouped_launches_are_deterministic(dev, case):
         F.conv2d(xs[i].cpu(), wr, br, padding=1).backward(dys[i].cpu())
         _close(first[i][0], wr.grad, 2e-5, f"dW of problem {i}")
         _close(first[i][1], br.grad, 2e-5, f"db of problem {i}")
+
+
+def test_in_kernel_uniform_generator_statistics(dev):
+    """csrc/vq_train.hip: rng_uniform -- the counter-based generator behind the soft assignment's draws when no tensors are given
+    (the reference draws torch.rand_like(logit) twice per level, quantizer.py:194-230; no RNG-stream parity exists on either
+    side, the draws only have to be i.i.d. uniforms on float32's [0, 1) grid).  4 M draws per stream: range, moments, a 256-bin
+    chi-square, independence of the two streams, of neighbouring elements and of consecutive snapshots; reproducible from the
+    snapshot alone."""
+    from mcquic_amd import ops
+    ops.seed_rng(1234, dev)
+    a = ops.rng_snapshot(dev)
+    b = ops.rng_snapshot(dev)
+    assert int(a[0]) == 1234 and int(b[1]) == int(a[1]) + 1
+    n = 1 << 22
+    u0, u1 = ops.hash_uniform(a, 0, (n,)), ops.hash_uniform(a, 1, (n,))
+    v0 = ops.hash_uniform(b, 0, (n,))
+    assert torch.equal(u0, ops.hash_uniform(a.clone(), 0, (n,)))                      # a function of the snapshot alone
+    for u in (u0, u1, v0):
+        assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+        assert bool(((u * 16777216.0) == (u * 16777216.0).round()).all())           # multiples of 2^-24
+        d = u.double()
+        assert abs(float(d.mean()) - 0.5) < 6e-4 and abs(float(d.var()) - 1.0 / 12.0) < 3e-4
+        hist = torch.histc(u, bins=256, min=0.0, max=1.0).double()
+        chi2 = float(((hist - n / 256) ** 2 / (n / 256)).sum())
+        assert chi2 < 400.0, chi2                                                      # 255 degrees of freedom: mean 255, sd 22.6
+
+    def corr(p, q):
+        p, q = p.double() - 0.5, q.double() - 0.5
+        return float((p * q).mean() / (p.std() * q.std()))
+    assert abs(corr(u0, u1)) < 3e-3 and abs(corr(u0, v0)) < 3e-3 and abs(corr(u0[:-1], u0[1:])) < 3e-3
+    assert abs(corr(u0[:-8192], u0[8192:])) < 3e-3                                    # the same column of neighbouring rows
+
+
+@pytest.mark.parametrize("mk", [(2, 8192), (2, 2048), (3, 512), (1, 20000)])
+def test_soft_assignment_with_in_kernel_draws_equals_given_tensors(dev, mk):
+    """The draws made inside the kernels are exactly mcq_hash_uniform_f32's: the soft assignment run from a generator snapshot
+    (no u_drop / u_gumbel tensors) gives bit-identical codes, samples, logits and gradients to the same call on the materialised
+    tensors -- for every kernel variant (rows of 64 / 256 / 1024 threads, the wave-per-row form beyond 8192 codewords)."""
+    from mcquic_amd import ops
+    from mcquic_amd.autograd import SoftQuantizeFn
+    m, k = mk
+    d, n, h, w = 16, 2, 4, 4
+    g = torch.Generator().manual_seed(k)
+    cbp = (torch.randn((m, k, d), generator=g) * 0.3).to(dev).requires_grad_()
+    x0 = (torch.randn((n, m * d, h, w), generator=g) * 0.3).to(dev)
+    temp = (torch.rand((m, 1, 1, 1), generator=g) + 0.5).to(dev).requires_grad_()
+    f = torch.rand((m, k), generator=g) ** 3 + 1e-3
+    freq = (f / f.sum(-1, keepdim=True)).to(dev)
+    expo = torch.tensor([5.0], device=dev)
+    gd = torch.randn((n, m * d, h, w), generator=g).to(dev)
+    rng = ops.rng_snapshot(dev)
+    shape = (n, m, h, w, k)
+    ud, ug = ops.hash_uniform(rng, 0, shape), ops.hash_uniform(rng, 1, shape)
+    outs = []
+    for args in ((None, None, rng), (ud, ug, None), (ud, None, rng)):
+        x = x0.clone().requires_grad_()
+        cbp.grad = temp.grad = None
+        pk = ops.PackedCodebook(cbp)
+        deq, code, logit = SoftQuantizeFn.apply(x, cbp, temp, freq, args[0], args[1], expo, pk, 1e-6, args[2])
+        (deq * gd).sum().backward()
+        outs.append((deq.detach(), code, logit.detach(), x.grad.clone(), cbp.grad.clone(), temp.grad.clone()))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+    assert float(outs[0][3].abs().max()) > 0
+    # the generator moves on: the next snapshot gives another sample
+    rng2 = ops.rng_snapshot(dev)
+    assert int(rng2[1]) == int(rng[1]) + 1
+    assert not torch.equal(ops.hash_uniform(rng2, 1, shape), ug)

@@ -476,6 +476,7 @@ extern "C" int mcq_vq_assign_ws_f32(const float* x, const float* cb_packed, int6
     const unsigned gx = (unsigned)((vtiles + per_wg - 1) / per_wg);
     const dim3 grid(gx, (unsigned)m, (unsigned)p.zs);
     if (p.Sp == 32) hipLaunchKernelGGL((vq_assign_kernel<32, false>), grid, dim3(256), 0, (hipStream_t)stream, p);          // d = 64
+    else if (p.Sp == 8) hipLaunchKernelGGL((vq_assign_kernel<8, false>), grid, dim3(256), 0, (hipStream_t)stream, p);      // d = 16 (model No. 12), d = 8 ... 15
     else if (p.Sp == 128 && cs_log2 == 2) hipLaunchKernelGGL((vq_assign_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, p);   // d = 256
     else if (p.Sp == 128) hipLaunchKernelGGL((vq_assign_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((vq_assign_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, p);

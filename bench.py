@@ -28,6 +28,8 @@ import time
 
 # hardware queues for the branch streams next to RCCL's own streams (see mcquic_amd/__init__.py); must precede HIP init
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# graph replays through the ordinary command path: ROCm 7.2's recorded launch packets replay memset nodes wrongly (same file)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import torch  # noqa: E402
 

@@ -316,6 +316,14 @@ int mcq_add_f32(const float* a, const float* b, float* out, float* out_silu /* o
  * identity term; what torch.autograd accumulates with two additions for mcquic/nn/blocks.py:281-288) in one launch. */
 int mcq_add3_f32(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream);
 
+/* mean((a - b)^2) over n floats -> out[0] (F.mse_loss, the distortion term of mcquic/loss/__init__.py:62), and its gradient
+ * da = 2 (a - b) / n * dloss[0] (db = -da when non-NULL).  Two launches, a fixed summation order (double partials in
+ * `workspace`, mcq_mse_workspace_bytes(n) bytes) and no memset: safe inside a captured hipGraph, which a library reduction that
+ * zeroes semaphores with hipMemsetAsync is not on ROCm 7.2 ("graph replays"). */
+size_t mcq_mse_workspace_bytes(int64_t n);
+int mcq_mse_f32(const float* a, const float* b, float* out, void* workspace, int64_t n, void* stream);
+int mcq_mse_bwd_f32(const float* a, const float* b, const float* dloss, float* da, float* db /* or NULL */, int64_t n, void* stream);
+
 /* u8 = trunc(clamp(((x + 1) / 2) * 255.999, 0, 255))   (mcquic/utils/vision.py:143-146 DeTransform). */
 int mcq_detransform_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 

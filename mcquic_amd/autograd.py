@@ -104,6 +104,29 @@ class SiluFn(torch.autograd.Function):
         return ops.silu_bwd(x, dy.contiguous())
 
 
+class MseFn(torch.autograd.Function):
+    """F.mse_loss(a, b) (mcquic/loss/__init__.py:62) from this library's own reduction: no library memset inside a captured step."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        return ops.mse(a, b)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        a, b = ctx.saved_tensors
+        da, db = ops.mse_bwd(a, b, dloss.contiguous().float(), want_db=ctx.needs_input_grad[1])
+        return (da if ctx.needs_input_grad[0] else None), db
+
+
+def mse_loss(a, b):
+    """mean((a - b)^2): `MseFn` on a HIP device in float32, torch's own elsewhere."""
+    if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.numel():
+        return MseFn.apply(a, b)
+    return torch.nn.functional.mse_loss(a, b)
+
+
 # ---- ResidualBlock / AttentionBlock as whole autograd nodes ---------------------------------------------------------
 def _rb_forward(block, x, sx):
     """y = conv2(silu(conv1(silu(x)))) + x in two fused launches; returns (y, silu(y), what backward needs)."""

@@ -186,6 +186,13 @@ __global__ void ms_ssim_combine_kernel(const float* __restrict__ levels, int N, 
     out[n] = sum / (float)C;
 }
 
+// (zeroing is a kernel, not hipMemsetAsync: a memset NODE of a captured hipGraph is replayed wrongly by ROCm 7.2 after eager blit
+//  work, see csrc/train_ops.hip)
+__global__ void zero_i64_kernel(int64_t* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = 0;
+}
+
 constexpr int SQ_CHUNK = 16384;       // bytes per workgroup (64 per thread: the uint32 partial cannot overflow)
 __global__ __launch_bounds__(256) void sqdiff_sum_u8_kernel(const uint8_t* __restrict__ x, const uint8_t* __restrict__ y,
                                                             int64_t per_image, int vec4, unsigned long long* __restrict__ out) {
@@ -324,7 +331,7 @@ extern "C" int mcq_sqdiff_sum_u8(const uint8_t* x, const uint8_t* y, int64_t* ou
                                  void* stream) {
     if (!x || !y || !out || per_image <= 0 || N <= 0 || N > 65535) return MCQ_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, (size_t)N * sizeof(int64_t), s) != hipSuccess) return MCQ_ELAUNCH;
+    hipLaunchKernelGGL(zero_i64_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, out, (int)N);
     const dim3 grid((unsigned)((per_image + SQ_CHUNK - 1) / SQ_CHUNK), (unsigned)N);
     const int vec4 = per_image % 16 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
     hipLaunchKernelGGL(sqdiff_sum_u8_kernel, grid, dim3(256), 0, s, x, y, per_image, vec4, (unsigned long long*)out);

@@ -362,6 +362,52 @@ __global__ void channel_sum_finish_kernel(const float* __restrict__ part, float*
     out[c] = s;
 }
 
+// ---- mean squared error (the distortion term, mcquic/loss/__init__.py:62) -------------------------------------------------------
+// Two launches, no atomics and no memset: one double partial per workgroup, summed in a fixed order by one workgroup.  ATen's own
+// large reductions zero their semaphores with hipMemsetAsync -- a memset NODE once captured, which ROCm 7.2's packet-captured graph
+// launches replay wrongly after eager blit work (tools/probes/memset_node_probe.py): the captured step uses these instead.
+constexpr int MSE_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ part,
+                                                          int64_t n) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = a[i] - b[i];
+        s += (double)(d * d);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void mse_finish_kernel(const double* __restrict__ part, int nblocks, double inv_n, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] * inv_n);
+}
+
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ dloss,
+                                                      float scale, float* __restrict__ da, float* __restrict__ db, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float g = (a[i] - b[i]) * (scale * dloss[0]);
+        da[i] = g;
+        if (db) db[i] = -g;
+    }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __global__ void silu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
@@ -526,6 +572,28 @@ extern "C" int mcq_channel_sum_f32(const float* x, float* out, float* workspace,
         hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C, (unsigned)nchunk), dim3(256), 0, s, x, workspace, N, C, HW, nchunk);
         hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, workspace, out, C, nchunk);
     }
+    return mcq_check_launch();
+}
+
+static int mse_blocks(int64_t n) {
+    const int64_t want = (n + 2047) / 2048;                  // >= 8 elements per lane before a workgroup is added
+    return (int)(want < 1 ? 1 : want > MSE_BLOCKS ? MSE_BLOCKS : want);
+}
+extern "C" size_t mcq_mse_workspace_bytes(int64_t n) { return n > 0 ? (size_t)mse_blocks(n) * sizeof(double) : 0; }
+
+extern "C" int mcq_mse_f32(const float* a, const float* b, float* out, void* workspace, int64_t n, void* stream) {
+    if (!a || !b || !out || !workspace || n <= 0) return MCQ_EINVAL;
+    const int nb = mse_blocks(n);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, a, b, (double*)workspace, n);
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, 1.0 / (double)n, out);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_mse_bwd_f32(const float* a, const float* b, const float* dloss, float* da, float* db, int64_t n, void* stream) {
+    if (!a || !b || !dloss || !da || n <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, dloss, (float)(2.0 / (double)n),
+                       da, db, n);
     return mcq_check_launch();
 }
 

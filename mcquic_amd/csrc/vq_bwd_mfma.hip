@@ -228,6 +228,12 @@ __global__ __launch_bounds__(1024) void vq_dx_mfma_kernel(VqBwdK p) {
         }
 }
 
+// (a kernel, not hipMemsetAsync: a memset NODE in a replayed hipGraph was seen to run out of order with the kernel nodes around it
+//  under ROCm 7.2's packet-captured graph launches -- tools/probes/replay_determinism.py, docs/experiments.md section 9.9)
+__global__ __launch_bounds__(256) void vq_zero_kernel(float4* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 }  // namespace
 
 bool mcq_vq_dc_mfma_ok(const VqBwdK& p) {
@@ -245,6 +251,10 @@ void mcq_vq_dc_mfma_launch(const VqBwdK& p, void* stream) {
 void mcq_vq_dx_mfma_launch(const VqBwdK& p, void* stream) {
     // fewer tiles than CUs (rows / 32 = 128 at the first training level): the codewords are halved over two workgroups per tile
     const unsigned zs = (p.rows / 32 < 256 && p.k % 256 == 0) ? 2u : 1u;
-    if (zs == 2) (void)hipMemsetAsync(p.dx, 0, (size_t)p.rows * p.d * sizeof(float), (hipStream_t)stream);
+    if (zs == 2) {                                       // rows % 32 == 0: a whole number of float4
+        const size_t n4 = (size_t)p.rows * p.d / 4;
+        hipLaunchKernelGGL(vq_zero_kernel, dim3((unsigned)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024)), dim3(256), 0, (hipStream_t)stream,
+                           (float4*)p.dx, n4);
+    }
     hipLaunchKernelGGL(vq_dx_mfma_kernel, dim3((unsigned)(p.rows / 32), zs), dim3(1024), 0, (hipStream_t)stream, p);
 }

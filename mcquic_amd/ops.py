@@ -703,6 +703,30 @@ def add3(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def mse(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """mean((a - b)^2) as a 0-dim tensor (mcq_mse_f32: two launches, fixed summation order, no memset -- see csrc/train_ops.hip)."""
+    a, b = _dev(a, "a"), _dev(b, "b")
+    if a.shape != b.shape or a.numel() == 0:
+        raise ValueError("mse: shape mismatch or empty input")
+    lib = _lib.load()
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    ws = torch.empty(lib.mcq_mse_workspace_bytes(a.numel()) // 8, dtype=torch.float64, device=a.device)
+    with _guard(a.device):
+        check(lib.mcq_mse_f32(_ptr(a), _ptr(b), _ptr(out), _ptr(ws), a.numel(), _stream()), "mcq_mse_f32")
+    return out
+
+
+def mse_bwd(a: torch.Tensor, b: torch.Tensor, dloss: torch.Tensor, want_db: bool = False):
+    """(da, db or None) of `mse`: da = 2 (a - b) / n * dloss (mcq_mse_bwd_f32); `dloss` stays on the device."""
+    a, b, dloss = _dev(a, "a"), _dev(b, "b"), _dev(dloss, "dloss")
+    da = torch.empty_like(a)
+    db = torch.empty_like(a) if want_db else None
+    with _guard(a.device):
+        check(_lib.load().mcq_mse_bwd_f32(_ptr(a), _ptr(b), _ptr(dloss), _ptr(da), _ptr(db) if want_db else None, a.numel(), _stream()),
+              "mcq_mse_bwd_f32")
+    return da, db
+
+
 def group_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], groups: int, eps: float = 1e-5,
                dual_silu: bool = False, want_stats: bool = False):
     """nn.GroupNorm(groups, C) on [n, C, h, w] (mcq_group_norm_f32; `denseNorm=True`, mcquic/nn/blocks.py:179-200).

@@ -161,6 +161,50 @@ def data_parallel(model: torch.nn.Module, device: torch.device, group=None, **kw
     return ddp
 
 
+def _default_loss(out, x):
+    """The distortion term alone, mean((xHat - x)^2) (mcquic/loss/__init__.py:62), through this library's own reduction."""
+    from .autograd import mse_loss
+    return mse_loss(out[0], x)
+
+
+_MEMSET_NODES_OK = {}
+
+
+def memset_nodes_replay_correctly(device=None, refresh: bool = False) -> bool:
+    """Does THIS process replay the memset nodes of a captured hipGraph correctly?  (ROCm 7.2 does not once eager blit work has
+    run between replays, unless DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was in the environment when the HIP runtime started -- see
+    mcquic_amd/__init__.py.)  The check is the defect's own reproducer at small scale: a captured ATen reduction large enough for
+    its two-stage path (whose semaphores are zeroed by a memset node), replayed over a changing input with 700 small eager
+    reductions + device-to-host copies in between; ~0.1 s, once per process and device.  GraphedTrainStep consults it for a caller-supplied
+    loss function -- the default loss and every kernel of this package are free of memset nodes either way."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index in _MEMSET_NODES_OK and not refresh:
+        return _MEMSET_NODES_OK[dev.index]
+    with torch.no_grad():
+        big = torch.rand(1 << 21, device=dev)
+        small = [torch.ones(1000 + 37 * i, device=dev) for i in range(700)]
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            big.sum()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        mode = dict(capture_error_mode="thread_local") if (dist.is_available() and dist.is_initialized()) else {}
+        with torch.cuda.graph(g, **mode):
+            out = big.sum()
+        ok = True
+        for _ in range(3):
+            big.add_(1.0)
+            g.replay()
+            sum(int(torch.isfinite(t).all()) for t in small)
+            torch.cuda.synchronize(dev)
+            want = float(big.sum())
+            ok = ok and abs(float(out) - want) <= 1e-4 * abs(want)
+    _MEMSET_NODES_OK[dev.index] = ok
+    return ok
+
+
 class GraphedTrainStep:
     """One rank's data-parallel training step (BASELINE configs[4]: `torchrun` + DDP in the reference, mcquic/train/ddp.py:79-95;
     its gradient exchange is overlapped with the backward pass bucket by bucket, mcquic/train/trainer.py:94,105) with the host out
@@ -223,7 +267,13 @@ class GraphedTrainStep:
         if segments == 3 and not staged:
             raise ValueError("segments=3 needs a model with _encoder / _quantizer / _decoder stages and no forward_kwargs but `uniforms`")
         self.segments = segments
-        self.loss_fn = loss_fn or (lambda out, x: torch.nn.functional.mse_loss(out[0], x))
+        if loss_fn is not None and not memset_nodes_replay_correctly(example_x.device):
+            import warnings
+            warnings.warn("this process replays memset nodes of captured hipGraphs wrongly (ROCm 7.2; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not "
+                          "in the environment when the HIP runtime started): a library reduction inside `loss_fn` (x.mean(), x.sum() over "
+                          "~1e5+ elements) may return stale values from a replay.  Import mcquic_amd before the first device call, or set the "
+                          "variable yourself.", RuntimeWarning, stacklevel=2)
+        self.loss_fn = loss_fn or _default_loss
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.coders = [m for m in model.modules() if hasattr(m, "deferCounts")]
         self.closed = False
@@ -240,12 +290,18 @@ class GraphedTrainStep:
         #  being invalidated by what OTHER threads do; the autograd thread's launches are captured either way -- capture follows
         #  the stream, not the thread)
         mode = dict(capture_error_mode="thread_local") if (dist.is_available() and dist.is_initialized()) else {}
+        # warm-up and capture share ONE side stream: autograd's gradient accumulators remember the stream they were created on, and
+        # a capture on another stream would pull that one (the legacy default stream, if the warm-up ran there) into the graph
+        self._stream = torch.cuda.Stream(self.x.device)
+        self._stream.wait_stream(torch.cuda.current_stream(self.x.device))
         try:
             ops.section_trace(True)                          # which copy of its operand stream every conv launch of the step reads
             try:
-                for _ in range(max(1, warmup)):              # caches, workspaces, the coders' count sinks
-                    for k in range(self.segments):
-                        self._segment(k)
+                with torch.cuda.stream(self._stream):
+                    for _ in range(max(1, warmup)):          # caches, workspaces, the coders' count sinks
+                        for k in range(self.segments):
+                            self._segment(k)
+                torch.cuda.current_stream(self.x.device).wait_stream(self._stream)
             finally:
                 ops.section_trace(False)
             masks, pinned = {}, []
@@ -278,7 +334,7 @@ class GraphedTrainStep:
             self.counts = None
             for k in range(self.segments):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, **mode):
+                with torch.cuda.graph(g, pool=pool, stream=self._stream, **mode):
                     self._segment(k)
                     if self.live_groups[k]:
                         torch.cat([p.grad.reshape(-1) for p in self.live_groups[k]], out=self.slices[k])
@@ -305,7 +361,7 @@ class GraphedTrainStep:
             before = self._snapshot_optimizer_state()
             try:
                 post = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(post, **mode):
+                with torch.cuda.graph(post, stream=self._stream, **mode):
                     self._post()
                 self.post = post
             except Exception:                                # an optimizer that cannot be captured: its update runs eagerly

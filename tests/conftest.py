@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# (read once when the HIP runtime starts -- mcquic_amd/__init__.py explains; set here because a test may touch the device first)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

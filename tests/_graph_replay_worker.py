@@ -60,6 +60,23 @@ def main():
     out["losses"] = losses
     out["non_finite_tensors_per_step"] = bad
     step.close()
+
+    # (3) the inference graphs (enableGraphs: what batch-1 serving replays) with the same eager work between replays
+    model.eval()
+    xs = [(torch.rand((1, 3, 256, 384), generator=torch.Generator().manual_seed(40 + i)) * 2 - 1).to(dev) for i in range(4)]
+    want = []
+    for xi in xs:
+        codes = model.encode(xi)
+        want.append(([c.clone() for c in codes], model.decode(codes).clone()))
+    model.enableGraphs(True)
+    same = []
+    for rnd in range(2):
+        for xi, (wc, wr) in zip(xs, want):
+            codes = model.encode(xi)
+            rec = model.decode(codes)
+            sum(int(not torch.isfinite(p).all()) for p in model.parameters())
+            same.append(all(torch.equal(a, b) for a, b in zip(codes, wc)) and torch.equal(rec, wr))
+    out["inference_graph_replays_equal_eager"] = same
     print(json.dumps(out), flush=True)
 
 

@@ -37,6 +37,7 @@ def test_step_survives_eager_work_on_both_launch_paths(both):
         assert r["non_finite_tensors_per_step"] == [0] * 6, r
         assert r["replay_vs_first_worst_relative"] <= 1e-4, r          # (measured ~1e-6: two atomic addends in either order)
         assert len(set(r["losses"])) == 6, f"a replay returned an earlier replay's loss: {r['losses']}"
+        assert r["inference_graph_replays_equal_eager"] == [True] * 8, r
     on, off = both
     for a, b in zip(on["losses"], off["losses"]):
         assert abs(a - b) <= 2e-6 * abs(b), (on["losses"], off["losses"])

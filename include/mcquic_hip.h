@@ -323,6 +323,12 @@ int mcq_add3_f32(const float* a, const float* b, const float* c, float* out, int
 size_t mcq_mse_workspace_bytes(int64_t n);
 int mcq_mse_f32(const float* a, const float* b, float* out, void* workspace, int64_t n, void* stream);
 int mcq_mse_bwd_f32(const float* a, const float* b, const float* dloss, float* da, float* db /* or NULL */, int64_t n, void* stream);
+/* Gradient clipping by global norm over ONE flat buffer (mcquic/train/trainer.py:280 `self._optimizer.clip_grad_norm(4.0)`;
+ * torch.nn.utils.clip_grad_norm_'s arithmetic): out[0] = sum(x^2) with the reduction above (workspace: mcq_mse_workspace_bytes(n)),
+ * then x *= max_norm / (sqrt(sumsq) + eps) where that factor is < 1; the norm goes to norm_out[0] when non-NULL.  Everything
+ * stays on the device: no host read between the two launches, so both are captured with the optimizer's update. */
+int mcq_sumsq_f32(const float* x, float* out, void* workspace, int64_t n, void* stream);
+int mcq_clip_by_norm_f32(float* x, const float* sumsq, float max_norm, float eps, float* norm_out /* or NULL */, int64_t n, void* stream);
 
 /* u8 = trunc(clamp(((x + 1) / 2) * 255.999, 0, 255))   (mcquic/utils/vision.py:143-146 DeTransform). */
 int mcq_detransform_u8(const float* x, uint8_t* out, int64_t n, void* stream);

@@ -108,6 +108,8 @@ SYMBOLS = {
     "mcq_mse_workspace_bytes": (c_size_t, [c_int64]),
     "mcq_mse_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_mse_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_sumsq_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_clip_by_norm_f32": (c_int32, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
     "mcq_detransform_u8": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_pmf_to_quantized_cdf": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
     "mcq_rans_encode_with_indexes": (c_int64, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,

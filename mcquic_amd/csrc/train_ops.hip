@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restric
     __shared__ double red[256];
     double s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float d = a[i] - b[i];
+        const float d = b ? a[i] - b[i] : a[i];
         s += (double)(d * d);
     }
     red[threadIdx.x] = s;
@@ -396,6 +396,16 @@ __global__ __launch_bounds__(256) void mse_finish_kernel(const double* __restric
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = (float)(red[0] * inv_n);
+}
+
+// x *= min(1, max_norm / (sqrt(sumsq) + eps)): torch.nn.utils.clip_grad_norm_'s scaling with the norm left on the device
+__global__ __launch_bounds__(256) void clip_by_norm_kernel(float* __restrict__ x, const float* __restrict__ sumsq, float max_norm, float eps,
+                                                           float* __restrict__ norm_out, int64_t n) {
+    const float norm = sqrtf(sumsq[0]);
+    const float coef = max_norm / (norm + eps);
+    if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
+    if (!(coef < 1.0f)) return;                              // (also leaves the gradients alone when the norm is not finite... see below)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= coef;
 }
 
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ dloss,
@@ -587,6 +597,23 @@ extern "C" int mcq_mse_f32(const float* a, const float* b, float* out, void* wor
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(mse_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, a, b, (double*)workspace, n);
     hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, 1.0 / (double)n, out);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_sumsq_f32(const float* x, float* out, void* workspace, int64_t n, void* stream) {
+    if (!x || !out || !workspace || n <= 0) return MCQ_EINVAL;
+    const int nb = mse_blocks(n);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, (const float*)nullptr, (double*)workspace, n);
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, 1.0, out);
+    return mcq_check_launch();
+}
+
+extern "C" int mcq_clip_by_norm_f32(float* x, const float* sumsq, float max_norm, float eps, float* norm_out, int64_t n, void* stream) {
+    if (!x || !sumsq || n <= 0 || !(max_norm > 0.0f) || !(eps >= 0.0f)) return MCQ_EINVAL;
+    const int64_t want = (n + 1023) / 1024;
+    hipLaunchKernelGGL(clip_by_norm_kernel, dim3((unsigned)(want < 1 ? 1 : want > 4096 ? 4096 : want)), dim3(256), 0, (hipStream_t)stream, x, sumsq,
+                       max_norm, eps, norm_out, n);
     return mcq_check_launch();
 }
 

@@ -727,6 +727,31 @@ def mse_bwd(a: torch.Tensor, b: torch.Tensor, dloss: torch.Tensor, want_db: bool
     return da, db
 
 
+def sumsq(x: torch.Tensor) -> torch.Tensor:
+    """sum(x^2) as a 0-dim float32 tensor (mcq_sumsq_f32: double partials, fixed order, no memset)."""
+    x = _dev(x, "x")
+    lib = _lib.load()
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.mcq_mse_workspace_bytes(x.numel()) // 8, dtype=torch.float64, device=x.device)
+    with _guard(x.device):
+        check(lib.mcq_sumsq_f32(_ptr(x), _ptr(out), _ptr(ws), x.numel(), _stream()), "mcq_sumsq_f32")
+    return out
+
+
+def clip_by_norm_(x: torch.Tensor, max_norm: float, eps: float = 1e-6) -> torch.Tensor:
+    """In place: x *= max_norm / (||x|| + eps) where that is < 1 (torch.nn.utils.clip_grad_norm_ over one flat buffer; the reference's
+    trainer.py:280).  Returns ||x|| BEFORE clipping as a 0-dim device tensor; no host read, so it can be captured."""
+    x = _dev(x, "x")
+    if not x.is_contiguous():
+        raise ValueError("clip_by_norm_: needs a contiguous buffer (it is scaled in place)")
+    sq = sumsq(x)
+    norm = torch.empty((), dtype=torch.float32, device=x.device)
+    with _guard(x.device):
+        check(_lib.load().mcq_clip_by_norm_f32(_ptr(x), _ptr(sq), float(max_norm), float(eps), _ptr(norm), x.numel(), _stream()),
+              "mcq_clip_by_norm_f32")
+    return norm
+
+
 def group_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], groups: int, eps: float = 1e-5,
                dual_silu: bool = False, want_stats: bool = False):
     """nn.GroupNorm(groups, C) on [n, C, h, w] (mcq_group_norm_f32; `denseNorm=True`, mcquic/nn/blocks.py:179-200).

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void clip_by_norm_kernel(float* __restrict__ x
     const float norm = sqrtf(sumsq[0]);
     const float coef = max_norm / (norm + eps);
     if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
-    if (!(coef < 1.0f)) return;                              // (also leaves the gradients alone when the norm is not finite... see below)
+    if (!(coef < 1.0f)) return;                              // (a NaN norm compares false: the gradients are left as they are)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= coef;
 }
 

@@ -248,11 +248,14 @@ class GraphedTrainStep:
     A captured update bakes in whatever the optimizer read on the host at capture time: give a scheduled learning rate to the
     optimizer as a TENSOR (torch.optim reads it on the device then; Adam / AdamW additionally need `capturable=True`), or pass
     `capture_post=False` and the update (with the EMA) runs eagerly after the exchange -- ~15 launches, still no per-layer host work.
+    `max_grad_norm` clips the averaged gradient by its global norm in front of the update (the reference's step does,
+    mcquic/train/trainer.py:280; torch.nn.utils.clip_grad_norm_'s arithmetic over the flat buffer, on the device); the norm before
+    clipping is `step.grad_norm` (a 0-dim device tensor, valid after each call).
     """
 
     def __init__(self, model: torch.nn.Module, optimizer, example_x: torch.Tensor, loss_fn=None, group=None,
                  forward_kwargs: dict | None = None, warmup: int = 2, capture_post: bool = True, segments: int | None = None,
-                 broadcast: bool = True):
+                 broadcast: bool = True, max_grad_norm: float | None = None):
         if not example_x.is_cuda:
             raise RuntimeError("GraphedTrainStep needs a HIP device (hipGraph capture)")
         self.model, self.optimizer, self.group = model, optimizer, group
@@ -267,6 +270,10 @@ class GraphedTrainStep:
         if segments == 3 and not staged:
             raise ValueError("segments=3 needs a model with _encoder / _quantizer / _decoder stages and no forward_kwargs but `uniforms`")
         self.segments = segments
+        if max_grad_norm is not None and not max_grad_norm > 0:
+            raise ValueError("max_grad_norm must be positive (or None: no clipping)")
+        self.max_grad_norm = max_grad_norm
+        self.grad_norm = None                                 # 0-dim device tensor: the global gradient norm of the last step, before clipping
         if loss_fn is not None and not memset_nodes_replay_correctly(example_x.device):
             import warnings
             warnings.warn("this process replays memset nodes of captured hipGraphs wrongly (ROCm 7.2; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not "
@@ -480,6 +487,9 @@ class GraphedTrainStep:
     def _post(self):
         if self.world > 1:
             self.flat.mul_(1.0 / self.world)
+        if self.max_grad_norm is not None:                    # trainer.py:280 `clip_grad_norm(4.0)`: global norm of the AVERAGED gradient,
+            from . import ops                                 # two launches over the flat buffer, nothing read by the host
+            self.grad_norm = ops.clip_by_norm_(self.flat, self.max_grad_norm)
         self.optimizer.step()
         off = 0
         for c in self.coders:

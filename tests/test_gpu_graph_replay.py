@@ -64,7 +64,7 @@ def test_mse_matches_torch(dev):
         want = torch.nn.functional.mse_loss(a2, b2)
         got = mse_loss(a, b)
         assert got.shape == () and got.dtype == torch.float32
-        assert abs(float(got) - float(want)) <= 2e-7 * float(want) + 1e-12
+        assert abs(float(got.detach()) - float(want.detach())) <= 2e-7 * float(want.detach()) + 1e-12
         (got * 3.0).backward()
         (want * 3.0).backward()
         assert float((a.grad.double() - a2.grad).abs().max()) <= 1e-6 * float(a2.grad.abs().max())

@@ -225,3 +225,64 @@ def test_no_autograd_graph_outlives_an_iteration(dev):
         alive = [(tuple(o.shape), type(o.grad_fn).__name__) for o in gc.get_objects()
                  if isinstance(o, torch.Tensor) and o.grad_fn is not None and id(o) not in earlier]
         assert not alive, (type(model).__name__, alive[:8])
+
+
+@pytest.mark.parametrize("cfg", [(32, [64, 32, 16], 64), (128, [8192, 2048, 512], 128)])
+@pytest.mark.parametrize("clips", [True, False])
+def test_graphed_step_clips_like_clip_grad_norm(dev, cfg, clips):
+    """The reference's step clips the gradient by its global norm before the update (mcquic/train/trainer.py:280): the graphed
+    step's `max_grad_norm` against torch.nn.utils.clip_grad_norm_ in an eager loop -- same norms, same parameters afterwards --
+    with a bound that bites (a third of the first step's norm) and one that never does."""
+    from mcquic_amd import Compressor, parallel
+    ch, ks, hw = cfg
+    n, steps, lr = 2, 3, 1e-2
+    torch.manual_seed(11)
+    eager = Compressor(ch, 2, ks).to(dev).train()
+    graphed = copy.deepcopy(eager)
+    xs = [(torch.rand((n, 3, hw, hw), generator=torch.Generator().manual_seed(60 + i)) * 2 - 1).to(dev) for i in range(steps)]
+    us = _uniforms(n, hw, ks, dev, 12)
+    # the first step's norm sets the bound
+    torch.nn.functional.mse_loss(eager(xs[0], uniforms=us)[0], xs[0]).backward()
+    first = float(torch.nn.utils.clip_grad_norm_(eager.parameters(), 1e9))
+    eager = copy.deepcopy(graphed)
+    bound = first / 3 if clips else first * 100
+    opt_e = torch.optim.SGD(eager.parameters(), lr=lr)
+    norms_e = []
+    for x in xs:
+        opt_e.zero_grad(set_to_none=True)
+        torch.nn.functional.mse_loss(eager(x, uniforms=us)[0], x).backward()
+        norms_e.append(float(torch.nn.utils.clip_grad_norm_(eager.parameters(), bound)))
+        opt_e.step()
+    step = parallel.GraphedTrainStep(graphed, torch.optim.SGD(graphed.parameters(), lr=lr), xs[0], forward_kwargs={"uniforms": us},
+                                     max_grad_norm=bound)
+    assert step.post is not None
+    norms_g = []
+    for x in xs:
+        step(x)
+        norms_g.append(float(step.grad_norm))
+    step.close()
+    assert abs(norms_e[0] - first) <= 1e-5 * first
+    for a, b in zip(norms_e, norms_g):
+        assert abs(a - b) <= 2e-5 * a, (norms_e, norms_g)
+    for (name, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
+        scale = max(float(pe.detach().abs().max()), 1e-12)
+        assert float((pe.detach() - pg.detach()).abs().max()) <= 4e-6 * scale, name
+    with pytest.raises(ValueError):
+        parallel.GraphedTrainStep(graphed, torch.optim.SGD(graphed.parameters(), lr=lr), xs[0], max_grad_norm=0.0)
+
+
+def test_sumsq_and_clip_by_norm(dev):
+    from mcquic_amd import ops
+    for n in (1, 300, 65537, 50558738):
+        x = torch.randn(n, generator=torch.Generator().manual_seed(n % 1000)).to(dev)
+        want = float(x.double().pow(2).sum())
+        assert abs(float(ops.sumsq(x)) - want) <= 3e-7 * want
+        norm = want ** 0.5
+        y = x.clone()
+        got = ops.clip_by_norm_(y, norm / 2)
+        assert abs(float(got) - norm) <= 3e-7 * norm
+        ref = x * ((norm / 2) / (norm + 1e-6))
+        assert float((y - ref).abs().max()) <= 2e-7 * float(ref.abs().max()) + 1e-30
+        z = x.clone()
+        ops.clip_by_norm_(z, norm * 2)
+        assert torch.equal(z, x)                                              # a bound above the norm leaves the buffer alone

@@ -330,6 +330,18 @@ int mcq_mse_bwd_f32(const float* a, const float* b, const float* dloss, float* d
 int mcq_sumsq_f32(const float* x, float* out, void* workspace, int64_t n, void* stream);
 int mcq_clip_by_norm_f32(float* x, const float* sumsq, float max_norm, float eps, float* norm_out /* or NULL */, int64_t n, void* stream);
 
+/* Adam / AdamW over a whole model in ONE launch (the `self._optimizer.step()` of mcquic/train/trainer.py:283 with the reference's
+ * `Adam`, configs/a800_8.yaml:20-25; arithmetic of torch.optim.Adam / AdamW: lerp of exp_avg, mul + addcmul of exp_avg_sq, bias
+ * corrections from the step count, param -= lr / bc1 * exp_avg / (sqrt(exp_avg_sq) / sqrt(bc2) + eps); L2 or decoupled decay).
+ * All lists are DEVICE arrays: ptr_tables = uint64[4][ntensors] (param, grad, exp_avg, exp_avg_sq addresses), numel[ntensors],
+ * and one (blk_tensor, blk_first) entry per mcq_adam_chunk()-element chunk of every tensor (nblocks entries).  `step` is a device
+ * float the call increments; `lr_dev` (device float) overrides `lr` when non-NULL, so a scheduled rate needs no re-capture;
+ * `scalars` = 16 bytes of device scratch.  Two launches, nothing read by the host. */
+int32_t mcq_adam_chunk(void);
+int mcq_adam_step_f32(const void* ptr_tables, int32_t ntensors, const int64_t* numel, const int32_t* blk_tensor, const int64_t* blk_first,
+                      int32_t nblocks, float* step, const float* lr_dev /* or NULL */, double lr, double beta1, double beta2, double eps,
+                      double weight_decay, int32_t decoupled, int32_t maximize, void* scalars, void* stream);
+
 /* u8 = trunc(clamp(((x + 1) / 2) * 255.999, 0, 255))   (mcquic/utils/vision.py:143-146 DeTransform). */
 int mcq_detransform_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 

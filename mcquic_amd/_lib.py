@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCQUIC_AMD_LIB") or os.path.join(HERE, "libmcquic_hip.so")   # override: kernel A/B experiments
@@ -108,6 +108,9 @@ SYMBOLS = {
     "mcq_mse_workspace_bytes": (c_size_t, [c_int64]),
     "mcq_mse_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_mse_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_adam_chunk": (c_int32, []),
+    "mcq_adam_step_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
+                                    c_double, c_int32, c_int32, c_void_p, c_void_p]),
     "mcq_sumsq_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_clip_by_norm_f32": (c_int32, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
     "mcq_detransform_u8": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),

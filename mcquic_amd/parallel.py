@@ -364,6 +364,8 @@ class GraphedTrainStep:
             p.grad = self.flat[off: off + p.numel()].view_as(p)
             off += p.numel()
         self.post = None
+        if hasattr(self.optimizer, "prepare"):                # (mcquic_amd.optim.Adam: device tables for the flat gradient views, built
+            self.optimizer.prepare()                          #  outside the capture)
         if capture_post:
             before = self._snapshot_optimizer_state()
             try:

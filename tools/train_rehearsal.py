@@ -51,7 +51,8 @@ def main():
     ap.add_argument("--every", type=int, default=100, help="validation + finiteness check + codebook re-assignment period")
     ap.add_argument("--warmup", type=int, default=0, help="linear learning-rate warm-up over this many steps (the reference: 2000, configs/a800_8.yaml); "
                                                           "the rate is a device tensor the captured update reads, refilled by the host every step")
-    ap.add_argument("--fused", action="store_true", help="torch.optim.Adam(fused=True): the update as one multi-tensor kernel")
+    ap.add_argument("--fused", action="store_true", help="torch.optim.Adam(fused=True): torch's multi-tensor kernel (19 launches for this model)")
+    ap.add_argument("--own-adam", action="store_true", help="mcquic_amd.optim.Adam: the whole model in one launch")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     from mcquic_amd import Compressor, parallel
@@ -62,7 +63,11 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1)
     val = images(4, args.crop, torch.Generator(device=dev).manual_seed(99), dev)
     lr = torch.tensor(args.lr, device=dev)
-    opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True, **({"fused": True} if args.fused else {}))
+    if args.own_adam:
+        from mcquic_amd import optim
+        opt = optim.Adam(model.parameters(), lr=lr)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True, **({"fused": True} if args.fused else {}))
     x = images(args.batch, args.crop, gen, dev)
     step = parallel.GraphedTrainStep(model, opt, x, max_grad_norm=4.0)
     trace = {"loss": [], "grad_norm": [], "psnr": [], "reassigned": [], "non_finite": 0}
@@ -98,9 +103,9 @@ def main():
     step.close()
     first = sum(v for _, v in trace["loss"][:3]) / 3
     last = sum(v for _, v in trace["loss"][-3:]) / 3
-    out = {"what": "GraphedTrainStep(Adam capturable, lr tensor, max_grad_norm=4.0) on fresh synthetic batches; loss.item() every step; every "
+    out = {"what": "GraphedTrainStep(Adam, lr in a device tensor, max_grad_norm=4.0) on fresh synthetic batches; loss.item() every step; every "
                    f"{args.every} steps: finiteness of all parameters, eager encode/decode PSNR on 4 held-out images, codebook re-assignment every {2 * args.every}",
-           "model": f"Compressor({args.channel}, 2, {ks})", "lr": args.lr, "lr_warmup_steps": args.warmup, "fused_adam": bool(args.fused), "post_captured": step.post is not None, "batch": args.batch, "crop": args.crop, "steps": args.steps,
+           "model": f"Compressor({args.channel}, 2, {ks})", "lr": args.lr, "lr_warmup_steps": args.warmup, "optimizer": "mcquic_amd.optim.Adam" if args.own_adam else ("torch Adam fused" if args.fused else "torch Adam foreach"), "post_captured": step.post is not None, "batch": args.batch, "crop": args.crop, "steps": args.steps,
            "ms_per_step": round(t_steps / args.steps * 1e3, 3), "loss_first": round(first, 6), "loss_last": round(last, 6),
            "psnr_first": trace["psnr"][0][1], "psnr_last": trace["psnr"][-1][1], "memset_nodes_ok": parallel.memset_nodes_replay_correctly(dev), **trace}
     line = json.dumps(out)

@@ -402,11 +402,13 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
         tm = Compressor(**MODEL).to(dev).train()
         xt = (torch.rand((8, 3, 256, 256), generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
 
+        from mcquic_amd.autograd import mse_loss
+
         def train_step():
             for p in tm.parameters():
                 p.grad = None
             xHat, _, _, _ = tm(xt)
-            loss = torch.nn.functional.mse_loss(xHat, xt)
+            loss = mse_loss(xHat, xt)                          # (this library's reduction: no memset node inside the captured step)
             loss.backward()
             return loss
         for _ in range(2):
@@ -417,7 +419,7 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             xHat, _, _, _ = tm(xt)
-            static_loss = torch.nn.functional.mse_loss(xHat, xt)
+            static_loss = mse_loss(xHat, xt)
             static_loss.backward()
         ms = _timed(graph.replay, 10, warmup=1)
         flops = 3.0 * 536.63e9 * 8 * (256 * 256) / (768 * 512)      # forward + input gradients + weight gradients
@@ -439,7 +441,7 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
             graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph2):
                 xHat, _, _, _ = tm(xt)
-                torch.nn.functional.mse_loss(xHat, xt).backward()
+                mse_loss(xHat, xt).backward()
                 opt.step()
             ms2 = _timed(graph2.replay, 10, warmup=1)
             sec["train_step"]["ms_with_sgd"] = round(ms2, 3)
@@ -461,6 +463,19 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
         except Exception as exc:                              # noqa: BLE001
             sec["train_step"]["ms_graphed_data_parallel"] = None
             sec["train_step"]["graphed_error"] = repr(exc)[:200]
+        # ... and the reference's own step (mcquic/train/trainer.py:270-283, configs/a800_8.yaml): Adam, gradient clipping by
+        # global norm 4.0, the rate in a device tensor -- mcquic_amd.optim.Adam updates the whole model in one launch
+        try:
+            from mcquic_amd import optim, parallel
+            gstep = parallel.GraphedTrainStep(tm, optim.Adam(tm.parameters(), lr=torch.tensor(1e-6, device=dev)), xt, max_grad_norm=4.0)
+            ms4 = _timed(lambda: gstep(xt), 10, warmup=2)
+            sec["train_step"]["ms_graphed_adam_clip"] = round(ms4, 3)
+            sec["train_step"]["grad_norm"] = round(float(gstep.grad_norm), 6)
+            gstep.close()
+            del gstep
+        except Exception as exc:                              # noqa: BLE001
+            sec["train_step"]["ms_graphed_adam_clip"] = None
+            sec["train_step"]["adam_error"] = repr(exc)[:200]
         del tm
     except Exception as exc:                                  # noqa: BLE001
         sec["train_step"] = {"error": repr(exc)[:300]}

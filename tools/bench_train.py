@@ -73,6 +73,7 @@ def main():
         if launch.rccl_check(dist, dev) != world:
             raise SystemExit("bench_train.py: RCCL does not span the requested ranks")
     from mcquic_amd import Compressor
+    from mcquic_amd.autograd import mse_loss
     torch.manual_seed(3407)
     model = Compressor(128, 2, [8192, 2048, 512]).to(dev).train()
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if use_dist and not args.graphed else model
@@ -84,7 +85,7 @@ def main():
         for p in model.parameters():
             p.grad = None
         xHat, yHat, codes, logits = net(x)
-        loss = torch.nn.functional.mse_loss(xHat, x)       # loss glue is the trainer's business (out of scope): plain MSE
+        loss = mse_loss(xHat, x)                            # plain MSE through this library's reduction (no memset node in a capture)
         loss.backward()
         if opt is not None:
             opt.step()
@@ -107,7 +108,7 @@ def main():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             xHat, yHat, codes, logits = net(x)
-            static_loss = torch.nn.functional.mse_loss(xHat, x)
+            static_loss = mse_loss(xHat, x)
             static_loss.backward()
             if opt is not None:
                 opt.step()                                 # (the update itself is part of the captured step; the forward above

@@ -115,9 +115,10 @@ def train_mode(rank, world, dev):
     return out
 
 
-def graphed_mode(rank, world, dev):
+def graphed_mode(rank, world, dev, clip=None):
     """parallel.GraphedTrainStep over the two ranks (2 crops each; main graph, flat gradient all-reduce + count all-reduce staged
-    through the host under gloo, post graph) against ONE process making the same SGD update on all 4 crops."""
+    through the host under gloo, post graph) against ONE process making the same SGD update on all 4 crops.  `clip`: both sides
+    clip by that global norm first (the graphed step: the norm of the AVERAGED gradient, inside its captured update)."""
     import copy
     from mcquic_amd import Compressor, parallel
     ks = [8192, 2048, 512]
@@ -142,6 +143,8 @@ def graphed_mode(rank, world, dev):
             opt = torch.optim.SGD(solo_model.parameters(), lr=lr)
             xHat = solo_model(x, uniforms=us)[0]
             torch.nn.functional.mse_loss(xHat, x).backward()
+            if clip is not None:
+                out["solo_grad_norm"] = float(torch.nn.utils.clip_grad_norm_(solo_model.parameters(), clip))
             opt.step()
         finally:
             P.code_histograms = orig
@@ -158,8 +161,10 @@ def graphed_mode(rank, world, dev):
             for p in model.parameters():
                 p.add_(0.01)
     step = parallel.GraphedTrainStep(model, torch.optim.SGD(model.parameters(), lr=lr), x[lo:hi],
-                                     forward_kwargs={"uniforms": [(a[lo:hi], b[lo:hi]) for a, b in us]})
+                                     forward_kwargs={"uniforms": [(a[lo:hi], b[lo:hi]) for a, b in us]}, max_grad_norm=clip)
     loss = step(x[lo:hi])
+    if clip is not None and rank == 0:
+        out["grad_norm"] = float(step.grad_norm)
     step.close()
     torch.cuda.synchronize()
     if rank == 0:
@@ -201,7 +206,8 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)                                       # BOTH ranks on the one GPU
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    out = {"validate": validate_mode, "train": train_mode, "graphed": graphed_mode}[mode](rank, world, dev)
+    out = {"validate": validate_mode, "train": train_mode, "graphed": graphed_mode,
+           "graphed_clip": lambda r, w, d: graphed_mode(r, w, d, clip=5e-3)}[mode](rank, world, dev)
     torch.cuda.synchronize()
     dist.barrier()
     if rank == 0:

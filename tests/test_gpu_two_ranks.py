@@ -66,3 +66,14 @@ def test_two_rank_graphed_step_matches_one_process(dev, tmp_path):
     assert r["largest_update"] > 0, r
     assert r["worst_update_rel_err"] < 1.0, r        # (in units of 1e-4 x the update + 4 ulps of the parameter)
     assert r["ema_max_abs_diff"] < 1e-7, r
+
+
+def test_two_rank_graphed_step_clips_the_averaged_gradient(dev, tmp_path):
+    """The same with `max_grad_norm` (the reference's step clips, mcquic/train/trainer.py:280): the norm the two ranks see is the
+    norm of the gradient of the WHOLE batch, and the clipped update equals one process's clip_grad_norm_ + SGD."""
+    r = _run("graphed_clip", tmp_path)
+    assert r["post_captured"], r
+    assert r["solo_grad_norm"] > 5e-3, r                           # (the bound bites)
+    assert abs(r["grad_norm"] - r["solo_grad_norm"]) <= 2e-5 * r["solo_grad_norm"], r
+    assert r["largest_update"] > 0 and r["worst_update_rel_err"] < 1.0, r
+    assert r["ema_max_abs_diff"] < 1e-7, r

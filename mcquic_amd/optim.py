@@ -112,6 +112,8 @@ class Adam(torch.optim.Optimizer):
                     and not g.is_sparse):
                 raise RuntimeError("mcquic_amd.optim.Adam: contiguous float32 parameters and gradients on a HIP device only "
                                    "(there is no CPU path)")
+            if p.device != params[0].device:
+                raise RuntimeError("mcquic_amd.optim.Adam: the parameters of one group must live on one device (one launch per group)")
         return params
 
     @torch.no_grad()

@@ -92,6 +92,18 @@ def test_bench_gpus_must_match_the_launcher(dev):
     assert out.returncode == 2
 
 
+def test_import_turns_packet_recorded_graph_launches_off():
+    """mcquic_amd/__init__.py: ROCm 7.2 replays memset nodes of captured graphs wrongly on its packet-recorded launch path; the
+    import switches that path off unless the caller has chosen (tests/test_gpu_graph_replay.py holds the behaviour itself)."""
+    code = "import os; os.environ.pop('DEBUG_CLR_GRAPH_PACKET_CAPTURE', None); import mcquic_amd; print(os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'])"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "0", out.stderr[-500:]
+    kept = subprocess.run([sys.executable, "-c", code.replace("os.environ.pop('DEBUG_CLR_GRAPH_PACKET_CAPTURE', None)",
+                                                                "os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = '1'")],
+                          capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert kept.returncode == 0 and kept.stdout.strip() == "1", kept.stderr[-500:]
+
+
 def test_import_sets_hw_queue_default():
     out = subprocess.run([sys.executable, "-c", "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import mcquic_amd; "
                           "print(os.environ['GPU_MAX_HW_QUEUES'])"], capture_output=True, text=True, cwd=ROOT, timeout=300)

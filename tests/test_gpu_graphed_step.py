@@ -123,8 +123,9 @@ def test_graphed_step_survives_eager_use_in_between(dev):
         step(xs[0])
 
 
-def test_graphed_step_keeps_a_resumed_optimizer_state(dev):
-    """an optimizer restored from a checkpoint (momentum buffers, Adam moments, step counters) must come out of the
+@pytest.mark.parametrize("own", [False, True])
+def test_graphed_step_keeps_a_resumed_optimizer_state(dev, own):
+    """(`own`: mcquic_amd.optim.Adam resumed from torch.optim.Adam's checkpoint.)  ADVICE r3: an optimizer restored from a checkpoint (momentum buffers, Adam moments, step counters) must come out of the
     constructor with that state -- the throw-away update that creates missing state restores what was there."""
     from mcquic_amd import Compressor, parallel
     ks, hw = [64, 32, 16], 64
@@ -140,6 +141,11 @@ def test_graphed_step_keeps_a_resumed_optimizer_state(dev):
     want = {(i, k): v.detach().clone() for i, (p, st) in enumerate(opt.state.items()) for k, v in st.items() if torch.is_tensor(v)}
     assert want and all(int(st["step"]) == 3 for st in opt.state.values())
     params = [p.detach().clone() for p in model.parameters()]
+    if own:
+        from mcquic_amd import optim
+        sd = opt.state_dict()
+        opt = optim.Adam(model.parameters(), lr=1e-3)
+        opt.load_state_dict(sd)
     step = parallel.GraphedTrainStep(model, opt, x, forward_kwargs={"uniforms": us})
     got = {(i, k): v for i, (p, st) in enumerate(opt.state.items()) for k, v in st.items() if torch.is_tensor(v)}
     assert got.keys() == want.keys()

@@ -87,11 +87,13 @@ def main():
         torch.cuda.synchronize()
         t_steps += time.perf_counter() - t0
         lv = loss.item()                                           # (what a logger does every step)
-        if i % 10 == 0 or i == 1 or os.environ.get("REHEARSAL_TRACE_ALL"):
+        if i % max(10, args.steps // 200) == 0 or i == 1 or os.environ.get("REHEARSAL_TRACE_ALL"):
             trace["loss"].append((i, round(lv, 6)))
             trace["grad_norm"].append((i, round(float(step.grad_norm), 5)))
         if lv != lv:
             trace["non_finite"] += 1
+        if i == args.every:
+            trace["_mem_first"] = round(torch.cuda.memory_allocated(dev) / 2 ** 20, 1)
         if i % args.every == 0:
             trace["non_finite"] += sum(int(not torch.isfinite(p).all()) for p in model.parameters())
             step.invalidate()
@@ -100,6 +102,9 @@ def main():
             model.train()
             if i % (2 * args.every) == 0 and i < args.steps:
                 trace["reassigned"].append((i, round(float(model.reAssignCodebook()), 4)))
+    mem = {"allocated_mb_after_first_period": None, "allocated_mb_at_end": round(torch.cuda.memory_allocated(dev) / 2 ** 20, 1),
+           "peak_allocated_mb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 20, 1), "reserved_mb": round(torch.cuda.memory_reserved(dev) / 2 ** 20, 1)}
+    mem["allocated_mb_after_first_period"] = trace.pop("_mem_first", None)
     step.close()
     first = sum(v for _, v in trace["loss"][:3]) / 3
     last = sum(v for _, v in trace["loss"][-3:]) / 3
@@ -107,7 +112,7 @@ def main():
                    f"{args.every} steps: finiteness of all parameters, eager encode/decode PSNR on 4 held-out images, codebook re-assignment every {2 * args.every}",
            "model": f"Compressor({args.channel}, 2, {ks})", "lr": args.lr, "lr_warmup_steps": args.warmup, "optimizer": "mcquic_amd.optim.Adam" if args.own_adam else ("torch Adam fused" if args.fused else "torch Adam foreach"), "post_captured": step.post is not None, "batch": args.batch, "crop": args.crop, "steps": args.steps,
            "ms_per_step": round(t_steps / args.steps * 1e3, 3), "loss_first": round(first, 6), "loss_last": round(last, 6),
-           "psnr_first": trace["psnr"][0][1], "psnr_last": trace["psnr"][-1][1], "memset_nodes_ok": parallel.memset_nodes_replay_correctly(dev), **trace}
+           "psnr_first": trace["psnr"][0][1], "psnr_last": trace["psnr"][-1][1], "memset_nodes_ok": parallel.memset_nodes_replay_correctly(dev), "memory": mem, **trace}
     line = json.dumps(out)
     print(line)
     if args.out:

@@ -44,6 +44,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--channel", type=int, default=128)
+    ap.add_argument("--m", type=int, default=2, help="codebooks per level (12 with --channel 192: the reference's model No. 12)")
     ap.add_argument("--ks", default="8192,2048,512")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--crop", type=int, default=256)
@@ -59,7 +60,7 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(3407)
     ks = [int(k) for k in args.ks.split(",")]
-    model = Compressor(args.channel, 2, ks).to(dev).train()
+    model = Compressor(args.channel, args.m, ks).to(dev).train()
     gen = torch.Generator(device=dev).manual_seed(1)
     val = images(4, args.crop, torch.Generator(device=dev).manual_seed(99), dev)
     lr = torch.tensor(args.lr, device=dev)
@@ -110,7 +111,7 @@ def main():
     last = sum(v for _, v in trace["loss"][-3:]) / 3
     out = {"what": "GraphedTrainStep(Adam, lr in a device tensor, max_grad_norm=4.0) on fresh synthetic batches; loss.item() every step; every "
                    f"{args.every} steps: finiteness of all parameters, eager encode/decode PSNR on 4 held-out images, codebook re-assignment every {2 * args.every}",
-           "model": f"Compressor({args.channel}, 2, {ks})", "lr": args.lr, "lr_warmup_steps": args.warmup, "optimizer": "mcquic_amd.optim.Adam" if args.own_adam else ("torch Adam fused" if args.fused else "torch Adam foreach"), "post_captured": step.post is not None, "batch": args.batch, "crop": args.crop, "steps": args.steps,
+           "model": f"Compressor({args.channel}, {args.m}, {ks})", "lr": args.lr, "lr_warmup_steps": args.warmup, "optimizer": "mcquic_amd.optim.Adam" if args.own_adam else ("torch Adam fused" if args.fused else "torch Adam foreach"), "post_captured": step.post is not None, "batch": args.batch, "crop": args.crop, "steps": args.steps,
            "ms_per_step": round(t_steps / args.steps * 1e3, 3), "loss_first": round(first, 6), "loss_last": round(last, 6),
            "psnr_first": trace["psnr"][0][1], "psnr_last": trace["psnr"][-1][1], "memset_nodes_ok": parallel.memset_nodes_replay_correctly(dev), "memory": mem, **trace}
     line = json.dumps(out)

@@ -317,3 +317,38 @@ def test_row_band_fallback_equals_the_single_launch(dev):
     for lv, (a, b) in enumerate(zip(codes, banded_codes)):
         assert torch.equal(a, b), f"level {lv}: {(a != b).sum().item()} codes differ between the banded and the single-launch run"
     assert float((rec - banded_rec).abs().max()) <= 2e-6
+
+
+def test_random_geometries_against_the_oracle(dev):
+    """Twenty-four seeded random (batch, height, width) triples -- odd sizes, the smallest sizes reflect padding admits (a side of s
+    pixels is padded to the next multiple of 128, which needs both pads < s: s >= 44), sizes around the 128-pixel padding steps,
+    tall and wide strips -- through two small models against the CPU oracle: codes under the near-tie protocol, pixels within
+    1e-4.  The fixed shapes above pin the tiles the benchmark runs; this sweeps the tails (partial pixel blocks, padding splits,
+    levels smaller than one tile)."""
+    import random
+    rng = random.Random(20260929)
+    edge = [44, 45, 63, 64, 65, 127, 128, 129, 130, 200, 255, 256, 257, 300, 383, 384, 385, 511, 512, 513]
+    total = 0
+    for it in range(24):
+        if it < 10:
+            h, w = rng.choice(edge), rng.choice(edge)
+        else:
+            h, w = rng.randint(44, 520), rng.randint(44, 520)
+        n = rng.choice([1, 1, 2, 3, 5])
+        if it % 2 == 0:
+            mism, _ = _compare(dev, 8, 2, [32, 16, 8], n=n, h=h, w=w, seed=100 + it, pix_tol=1e-4)
+        else:
+            mism, _ = _compare(dev, 16, 4, [64, 16, 8], n=n, h=h, w=w, seed=100 + it, pix_tol=1e-4)
+        total += mism
+    assert total <= 8, f"{total} audited near-tie mismatches over twenty-four geometries"
+
+
+def test_sizes_reflect_padding_cannot_take_are_refused_like_the_reference(dev):
+    """A 300 x 1 image would need 63 + 64 reflected columns from one: F.pad raises in the reference (transforms.py:86-99); same here."""
+    from mcquic_amd import Compressor
+    model = Compressor(8, 2, [32, 16, 8]).eval().to(dev)
+    x = R.make_images(2, 300, 1)
+    with pytest.raises(RuntimeError):
+        R.aligned_padding(x)
+    with pytest.raises(RuntimeError):
+        model.encode(x.to(dev))

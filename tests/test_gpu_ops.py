@@ -689,3 +689,52 @@ def test_conv_row_band_fallback_is_the_single_launch(dev, case):
         assert torch.equal(whole, banded), f"{case} {sorted(opts)}: max diff {(whole - banded).abs().max().item():.3e}"
         if opts.get("dual_silu"):
             assert torch.equal(ops.silu_twin(whole), ops.silu_twin(banded))
+
+
+def test_conv_random_shapes_and_epilogues(dev):
+    """150 seeded random convolutions -- channel counts from 1 to 256 that are no multiple of anything, maps from 1 x 1 to 70 x 70,
+    batches 1..5, 3x3 stride 1 / 2 and 1x1, with and without bias, with the epilogue combinations the network uses (SiLU in,
+    SiLU out, residual + scale, SiLU twin) -- against F.conv2d in float64 on the CPU.  The fixed grids above pin every tile on the
+    network's own shapes; this sweeps the launch heuristics (tile choice, split-K, small-launch kernels, ragged channel tails)."""
+    import random
+    from mcquic_amd import ops
+    rng = random.Random(20260929)
+    chans = [1, 2, 3, 5, 8, 12, 16, 17, 24, 31, 32, 33, 48, 64, 65, 96, 100, 128, 129, 192, 256]
+    for it in range(150):
+        cin, cout = rng.choice(chans), rng.choice(chans)
+        ks = rng.choice([3, 3, 3, 1])
+        stride = rng.choice([1, 1, 2]) if ks == 3 else 1
+        n = rng.randint(1, 5)
+        h, w = rng.randint(1, 70), rng.randint(1, 70)
+        bias = rng.random() < 0.8
+        x = _rand((n, cin, h, w), 1000 + it)
+        wt = _rand((cout, cin, ks, ks), 2000 + it, 1.0 / np.sqrt(cin * ks * ks))
+        b = _rand((cout,), 3000 + it, 0.1) if bias else None
+        opts, xin = {}, x.double()
+        if ks == 3 and rng.random() < 0.4:                    # (the 1x1 instances carry no SiLU prologue: nothing in the network asks for one,
+            opts["silu_in"] = True                             #  and the library refuses it -- checked at the end)
+            xin = F.silu(xin)
+        want = F.conv2d(xin, wt.double(), None if b is None else b.double(), stride=stride, padding=ks // 2)
+        if stride == 1 and rng.random() < 0.4:
+            res = _rand(tuple(want.shape), 4000 + it)
+            scale = rng.choice([1.0, 1.0, 0.5])
+            opts["res"] = res.to(dev)
+            if scale != 1.0:
+                opts["res_scale"] = scale
+            want = want + scale * res.double()
+        twin = rng.random() < 0.3
+        if twin:
+            opts["dual_silu"] = True
+        elif rng.random() < 0.3:
+            opts["silu_out"] = True
+            want = F.silu(want)
+        pk = ops.PackedConv(wt.to(dev), None if b is None else b.to(dev))
+        what = f"#{it} n{n} {cin}->{cout} {h}x{w} k{ks}s{stride} {sorted(opts)}"
+        got = ops.conv2d(x.to(dev), pk, stride, **opts)
+        assert tuple(got.shape) == tuple(want.shape), what
+        tol = 2e-6 if cin * ks * ks <= 1152 else 4e-6
+        _close(got, want.float(), tol, what)
+        if twin:
+            _close(ops.silu_twin(got), F.silu(want).float(), tol, what + " twin")
+    with pytest.raises(RuntimeError, match="MCQ_EINVAL"):
+        ops.conv2d(_rand((1, 8, 4, 4), 1).to(dev), ops.PackedConv(_rand((8, 8, 1, 1), 2).to(dev), None), 1, silu_in=True)

@@ -692,3 +692,43 @@ def test_soft_assignment_with_in_kernel_draws_equals_given_tensors(dev, mk):
     rng2 = ops.rng_snapshot(dev)
     assert int(rng2[1]) == int(rng[1]) + 1
     assert not torch.equal(ops.hash_uniform(rng2, 1, shape), ug)
+
+
+def test_conv_backward_random_shapes(dev):
+    """100 seeded random convolution layers (channel counts 1 ... 256 that divide nothing, maps 1 x 1 ... 48 x 48, batches 1 ... 6,
+    3x3 stride 1 / 2 and 1x1) forward + backward through nn.Conv2d's HIP path against torch.autograd in float64: the fixed cases
+    above pin the network's shapes, this sweeps which weight-gradient / input-gradient kernel a shape is routed to (row walk,
+    few-pixel tiles, NHWC fallback, stride-2 ring, ragged channel tails, grouped plans)."""
+    import random
+    from mcquic_amd.nn import Conv2d
+    rng = random.Random(4)
+    chans = [1, 2, 3, 5, 8, 12, 16, 17, 24, 32, 33, 48, 64, 65, 96, 128, 129, 192, 256]
+    worst = 0.0
+    for it in range(100):
+        cin, cout = rng.choice(chans), rng.choice(chans)
+        ks = rng.choice([3, 3, 3, 1])
+        stride = rng.choice([1, 1, 2]) if ks == 3 else 1
+        n, h, w = rng.randint(1, 6), rng.randint(1, 48), rng.randint(1, 48)
+        if rng.random() < 0.3:                                   # the row-walk kernel's own domain: multiples of 8
+            h, w = 8 * rng.randint(1, 6), 8 * rng.randint(1, 6)
+        x = _rand((n, cin, h, w), 5000 + it)
+        conv = Conv2d(cin, cout, ks, stride)
+        wr, br = conv.weight.detach().double().requires_grad_(), conv.bias.detach().double().requires_grad_()
+        xr = x.double().requires_grad_()
+        y = F.conv2d(xr, wr, br, stride=stride, padding=ks // 2)
+        gy = _rand(tuple(y.shape), 6000 + it)
+        y.backward(gy.double())
+        conv = conv.to(dev).train()
+        xd = x.to(dev).requires_grad_()
+        yd = conv(xd)
+        what = f"#{it} n{n} {cin}->{cout} {h}x{w} k{ks}s{stride}"
+        # float32 sums of K terms against float64: the bars of the fixed cases (K = 1152 products, <= 4096 pixels), widened by
+        # sqrt(K / that) for longer sums
+        grow = lambda terms, base: max(1.0, (terms / base) ** 0.5)                                   # noqa: E731
+        _close(yd, y.detach().float(), 2e-6 * grow(cin * ks * ks, 1152), what + " forward")
+        yd.backward(gy.to(dev))
+        _close(xd.grad, xr.grad.float(), 3e-6 * grow(cout * ks * ks, 1152), what + " dx")
+        _close(conv.weight.grad, wr.grad.float(), 3e-6 * grow(n * h * w, 4096), what + " dW")
+        _close(conv.bias.grad, br.grad.float(), 3e-6 * grow(n * h * w, 4096), what + " db")
+        worst = max(worst, float((conv.weight.grad.cpu() - wr.grad.float()).abs().max()) / max(float(wr.grad.abs().max()), 1e-3))
+    record("conv_backward_random_shapes", worst_dW_relative=worst)

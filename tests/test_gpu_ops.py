@@ -738,3 +738,31 @@ def test_conv_random_shapes_and_epilogues(dev):
             _close(ops.silu_twin(got), F.silu(want).float(), tol, what + " twin")
     with pytest.raises(RuntimeError, match="MCQ_EINVAL"):
         ops.conv2d(_rand((1, 8, 4, 4), 1).to(dev), ops.PackedConv(_rand((8, 8, 1, 1), 2).to(dev), None), 1, silu_in=True)
+
+
+def test_vq_assign_and_gather_random_shapes(dev):
+    """80 seeded random (codebooks, codewords, vector length, batch, map) shapes -- k from 2 to 8192 that is no multiple of the
+    128-codeword tile, d from 1 to 256 including odd lengths, maps from 1 x 1 up, launches that range their codewords and launches
+    that do not -- against the oracle's distances (near-tie audit at 2e-6, like the fixed shapes), and the gather bit-equal."""
+    import random
+    from mcquic_amd import ops
+    rng = random.Random(7)
+    flips = 0
+    for it in range(80):
+        m = rng.choice([1, 1, 2, 2, 3, 4, 6, 12])
+        k = rng.choice([2, 3, 8, 31, 32, 100, 128, 129, 200, 512, 1000, 2048, 4096, 5000, 8192])
+        d = rng.choice([1, 2, 4, 5, 8, 16, 24, 64, 64, 100, 256])
+        n, h, w = rng.randint(1, 4), rng.randint(1, 20), rng.randint(1, 20)
+        if m * k * d > 4e6 or n * h * w * m * k > 6e7:             # (keeps the oracle's [n, m, h, w, k] tensor small)
+            k = min(k, 512)
+        x, cb = _vq_case(m, k, d, n, h, w, 7000 + it)
+        pk = ops.PackedCodebook(cb.to(dev))
+        got = ops.vq_assign(x.to(dev), pk)
+        what = f"#{it} m{m} k{k} d{d} n{n} {h}x{w}"
+        assert got.dtype == torch.int64 and tuple(got.shape) == (n, m, h, w), what
+        assert int(got.min()) >= 0 and int(got.max()) < k, what
+        flips += _audit_codes(got, x, cb, 2e-6, what)
+        out = ops.vq_gather(got, pk).cpu()
+        want = torch.stack([cb[g][got.cpu()[:, g]] for g in range(m)], 1)                  # [n, m, h, w, d]
+        assert torch.equal(out, want.permute(0, 1, 4, 2, 3).reshape(n, m * d, h, w)), what
+    assert flips <= 8, f"{flips} audited near-tie flips over 80 shapes"

@@ -732,3 +732,46 @@ def test_conv_backward_random_shapes(dev):
         _close(conv.bias.grad, br.grad.float(), 3e-6 * grow(n * h * w, 4096), what + " db")
         worst = max(worst, float((conv.weight.grad.cpu() - wr.grad.float()).abs().max()) / max(float(wr.grad.abs().max()), 1e-3))
     record("conv_backward_random_shapes", worst_dW_relative=worst)
+
+
+def test_soft_assignment_backward_random_shapes(dev):
+    """40 seeded random (batch, codebooks, vector length, map, codewords) shapes through mcq_vq_soft_bwd_f32 against the two
+    contractions in float64: which of the MFMA / tiled / lane-per-channel forms takes a shape depends on d, k, the map and the row
+    count (csrc/vq_bwd_mfma.hip: mcq_vq_dc_mfma_ok / mcq_vq_dx_mfma_ok) -- the fixed cases pin one shape per form, this sweeps
+    their borders."""
+    import random
+    import numpy as np
+    from mcquic_amd import ops
+    rng = random.Random(11)
+    for it in range(40):
+        m = rng.choice([1, 2, 2, 3, 12])
+        d = rng.choice([1, 4, 5, 8, 16, 24, 40, 64, 64])
+        k = rng.choice([8, 32, 48, 100, 128, 256, 512, 1024, 2048])
+        n, h, w = rng.randint(1, 8), rng.randint(1, 16), rng.randint(1, 16)
+        if rng.random() < 0.4:
+            h, w = rng.choice([2, 4, 8, 16]), rng.choice([2, 4, 8, 16])
+        if n * m * h * w * k > 6e6:
+            n = 1
+        hw = h * w
+        ddist = _rand((n, m, h, w, k), 8000 + it, 1e-3)
+        x = _rand((n, m * d, h, w), 8100 + it)
+        ddeq = _rand((n, m * d, h, w), 8200 + it)
+        cb = _rand((m, k, d), 8300 + it)
+        index = torch.randint(0, k, (n, m, h, w), generator=torch.Generator().manual_seed(8400 + it))
+        hot = 1.0 + _rand((n, m, h, w), 8500 + it, 1e-3)
+        rowsum = ddist.double().sum(-1).float()
+        dd = ddist.double().numpy().reshape(n, m, hw, k)
+        xx = x.double().numpy().reshape(n, m, d, hw)
+        dq = ddeq.double().numpy().reshape(n, m, d, hw)
+        cc = cb.double().numpy()
+        want_dx = 2 * xx * rowsum.double().numpy().reshape(n, m, 1, hw) - 2 * np.einsum("ngvk,gkj->ngjv", dd, cc)
+        want_dc = 2 * cc * dd.sum((0, 2))[:, :, None] - 2 * np.einsum("ngvk,ngjv->gkj", dd, xx)
+        idx, hv = index.numpy().reshape(n, m, hw), hot.double().numpy().reshape(n, m, hw)
+        for a in range(n):
+            for b in range(m):
+                np.add.at(want_dc[b], idx[a, b], (hv[a, b][None, :] * dq[a, b]).T)
+        pk = ops.PackedCodebook(cb.to(dev))
+        dx, dcb = ops.vq_soft_bwd(ddist.to(dev), rowsum.to(dev), x.to(dev), ddeq.to(dev), index.to(dev), hot.to(dev), pk)
+        what = f"#{it} n{n} m{m} d{d} {h}x{w} k{k}"
+        _close(dx, torch.from_numpy(want_dx.reshape(n, m * d, h, w)).float(), 2e-6, "dx " + what)
+        _close(dcb, torch.from_numpy(want_dc).float(), 3e-6, "dcodebook " + what)

@@ -137,3 +137,52 @@ def test_training_forward_draws_its_own_uniforms(dev):
     assert [tuple(l.shape) for l in logits] == [(2, m, 8, 8, 32), (2, m, 4, 4, 16), (2, m, 2, 2, 8)]
     assert all(torch.isfinite(t).all() for t in (xHat, yHat))
     assert xHat.requires_grad
+
+
+def test_logits_and_sample_random_shapes(dev):
+    """50 seeded random (codebooks, codewords, vector length, batch, map) shapes through the logits kernel and the row kernels of
+    the Gumbel sample (k from 8 to 8192, row widths 64 / 256 / 1024 threads and the tails between them): logits within 2e-6,
+    codes / sample indices / straight-through values equal to the oracle's except where a random-drop decision sits on its
+    threshold (audited as in the fixed case above)."""
+    import random
+    from mcquic_amd import ops
+    rng = random.Random(13)
+    flipped_cases = 0
+    for it in range(50):
+        m = rng.choice([1, 2, 2, 3, 12])
+        k = rng.choice([8, 31, 32, 64, 100, 200, 256, 512, 1000, 2048, 8192])
+        d = rng.choice([1, 4, 8, 10, 16, 64])
+        n, h, w = rng.randint(1, 3), rng.randint(1, 8), rng.randint(1, 8)
+        if n * m * h * w * k > 3e6:
+            n, h = 1, min(h, 2)
+        x, cb, g = _vq_case(m, k, d, n, h, w, 9000 + it)
+        temp = torch.rand((m, 1, 1, 1), generator=g) + 0.5
+        what = f"#{it} m{m} k{k} d{d} n{n} {h}x{w}"
+        logit0 = R.vq_logit(x, cb, temp, torch.tensor([R.EPS]))
+        pk = ops.PackedCodebook(cb.to(dev))
+        lg = ops.vq_logits(x.to(dev), pk, temp.to(dev), R.EPS)
+        err = (lg.cpu() - logit0).abs().max().item()
+        assert err <= 2e-6 * max(1.0, logit0.abs().max().item()), f"{what}: logits max abs err {err:.3e}"
+        freq = torch.rand((m, k), generator=g) ** 3 + 1e-3
+        freq = freq / freq.sum(-1, keepdim=True)
+        u1, u2 = torch.rand(logit0.shape, generator=g), torch.rand(logit0.shape, generator=g)
+        bits = np.log2(k)
+        usage = (freq > R.EPS).float().mean().clamp(0., 1.)
+        expo = (-(bits - 1) * (usage ** 2) + bits)
+        lg = logit0.clone().to(dev)                                  # (the oracle's logits in: the sample is compared on equal inputs)
+        want_logit = R.random_drop(logit0, freq, u1)
+        want_sample, _, want_index = R.gumbel_softmax_hard(want_logit, u2)
+        code, index, hot = ops.vq_gumbel_sample(lg, u1.to(dev), u2.to(dev), freq.to(dev), expo.to(dev))
+        diff = (lg.cpu() - want_logit).abs() > 1e-3
+        if diff.any():
+            margin = ((u1 ** expo) - freq[:, None, None, :]).abs()[diff]
+            assert margin.max().item() < 1e-6 and diff.sum() < 3, f"{what}: random-drop mask differs away from the threshold"
+            flipped_cases += 1
+            continue
+        assert torch.equal(code.cpu(), want_logit.argmax(-1)), what
+        assert torch.equal(index.cpu(), want_index[..., 0]), what
+        want_hot = torch.gather(want_sample, -1, want_index)[..., 0]
+        assert (hot.cpu() - want_hot).abs().max().item() < 1e-6, what
+        deq = ops.vq_dequant_soft(index, hot, pk).cpu()
+        assert (deq - R.dequant_soft(want_sample, cb)).abs().max().item() < 1e-6, what
+    assert flipped_cases <= 5, f"{flipped_cases} of 50 cases had a threshold decision"

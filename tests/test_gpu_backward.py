@@ -775,3 +775,38 @@ def test_soft_assignment_backward_random_shapes(dev):
         what = f"#{it} n{n} m{m} d{d} {h}x{w} k{k}"
         _close(dx, torch.from_numpy(want_dx.reshape(n, m * d, h, w)).float(), 2e-6, "dx " + what)
         _close(dcb, torch.from_numpy(want_dc).float(), 3e-6, "dcodebook " + what)
+
+
+def test_blocks_backward_random_shapes(dev):
+    """The four block types in training mode at 14 seeded random (channels, batch, map) shapes -- channel counts that are no
+    multiple of 32 (GDN's 1x1 launches, the 16-row tiles), odd maps (stride-2 blocks round up, pixel-shuffle blocks double) --
+    forward and every gradient against CPU autograd through the oracle's functions."""
+    import random
+    from mcquic_amd import nn as N
+    rng = random.Random(17)
+    for it in range(14):
+        c = rng.choice([8, 12, 20, 32, 48, 64, 128, 192])
+        n, h, w = rng.randint(1, 4), rng.randint(2, 20), rng.randint(2, 20)
+        x = _rand((n, c, h, w), 9500 + it)
+        cases = [(N.ResidualBlock(c, c), R._rb, R.residual_block), (N.ResidualBlockWithStride(c, c), R._rb_stride, R.residual_block_with_stride),
+                 (N.ResidualBlockShuffle(c, c), R._rb_shuffle, R.residual_block_shuffle), (N.AttentionBlock(c), R._attn, R.attention_block)]
+        for mod, mk, fn in cases:
+            sd = {}
+            mk(sd, "", c, 9600 + it)
+            mod.load_state_dict(sd, strict=True)
+            params = {k: v.clone().requires_grad_() if v.is_floating_point() and v.dim() > 0 and "reparam" not in k else v for k, v in sd.items()}
+            xr = x.clone().requires_grad_()
+            y = fn(params, "", xr)
+            gy = _rand(tuple(y.shape), 9700 + it)
+            y.backward(gy)
+            mod = mod.to(dev).train()
+            xd = x.to(dev).requires_grad_()
+            yd = mod(xd)
+            what = f"#{it} {type(mod).__name__} c{c} n{n} {h}x{w}"
+            _close(yd, y.detach(), 5e-6, what + " forward")
+            yd.backward(gy.to(dev))
+            _close(xd.grad, xr.grad, 2e-5, what + " dx")
+            for name, p in mod.named_parameters():
+                want = params[name].grad
+                assert want is not None, name
+                _close(p.grad, want, 2e-5, what + " d" + name)

@@ -104,3 +104,20 @@ def test_ms_ssim_full_size_batch(dev):
     assert torch.equal(ops.ms_ssim(yd, xd), got)
     assert torch.equal(ops.ms_ssim(xd[7:9], yd[7:9]), got[7:9])
     assert ((got > 0) & (got < 1)).all()
+
+
+def test_metrics_random_shapes(dev):
+    """20 seeded random (batch, height, width) image pairs from the smallest size the five-level pyramid admits (161) up: MS-SSIM
+    within 2e-6 of the oracle, the squared-error sums behind PSNR exact."""
+    import random
+    from mcquic_amd import ops
+    rng = random.Random(19)
+    for it in range(20):
+        n = rng.randint(1, 4)
+        h, w = rng.choice([161, 162, 176, 255, 256, 257, rng.randint(161, 600)]), rng.choice([161, 163, 192, 320, 321, rng.randint(161, 600)])
+        x, y = M.make_u8_pair(700 + it, n, h, w)
+        got = ops.ms_ssim(x.to(dev), y.to(dev)).cpu()
+        np.testing.assert_allclose(got.numpy(), M.ms_ssim(x, y).numpy(), rtol=0, atol=2e-6, err_msg=f"#{it} n{n} {h}x{w}")
+        sq = ops.sqdiff_sum(x.to(dev), y.to(dev)).cpu()
+        want = ((x.to(torch.int64) - y.to(torch.int64)) ** 2).flatten(1).sum(1)
+        assert torch.equal(sq, want), f"#{it} n{n} {h}x{w}"

@@ -352,3 +352,52 @@ def test_sizes_reflect_padding_cannot_take_are_refused_like_the_reference(dev):
         R.aligned_padding(x)
     with pytest.raises(RuntimeError):
         model.encode(x.to(dev))
+
+
+def test_row_bands_at_random_limits_and_sizes(dev):
+    """The row-band fallback at 16 seeded random (image size, slab limit) pairs through a 32-channel model: limits from 'only the
+    largest maps are banded' down to 'a band is a handful of rows' (halo rows of 3x3 layers, stride-2 layers whose bands must start
+    on even rows, pixel-shuffle layers that double them, 1x1 layers without halo): the same codes as the single-launch run and
+    pixels to float32 reassociation; then `compress` -> `decompress` under a limit equals the unbanded round trip."""
+    import random
+    from mcquic_amd import Compressor, ops
+    rng = random.Random(23)
+    ks = [64, 32, 16]
+    sd = R.make_state_dict(32, 2, ks, seed=4)
+    model = Compressor(32, 2, ks).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    banded_calls, orig = [0], ops._conv2d_banded
+
+    def counting(*a, **k):
+        banded_calls[0] += 1
+        return orig(*a, **k)
+    ops._conv2d_banded = counting
+    for it in range(16):
+        n, h, w = rng.randint(1, 3), rng.randint(44, 700), rng.randint(44, 500)
+        x = R.make_images(n, h, w, seed=300 + it).to(dev)
+        codes = model.encode(x)
+        rec = model.decode(codes)
+        # the largest activation of this image: 64 channels' worth (cin + 32) x the padded half-resolution map
+        ph, pw = -(-h // 128) * 128, -(-w // 128) * 128
+        largest = 64 * (ph // 2) * (pw // 2) * 4
+        limit = max(int(largest * rng.choice([0.6, 0.3, 0.1, 0.03])), 40 * 64 * pw * 4)      # (never below ~40 rows of the widest map:
+        # a limit under one row's worth is refused loudly, ops._band_rows)
+        prev = ops.set_slab_limit(limit)
+        try:
+            banded_codes = model.encode(x)
+            banded_rec = model.decode(codes)
+            if it % 4 == 0:
+                _, binaries, headers = model.compress(x)
+                back = model.decompress(binaries, headers)
+        finally:
+            ops.set_slab_limit(prev)
+        what = f"#{it} n{n} {h}x{w} limit {limit}"
+        for lv, (a, b) in enumerate(zip(codes, banded_codes)):
+            assert torch.equal(a, b), f"{what} level {lv}: {(a != b).sum().item()} codes differ"
+        assert float((rec - banded_rec).abs().max()) <= 2e-6, what
+        if it % 4 == 0:
+            top, left = (rec.shape[-2] - h) // 2, (rec.shape[-1] - w) // 2
+            assert float((back - rec[..., top: top + h, left: left + w]).abs().max()) <= 2e-6, what
+    ops._conv2d_banded = orig
+    assert banded_calls[0] >= 100, f"only {banded_calls[0]} banded launches: the limits did not bite"

@@ -19,6 +19,10 @@
 
 namespace {
 
+#ifndef MCQ_LOGITS_WAVES
+#define MCQ_LOGITS_WAVES 2048      // waves a logits launch aims for before it stops splitting the codeword tiles over grid.z
+#endif
+
 struct VqLogitK {
     VqK v;
     const float* temperature;   // [m]
@@ -656,7 +660,7 @@ extern "C" int mcq_vq_logits_f32(const float* x, const float* cb_packed, const f
     {
         const long long waves = (long long)gx * 4 * m;
         int zs = 1;
-        while (zs < q.v.ntile && waves * zs < 2048) zs *= 2;
+        while (zs < q.v.ntile && waves * zs < MCQ_LOGITS_WAVES) zs *= 2;
         q.tiles_per_z = (q.v.ntile + zs - 1) / zs;
         const unsigned gz = (unsigned)((q.v.ntile + q.tiles_per_z - 1) / q.tiles_per_z);
         hipLaunchKernelGGL(vq_logits_kernel, dim3(gx, (unsigned)m, gz), dim3(256), 0, (hipStream_t)stream, q);
@@ -677,7 +681,7 @@ extern "C" int mcq_vq_inner_f32(const float* x, const float* cb_packed, float* o
     {
         const long long waves = (long long)gx * 4 * m;
         int zs = 1;
-        while (zs < q.v.ntile && waves * zs < 2048) zs *= 2;
+        while (zs < q.v.ntile && waves * zs < MCQ_LOGITS_WAVES) zs *= 2;
         q.tiles_per_z = (q.v.ntile + zs - 1) / zs;
         const unsigned gz = (unsigned)((q.v.ntile + q.tiles_per_z - 1) / q.tiles_per_z);
         hipLaunchKernelGGL(vq_logits_kernel, dim3(gx, (unsigned)m, gz), dim3(256), 0, (hipStream_t)stream, q);

@@ -4,9 +4,13 @@ usage: python profiles/pmc_stats.py gpurun_out/pmc_FETCH_SIZE/pmc_results.db gpu
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide
 coalesced reads (MI355X_MICROARCH.md, HBM section), so the corrected read bytes are 2 x FETCH_SIZE x 1024."""
 import json
+import os
 import sqlite3
 import sys
 from collections import defaultdict
+
+# kernels summarised: name substrings, PMC_KERNELS=a,b,c overrides (the training step adds the weight-gradient and VQ-training kernels)
+WANT = [w for w in os.environ.get("PMC_KERNELS", "conv_mfma,conv_head16,vq_assign").split(",") if w]
 
 agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for path in sys.argv[1:]:
@@ -16,7 +20,7 @@ for path in sys.argv[1:]:
     meta = {}
     for did, name, gx, gy, wx, cname, val, dur in cur.execute(
             "select dispatch_id, kernel_name, grid_size_x, grid_size_y, workgroup_size_x, counter_name, value, duration from counters_collection"):
-        if "conv_mfma" not in name and "conv_head16" not in name and "vq_assign" not in name:
+        if not any(w in name for w in WANT):
             continue
         per[(did, cname)] += val
         meta[did] = (name, gx, gy, wx, dur)

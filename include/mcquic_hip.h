@@ -30,7 +30,7 @@ extern "C" {
  * compares it with mcq_abi_version() of the library it loaded before calling anything else: a stale .so under new
  * prototypes (or the reverse) misaligns arguments silently otherwise.  3 = round 3 (mcq_rans_*_with_indexes take cdf_lens,
  * mcq_gate_f32 takes out_silu -- both changed in round 2 without a bump --, GroupNorm / logits-gradient entry points). */
-#define MCQ_ABI_VERSION   6
+#define MCQ_ABI_VERSION   7
 
 #define MCQ_OK            0
 #define MCQ_EINVAL       -1   /* NULL pointer / non-positive dimension / unsupported combination */
@@ -197,7 +197,11 @@ int mcq_vq_logits_f32(const float* x, const float* cb_packed, const float* tempe
 int mcq_vq_gumbel_sample_f32(float* logits, const float* u_drop /* or NULL */, const float* u_gumbel /* or NULL */,
                              const uint64_t* rng_state /* or NULL */, const float* freq_ema /* [m, k] */,
                              const float* drop_exponent /* device scalar */, int64_t* codes, int64_t* sample_index,
-                             float* sample_hot, int32_t N, int32_t m, int32_t h, int32_t w, int32_t k, void* stream);
+                             float* sample_hot, int64_t* code_counts /* [m, k] or NULL */, int32_t N, int32_t m, int32_t h, int32_t w,
+                             int32_t k, void* stream);
+/* `code_counts` (round 5): the level's code histogram -- what EntropyCoder.forward obtains by summing one-hot codes over images
+ * and pixels (mcquic/modules/entropyCoder.py:33-35) -- is added to where each code is made (integer atomics: exact in any order);
+ * the caller zeroes the buffer once per step (mcq_vq_step_prologue_f32). */
 /* out[i] = the generator's draw for element i of `stream_id` under `rng_state` -- exactly what the two kernels around it use in
  * place of a NULL u_drop (stream 0) / u_gumbel (stream 1): for tests and for callers that want the tensors after all. */
 int mcq_hash_uniform_f32(const uint64_t* rng_state, uint32_t stream_id, float* out, int64_t n, void* stream);
@@ -205,6 +209,7 @@ int mcq_hash_uniform_f32(const uint64_t* rng_state, uint32_t stream_id, float* o
 /* out[n, g*d + j, y, x] = sample_hot * codebook[g, sample_index, j]: bmm(sample, codebook) for the one-hot-valued
  * straight-through sample (_multiCodebookDeQuantization.forward, quantizer.py:262-274). */
 int mcq_vq_dequant_soft_f32(const int64_t* sample_index, const float* sample_hot, const float* codebook, float* out,
+                            float* out_silu /* or NULL: also silu(out), the consumer's first activation */,
                             int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k, void* stream);
 
 /* out[n, g, y, x, k] = <x_v, c_k>: the logits kernel's GEMM without the distance / temperature transform
@@ -227,6 +232,31 @@ int mcq_vq_softmax_bwd_f32(const float* logits, const float* u_gumbel /* or NULL
 int mcq_vq_soft_bwd_f32(const float* ddist, const float* rowsum, const float* x, const float* x_nhwc, const float* ddeq_nhwc,
                         const int64_t* sample_index, const float* sample_hot, const float* codebook, float* dx,
                         float* dcodebook, int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k, void* stream);
+
+/* ---- per-step bookkeeping of the training quantizer (round 5; csrc/step_ops.hip) ------------------------------ */
+#define MCQ_VQ_MAX_LEVELS 8
+/* ONE launch in front of the level cascade of a training forward (host arrays of `levels` <= MCQ_VQ_MAX_LEVELS entries):
+ *   exponents[l] = -(log2 k_l - 1) * usage_l^2 + log2 k_l,  usage_l = mean(freq_ema_l > eps) clamped to [0, 1]
+ *                  -- the exponent of _randomDrop (mcquic/modules/quantizer.py:194-198), rounded op by op like torch;
+ *   rng_snaps[l] = {seed, offset + l} and the generator state {seed, offset} advanced by `levels` (both NULL: no generator);
+ *   counts[0 .. counts_n) = 0  (the buffer mcq_vq_gumbel_sample_f32 adds the levels' code histograms into; NULL / 0: none).
+ * Replaces seven tensor ops per level and the generator's clone + add. */
+int mcq_vq_step_prologue_f32(const float* const* freq_ema /* [levels] device pointers to [m_l, k_l] */, const int32_t* m, const int32_t* k,
+                             int32_t levels, float eps, float* exponents /* device [levels] */, uint64_t* rng_state /* device, or NULL */,
+                             uint64_t* rng_snaps /* device [levels][2], or NULL */, int64_t* counts /* device, or NULL */, int64_t counts_n,
+                             void* stream);
+/* dtemperature[g] = mask_g * sum_{n, y, x} dtrow[n, g, y, x] with mask_g = (temperature[g] >= bound) | (sum < 0): the soft-max
+ * backward's per-row temperature terms reduced in a fixed order, then LowerBound's gradient rule (mcquic/nn/base.py:24-29). */
+int mcq_vq_temperature_grad_f32(const float* dtrow /* [N, m, hw] */, const float* temperature /* [m] */, float bound,
+                                float* dtemperature /* [m] */, int32_t N, int32_t m, int32_t hw, void* stream);
+/* freq_ema_l = (1 - ema) * counts_l / sum_k counts_l + ema * freq_ema_l for every level in ONE launch, in place
+ * (EntropyCoder.forward, mcquic/modules/entropyCoder.py:28-44, after its all-reduce); `counts` = the levels' [m_l, k_l]
+ * histograms back to back (mcq_vq_gumbel_sample_f32's code_counts). */
+int mcq_freq_ema_update_f32(float* const* freq_ema /* [levels] device pointers */, const int32_t* m, const int32_t* k, int32_t levels,
+                            const int64_t* counts, float ema, void* stream);
+/* mcq_nonneg_reparam_bwd_f32 (below) for two parameters -- a GDN layer's beta [C] and gamma [C, C] -- in one launch. */
+int mcq_nonneg_reparam_bwd2_f32(const float* p0, const float* dfolded0, float bound0, float* dp0, int64_t n0, const float* p1,
+                                const float* dfolded1, float bound1, float* dp1, int64_t n1, void* stream);
 
 /* ---- backward pass of the training step (BASELINE config #5) ----------------------------------------- */
 /* Input gradients of the convolutions reuse mcq_conv2d_f32 with transformed weights (see mcquic_amd/autograd.py);
@@ -293,10 +323,12 @@ int mcq_channel_sum_f32(const float* x, float* out, float* workspace, int32_t N,
  * them separate so that each has its own backward:  y = silu(x);  out = a * sigmoid(b) + x;  out = alpha a + beta b. */
 int mcq_silu_f32(const float* x, float* y, int64_t n, void* stream);
 int mcq_gate_f32(const float* a, const float* b, const float* x, float* out, float* out_silu /* or NULL */, int64_t n, void* stream);
-int mcq_axpby_f32(const float* a, const float* b, float alpha, float beta, float* out, int64_t n, void* stream);
+int mcq_axpby_f32(const float* a, const float* b, float alpha, float beta, float* out, float* out_silu /* or NULL */, int64_t n,
+                  void* stream);
 
-/* dx = dy * d/dx silu(x). */
-int mcq_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* dx = dy * d/dx silu(x) (+ other: the gradient reaching x along a second path, e.g. a strided block's skip convolution,
+ * mcquic/nn/blocks.py:98-122 -- the sum torch.autograd's engine would make with a launch of its own). */
+int mcq_silu_bwd_f32(const float* x, const float* dy, const float* other /* or NULL */, float* dx, int64_t n, void* stream);
 
 /* AttentionBlock gate out = a * sigmoid(b) + x: da = dout * s, db = dout * a * s (1 - s). */
 int mcq_gate_bwd_f32(const float* a, const float* b, const float* dout, float* da, float* db, int64_t n, void* stream);

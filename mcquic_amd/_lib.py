@@ -68,10 +68,14 @@ SYMBOLS = {
                                     c_int32, c_void_p]),
     "mcq_vq_logits_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
-    "mcq_vq_gumbel_sample_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "mcq_vq_gumbel_sample_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "mcq_vq_step_prologue_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_vq_temperature_grad_f32": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "mcq_freq_ema_update_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_float, c_void_p]),
+    "mcq_nonneg_reparam_bwd2_f32": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "mcq_hash_uniform_f32": (c_int32, [c_void_p, c_uint32, c_void_p, c_int64, c_void_p]),
-    "mcq_vq_dequant_soft_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+    "mcq_vq_dequant_soft_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_int32, c_void_p]),
     "mcq_vq_inner_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_vq_softmax_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -98,8 +102,8 @@ SYMBOLS = {
     "mcq_channel_sum_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_silu_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_gate_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
-    "mcq_axpby_f32": (c_int32, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
-    "mcq_silu_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_axpby_f32": (c_int32, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_silu_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_gate_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_gdn_bwd_prep_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_pixel_unshuffle2_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
@@ -135,7 +139,7 @@ SYMBOLS = {
     "mcq_abi_version": (c_int32, []),
 }
 
-ABI_VERSION = 6          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
+ABI_VERSION = 7          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
 
 _lib = None
 

@@ -104,6 +104,50 @@ class SiluFn(torch.autograd.Function):
         return ops.silu_bwd(x, dy.contiguous())
 
 
+class SiluForkFn(torch.autograd.Function):
+    """(silu(x), x) for a block whose branch starts with the activation while its skip convolution reads x itself
+    (ResidualBlockWithStride / ResidualBlockShuffle, mcquic/nn/blocks.py:98-159): the two gradients meet in ONE launch,
+    dx = d_silu * silu'(x) + d_skip, instead of a SiLU-backward launch followed by an add issued by the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        twin = ops.silu_twin(x)
+        ctx.set_materialize_grads(False)
+        return (twin.detach() if twin is not None else ops.silu(x)), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dsx, dx2):
+        (x,) = ctx.saved_tensors
+        if dsx is None:
+            return dx2
+        return ops.silu_bwd(x, dsx.contiguous(), None if dx2 is None else dx2.contiguous())
+
+
+class SubPassFn(torch.autograd.Function):
+    """(a - b, b) where b is consumed once more downstream -- a level's residual z - dequant next to the decoder's use of the
+    dequantised sample (mcquic/modules/quantizer.py:295-305): b's two gradients meet in one launch, d b = d_b2 - d_residual
+    (a negation launch plus an engine-issued add otherwise).  The residual carries its SiLU twin: the next level starts with
+    an activation."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        r = ops.axpby(a, b, 1.0, -1.0, dual_silu=True)
+        sr = ops.silu_twin(r)
+        ctx.mark_non_differentiable(sr)
+        ctx.set_materialize_grads(False)
+        return r, b.view_as(b), sr
+
+    @staticmethod
+    def backward(ctx, dr, db2, _dsr):
+        if dr is None:
+            return None, db2
+        dr = dr.contiguous()
+        if db2 is None:
+            return dr, ops.axpby(dr, dr, -1.0, 0.0)
+        return dr, ops.axpby(db2.contiguous(), dr, 1.0, -1.0)
+
+
 class MseFn(torch.autograd.Function):
     """F.mse_loss(a, b) (mcquic/loss/__init__.py:62) from this library's own reduction: no library memset inside a captured step."""
 
@@ -382,9 +426,12 @@ class LockstepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, *args):
-        stacks = args[-1]
+        stacks, shared = args[-1]
         k = len(stacks)
-        ys, tape = _lockstep_forward(stacks, args[:k], keep=True)
+        ctx.shared = shared
+        # (`shared`: ONE input feeds all k stacks -- latentHead / quantizationHead on the same z: its k gradients are summed here,
+        #  by this library's add, instead of by the autograd engine)
+        ys, tape = _lockstep_forward(stacks, args[:1] * k if shared else args[:k], keep=True)
         tensors = []
         ctx.tape_spec = _tape_flatten([(kind, saved) for kind, _, saved in tape], tensors)
         ctx.layers = [layer for _, layer, _ in tape]
@@ -399,6 +446,13 @@ class LockstepFn(torch.autograd.Function):
         tape = [(kind, layer, saved) for (kind, saved), layer in zip(entries, ctx.layers)]
         dxs = _lockstep_backward(tape, list(dys), grads)
         params = [p for st in ctx.stacks for p in st.parameters()]
+        if ctx.shared:
+            dx = dxs[0]
+            for i in range(1, len(dxs) - 1, 2):
+                dx = ops.add3(dx, dxs[i], dxs[i + 1])
+            if len(dxs) % 2 == 0:
+                dx = ops.add(dx, dxs[-1])
+            dxs = [dx]
         return (*dxs, *[grads.get(id(p)) for p in params], None)
 
 
@@ -407,7 +461,8 @@ def lockstep(stacks, xs):
     if not (ops._MULTI and lockstep_compatible(stacks)):
         return [st(x) for st, x in zip(stacks, xs)]
     params = [p for st in stacks for p in st.parameters()]
-    return list(LockstepFn.apply(*xs, *params, tuple(stacks)))
+    shared = len(xs) > 1 and all(x is xs[0] for x in xs[1:])
+    return list(LockstepFn.apply(*(xs[:1] if shared else xs), *params, (tuple(stacks), shared)))
 
 
 class GateFn(torch.autograd.Function):
@@ -430,16 +485,23 @@ class AxpbyFn(torch.autograd.Function):
     """out = alpha * a + beta * b (alpha, beta in {+1, -1})."""
 
     @staticmethod
-    def forward(ctx, a, b, alpha, beta):
+    def forward(ctx, a, b, alpha, beta, dual_silu=False):
         ctx.alpha, ctx.beta = alpha, beta
-        return ops.axpby(a, b, alpha, beta)
+        out = ops.axpby(a, b, alpha, beta, dual_silu=bool(dual_silu))
+        sout = ops.silu_twin(out)
+        if sout is not None:
+            ctx.mark_non_differentiable(sout)
+        ctx.set_materialize_grads(False)
+        return out, sout
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dsout=None):
+        if dout is None:
+            return None, None, None, None, None
         dout = dout.contiguous()
         da = dout if ctx.alpha == 1.0 else ops.axpby(dout, dout, ctx.alpha, 0.0)
         db = dout if ctx.beta == 1.0 else ops.axpby(dout, dout, ctx.beta, 0.0)
-        return da, db, None, None
+        return da, db, None, None, None
 
 
 class LowerBoundFn(torch.autograd.Function):
@@ -510,7 +572,8 @@ class GdnFn(torch.autograd.Function):
         dx = ops.conv2d(ds, ctx.back, mul=x, res=dxd)                          # dy f(s) + 2 x (gamma^T ds)
         dgamma, dbeta = ops.conv2d_wgrad(x, ds, 1, 1, square_x=True, want_bias=True)
         bb, gb = ctx.bounds
-        return (dx, ops.nonneg_reparam_bwd(beta_p, dbeta, bb), ops.nonneg_reparam_bwd(gamma_p, dgamma[:, :, 0, 0], gb), None, None)
+        dbeta_p, dgamma_p = ops.nonneg_reparam_bwd2(beta_p, dbeta, bb, gamma_p, dgamma[:, :, 0, 0], gb)    # both in one launch
+        return dx, dbeta_p, dgamma_p, None, None
 
 
 class GroupNormFn(torch.autograd.Function):
@@ -583,12 +646,38 @@ def gate(a, b, x):
     return GateFn.apply(a, b, x)
 
 
-def add(a, b):
-    return AxpbyFn.apply(a, b, 1.0, 1.0)
+def _with_twin(out, sout):
+    if sout is not None:
+        ops.set_silu_twin(out, sout)
+    return out
+
+
+def add(a, b, dual_silu: bool = False):
+    """a + b; `dual_silu`: the result carries silu(result) as its twin (its consumer starts with an activation)."""
+    return _with_twin(*AxpbyFn.apply(a, b, 1.0, 1.0, dual_silu))
 
 
 def sub(a, b):
-    return AxpbyFn.apply(a, b, 1.0, -1.0)
+    return _with_twin(*AxpbyFn.apply(a, b, 1.0, -1.0, False))
+
+
+def sub_pass(a, b):
+    """(a - b, b'): b' is b for its second consumer (SubPassFn); both results keep / carry their SiLU twins."""
+    tb = ops.silu_twin(b)
+    r, b2, sr = SubPassFn.apply(a, b)
+    ops.set_silu_twin(r, sr)
+    if tb is not None:
+        ops.set_silu_twin(b2, tb)
+    return r, b2
+
+
+def silu_fork(x):
+    """(silu(x), x') for a block whose skip path reads x itself (SiluForkFn)."""
+    tx = ops.silu_twin(x)
+    sx, x2 = SiluForkFn.apply(x)
+    if tx is not None:
+        ops.set_silu_twin(x2, tx)
+    return sx, x2
 
 
 def gdn(x, module, inverse: bool):
@@ -610,22 +699,23 @@ class SoftQuantizeFn(torch.autograd.Function):
     extra is launched)."""
 
     @staticmethod
-    def forward(ctx, x, codebook, temperature, freq_ema, u_drop, u_gumbel, drop_exponent, packed, bound, rng=None):
+    def forward(ctx, x, codebook, temperature, freq_ema, u_drop, u_gumbel, drop_exponent, packed, bound, rng=None, counts=None):
         logits = ops.vq_logits(x, packed, temperature, bound)
-        code, index, hot = ops.vq_gumbel_sample(logits, u_drop, u_gumbel, freq_ema, drop_exponent, rng)
-        deq = ops.vq_dequant_soft(index, hot, packed)
+        code, index, hot = ops.vq_gumbel_sample(logits, u_drop, u_gumbel, freq_ema, drop_exponent, rng, counts)
+        deq = ops.vq_dequant_soft(index, hot, packed, dual_silu=True)          # (+ silu(deq): the decoder side starts with an activation)
+        sdeq = ops.silu_twin(deq)
         ctx.save_for_backward(x, logits, u_gumbel, index, hot, temperature, rng)     # (u_gumbel None: remade from `rng` in backward)
         ctx.packed, ctx.bound = packed, bound
-        ctx.mark_non_differentiable(code)
+        ctx.mark_non_differentiable(code, sdeq)
         ctx.set_materialize_grads(False)        # (an unused `dlogits` would be a zero fill of the [n, m, h, w, k] logits: 134 MB at level 0)
-        return deq, code, logits
+        return deq, code, logits, sdeq
 
     @staticmethod
-    def backward(ctx, ddeq, _dcode, dlogits):
+    def backward(ctx, ddeq, _dcode, dlogits, _dsdeq=None):
         x, logits, u_gumbel, index, hot, temperature, rng = ctx.saved_tensors
         packed = ctx.packed
         if ddeq is None and dlogits is None:
-            return (None,) * 10
+            return (None,) * 11
         ddeq = torch.zeros_like(x) if ddeq is None else ddeq.contiguous()
         ds = ops.vq_inner(ddeq, packed)                                        # dSample = dDeq . C^T
         raw = None
@@ -634,7 +724,5 @@ class SoftQuantizeFn(torch.autograd.Function):
             raw = ops.vq_logits(x, packed, temperature, ctx.bound)
         rowsum, dtrow = ops.vq_softmax_bwd(logits, u_gumbel, ds, temperature, ctx.bound, dlogits, raw, rng)   # ds now holds d dist
         dx, dcb = ops.vq_soft_bwd(ds, rowsum, x, ddeq, index, hot, packed)
-        dtb = ops.channel_sum(dtrow)                                           # [m]: d max(T, bound)
-        t = temperature.detach().reshape(-1)
-        dt = (((t >= ctx.bound) | (dtb < 0)).to(dtb.dtype) * dtb).reshape(temperature.shape)   # LowerBound's rule
-        return dx, dcb, dt, None, None, None, None, None, None, None
+        dt = ops.vq_temperature_grad(dtrow, temperature, ctx.bound)            # [m, 1, 1, 1]: the rows' terms summed, LowerBound's rule
+        return dx, dcb, dt, None, None, None, None, None, None, None, None

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libmcquic_hip.so")
-SOURCES = ["conv_mfma.hip", "conv_wino16.hip", "vq.hip", "vq_train.hip", "vq_bwd_mfma.hip", "train_ops.hip", "wgrad_rows.hip", "metrics.hip", "norm.hip", "rans.cpp"]
+SOURCES = ["conv_mfma.hip", "conv_wino16.hip", "vq.hip", "vq_train.hip", "vq_bwd_mfma.hip", "train_ops.hip", "step_ops.hip", "wgrad_rows.hip", "metrics.hip", "norm.hip", "rans.cpp"]
 HEADERS = ["mcq_common.h", "vq_common.h", "conv_head16.h", "conv_t16.h", "conv_wino16.h", "vq_bwd_mfma.h", "wgrad_t16.h", os.path.join("..", "..", "include", "mcquic_hip.h")]
 # -ffp-contract=off: element-wise epilogues keep the reference's one-rounding-per-op sequence
 #   (e.g. a * sigmoid(b) then + x are two torch kernels in mcquic/nn/blocks.py:286-287).

@@ -488,17 +488,25 @@ __global__ void gate_fwd_kernel(const float* __restrict__ a, const float* __rest
 }
 
 __global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float alpha, float beta,
-                             float* __restrict__ out, int64_t n) {
+                             float* __restrict__ out, float* __restrict__ out_silu, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = alpha * a[i] + beta * b[i];
+    if (i < n) {
+        const float v = alpha * a[i] + beta * b[i];
+        out[i] = v;
+        if (out_silu) out_silu[i] = mcq_silu(v);               // the consumer's act1(.), like MCQ_CONV_DUAL_SILU
+    }
 }
 
 // dx = dy * silu'(x),  silu'(x) = s (1 + x (1 - s)),  s = sigmoid(x)
-__global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int64_t n) {
+// (+ `other`: the gradient that reaches x along a second path -- a strided / shuffle block's skip convolution reads x itself --,
+//  added here instead of by an engine-issued add)
+__global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ other,
+                                float* __restrict__ dx, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const float s = sigmoidf_(x[i]);
-        dx[i] = dy[i] * (s * (1.0f + x[i] * (1.0f - s)));
+        const float v = dy[i] * (s * (1.0f + x[i] * (1.0f - s)));
+        dx[i] = other ? v + other[i] : v;
     }
 }
 
@@ -705,15 +713,15 @@ extern "C" int mcq_gate_f32(const float* a, const float* b, const float* x, floa
     return mcq_check_launch();
 }
 
-extern "C" int mcq_axpby_f32(const float* a, const float* b, float alpha, float beta, float* out, int64_t n, void* stream) {
+extern "C" int mcq_axpby_f32(const float* a, const float* b, float alpha, float beta, float* out, float* out_silu, int64_t n, void* stream) {
     if (!a || !b || !out || n <= 0) return MCQ_EINVAL;
-    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, beta, out, n);
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, beta, out, out_silu, n);
     return mcq_check_launch();
 }
 
-extern "C" int mcq_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+extern "C" int mcq_silu_bwd_f32(const float* x, const float* dy, const float* other, float* dx, int64_t n, void* stream) {
     if (!x || !dy || !dx || n <= 0) return MCQ_EINVAL;
-    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n);
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, other, dx, n);
     return mcq_check_launch();
 }
 

@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void vq_gumbel_sample_kernel(float* __restrict
                                                                const float* __restrict__ u_gumbel, const unsigned long long* __restrict__ rng_state,
                                                                const float* __restrict__ freq, const float* __restrict__ drop_exponent_ptr,
                                                                int64_t* __restrict__ codes, int64_t* __restrict__ index,
-                                                               float* __restrict__ hot, int rows, int m, int hw, int k) {
+                                                               float* __restrict__ hot, unsigned long long* __restrict__ counts,
+                                                               int rows, int m, int hw, int k) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -306,11 +307,13 @@ __global__ __launch_bounds__(256) void vq_gumbel_sample_kernel(float* __restrict
         codes[row] = code;
         index[row] = idx;
         hot[row] = (1.0f - s) + s;                  // y_hard - y_soft + y_soft at the hot position
+        if (counts) atomicAdd(counts + (size_t)g * k + code, 1ull);      // integer counts: the order of arrival does not matter
     }
 }
 
 __global__ void vq_dequant_soft_kernel(const int64_t* __restrict__ index, const float* __restrict__ hot,
-                                       const float* __restrict__ cb, float* __restrict__ out, int N, int m, int d, int hw, int k) {
+                                       const float* __restrict__ cb, float* __restrict__ out, float* __restrict__ out_silu, int N, int m,
+                                       int d, int hw, int k) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)N * m * hw;
     if (i >= total) return;
@@ -322,8 +325,13 @@ __global__ void vq_dequant_soft_kernel(const int64_t* __restrict__ index, const 
     code = code < 0 ? 0 : (code >= k ? k - 1 : code);
     const float v = hot[i];
     const float* row = cb + ((size_t)g * k + (size_t)code) * d;
-    float* o = out + ((n * m + g) * (size_t)d) * hw + pix;
+    const size_t o0 = ((n * m + g) * (size_t)d) * hw + pix;
+    float* o = out + o0;
     for (int c = 0; c < d; ++c) o[(size_t)c * hw] = v * row[c];
+    if (out_silu) {                                             // the consumer's act1(.), like mcq_vq_gather_f32's twin
+        float* o2 = out_silu + o0;
+        for (int c = 0; c < d; ++c) o2[(size_t)c * hw] = mcq_silu(v * row[c]);
+    }
 }
 
 // ---- backward of the soft assignment ----------------------------------------------------------------------------
@@ -517,7 +525,8 @@ __global__ __launch_bounds__(T < 256 ? 256 : T, T == 1024 ? 8 : 1) void vq_gumbe
                                                                                   const float* __restrict__ freq,
                                                                                   const float* __restrict__ drop_exponent_ptr,
                                                                                   int64_t* __restrict__ codes, int64_t* __restrict__ index,
-                                                                                  float* __restrict__ hot, int rows, int m, int hw, int k) {
+                                                                                  float* __restrict__ hot, unsigned long long* __restrict__ counts,
+                                                                                  int rows, int m, int hw, int k) {
     __shared__ RowShared<T> sm;
     constexpr int RPW = T < 256 ? 256 / T : 1;
     const int tid = T < 256 ? (int)(threadIdx.x & (T - 1)) : (int)threadIdx.x;
@@ -568,9 +577,12 @@ __global__ __launch_bounds__(T < 256 ? 256 : T, T == 1024 ? 8 : 1) void vq_gumbe
     row_sum2<T>(sum, unused, sm, 2);
     if (tid == 0) {
         const float s = 1.0f / sum;
-        codes[row] = code == 0x7fffffff ? 0 : code;
+        const int cd = code == 0x7fffffff ? 0 : code;
+        codes[row] = cd;
         index[row] = idx == 0x7fffffff ? 0 : idx;
         hot[row] = (1.0f - s) + s;
+        // the level's code histogram (entropyCoder.py:33-35: one-hot codes summed over images and pixels), added where the code is made
+        if (counts) atomicAdd(counts + (size_t)g * k + cd, 1ull);
     }
 }
 
@@ -699,8 +711,9 @@ extern "C" int mcq_hash_uniform_f32(const uint64_t* rng_state, uint32_t stream_i
 extern "C" int mcq_vq_gumbel_sample_f32(float* logits, const float* u_drop, const float* u_gumbel, const uint64_t* rng_state_u64,
                                         const float* freq_ema,
                                         const float* drop_exponent, int64_t* codes, int64_t* sample_index, float* sample_hot,
-                                        int32_t N, int32_t m, int32_t h, int32_t w, int32_t k, void* stream) {
+                                        int64_t* code_counts, int32_t N, int32_t m, int32_t h, int32_t w, int32_t k, void* stream) {
     const unsigned long long* rng_state = reinterpret_cast<const unsigned long long*>(rng_state_u64);
+    unsigned long long* counts = reinterpret_cast<unsigned long long*>(code_counts);
     if (!logits || !freq_ema || !drop_exponent || !codes || !sample_index || !sample_hot) return MCQ_EINVAL;
     if ((!u_drop || !u_gumbel) && !rng_state) return MCQ_EINVAL;        // every draw comes from a tensor or from the generator state
     if (N <= 0 || m <= 0 || h <= 0 || w <= 0 || k <= 0) return MCQ_EINVAL;
@@ -709,25 +722,25 @@ extern "C" int mcq_vq_gumbel_sample_f32(float* logits, const float* u_drop, cons
     hipStream_t s = (hipStream_t)stream;
     if (k <= 64 * ROW_E)
         hipLaunchKernelGGL(vq_gumbel_sample_row_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, u_drop, u_gumbel, rng_state,
-                           freq_ema, drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
+                           freq_ema, drop_exponent, codes, sample_index, sample_hot, counts, (int)rows, m, h * w, k);
     else if (k <= 256 * ROW_E)
         hipLaunchKernelGGL(vq_gumbel_sample_row_kernel<256>, dim3((unsigned)rows), dim3(256), 0, s, logits, u_drop, u_gumbel, rng_state, freq_ema,
-                           drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
+                           drop_exponent, codes, sample_index, sample_hot, counts, (int)rows, m, h * w, k);
     else if (k <= 1024 * ROW_E)
         hipLaunchKernelGGL(vq_gumbel_sample_row_kernel<1024>, dim3((unsigned)rows), dim3(1024), 0, s, logits, u_drop, u_gumbel, rng_state, freq_ema,
-                           drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
+                           drop_exponent, codes, sample_index, sample_hot, counts, (int)rows, m, h * w, k);
     else
         hipLaunchKernelGGL(vq_gumbel_sample_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits,
-                           u_drop, u_gumbel, rng_state, freq_ema, drop_exponent, codes, sample_index, sample_hot, (int)rows, m, h * w, k);
+                           u_drop, u_gumbel, rng_state, freq_ema, drop_exponent, codes, sample_index, sample_hot, counts, (int)rows, m, h * w, k);
     return mcq_check_launch();
 }
 
 extern "C" int mcq_vq_dequant_soft_f32(const int64_t* sample_index, const float* sample_hot, const float* codebook, float* out,
-                                       int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k, void* stream) {
+                                       float* out_silu, int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k, void* stream) {
     if (!sample_index || !sample_hot || !codebook || !out || N <= 0 || m <= 0 || d <= 0 || h <= 0 || w <= 0 || k <= 0) return MCQ_EINVAL;
     const size_t total = (size_t)N * m * h * w;
     hipLaunchKernelGGL(vq_dequant_soft_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       sample_index, sample_hot, codebook, out, N, m, d, h * w, k);
+                       sample_index, sample_hot, codebook, out, out_silu, N, m, d, h * w, k);
     return mcq_check_launch();
 }
 

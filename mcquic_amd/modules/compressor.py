@@ -156,13 +156,21 @@ class BaseCompressor(nn.Module):
         self._check(x)
         if torch.is_grad_enabled():
             self._repackStale()
-            y = self._encoder(x)                          # no padding in the training forward (compressor.py:39)
+            y = self._trainEncode(x)
             yHat, codes, logits = self._quantizer(y, uniforms)
             return self._decoder(yHat), yHat, codes, logits
         y = self._encode_latent(x, pad=False)
         yHat, codes, logits = self._quantizer(y, uniforms)
         xHat = self._decoder(yHat)
         return xHat, yHat, codes, logits
+
+    def _trainEncode(self, x: torch.Tensor) -> torch.Tensor:
+        """`self._encoder(x)` in the training graph -- no padding there (compressor.py:39); the stem conv also stores silu(.)
+        for the block that follows (every encoder here continues with an activation)."""
+        y = self._encoder[0](x, dual_silu=True)
+        for i in range(1, len(self._encoder)):
+            y = self._encoder[i](y)
+        return y
 
     def _repackStale(self):
         """After an optimizer step every convolution's operand streams are stale: refresh them in grouped launches

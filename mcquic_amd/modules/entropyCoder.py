@@ -143,21 +143,51 @@ class EntropyCoder(nn.Module):
         self._key = None
 
     @torch.no_grad()
-    def forward(self, codes: List[torch.Tensor]):
+    def forward(self, codes: List[torch.Tensor], counts: Optional[torch.Tensor] = None):
         """Frequency EMA update of a training step (entropyCoder.py:28-44).  The reference sums one-hot codes
         [n, m, h, w, k] over (n, h, w) and all-reduces each level; here the counts are histograms of the int64 codes
-        and the three levels share ONE all-reduce (parallel.code_histograms)."""
-        from ..parallel import code_histograms
-        if self._deferCounts(codes):
+        and the levels share ONE all-reduce.  `counts`: this rank's histograms of all levels back to back (int64), already
+        made where the codes were (the sampling kernels add into `countBuffer()`); without it they are counted from `codes`."""
+        from ..parallel import all_reduce_, local_code_counts
+        if counts is None:
+            counts = local_code_counts(codes, self._k)
+            sink = self.__dict__.get("_countBuf")
+            if self.__dict__.get("_countSinkOn", False) and sink is not None and sink.shape == counts.shape and sink.device == counts.device:
+                sink.copy_(counts)
+                counts = sink
+        self.__dict__["_countMs"] = [int(c.shape[1]) for c in codes]
+        if self.__dict__.get("_countSinkOn", False):
+            self.__dict__["_countSinkBuf"] = counts           # deferred: the caller reduces it over the ranks and calls applyCounts
             return
-        self._emaUpdate(code_histograms(codes, self._k))
+        self._emaUpdate(all_reduce_(counts))
+
+    def _levelMs(self) -> List[int]:
+        return list(self._m) if isinstance(self._m, (list, tuple)) else [self._m] * len(self._k)
+
+    def countBuffer(self, device) -> torch.Tensor:
+        """This coder's code-count buffer on `device` (int64, level l's [m_l, k_l] histogram at sum_{j<l} m_j k_j): allocated
+        once, so a captured training step keeps its address; zeroed by the step's prologue launch, added into by the sampling
+        kernels, read by the EMA update (here or, deferred, after the caller's all-reduce)."""
+        buf = self.__dict__.get("_countBuf")
+        n = sum(m * k for m, k in zip(self._levelMs(), self._k))
+        if buf is None or buf.device != torch.device(device) or buf.numel() != n:
+            buf = self.__dict__["_countBuf"] = torch.empty(n, dtype=torch.int64, device=device)
+        return buf
 
     def _emaUpdate(self, counts):
-        for lv, totalCount in enumerate(counts):
-            totalCount = totalCount.to(self._freqEMA[lv].dtype)
-            normalized = totalCount / totalCount.sum(-1, keepdim=True)
-            ema = (1 - self._ema) * normalized + self._ema * self._freqEMA[lv]
-            self._freqEMA[lv].copy_(ema)
+        """`counts`: the global histograms, flat (level after level) or as a list of [m_l, k_l] tensors."""
+        if torch.is_tensor(counts) and counts.is_cuda:
+            from .. import ops
+            ops.freq_ema_update_([f for f in self._freqEMA], counts, self._ema)      # all levels in one launch, in place
+        else:
+            if torch.is_tensor(counts):
+                from ..parallel import split_code_counts
+                counts = split_code_counts(counts, self._levelMs(), self._k)
+            for lv, totalCount in enumerate(counts):
+                totalCount = totalCount.to(self._freqEMA[lv].dtype)
+                normalized = totalCount / totalCount.sum(-1, keepdim=True)
+                ema = (1 - self._ema) * normalized + self._ema * self._freqEMA[lv]
+                self._freqEMA[lv].copy_(ema)
         self.resetFreqAndCDF()
 
     # ---- deferred mode (parallel.GraphedTrainStep): forward leaves this rank's counts in a static buffer, the caller
@@ -173,23 +203,9 @@ class EntropyCoder(nn.Module):
             raise RuntimeError("countSink: no training forward has run in deferred mode yet")
         return buf
 
-    def _deferCounts(self, codes) -> bool:
-        if not self.__dict__.get("_countSinkOn", False):
-            return False
-        from ..parallel import local_code_counts
-        local = local_code_counts(codes, self._k)
-        buf = self.__dict__.get("_countSinkBuf")
-        if buf is None or buf.shape != local.shape or buf.device != local.device:
-            self.__dict__["_countSinkBuf"] = local.clone()
-        else:
-            buf.copy_(local)
-        self.__dict__["_countMs"] = [int(c.shape[1]) for c in codes]
-        return True
-
     @torch.no_grad()
     def applyCounts(self, flat: torch.Tensor):
-        from ..parallel import split_code_counts
-        self._emaUpdate(split_code_counts(flat, self.__dict__["_countMs"], self._k))
+        self._emaUpdate(flat)
 
     # ---- frequency / CDF tables (entropyCoder.py:46-79) ------------------------------------------------------
     def resetFreqAndCDF(self):
@@ -334,24 +350,13 @@ class VariousMCoder(nn.Module):
         self._cdfs = None
         self._normalizedFreq = None
 
-    @torch.no_grad()
-    def forward(self, codes: List[torch.Tensor]):
-        """EMA update (:306-323) from integer codes (level l: [n, m_l, h, w]); one fused all-reduce for all levels."""
-        from ..parallel import code_histograms
-        if self._deferCounts(codes):
-            return
-        self._emaUpdate(code_histograms(codes, self._k))
-
-    def _emaUpdate(self, counts):
-        for lv, totalCount in enumerate(counts):
-            totalCount = totalCount.to(self._freqEMA[lv].dtype)
-            normalized = totalCount / totalCount.sum(-1, keepdim=True)
-            self._freqEMA[lv].copy_((1 - self._ema) * normalized + self._ema * self._freqEMA[lv])
-        self.resetFreqAndCDF()
-
+    # EMA update (:306-323) from integer codes (level l: [n, m_l, h, w]); one fused all-reduce for all levels
+    forward = EntropyCoder.forward
+    _levelMs = EntropyCoder._levelMs
+    countBuffer = EntropyCoder.countBuffer
+    _emaUpdate = EntropyCoder._emaUpdate
     deferCounts = EntropyCoder.deferCounts
     countSink = EntropyCoder.countSink
-    _deferCounts = EntropyCoder._deferCounts
     applyCounts = EntropyCoder.applyCounts
 
     def resetFreqAndCDF(self):

@@ -118,38 +118,38 @@ class _multiCodebookQuantization(nn.Module):
         """[n, m*d, h, w] -> int64 [n, m, h, w] = argmin_k ((x2 + c2) - 2 x.c), first index on ties (:144-179)."""
         return ops.vq_assign(x, self._cache[0].get(self._codebook))
 
-    def forward(self, x: torch.Tensor, freqEMA: torch.Tensor, uniforms=None):
+    def forward(self, x: torch.Tensor, freqEMA: torch.Tensor, uniforms=None, step=None):
         """Training-mode forward (:181-239), forward values only (no autograd graph yet).
 
         logit = (-dist / sqrt(k)) * max(temperature, eps); random drop against the level's frequency EMA;
         gumbelSoftmax(hard=True); code = argmax(logit).  The straight-through sample y_hard - y_soft + y_soft is
         zero except at its arg-max, so it is carried as (index, hot value) instead of a dense [n, m, h, w, k]
-        tensor.  `uniforms` = (u_drop, u_gumbel), the reference's two `torch.rand_like(logit)` draws; drawn here
-        with torch.rand when None.  Returns ((index, hot), code, logit)."""
+        tensor.  `uniforms` = (u_drop, u_gumbel), the reference's two `torch.rand_like(logit)` draws; without them the
+        draws are made inside the kernels that use them, from a generator snapshot (2 x 134 MB per training step that are
+        never written or read; MCQUIC_AMD_TORCH_RAND=1 draws the tensors with torch.rand instead, the round-3 form).
+        `step` = this level's share of the cascade's prologue launch (ops.VqStep.level: drop exponent, generator snapshot,
+        code-count buffer); a stand-alone call makes its own.  Returns ((index, hot), code, logit)."""
         cb = self._cache[0].get(self._codebook)
         n, _, h, w = x.shape
-        shape = (n, self._m, h, w, self._k)
-        rng = None
+        if uniforms is None and (_TORCH_RAND or not x.is_cuda):
+            shape = (n, self._m, h, w, self._k)
+            uniforms = (torch.rand(shape, device=x.device), torch.rand(shape, device=x.device))
+        if step is None:
+            # exponent of _randomDrop (:196-198) and the generator snapshot, made on the device (no host sync in the step)
+            step = ops.vq_step_prologue([freqEMA], EPS, want_rng=uniforms is None).level(0)
+        exponent, rng, counts = step
         if uniforms is None:
-            # the two `torch.rand_like(logit)` draws of the reference are made inside the kernels that use them, from a generator
-            # snapshot (ops.rng_snapshot): 2 x 134 MB per training step that are never written or read.  MCQUIC_AMD_TORCH_RAND=1
-            # draws the tensors with torch.rand instead (the round-3 form).
-            if _TORCH_RAND or not x.is_cuda:
-                uniforms = (torch.rand(shape, device=x.device), torch.rand(shape, device=x.device))
-            else:
-                uniforms, rng = (None, None), ops.rng_snapshot(x.device)
-        bits = math.log2(self._k)
-        # exponent of _randomDrop (:196-198), kept on the device: no host sync in the step
-        with torch.no_grad():
-            usage = (freqEMA > EPS).float().mean().clamp(0., 1.)
-            exponent = -(bits - 1) * (usage ** 2) + bits
+            uniforms = (None, None)
+        else:
+            rng = None
         if torch.is_grad_enabled():
             from ..autograd import SoftQuantizeFn
-            deq, code, logit = SoftQuantizeFn.apply(x, self._codebook, self._temperature, freqEMA.detach(), uniforms[0], uniforms[1],
-                                                    exponent, cb, float(EPS), rng)
+            deq, code, logit, sdeq = SoftQuantizeFn.apply(x, self._codebook, self._temperature, freqEMA.detach(), uniforms[0], uniforms[1],
+                                                          exponent, cb, float(EPS), rng, counts)
+            ops.set_silu_twin(deq, sdeq)
             return deq, code, logit           # the sample is represented by its (differentiable) dequantisation
         logit = ops.vq_logits(x, cb, self._temperature, float(EPS))
-        code, index, hot = ops.vq_gumbel_sample(logit, uniforms[0], uniforms[1], freqEMA, exponent, rng)
+        code, index, hot = ops.vq_gumbel_sample(logit, uniforms[0], uniforms[1], freqEMA, exponent, rng, counts)
         return (index, hot), code, logit
 
 
@@ -218,11 +218,11 @@ class _quantizerEncoder(nn.Module):
         return head[len(head) - 1](t, res=deq, res_scale=-1.0, dual_silu=True), code
 
 
-    def _forward(self, x: torch.Tensor, freqEMA: torch.Tensor, uniforms=None):
+    def _forward(self, x: torch.Tensor, freqEMA: torch.Tensor, uniforms=None, step=None):
         """Training-mode level (:295-305): returns (sample, residual for the next level, code, logit)."""
         z = self._latentStageEncoder(x)
         if self._latentHead is None:
-            q, code, logit = self._quantizer(self._quantizationHead(z), freqEMA, uniforms)
+            q, code, logit = self._quantizer(self._quantizationHead(z), freqEMA, uniforms, step)
             return q, None, code, logit
         head = self._latentHead
         if torch.is_grad_enabled():
@@ -231,17 +231,20 @@ class _quantizerEncoder(nn.Module):
             # 16x16 ... 4x4 maps of a training crop, become 10 launches each way)
             from .. import autograd as AG
             hz, qin = AG.lockstep([head, self._quantizationHead], [z, z])
-            q, code, logit = self._quantizer(qin, freqEMA, uniforms)
-            return q, AG.sub(hz, self._dequantizer(q)), code, logit
-        q, code, logit = self._quantizer(self._quantizationHead(z), freqEMA, uniforms)
+            q, code, logit = self._quantizer(qin, freqEMA, uniforms, step)
+            # z' - dequant (:303); the sample's second use (the decoder) goes through the same node, so that its two gradients
+            # meet in one launch of ours
+            residual, q = AG.sub_pass(hz, self._dequantizer(q))
+            return q, residual, code, logit
+        q, code, logit = self._quantizer(self._quantizationHead(z), freqEMA, uniforms, step)
         deq = self._dequantizer(q)
         t = z
         for i in range(len(head) - 1):
             t = head[i](t)
         return q, head[len(head) - 1](t, res=deq, res_scale=-1.0, dual_silu=True), code, logit
 
-    def forward(self, x: torch.Tensor, freqEMA: torch.Tensor, uniforms=None):
-        return self._forward(x, freqEMA, uniforms)
+    def forward(self, x: torch.Tensor, freqEMA: torch.Tensor, uniforms=None, step=None):
+        return self._forward(x, freqEMA, uniforms, step)
 
 
 class _quantizerDecoder(nn.Module):
@@ -271,12 +274,12 @@ class _quantizerDecoder(nn.Module):
         if self._sideHead is not None and torch.is_grad_enabled():
             from .. import autograd as AG                      # sideHead and dequantizationHead in lockstep (see _quantizerEncoder._forward)
             x, side = AG.lockstep([self._dequantizationHead, self._sideHead], [self._dequantizer(q), formerLevel])
-            return self._restoreHead(AG.add(x, side))
+            return self._restoreHead(AG.add(x, side, dual_silu=True))
         x = self._dequantizationHead(self._dequantizer(q))
         if self._sideHead is not None:
             if torch.is_grad_enabled():
                 from .. import autograd as AG
-                x = AG.add(x, self._sideHead(formerLevel))
+                x = AG.add(x, self._sideHead(formerLevel), dual_silu=True)
             else:
                 x = ops.add(x, self._sideHead(formerLevel), dual_silu=True)
         return self._restoreHead(x)
@@ -298,6 +301,16 @@ class BaseQuantizer(nn.Module):
     @property
     def NormalizedFreq(self):
         return self._entropyCoder.NormalizedFreq
+
+    def _stepPrologue(self, x: torch.Tensor, uniforms):
+        """The per-step bookkeeping of all levels in ONE launch (ops.vq_step_prologue): every level's drop exponent and generator
+        snapshot, and the zeroed code-count buffer of the entropy coder that the sampling kernels add into.  None on the CPU
+        (module-level fallbacks: the levels then make their own)."""
+        if not x.is_cuda:
+            return None
+        coder = self._entropyCoder
+        want_rng = uniforms is None and not _TORCH_RAND
+        return ops.vq_step_prologue(list(coder._freqEMA), EPS, want_rng, coder.countBuffer(x.device))
 
     def compress(self, x: torch.Tensor):
         codes = self.encode(x)
@@ -357,15 +370,17 @@ class UMGMQuantizer(BaseQuantizer):
         reverse, then the code-frequency EMA update with its all-reduce (entropyCoder.py:28-44).
         `uniforms`: optional list of (u_drop, u_gumbel) per level.  Returns (yHat, codes, logits)."""
         quantizeds, codes, logits = [], [], []
+        st = self._stepPrologue(x, uniforms)
         for lv, encoder in enumerate(self._encoders):
-            quantized, x, code, logit = encoder(x, self._entropyCoder._freqEMA[lv], None if uniforms is None else uniforms[lv])
+            quantized, x, code, logit = encoder(x, self._entropyCoder._freqEMA[lv], None if uniforms is None else uniforms[lv],
+                                                None if st is None else st.level(lv))
             quantizeds.append(quantized)
             codes.append(code)
             logits.append(logit)
         formerLevel = None
         for decoder, quantized in zip(self._decoders[::-1], quantizeds[::-1]):
             formerLevel = decoder(quantized, formerLevel)
-        self._entropyCoder(codes)
+        self._entropyCoder(codes, counts=None if st is None else st.counts)
         return formerLevel, codes, logits
 
     def reAssignCodebook(self) -> torch.Tensor:
@@ -503,13 +518,15 @@ class ResidualBackwardQuantizer(VariousMQuantizer):
         latents = self._latents(x)
         quantizeds, codes, logits = [], [], []
         current = None
+        st = self._stepPrologue(x, uniforms)          # (the j-th quantization reads `_entropyCoder._freqEMA[j]`, see __init__)
         for j, (quantizer, dequantizer, backward, latent) in enumerate(zip(self._quantizers[::-1], self._dequantizers[::-1],
                                                                            self._backwards[::-1], latents[::-1])):
             if current is None:
                 residual = latent
             else:
                 residual = AG.sub(latent, current) if grad else ops.axpby(latent, current, 1.0, -1.0)
-            sample, code, logit = quantizer(residual, quantizer._freqEMA, None if uniforms is None else uniforms[j])
+            sample, code, logit = quantizer(residual, quantizer._freqEMA, None if uniforms is None else uniforms[j],
+                                            None if st is None else st.level(j))
             quantized = dequantizer(sample)
             quantizeds.append(quantized)
             codes.append(code)
@@ -521,5 +538,5 @@ class ResidualBackwardQuantizer(VariousMQuantizer):
                 formerLevel = decoder(quantized)                                  # (0 + quantized is quantized, bit for bit)
             else:
                 formerLevel = decoder(AG.add(formerLevel, quantized) if grad else ops.add(formerLevel, quantized))
-        self._entropyCoder(codes)
+        self._entropyCoder(codes, counts=None if st is None else st.counts)
         return formerLevel, codes, logits

@@ -140,7 +140,8 @@ class ResidualBlockWithStride(_residulBlock):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
-            t = self._branch[2](self._branch[1](AG.silu(x)))
+            sx, x = AG.silu_fork(x)                                           # (the branch's and the skip's gradients meet in one launch)
+            t = self._branch[2](self._branch[1](sx))
             return self._branch[3](t, res=self._skip(x), dual_silu=True)      # (+ silu(out) for the block that follows)
         with _fork(x) as f:
             identity = self._skip(x)
@@ -160,7 +161,8 @@ class ResidualBlockShuffle(_residulBlock):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
-            t = self._branch[2](self._branch[1](AG.silu(x)))
+            sx, x = AG.silu_fork(x)
+            t = self._branch[2](self._branch[1](sx))
             return self._branch[3](t, res=self._skip(x), dual_silu=True)
         with _fork(x) as f:
             identity = self._skip(x)

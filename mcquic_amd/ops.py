@@ -542,6 +542,18 @@ def nonneg_reparam_bwd(p: torch.Tensor, dfolded: torch.Tensor, bound: float) -> 
     return out
 
 
+def nonneg_reparam_bwd2(p0: torch.Tensor, d0: torch.Tensor, bound0: float, p1: torch.Tensor, d1: torch.Tensor, bound1: float):
+    """nonneg_reparam_bwd for two parameters (a GDN layer's beta and gamma) in one launch (mcq_nonneg_reparam_bwd2_f32)."""
+    p0, d0, p1, d1 = _dev(p0.detach(), "p0"), _dev(d0, "d0"), _dev(p1.detach(), "p1"), _dev(d1, "d1")
+    if p0.numel() != d0.numel() or p1.numel() != d1.numel():
+        raise ValueError("nonneg_reparam_bwd2: shape mismatch")
+    o0, o1 = torch.empty_like(p0), torch.empty_like(p1)
+    with _guard(p0.device):
+        check(_lib.load().mcq_nonneg_reparam_bwd2_f32(_ptr(p0), _ptr(d0), float(bound0), _ptr(o0), p0.numel(), _ptr(p1), _ptr(d1), float(bound1),
+                                                      _ptr(o1), p1.numel(), _stream()), "mcq_nonneg_reparam_bwd2_f32")
+    return o0, o1
+
+
 class PackedCodebook:
     """Codebook [m, k, d] in MFMA operand order + codeword norms (mcq_vq_pack_codebook_f32)."""
 
@@ -633,6 +645,83 @@ def rng_snapshot(device) -> torch.Tensor:
     return snap
 
 
+class VqStep:
+    """What ONE mcq_vq_step_prologue_f32 launch prepared for a training forward of `levels` quantizations: the random drop's
+    exponents (float32 [levels]), one generator snapshot per level (int64 [levels, 2]; None when the caller brings the draws)
+    and the zeroed code-count buffer the sampling kernels add into (int64, level l at `offsets[l]`; None: no counting)."""
+
+    __slots__ = ("exponents", "snaps", "counts", "offsets", "sizes")
+
+    def level(self, l: int):
+        """(drop exponent [1], generator snapshot [2] or None, this level's [m * k] counts or None)."""
+        cnt = None if self.counts is None else self.counts[self.offsets[l]: self.offsets[l] + self.sizes[l]]
+        return self.exponents[l: l + 1], (None if self.snaps is None else self.snaps[l]), cnt
+
+
+def vq_step_prologue(freqs: Sequence[torch.Tensor], eps: float, want_rng: bool, counts: Optional[torch.Tensor] = None) -> VqStep:
+    """The bookkeeping in front of a training forward's level cascade as ONE launch (mcq_vq_step_prologue_f32): per level the
+    exponent of `_randomDrop` from its frequency EMA `freqs[l]` [m_l, k_l] (mcquic/modules/quantizer.py:194-198), a generator
+    snapshot per level with the generator advanced past them (`want_rng`), and `counts` (int64, sum of m_l * k_l entries) zeroed."""
+    fs = [_dev(f.detach(), "freq_ema") for f in freqs]
+    levels = len(fs)
+    lib = _lib.load()
+    dev = fs[0].device
+    ms = (ctypes.c_int32 * levels)(*[int(f.shape[0]) for f in fs])
+    ks = (ctypes.c_int32 * levels)(*[int(f.shape[1]) for f in fs])
+    st = VqStep()
+    st.sizes = [int(f.shape[0]) * int(f.shape[1]) for f in fs]
+    st.offsets = [sum(st.sizes[:l]) for l in range(levels)]
+    st.exponents = torch.empty(levels, dtype=torch.float32, device=dev)
+    st.snaps, state = None, None
+    if want_rng:
+        state = _rng_states.get(dev.index)
+        if state is None:
+            seed_rng(torch.initial_seed(), dev)
+            state = _rng_states[dev.index]
+        st.snaps = torch.empty((levels, 2), dtype=torch.int64, device=dev)
+    st.counts = None
+    if counts is not None:
+        st.counts = _dev(counts, "counts", torch.int64)
+        if st.counts.numel() != sum(st.sizes):
+            raise ValueError("vq_step_prologue: the count buffer must hold sum(m_l * k_l) entries")
+    ptrs = (ctypes.c_void_p * levels)(*[f.data_ptr() for f in fs])
+    with _guard(dev):
+        check(lib.mcq_vq_step_prologue_f32(ptrs, ms, ks, levels, float(eps), _ptr(st.exponents), _ptr(state), _ptr(st.snaps), _ptr(st.counts),
+                                           0 if st.counts is None else st.counts.numel(), _stream()), "mcq_vq_step_prologue_f32")
+    return st
+
+
+def vq_temperature_grad(dtrow: torch.Tensor, temperature: torch.Tensor, bound: float) -> torch.Tensor:
+    """d temperature (the Parameter's shape) from the soft-max backward's per-row terms [n, m, h, w]: their sum over images and
+    pixels per group, then LowerBound's gradient rule (mcquic/nn/base.py:24-29) -- one launch (mcq_vq_temperature_grad_f32)."""
+    dtrow = _dev(dtrow, "dtrow")
+    n, m, h, w = dtrow.shape
+    t = _dev(temperature.detach().reshape(-1), "temperature")
+    out = torch.empty(temperature.shape, dtype=torch.float32, device=dtrow.device)
+    with _guard(dtrow.device):
+        check(_lib.load().mcq_vq_temperature_grad_f32(_ptr(dtrow), _ptr(t), float(bound), _ptr(out), n, m, h * w, _stream()),
+              "mcq_vq_temperature_grad_f32")
+    return out
+
+
+def freq_ema_update_(freqs: Sequence[torch.Tensor], counts: torch.Tensor, ema: float) -> None:
+    """In place on every level's frequency EMA [m_l, k_l]: (1 - ema) * counts_l / sum_k counts_l + ema * freq_l
+    (mcquic/modules/entropyCoder.py:37-43) for all levels in ONE launch; `counts` = the levels' histograms back to back (int64)."""
+    fs = [_dev(f.detach(), "freq_ema") for f in freqs]
+    for f, g in zip(fs, freqs):
+        if f.data_ptr() != g.data_ptr():
+            raise ValueError("freq_ema_update_: the frequency tensors must be contiguous (they are updated in place)")
+    levels = len(fs)
+    counts = _dev(counts, "counts", torch.int64)
+    if counts.numel() != sum(int(f.numel()) for f in fs):
+        raise ValueError("freq_ema_update_: `counts` must hold sum(m_l * k_l) entries")
+    ms = (ctypes.c_int32 * levels)(*[int(f.shape[0]) for f in fs])
+    ks = (ctypes.c_int32 * levels)(*[int(f.shape[1]) for f in fs])
+    ptrs = (ctypes.c_void_p * levels)(*[f.data_ptr() for f in fs])
+    with _guard(counts.device):
+        check(_lib.load().mcq_freq_ema_update_f32(ptrs, ms, ks, levels, _ptr(counts), float(ema), _stream()), "mcq_freq_ema_update_f32")
+
+
 def hash_uniform(rng: torch.Tensor, stream_id: int, shape) -> torch.Tensor:
     """The generator's draws for a tensor of `shape` (stream 0 = random drop, 1 = Gumbel noise) under the snapshot `rng`:
     exactly what the kernels use in place of a missing u_drop / u_gumbel (mcq_hash_uniform_f32)."""
@@ -644,9 +733,10 @@ def hash_uniform(rng: torch.Tensor, stream_id: int, shape) -> torch.Tensor:
 
 
 def vq_gumbel_sample(logits: torch.Tensor, u_drop: Optional[torch.Tensor], u_gumbel: Optional[torch.Tensor], freq_ema: torch.Tensor,
-                     drop_exponent: torch.Tensor, rng: Optional[torch.Tensor] = None):
+                     drop_exponent: torch.Tensor, rng: Optional[torch.Tensor] = None, counts: Optional[torch.Tensor] = None):
     """In place on `logits`: random drop; returns (codes, sample_index, sample_hot), each [n, m, h, w].  A draw that is None is
-    made inside the kernel from the generator snapshot `rng` (rng_snapshot)."""
+    made inside the kernel from the generator snapshot `rng` (rng_snapshot).  `counts` (int64 [m * k], zeroed by the caller once
+    per step): every code made here is counted into it -- the level's histogram for the frequency EMA."""
     logits = _dev(logits, "logits")
     n, m, h, w, k = logits.shape
     if (u_drop is None or u_gumbel is None) and rng is None:
@@ -661,21 +751,28 @@ def vq_gumbel_sample(logits: torch.Tensor, u_drop: Optional[torch.Tensor], u_gum
     codes = torch.empty((n, m, h, w), dtype=torch.int64, device=logits.device)
     index = torch.empty_like(codes)
     hot = torch.empty((n, m, h, w), dtype=torch.float32, device=logits.device)
+    if counts is not None:
+        counts = _dev(counts, "counts", torch.int64)
+        if counts.numel() != m * k:
+            raise ValueError("vq_gumbel_sample: `counts` must hold m * k entries")
     with _guard(logits.device):
         check(_lib.load().mcq_vq_gumbel_sample_f32(_ptr(logits), _ptr(u_drop), _ptr(u_gumbel), _ptr(rng), _ptr(freq), _ptr(expo), _ptr(codes),
-                                                   _ptr(index), _ptr(hot), n, m, h, w, k, _stream()), "mcq_vq_gumbel_sample_f32")
+                                                   _ptr(index), _ptr(hot), _ptr(counts), n, m, h, w, k, _stream()), "mcq_vq_gumbel_sample_f32")
     return codes, index, hot
 
 
-def vq_dequant_soft(index: torch.Tensor, hot: torch.Tensor, cb: PackedCodebook) -> torch.Tensor:
-    """sample @ codebook for the one-hot-valued straight-through sample -> [n, m*d, h, w]."""
+def vq_dequant_soft(index: torch.Tensor, hot: torch.Tensor, cb: PackedCodebook, dual_silu: bool = False) -> torch.Tensor:
+    """sample @ codebook for the one-hot-valued straight-through sample -> [n, m*d, h, w] (`dual_silu`: + its SiLU twin)."""
     index = _dev(index, "sample_index", torch.int64)
     hot = _dev(hot, "sample_hot")
     n, m, h, w = index.shape
     out = torch.empty((n, m * cb.d, h, w), dtype=torch.float32, device=index.device)
+    out2 = torch.empty_like(out) if dual_silu else None
     with _guard(index.device):
-        check(_lib.load().mcq_vq_dequant_soft_f32(_ptr(index), _ptr(hot), _ptr(cb.codebook), _ptr(out), n, m, cb.d, h, w, cb.k,
+        check(_lib.load().mcq_vq_dequant_soft_f32(_ptr(index), _ptr(hot), _ptr(cb.codebook), _ptr(out), _ptr(out2), n, m, cb.d, h, w, cb.k,
                                                   _stream()), "mcq_vq_dequant_soft_f32")
+    if out2 is not None:
+        set_silu_twin(out, out2)
     return out
 
 
@@ -944,11 +1041,15 @@ def channel_sum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def silu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+def silu_bwd(x: torch.Tensor, dy: torch.Tensor, other: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy * silu'(x) (+ other, a gradient that reaches x along a second path) in one launch."""
     x, dy = _dev(x, "x"), _dev(dy, "dy")
+    other = None if other is None else _dev(other, "other")
+    if dy.shape != x.shape or (other is not None and other.shape != x.shape):
+        raise ValueError("silu_bwd: shape mismatch")
     dx = torch.empty_like(x)
     with _guard(x.device):
-        check(_lib.load().mcq_silu_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _stream()), "mcq_silu_bwd_f32")
+        check(_lib.load().mcq_silu_bwd_f32(_ptr(x), _ptr(dy), _ptr(other), _ptr(dx), x.numel(), _stream()), "mcq_silu_bwd_f32")
     return dx
 
 
@@ -998,11 +1099,16 @@ def gate(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor, dual_silu: bool = Fa
     return out
 
 
-def axpby(a: torch.Tensor, b: torch.Tensor, alpha: float, beta: float) -> torch.Tensor:
+def axpby(a: torch.Tensor, b: torch.Tensor, alpha: float, beta: float, dual_silu: bool = False) -> torch.Tensor:
     a, b = _dev(a, "a"), _dev(b, "b")
+    if a.shape != b.shape:
+        raise ValueError("axpby: shape mismatch")
     out = torch.empty_like(a)
+    out2 = torch.empty_like(a) if dual_silu else None
     with _guard(a.device):
-        check(_lib.load().mcq_axpby_f32(_ptr(a), _ptr(b), float(alpha), float(beta), _ptr(out), a.numel(), _stream()), "mcq_axpby_f32")
+        check(_lib.load().mcq_axpby_f32(_ptr(a), _ptr(b), float(alpha), float(beta), _ptr(out), _ptr(out2), a.numel(), _stream()), "mcq_axpby_f32")
+    if out2 is not None:
+        set_silu_twin(out, out2)
     return out
 
 
@@ -1045,7 +1151,12 @@ def vq_soft_bwd(ddist: torch.Tensor, rowsum: torch.Tensor, x: torch.Tensor, ddeq
     """(dx [n, m*d, h, w], dcodebook [m, k, d]) of the soft assignment + soft dequantisation."""
     x, ddeq = _dev(x, "x"), _dev(ddeq, "ddeq")
     n, m, h, w, k = ddist.shape
-    xt, dqt = nchw_to_nhwc(x), nchw_to_nhwc(ddeq)
+    c, hw = x.shape[1], h * w
+    xt = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    dqt = torch.empty_like(xt)
+    with _guard(x.device):                                     # both channel-major copies from one launch
+        check(_lib.load().mcq_nchw_to_nhwc_pair_f32(_ptr(x), _ptr(xt), c, hw, 0, _ptr(ddeq), _ptr(dqt), c, hw, n, _stream()),
+              "mcq_nchw_to_nhwc_pair_f32")
     dx = torch.empty_like(x)
     dcb = torch.empty_like(cb.codebook)
     with _guard(x.device):

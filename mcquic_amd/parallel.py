@@ -347,7 +347,8 @@ class GraphedTrainStep:
                         torch.cat([p.grad.reshape(-1) for p in self.live_groups[k]], out=self.slices[k])
                     if k == 0:
                         sinks = [c.countSink() for c in self.coders]
-                        self.counts = torch.cat(sinks) if sinks else None
+                        # (one coder per model: its count buffer itself -- the sampling kernels add into it, nothing is copied)
+                        self.counts = (sinks[0] if len(sinks) == 1 else torch.cat(sinks)) if sinks else None
                 self.graphs.append(g)
             self.graph = self.graphs[0]
             self._carry = None                               # (the autograd graph between segments: only needed while capturing)
@@ -449,7 +450,7 @@ class GraphedTrainStep:
             for p in self.params:
                 p.grad = None
             m._repackStale()
-            y = m._encoder(self.x)                            # (no padding in the training forward, compressor.py:39)
+            y = m._trainEncode(self.x) if hasattr(m, "_trainEncode") else m._encoder(self.x)     # (no padding in the training forward, compressor.py:39)
             yl = y.detach().requires_grad_()
             tw = ops.silu_twin(y)
             if tw is not None:

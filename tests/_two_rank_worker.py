@@ -73,12 +73,12 @@ def train_mode(rank, world, dev):
         # ONE process, all four crops, before DDP hooks exist.  No cross-rank collective may run in here (rank 1 waits at the
         # barrier below): the frequency-EMA update's all-reduce is pointed at the single-rank group
         import mcquic_amd.parallel as P
-        orig = P.code_histograms
-        P.code_histograms = lambda c, k, group=None: orig(c, k, group=solo)
+        orig = P.all_reduce_
+        P.all_reduce_ = lambda buf, group=None: orig(buf, solo)
         try:
             xHat1, _, codes1, _ = model(x, uniforms=us)
         finally:
-            P.code_histograms = orig
+            P.all_reduce_ = orig
         torch.nn.functional.mse_loss(xHat1, x).backward()
         torch.cuda.synchronize()
         want = {name: p.grad.detach().clone() for name, p in model.named_parameters() if p.grad is not None}
@@ -137,8 +137,8 @@ def graphed_mode(rank, world, dev, clip=None):
         solo_model = copy.deepcopy(model)
         solo = dist.new_group([0])
         import mcquic_amd.parallel as P
-        orig = P.code_histograms
-        P.code_histograms = lambda c, k, group=None: orig(c, k, group=solo)
+        orig = P.all_reduce_
+        P.all_reduce_ = lambda buf, group=None: orig(buf, solo)
         try:
             opt = torch.optim.SGD(solo_model.parameters(), lr=lr)
             xHat = solo_model(x, uniforms=us)[0]
@@ -147,7 +147,7 @@ def graphed_mode(rank, world, dev, clip=None):
                 out["solo_grad_norm"] = float(torch.nn.utils.clip_grad_norm_(solo_model.parameters(), clip))
             opt.step()
         finally:
-            P.code_histograms = orig
+            P.all_reduce_ = orig
         torch.cuda.synchronize()
         ref = [p.detach().clone() for p in solo_model.parameters()]
         ref_ema = [f.detach().clone() for f in solo_model._quantizer._entropyCoder._freqEMA]

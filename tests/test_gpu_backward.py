@@ -681,7 +681,7 @@ def test_soft_assignment_with_in_kernel_draws_equals_given_tensors(dev, mk):
         x = x0.clone().requires_grad_()
         cbp.grad = temp.grad = None
         pk = ops.PackedCodebook(cbp)
-        deq, code, logit = SoftQuantizeFn.apply(x, cbp, temp, freq, args[0], args[1], expo, pk, 1e-6, args[2])
+        deq, code, logit, _sdeq = SoftQuantizeFn.apply(x, cbp, temp, freq, args[0], args[1], expo, pk, 1e-6, args[2])
         (deq * gd).sum().backward()
         outs.append((deq.detach(), code, logit.detach(), x.grad.clone(), cbp.grad.clone(), temp.grad.clone()))
     for other in outs[1:]:

@@ -1,0 +1,179 @@
+"""The per-step bookkeeping kernels of the training quantizer (csrc/step_ops.hip) and the small fused forms that replaced
+engine- / ATen-issued launches in the captured training step, each against the tensor ops the reference spells them with
+(mcquic/modules/quantizer.py:194-200, mcquic/modules/entropyCoder.py:28-44, mcquic/nn/base.py:17-29)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _freqs(ms, ks, seed, dead=0.3):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for m, k in zip(ms, ks):
+        f = torch.rand((m, k), generator=g)
+        f = torch.where(torch.rand((m, k), generator=g) < dead, torch.zeros_like(f), f)      # unused codewords: frequency 0
+        out.append(f / f.sum(-1, keepdim=True))
+    return out
+
+
+@pytest.mark.parametrize("ms,ks", [([2, 2, 2], [8192, 2048, 512]), ([1, 1, 1, 1], [4096] * 4), ([3], [1000]), ([12, 12], [8192, 37])])
+def test_step_prologue_matches_the_reference_ops(dev, ms, ks):
+    """Exponent of `_randomDrop` bit for bit (quantizer.py:196-198 evaluated with torch on the CPU), generator snapshots =
+    {seed, offset + l} with the state moved past them, count buffer zeroed."""
+    from mcquic_amd import ops
+    freqs = _freqs(ms, ks, 7)
+    ops.seed_rng(99, dev)
+    first = ops.rng_snapshot(dev)                                   # (moves the offset to 1)
+    counts = torch.full((sum(m * k for m, k in zip(ms, ks)),), 7, dtype=torch.int64, device=dev)
+    st = ops.vq_step_prologue([f.to(dev) for f in freqs], 1e-6, True, counts)
+    for lv, (f, k) in enumerate(zip(freqs, ks)):
+        bits = math.log2(k)
+        usage = (f > 1e-6).float().mean().clamp(0., 1.)
+        want = -(bits - 1) * (usage ** 2) + bits
+        e, rng, cnt = st.level(lv)
+        assert float(e.cpu()) == float(want), (lv, float(e.cpu()), float(want))
+        assert int(rng[0]) == 99 and int(rng[1]) == int(first[1]) + 1 + lv
+        assert cnt.numel() == ms[lv] * k
+    assert int(st.counts.abs().sum()) == 0
+    nxt = ops.rng_snapshot(dev)
+    assert int(nxt[1]) == int(first[1]) + 1 + len(ks)
+    # without a generator / a count buffer
+    st2 = ops.vq_step_prologue([f.to(dev) for f in freqs], 1e-6, False)
+    assert st2.snaps is None and st2.counts is None and torch.equal(st2.exponents, st.exponents)
+
+
+@pytest.mark.parametrize("m,k,hw", [(2, 8192, 16), (2, 2048, 8), (2, 512, 4), (1, 20000, 3), (3, 40, 5)])
+def test_sampling_kernel_counts_its_codes(dev, m, k, hw):
+    """`counts` of mcq_vq_gumbel_sample_f32 = the histogram of the codes it returns (entropyCoder.py:33-35), every kernel variant."""
+    from mcquic_amd import ops, parallel
+    g = torch.Generator().manual_seed(k)
+    n = 3
+    logits = torch.randn((n, m, hw, hw, k), generator=g).to(dev)
+    freq = _freqs([m], [k], 3)[0].to(dev)
+    ops.seed_rng(5, dev)
+    st = ops.vq_step_prologue([freq], 1e-6, True, torch.empty(m * k, dtype=torch.int64, device=dev))
+    e, rng, cnt = st.level(0)
+    codes, index, hot = ops.vq_gumbel_sample(logits, None, None, freq, e, rng, cnt)
+    want = parallel.local_code_counts([codes], [k])
+    assert torch.equal(cnt, want) and int(cnt.sum()) == n * m * hw * hw
+
+
+@pytest.mark.parametrize("ms,ks", [([2, 2, 2], [8192, 2048, 512]), ([1, 1], [4096, 4096]), ([3, 5], [100, 7])])
+def test_freq_ema_update_is_the_reference_update(dev, ms, ks):
+    """(1 - ema) * count / total + ema * freq, bit for bit the tensor-op form of entropyCoder.py:37-43 (float32, CPU)."""
+    from mcquic_amd import ops
+    g = torch.Generator().manual_seed(11)
+    freqs = _freqs(ms, ks, 13, dead=0.0)
+    counts = [torch.randint(0, 50, (m, k), generator=g) for m, k in zip(ms, ks)]
+    for ema in (0.9, 0.998):
+        want = []
+        for f, c in zip(freqs, counts):
+            total = c.to(torch.float32)
+            normalized = total / total.sum(-1, keepdim=True)
+            want.append((1 - ema) * normalized + ema * f)
+        got = [f.clone().to(dev) for f in freqs]
+        ops.freq_ema_update_(got, torch.cat([c.reshape(-1) for c in counts]).to(dev), ema)
+        for a, b in zip(got, want):
+            assert torch.equal(a.cpu(), b)
+
+
+def test_entropy_coder_forward_from_counted_codes(dev):
+    """EntropyCoder.forward fed by the step's count buffer = the same call counting from the codes (and = the CPU module)."""
+    from mcquic_amd import ops
+    from mcquic_amd.modules.entropyCoder import EntropyCoder
+    ks = [64, 32, 16]
+    g = torch.Generator().manual_seed(2)
+    codes = [torch.randint(0, k, (5, 2, s, s), generator=g) for k, s in zip(ks, (8, 4, 2))]
+    cpu, a, b = EntropyCoder(2, ks), EntropyCoder(2, ks).to(dev), EntropyCoder(2, ks).to(dev)
+    cpu(codes)
+    a([c.to(dev) for c in codes])
+    buf = b.countBuffer(dev)
+    from mcquic_amd import parallel
+    buf.copy_(parallel.local_code_counts([c.to(dev) for c in codes], ks))
+    b([c.to(dev) for c in codes], counts=buf)
+    for x, y, z in zip(cpu._freqEMA, a._freqEMA, b._freqEMA):
+        assert torch.equal(x, y.cpu()) and torch.equal(x, z.cpu())
+    assert b.countBuffer(dev).data_ptr() == buf.data_ptr()          # allocated once: a captured step keeps its address
+
+
+def test_temperature_grad_applies_lower_bound_rule(dev):
+    from mcquic_amd import ops
+    g = torch.Generator().manual_seed(4)
+    n, m, h, w = 8, 4, 16, 16
+    dtrow = torch.randn((n, m, h, w), generator=g)
+    dtrow[:, 2] = dtrow[:, 2].abs()                                # group 2: positive sum, temperature below the bound -> blocked
+    dtrow[:, 3] = -dtrow[:, 3].abs()                               # group 3: negative sum, temperature below the bound -> passes
+    temp = torch.tensor([1.0, 0.5, 1e-9, 1e-9]).reshape(m, 1, 1, 1)
+    bound = 1e-6
+    got = ops.vq_temperature_grad(dtrow.to(dev), temp.to(dev), bound).cpu()
+    s = dtrow.double().sum((0, 2, 3))
+    mask = (temp.reshape(-1) >= bound) | (s < 0)
+    want = (mask.double() * s).reshape(m, 1, 1, 1)
+    assert got.shape == temp.shape
+    assert float(got[2]) == 0.0 and float(got[3]) < 0
+    assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_small_fused_forms(dev):
+    """nonneg_reparam_bwd2 = two nonneg_reparam_bwd; silu_bwd(x, dy, other) = silu_bwd(x, dy) + other; axpby / soft dequantisation
+    with their SiLU twins = silu of the result -- bit for bit against the separate launches."""
+    from mcquic_amd import ops
+    g = torch.Generator().manual_seed(8)
+    p0, d0 = torch.randn(128, generator=g).to(dev), torch.randn(128, generator=g).to(dev)
+    p1, d1 = torch.randn((128, 128), generator=g).to(dev), torch.randn((128, 128), generator=g).to(dev)
+    a, b = ops.nonneg_reparam_bwd2(p0, d0, 0.1, p1, d1, 0.2)
+    assert torch.equal(a, ops.nonneg_reparam_bwd(p0, d0, 0.1)) and torch.equal(b, ops.nonneg_reparam_bwd(p1, d1, 0.2))
+    x, dy, other = [torch.randn((2, 16, 12, 12), generator=g).to(dev) for _ in range(3)]
+    assert torch.equal(ops.silu_bwd(x, dy, other), ops.silu_bwd(x, dy) + other)
+    r = ops.axpby(x, dy, 1.0, -1.0, dual_silu=True)
+    assert torch.equal(r, x - dy) and torch.equal(ops.silu_twin(r), ops.silu(r))
+    cb = ops.PackedCodebook((torch.randn((2, 64, 8), generator=g) * 0.3).to(dev))
+    index = torch.randint(0, 64, (2, 2, 12, 12), generator=g).to(dev)
+    hot = torch.rand((2, 2, 12, 12), generator=g).to(dev)
+    q = ops.vq_dequant_soft(index, hot, cb, dual_silu=True)
+    assert torch.equal(q, ops.vq_dequant_soft(index, hot, cb)) and torch.equal(ops.silu_twin(q), ops.silu(q))
+
+
+def test_training_step_replay_issues_no_aten_kernels(dev):
+    """The captured forward + backward of the qp=2 model holds only this library's kernel nodes: no `at::native::*` launch, no
+    memset / memcpy node (98 ATen launches per replay).  Read from the graph's own debug dump."""
+    import os
+    import tempfile
+    from mcquic_amd import Compressor
+    from mcquic_amd.autograd import mse_loss
+    from mcquic_amd.nn import blocks
+    streams = blocks._BRANCH_STREAMS
+    blocks._BRANCH_STREAMS = False
+    try:
+        torch.manual_seed(3407)
+        model = Compressor(8, 2, [64, 32, 16]).to(dev).train()
+        x = (torch.rand((2, 3, 128, 128), generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
+
+        def step():
+            for p in model.parameters():
+                p.grad = None
+            xHat, _, _, _ = model(x)
+            loss = mse_loss(xHat, x)
+            loss.backward()
+            return loss
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        for p in model.parameters():
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        graph.enable_debug_mode()
+        with torch.cuda.graph(graph):
+            loss = step()
+        path = os.path.join(tempfile.mkdtemp(), "step.dot")
+        graph.debug_dump(path)
+        dot = open(path).read()
+    finally:
+        blocks._BRANCH_STREAMS = streams
+    assert "at::native" not in dot and "at_native" not in dot, [ln for ln in dot.splitlines() if "native" in ln][:5]
+    low = dot.lower()
+    assert "memset" not in low, [ln for ln in dot.splitlines() if "emset" in ln][:5]
+    assert "kernel" in low or "conv" in low                        # (the dump does name its kernel nodes)

@@ -53,6 +53,10 @@ extern "C" {
                                      * (the direct term dy f(s)), y_silu = res * mul * (-1/2 s^-3/2) (d s); res = dy, mul = x, RESIDUAL not set.
                                      * What torch.autograd derives for mcquic/nn/gdn.py:75-79; round 3 ran it as a launch of its own behind s. */
 #define MCQ_CONV_IGDN_BWD   0x8000u /* the same for InvGenDivNorm (gdn.py:87-91): y = res * sqrt(s), y_silu = res * mul * (1/2 s^-1/2) */
+#define MCQ_CONV_GATE_BWD   0x10000u /* (round 5) AttentionBlock gate backward in the epilogue of the recomputed s = conv1x1(b) launch (ksize 1, no other flag):
+                                      * y = res * sigmoid(s) (d a), y_silu = res * mul * sigmoid(s) (1 - sigmoid(s)) (d s); res = d out, mul = a.
+                                      * What torch.autograd derives for mcquic/nn/blocks.py:286-287; the forward keeps no s (the gate is the 1x1
+                                      * launch's MCQ_CONV_GATE epilogue in training as in inference). */
 #define MCQ_CONV_DUAL_SILU  0x100u /* also store silu(y) to y_silu: the next block's act1(x), computed once per element */
 #define MCQ_CONV_WINOGRAD2D 0x1000u /* OPT-IN like MCQ_CONV_WINOGRAD: F(2x2, 3x3), 4/9 of the multiplications; w_packed from   */
                                     /* mcq_pack_conv_weight_winograd2d_f32; Cout % 128 == 0, Cin % 8 == 0                                */
@@ -253,7 +257,7 @@ int mcq_vq_temperature_grad_f32(const float* dtrow /* [N, m, hw] */, const float
  * (EntropyCoder.forward, mcquic/modules/entropyCoder.py:28-44, after its all-reduce); `counts` = the levels' [m_l, k_l]
  * histograms back to back (mcq_vq_gumbel_sample_f32's code_counts). */
 int mcq_freq_ema_update_f32(float* const* freq_ema /* [levels] device pointers */, const int32_t* m, const int32_t* k, int32_t levels,
-                            const int64_t* counts, float ema, void* stream);
+                            const int64_t* counts, double ema /* a Python float on the reference side */, void* stream);
 /* mcq_nonneg_reparam_bwd_f32 (below) for two parameters -- a GDN layer's beta [C] and gamma [C, C] -- in one launch. */
 int mcq_nonneg_reparam_bwd2_f32(const float* p0, const float* dfolded0, float bound0, float* dp0, int64_t n0, const float* p1,
                                 const float* dfolded1, float bound1, float* dp1, int64_t n1, void* stream);

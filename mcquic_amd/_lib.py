@@ -22,6 +22,7 @@ CONV_WINOGRAD = 0x800
 CONV_WINOGRAD2D = 0x1000
 CONV_WINOGRAD2D16 = 0x2000
 CONV_GDN_BWD, CONV_IGDN_BWD = 0x4000, 0x8000
+CONV_GATE_BWD = 0x10000
 
 
 class ConvDesc(Structure):
@@ -72,7 +73,7 @@ SYMBOLS = {
                                            c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_vq_step_prologue_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_vq_temperature_grad_f32": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
-    "mcq_freq_ema_update_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_float, c_void_p]),
+    "mcq_freq_ema_update_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_double, c_void_p]),
     "mcq_nonneg_reparam_bwd2_f32": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "mcq_hash_uniform_f32": (c_int32, [c_void_p, c_uint32, c_void_p, c_int64, c_void_p]),
     "mcq_vq_dequant_soft_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,

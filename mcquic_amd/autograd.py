@@ -164,6 +164,19 @@ class MseFn(torch.autograd.Function):
         return (da if ctx.needs_input_grad[0] else None), db
 
 
+_ONES = {}
+
+
+def backward(loss: torch.Tensor) -> None:
+    """`loss.backward()` with the root gradient taken from a cached 1.0 on the loss's device: the engine otherwise allocates and
+    FILLS one per call -- the one ATen launch left in a captured training step."""
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    loss.backward(one if loss.dim() == 0 else None)
+
+
 def mse_loss(a, b):
     """mean((a - b)^2): `MseFn` on a HIP device in float32, torch's own elsewhere."""
     if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.numel():
@@ -263,10 +276,11 @@ class AttentionBlockFn(torch.autograd.Function):
             (a, b), (sa, sb), keep = _rb_forward_multi([block._mainBranch[i], block._sideBranch[i]], [a, b], [sa, sb])
             saved.extend(keep[0])
             saved.extend(keep[1])
-        bb = ops.conv2d(b, block._sideBranch[3].packed())
-        out = ops.gate(a, bb, x, dual_silu=True)                 # silu(out) for the block that follows, in the same launch
+        # a * sigmoid(conv1x1(b)) + x as the 1x1 launch's epilogue (like inference), silu(out) for the block that follows from the same
+        # launch; the 1x1 output itself is not kept: backward recomputes it in the launch that needs it (MCQ_CONV_GATE_BWD)
+        out = ops.conv2d(b, block._sideBranch[3].packed(), gate_mul=a, gate_id=x, dual_silu=True)
         sout = ops.silu_twin(out)
-        ctx.save_for_backward(a, b, bb, *saved)
+        ctx.save_for_backward(a, b, *saved)
         ctx.block = block
         ctx.mark_non_differentiable(sout)
         ctx.set_materialize_grads(False)
@@ -275,13 +289,13 @@ class AttentionBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dsout):
         block = ctx.block
-        a, b, bb = ctx.saved_tensors[:3]
-        saved = ctx.saved_tensors[3:]
+        a, b = ctx.saved_tensors[:2]
+        saved = ctx.saved_tensors[2:]
         main = [saved[8 * i: 8 * i + 4] for i in range(3)]
         side = [saved[8 * i + 4: 8 * i + 8] for i in range(3)]
         dout = dout.contiguous()
-        h, dbb = ops.gate_bwd(a, bb, dout)                       # d a, d (conv1x1 output)
         c11 = block._sideBranch[3]
+        (h, dbb), = ops.conv2d_gate_bwd([b], [c11.packed()], [a], [dout])     # d a, d (conv1x1 output)
         g = ops.conv2d(dbb, _dgrad_packed(c11, c11.weight))
         dw11, db11 = ops.conv2d_wgrad(b, dbb, 1, 1, want_bias=True)
         pairs = []                                               # appended RB 2, 1, 0; per RB: main (conv1, conv2), side (conv1, conv2)
@@ -346,9 +360,9 @@ def _lockstep_forward(stacks, xs, keep: bool):
                 ys, sys_, sv = _rb_forward_multi(blocks, a + b, sa + sb)
                 a, b, sa, sb = ys[:k], ys[k:], sys_[:k], sys_[k:]
                 saved.append(sv)
-            bbs = ops.conv2d_multi(b, [m._sideBranch[3].packed() for m in layer])
-            outs = [ops.gate(ai, bbi, xi, dual_silu=True) for ai, bbi, xi in zip(a, bbs, xs)]
-            tape.append((kind, layer, (a, b, bbs, saved)))
+            outs = ops.conv2d_multi(b, [m._sideBranch[3].packed() for m in layer],
+                                    per_problem=[dict(gate_mul=ai, gate_id=xi) for ai, xi in zip(a, xs)], dual_silu=True)
+            tape.append((kind, layer, (a, b, saved)))
             xs = outs
         else:
             # (a conv3x3 in the middle of a head feeds a ResidualBlock: its launch writes the SiLU twin that block starts from)
@@ -371,15 +385,14 @@ def _lockstep_backward(tape, dys, grads):
                 owners.extend([m._branch[1], m._branch[3]])
             assert len(pairs) - before == 2 * k
         elif kind == "attn":
-            a, b, bbs, rbsaved = saved
-            hs, gs = [], []
-            for m, ai, bi, bbi, dout in zip(layer, a, b, bbs, dys):
-                h, dbb = ops.gate_bwd(ai, bbi, dout)
-                c11 = m._sideBranch[3]
-                gs.append(ops.conv2d(dbb, _dgrad_packed(c11, c11.weight)))
+            a, b, rbsaved = saved
+            c11s = [m._sideBranch[3] for m in layer]
+            pairs11 = ops.conv2d_gate_bwd(b, [c.packed() for c in c11s], a, dys)        # all stacks' gates in one launch
+            hs = [h for h, _ in pairs11]
+            gs = ops.conv2d_multi([dbb for _, dbb in pairs11], [_dgrad_packed(c, c.weight) for c in c11s])
+            for c11, bi, (_, dbb) in zip(c11s, b, pairs11):
                 dw11, db11 = ops.conv2d_wgrad(bi, dbb, 1, 1, want_bias=True)
                 grads[id(c11.weight)], grads[id(c11.bias)] = dw11, db11
-                hs.append(h)
             for i in (2, 1, 0):
                 blocks = [m._mainBranch[i] for m in layer] + [m._sideBranch[i] for m in layer]
                 out = _rb_backward_multi(blocks, rbsaved[i], hs + gs, pairs)

@@ -507,7 +507,7 @@ next_tile:
         for (int nb = 0; nb < NB; ++nb) {
             const size_t slab = (size_t)img[nb] * p.Cout * HoWo;
             yr[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_y + slab), slab_bytes);
-            constexpr unsigned GBWD = MCQ_CONV_GDN_BWD | MCQ_CONV_IGDN_BWD;
+            constexpr unsigned GBWD = MCQ_CONV_GDN_BWD | MCQ_CONV_IGDN_BWD | MCQ_CONV_GATE_BWD;
             if (f & (MCQ_CONV_DUAL_SILU | GBWD)) y2r[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_y2 + slab), slab_bytes);
             if (f & (MCQ_CONV_RESIDUAL | GBWD)) rr_[nb] = mcq_make_rsrc(mcq_uniform_ptr(P_res + slab), slab_bytes);
             if (f & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL | MCQ_CONV_DSILU_MUL | GBWD))
@@ -628,6 +628,21 @@ next_tile:
                         else { dxd = g[r] * rs; ds = g[r] * m[r] * (-0.5f * rs * rs * rs); }
                         mcq_buffer_store_s(dxd, yr[nb], pvo[nb], so[r]);
                         mcq_buffer_store_s(ds, y2r[nb], pvo[nb], so[r]);
+                    }
+                    continue;
+                }
+                // (the same for the AttentionBlock gate out = a sigmoid(s) + x, s = conv1x1(b) recomputed here: the training forward then
+                //  runs the gate as the 1x1 launch's epilogue like inference does and keeps no s; compiled into the plain 1x1
+                //  one-pixel-block instances only)
+                if (TAPS == 1 && PRO == PRO_NONE && NB == 1 && (f & MCQ_CONV_GATE_BWD)) {
+                    float m[16], g[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { m[r] = mcq_buffer_load_s(mr[nb], pvo[nb], so[r]); g[r] = mcq_buffer_load_s(rr_[nb], pvo[nb], so[r]); }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float sg = mcq_sigmoid(v[r]);
+                        mcq_buffer_store_s(g[r] * sg, yr[nb], pvo[nb], so[r]);                                    // d a
+                        mcq_buffer_store_s(g[r] * m[r] * sg * (1.0f - sg), y2r[nb], pvo[nb], so[r]);              // d s
                     }
                     continue;
                 }
@@ -1427,6 +1442,9 @@ int conv_validate(const mcq_conv_desc* d) {
         if (!d->res || !d->mul || !d->y_silu || (fl & ~(unsigned)(MCQ_CONV_SQUARE_IN | MCQ_CONV_GDN_BWD | MCQ_CONV_IGDN_BWD)) ||
             (fl & MCQ_CONV_GDN_BWD && fl & MCQ_CONV_IGDN_BWD) || d->ksize != 1) return MCQ_EINVAL;
     }
+    if (fl & MCQ_CONV_GATE_BWD) {                            // s-launch with the gate's backward as its epilogue
+        if (!d->res || !d->mul || !d->y_silu || (fl & ~(unsigned)MCQ_CONV_GATE_BWD) || d->ksize != 1 || d->stride != 1) return MCQ_EINVAL;
+    }
     if ((fl & MCQ_CONV_SILU_IN) && (fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;
     if (fl & MCQ_CONV_SHUFFLE2) {
         if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN | MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D | MCQ_CONV_WINOGRAD2D16))) return MCQ_EINVAL;
@@ -1663,6 +1681,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         if (!(fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;
         NB = 1; ksl = 0;
     }
+    if (fl & MCQ_CONV_GATE_BWD) { NB = 1; ksl = 0; }        // (likewise)
     const int pro = (fl & MCQ_CONV_SILU_IN) ? PRO_SILU : (fl & MCQ_CONV_SQUARE_IN) ? PRO_SQUARE : PRO_NONE;
     const long long ptiles = (tb + NB - 1) / NB;
     const int co_tiles = (co32 + MB - 1) / MB;

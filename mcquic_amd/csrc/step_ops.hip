@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int STEP_T = 256;
+constexpr int STEP_T = 1024;                   // (a row of 8192 entries is 8 loads per thread, issued together)
 
 struct StepPrologueK {
     const float* freq[MCQ_VQ_MAX_LEVELS];     // level l: [m_l, k_l] frequency EMA
@@ -64,7 +64,16 @@ __global__ __launch_bounds__(STEP_T) void vq_step_prologue_kernel(StepPrologueK 
         const float* f = q.freq[b];
         const int n = q.mk[b];
         int cnt = 0;
-        for (int i = threadIdx.x; i < n; i += STEP_T) cnt += f[i] > q.eps ? 1 : 0;
+        for (int i0 = 0; i0 < n; i0 += STEP_T * 4) {                  // four independent loads in flight per thread
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e * STEP_T + (int)threadIdx.x;
+                v[e] = i < n ? f[i] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cnt += v[e] > q.eps ? 1 : 0;   // (eps > 0: the padding never counts)
+        }
         cnt = block_sum_int(cnt, sm);
         if (threadIdx.x == 0) {
             // codeUsage = (freqEMA > eps).float().mean().clamp(0, 1): a count of ones divided by the element count
@@ -132,7 +141,15 @@ __global__ __launch_bounds__(STEP_T) void freq_ema_update_kernel(FreqEmaK q) {
     const long long* c = q.counts + q.offset[lv] + (long long)g * k;
     float* f = q.freq[lv] + (size_t)g * k;
     long long tot = 0;
-    for (int i = threadIdx.x; i < k; i += STEP_T) tot += c[i];
+    for (int i0 = 0; i0 < k; i0 += STEP_T * 4) {
+        long long v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + e * STEP_T + (int)threadIdx.x;
+            v[e] = i < k ? c[i] : 0ll;
+        }
+        tot += (v[0] + v[1]) + (v[2] + v[3]);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
     if ((threadIdx.x & 63) == 0) sml[threadIdx.x >> 6] = tot;
@@ -141,11 +158,23 @@ __global__ __launch_bounds__(STEP_T) void freq_ema_update_kernel(FreqEmaK q) {
 #pragma unroll
     for (int w = 0; w < STEP_T / 64; ++w) tot += sml[w];
     const float total = (float)tot;               // (counts are exact integers: their float sum is this conversion below 2^24)
-    for (int i = threadIdx.x; i < k; i += STEP_T) {
-        const float normalized = (float)c[i] / total;
-        const float a = q.fresh * normalized;
-        const float b = q.keep * f[i];
-        f[i] = a + b;
+    for (int i0 = 0; i0 < k; i0 += STEP_T * 4) {
+        long long cv[4];
+        float fv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + e * STEP_T + (int)threadIdx.x;
+            cv[e] = i < k ? c[i] : 0ll;
+            fv[e] = i < k ? f[i] : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + e * STEP_T + (int)threadIdx.x;
+            const float normalized = (float)cv[e] / total;
+            const float a = q.fresh * normalized;
+            const float b = q.keep * fv[e];
+            if (i < k) f[i] = a + b;
+        }
     }
 }
 
@@ -203,7 +232,7 @@ extern "C" int mcq_vq_temperature_grad_f32(const float* dtrow, const float* temp
 }
 
 extern "C" int mcq_freq_ema_update_f32(float* const* freq_ema, const int32_t* m, const int32_t* k, int32_t levels, const int64_t* counts,
-                                       float ema, void* stream) {
+                                       double ema, void* stream) {
     if (!freq_ema || !m || !k || !counts || levels <= 0 || levels > MCQ_VQ_MAX_LEVELS) return MCQ_EINVAL;
     FreqEmaK q;
     long long off = 0;
@@ -217,7 +246,7 @@ extern "C" int mcq_freq_ema_update_f32(float* const* freq_ema, const int32_t* m,
     q.row0[levels] = rows;
     q.levels = levels;
     // (1 - ema) and ema reach torch's kernels as Python floats cast to float32 (entropyCoder.py:42)
-    q.keep = (float)(double)ema; q.fresh = (float)(1.0 - (double)ema);
+    q.keep = (float)ema; q.fresh = (float)(1.0 - ema);
     q.counts = reinterpret_cast<const long long*>(counts);
     hipLaunchKernelGGL(freq_ema_update_kernel, dim3((unsigned)rows), dim3(STEP_T), 0, (hipStream_t)stream, q);
     return mcq_check_launch();

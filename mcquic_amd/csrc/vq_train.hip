@@ -314,24 +314,22 @@ __global__ __launch_bounds__(256) void vq_gumbel_sample_kernel(float* __restrict
 __global__ void vq_dequant_soft_kernel(const int64_t* __restrict__ index, const float* __restrict__ hot,
                                        const float* __restrict__ cb, float* __restrict__ out, float* __restrict__ out_silu, int N, int m,
                                        int d, int hw, int k) {
+    // one thread per OUTPUT element (pixel fastest: coalesced stores; the (index, hot) pair of a latent vector is re-read by its d
+    // channel threads from cache) -- a thread per vector walking its d channels left 4096 threads for 8 x 2 x 16 x 16 vectors
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)N * m * hw;
+    const size_t total = (size_t)N * m * d * hw;
     if (i >= total) return;
     const int pix = (int)(i % hw);
-    const size_t ng = i / hw;
+    const size_t t = i / hw;
+    const int c = (int)(t % d);
+    const size_t ng = t / d;                                    // n * m + g
     const int g = (int)(ng % m);
-    const size_t n = ng / m;
-    int64_t code = index[i];
+    const size_t v = ng * hw + pix;
+    int64_t code = index[v];
     code = code < 0 ? 0 : (code >= k ? k - 1 : code);
-    const float v = hot[i];
-    const float* row = cb + ((size_t)g * k + (size_t)code) * d;
-    const size_t o0 = ((n * m + g) * (size_t)d) * hw + pix;
-    float* o = out + o0;
-    for (int c = 0; c < d; ++c) o[(size_t)c * hw] = v * row[c];
-    if (out_silu) {                                             // the consumer's act1(.), like mcq_vq_gather_f32's twin
-        float* o2 = out_silu + o0;
-        for (int c = 0; c < d; ++c) o2[(size_t)c * hw] = mcq_silu(v * row[c]);
-    }
+    const float val = hot[v] * cb[((size_t)g * k + (size_t)code) * d + c];
+    out[i] = val;
+    if (out_silu) out_silu[i] = mcq_silu(val);                  // the consumer's act1(.), like mcq_vq_gather_f32's twin
 }
 
 // ---- backward of the soft assignment ----------------------------------------------------------------------------
@@ -738,7 +736,7 @@ extern "C" int mcq_vq_gumbel_sample_f32(float* logits, const float* u_drop, cons
 extern "C" int mcq_vq_dequant_soft_f32(const int64_t* sample_index, const float* sample_hot, const float* codebook, float* out,
                                        float* out_silu, int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k, void* stream) {
     if (!sample_index || !sample_hot || !codebook || !out || N <= 0 || m <= 0 || d <= 0 || h <= 0 || w <= 0 || k <= 0) return MCQ_EINVAL;
-    const size_t total = (size_t)N * m * h * w;
+    const size_t total = (size_t)N * m * d * h * w;
     hipLaunchKernelGGL(vq_dequant_soft_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        sample_index, sample_hot, codebook, out, out_silu, N, m, d, h * w, k);
     return mcq_check_launch();

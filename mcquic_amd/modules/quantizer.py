@@ -275,7 +275,8 @@ class _quantizerDecoder(nn.Module):
             from .. import autograd as AG                      # sideHead and dequantizationHead in lockstep (see _quantizerEncoder._forward)
             x, side = AG.lockstep([self._dequantizationHead, self._sideHead], [self._dequantizer(q), formerLevel])
             return self._restoreHead(AG.add(x, side, dual_silu=True))
-        x = self._dequantizationHead(self._dequantizer(q))
+        from ..nn import blocks
+        x = blocks.run_stack(self._dequantizationHead, self._dequantizer(q))
         if self._sideHead is not None:
             if torch.is_grad_enabled():
                 from .. import autograd as AG

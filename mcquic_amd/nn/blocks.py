@@ -205,6 +205,21 @@ class AttentionBlock(nn.Module):
         return self._sideBranch[3](f.join(b), gate_mul=a, gate_id=x, dual_silu=True)
 
 
+def run_stack(stack, x: torch.Tensor) -> torch.Tensor:
+    """`stack(x)` for an nn.Sequential of this package's layers in the TRAINING graph, with one look-ahead: a plain convolution
+    that feeds a block starting with an activation also stores silu(.) (its launch's twin output) -- what lockstep does for the
+    paired heads; a stack run on its own (the last level's dequantizationHead: AttentionBlock, conv3x3, ResidualBlock) otherwise
+    pays a stand-alone SiLU launch."""
+    mods = list(stack)
+    for i, m in enumerate(mods):
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        if type(m).__name__ == "Conv2d" and isinstance(nxt, (_residulBlock, AttentionBlock)) and m.training and torch.is_grad_enabled():
+            x = m(x, dual_silu=True)
+        else:
+            x = m(x)
+    return x
+
+
 # ---- same-structure stacks in lockstep (inference) -----------------------------------------------------------------------------
 # `latentHead` / `quantizationHead` (ResidualBlock, AttentionBlock, conv3x3 on the same z; mcquic/modules/compressor.py:148-160)
 # and `dequantizationHead` / `sideHead` (AttentionBlock, conv3x3, ResidualBlock; :166-175) apply the same layer shapes to

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import (CONV_DSILU_MUL, CONV_DUAL_SILU, CONV_MUL, CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN,
-                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, CONV_WINOGRAD2D, CONV_WINOGRAD2D16, CONV_GDN_BWD, CONV_IGDN_BWD, ConvDesc, check)
+                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, CONV_WINOGRAD2D, CONV_WINOGRAD2D16, CONV_GDN_BWD, CONV_IGDN_BWD, CONV_GATE_BWD, ConvDesc, check)
 
 # OPT-IN fast path, never the default and never the headline bench: large 3x3 stride-1 layers in the Winograd F(2, 3) form
 # along x (mcq_pack_conv_weight_winograd_f32 + MCQ_CONV_WINOGRAD): 2/3 of the multiplications, float32 throughout, but not
@@ -492,6 +492,33 @@ def conv2d_gdn_bwd(x: torch.Tensor, w: PackedConv, dy: torch.Tensor, inverse: bo
     with _guard(x.device):
         check(_lib.load().mcq_conv2d_f32(ctypes.byref(d), _stream()), "mcq_conv2d_f32")
     return dxd, ds
+
+
+def conv2d_gate_bwd(bs, ws, as_, douts):
+    """[(d a_i, d s_i)] of out_i = a_i * sigmoid(s_i) + x_i with s_i = conv1x1(b_i) RECOMPUTED by this launch (`ws[i]` = the gate's
+    1x1 operand stream): d a = dout sigmoid(s), d s = dout a sigmoid(s) (1 - sigmoid(s)) leave from the epilogue
+    (MCQ_CONV_GATE_BWD), so the forward stores no s and runs the gate as its 1x1 launch's epilogue (mcquic/nn/blocks.py:281-288).
+    Several gates of one geometry (the paired heads' AttentionBlocks) share the launch."""
+    built = []
+    for b, w, a, dout in zip(bs, ws, as_, douts):
+        b, a, dout = _dev(b, "b"), _dev(a, "a"), _dev(dout, "dout")
+        if w.ksize != 1 or b.shape[1] != w.cin or a.shape != dout.shape or a.shape[1] != w.cout or a.shape[0] != b.shape[0] or a.shape[2:] != b.shape[2:]:
+            raise ValueError("conv2d_gate_bwd: a 1x1 layer, `a` and `dout` of its output's shape")
+        n, c, h, wd = b.shape
+        da, ds = torch.empty_like(a), torch.empty_like(a)
+        d = ConvDesc(_ptr(b), _ptr(w.wp), _ptr(w.bias), _ptr(da), _ptr(ds), _ptr(dout), _ptr(a), None,
+                     n, c, h, wd, w.cout, 1, 1, CONV_GATE_BWD, 1.0, 0)
+        built.append((d, da, ds, (b, a, dout)))
+    lib = _lib.load()
+    cap = lib.mcq_conv2d_max_multi() if _MULTI else 1
+    with _guard(built[0][1].device):
+        for lo in range(0, len(built), cap):
+            part = built[lo:lo + cap]
+            if len(part) == 1:
+                check(lib.mcq_conv2d_f32(ctypes.byref(part[0][0]), _stream()), "mcq_conv2d_f32")
+            else:
+                check(lib.mcq_conv2d_multi_f32((ConvDesc * len(part))(*[p[0] for p in part]), len(part), _stream()), "mcq_conv2d_multi_f32")
+    return [(da, ds) for _, da, ds, _ in built]
 
 
 _MULTI = os.environ.get("MCQUIC_AMD_MULTI_CONV", "1") != "0"      # A/B switch: 0 = one launch per convolution

@@ -161,6 +161,11 @@ def data_parallel(model: torch.nn.Module, device: torch.device, group=None, **kw
     return ddp
 
 
+def _backward(loss):
+    from .autograd import backward
+    backward(loss)
+
+
 def _default_loss(out, x):
     """The distortion term alone, mean((xHat - x)^2) (mcquic/loss/__init__.py:62), through this library's own reduction."""
     from .autograd import mse_loss
@@ -463,7 +468,7 @@ class GraphedTrainStep:
             lgl = [lg.detach().requires_grad_() if (torch.is_tensor(lg) and lg.requires_grad) else lg for lg in logits]
             xHat = m._decoder(yh)
             loss = self.loss_fn((xHat, yh, codes, lgl), self.x)
-            loss.backward()                                   # decoder parameters, d yHat (, d logits)
+            _backward(loss)                                   # decoder parameters, d yHat (, d logits)
             self.loss = loss.detach()
             self._carry = (y, yl, yHat, yh, logits, lgl)
         elif k == 1:
@@ -484,7 +489,7 @@ class GraphedTrainStep:
             p.grad = None
         out = self.model(self.x, **self.kwargs)
         loss = self.loss_fn(out, self.x)
-        loss.backward()
+        _backward(loss)
         return loss.detach()
 
     def _post(self):

@@ -73,7 +73,7 @@ def main():
         if launch.rccl_check(dist, dev) != world:
             raise SystemExit("bench_train.py: RCCL does not span the requested ranks")
     from mcquic_amd import Compressor
-    from mcquic_amd.autograd import mse_loss
+    from mcquic_amd.autograd import backward, mse_loss
     torch.manual_seed(3407)
     model = Compressor(128, 2, [8192, 2048, 512]).to(dev).train()
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if use_dist and not args.graphed else model
@@ -86,7 +86,7 @@ def main():
             p.grad = None
         xHat, yHat, codes, logits = net(x)
         loss = mse_loss(xHat, x)                            # plain MSE through this library's reduction (no memset node in a capture)
-        loss.backward()
+        backward(loss)
         if opt is not None:
             opt.step()
         return loss
@@ -109,7 +109,7 @@ def main():
         with torch.cuda.graph(graph):
             xHat, yHat, codes, logits = net(x)
             static_loss = mse_loss(xHat, x)
-            static_loss.backward()
+            backward(static_loss)
             if opt is not None:
                 opt.step()                                 # (the update itself is part of the captured step; the forward above
                                                            #  starts with the grouped re-pack of every stale operand stream)

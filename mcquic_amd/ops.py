@@ -445,6 +445,10 @@ def _conv2d_banded(x: torch.Tensor, w: PackedConv, stride: int, rows: int, fused
     y = torch.empty((n, w.cout // 4, 2 * ho, 2 * wo) if shuffle2 else (n, w.cout, ho, wo), dtype=torch.float32, device=x.device)
     y2 = torch.empty_like(y) if dual else None
     sides = {kk: _dev(fused[kk], kk) for kk in _TENSOR_OPTS if fused.get(kk) is not None}
+    if shuffle2 and sides:
+        # (side inputs have the SHUFFLED output's 2 ho rows; the bands below are cut in pre-shuffle rows.  The kernels take no side
+        #  tensor with the PixelShuffle store either -- conv_validate -- so nothing in the model asks for this)
+        raise NotImplementedError("row bands: a PixelShuffle store together with output-shaped side tensors is not supported")
     plain = {kk: v for kk, v in fused.items() if kk not in _TENSOR_OPTS}
     for o0, o1, b0, b1, g0 in _band_plan(h, k, stride, rows):
         xb = x[:, :, b0:b1].contiguous()

@@ -161,6 +161,8 @@ class Adam(torch.optim.Optimizer):
         increment each entry they are handed, so a shared one would be advanced once per parameter after loading there."""
         sd = super().state_dict()
         sd["state"] = {k: {n: (v.clone() if n == "step" and torch.is_tensor(v) else v) for n, v in st.items()} for k, st in sd["state"].items()}
+        # torch spells the decoupled decay `decoupled_weight_decay` (torch.optim.AdamW sets it): both names travel
+        sd["param_groups"] = [dict(g, decoupled_weight_decay=bool(g.get("decoupled", False))) for g in sd["param_groups"]]
         return sd
 
     def load_state_dict(self, state_dict):
@@ -168,13 +170,19 @@ class Adam(torch.optim.Optimizer):
         into the flat buffers on the next `step()`."""
         super().load_state_dict(state_dict)
         for group in self.param_groups:
-            group.setdefault("decoupled", False)
+            # (torch replaces the groups by the saved ones: a torch.optim.AdamW checkpoint carries `decoupled_weight_decay: True` and
+            #  no `decoupled` -- dropping it would turn the decay into Adam's L2 term silently)
+            group["decoupled"] = bool(group.get("decoupled", group.get("decoupled_weight_decay", isinstance(self, AdamW))))
+            group["decoupled_weight_decay"] = group["decoupled"]
             group.setdefault("maximize", False)
             group["capturable"] = True
             for k in ("amsgrad", "foreach", "fused", "differentiable"):
                 if group.get(k):
                     raise NotImplementedError(f"mcquic_amd.optim.Adam: `{k}` checkpoints are not supported")
-        self._plans = {}
+        # the loaded tensors are copied INTO the existing flat buffers on the next step (same parameters: same addresses, which a
+        # captured update may hold); only a plan whose parameter set changed is rebuilt
+        for plan in self._plans.values():
+            plan.adopted = False
 
 
 class AdamW(Adam):

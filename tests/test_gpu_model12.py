@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import mcquic_ref as R
+from _record import record
 from test_gpu_golden import _audit_codes as _audit_model_codes
 from test_gpu_ops import _audit_codes as _audit_vq_codes, _close, _rand, _vq_case
 
@@ -22,6 +23,9 @@ pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODEL12 = (192, 12, [8192, 2048, 512])
+# index bars = 4x what profiles/r05_parity_measurements.json records for these cases (never below 1): set after the measurement
+MAX_FLIPS12 = {"kodak": 1, "ragged": 1}
+MAX_DIFF12 = 12
 TOL192 = 4e-6          # sums of 192 x 9 = 1728 products (2e-6 holds for the 1152 of channel 128: measured 3.2e-6 here)
 
 
@@ -45,7 +49,9 @@ def test_model12_against_reference_vectors(dev, model12, tag):
         assert c.dtype == torch.int64 and c.shape == wc.shape
     flips, cut = _audit_model_codes(codes, want, [z[f"{tag}_gap{lv}"] for lv in range(3)])
     near = sum(int((z[f"{tag}_gap{lv}"] < 1e-5).sum()) for lv in range(3))
-    assert flips <= max(1, near), f"{flips} audited flips but only {near} near-tie vectors in the reference's own distances"
+    bar = MAX_FLIPS12[tag]
+    record(f"model12_reference_vectors_{tag}", first_flips=flips, near_tie_vectors_below_1e-5=near, codes=sum(c.numel() for c in want), bar=bar)
+    assert flips <= bar, f"{flips} audited flips (bar {bar}); {near} near-tie vectors in the reference's own distances"
     rec = model.decode([c.to(dev) for c in want]).cpu()
     np.testing.assert_allclose(rec[..., ::16, ::16].numpy(), z[tag + "_rec_strided"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(rec[:, :, h // 2 - 32:h // 2 + 32, w // 2 - 32:w // 2 + 32].numpy(), z[tag + "_rec_crop"], rtol=0, atol=1e-4)
@@ -63,7 +69,9 @@ def test_model12_against_oracle_batch(dev, model12):
     got = [c.cpu() for c in model.encode(x.to(dev))]
     total = sum(c.numel() for c in want)
     diff = sum(int((a != b).sum()) for a, b in zip(got, want))
-    assert diff <= max(4, total // 2000), f"{diff} of {total} codes differ from the oracle's (near-ties explain a handful per image, not this)"
+    images = sum(int(any(bool((a[i] != b[i]).any()) for a, b in zip(got, want))) for i in range(x.shape[0]))
+    record("model12_oracle_batch", differing_codes=diff, images_with_a_difference=images, codes=total, bar=MAX_DIFF12)
+    assert diff <= MAX_DIFF12, f"{diff} of {total} codes differ from the oracle's (bar {MAX_DIFF12}: near-ties explain a handful per image)"
     rec = model.decode([c.to(dev) for c in want]).cpu()
     ref = R.decode(sd, want)
     assert float((rec - ref).abs().max()) <= 1e-4

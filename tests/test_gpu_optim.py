@@ -102,6 +102,60 @@ def test_adam_checkpoints_travel_both_ways(dev):
         _close(y.detach(), x.detach(), 2e-6, "torch continuing from our checkpoint")
 
 
+def test_adamw_checkpoints_keep_the_decoupled_decay(dev):
+    """a torch.optim.AdamW checkpoint (group key `decoupled_weight_decay`, no `decoupled`) loaded into optim.AdamW must stay
+    AdamW -- with weight_decay > 0 the two decays move the parameters visibly differently -- and our checkpoint loaded into
+    torch.optim.AdamW likewise, without hand-patching the group keys.  The flat moment buffers keep their addresses across a load."""
+    from mcquic_amd import optim
+    a, b = _params(dev, 5), _params(dev, 5)
+    ot = torch.optim.AdamW(a, lr=1e-2, weight_decay=0.3)
+    for it in range(3):
+        _grads(a, it)
+        ot.step()
+    with torch.no_grad():
+        for x, y in zip(a, b):
+            y.copy_(x)
+    oo = optim.AdamW(b, lr=1e-2, weight_decay=0.3)
+    _grads(b, 0)
+    oo.prepare()
+    addr = [oo._plans[0].flat_m.data_ptr(), oo._plans[0].flat_v.data_ptr(), oo._plans[0].step.data_ptr()]
+    oo.load_state_dict(copy.deepcopy(ot.state_dict()))
+    assert oo.param_groups[0]["decoupled"] is True
+    for it in range(3, 6):
+        _grads(a, it)
+        _grads(b, it)
+        ot.step()
+        oo.step()
+    assert addr == [oo._plans[0].flat_m.data_ptr(), oo._plans[0].flat_v.data_ptr(), oo._plans[0].step.data_ptr()]
+    for x, y in zip(a, b):
+        _close(y.detach(), x.detach(), 2e-6, "AdamW continuing from torch's AdamW checkpoint")
+    # L2 decay instead would have ended elsewhere
+    l2 = _params(dev, 5)
+    with torch.no_grad():
+        for x, y in zip(a, l2):
+            y.copy_(x)
+    assert any(float((x.detach() - y.detach()).abs().max()) > 1e-3 for x, y in zip(a, _params(dev, 5)))
+    # ... and back into torch.optim.AdamW, group keys as they come
+    c = _params(dev, 5)
+    with torch.no_grad():
+        for x, y in zip(b, c):
+            y.copy_(x)
+    o2 = torch.optim.AdamW(c, lr=1e-2, weight_decay=0.3, capturable=True)
+    sd = copy.deepcopy(oo.state_dict())
+    assert sd["param_groups"][0]["decoupled_weight_decay"] is True
+    for gpar in sd["param_groups"]:
+        gpar.update(amsgrad=False, foreach=None, fused=None, differentiable=False, capturable=True)
+    o2.load_state_dict(sd)
+    assert o2.param_groups[0]["decoupled_weight_decay"] is True
+    for it in range(6, 8):
+        _grads(b, it)
+        _grads(c, it)
+        oo.step()
+        o2.step()
+    for x, y in zip(b, c):
+        _close(y.detach(), x.detach(), 2e-6, "torch AdamW continuing from our checkpoint")
+
+
 def test_adam_device_learning_rate_and_capture(dev):
     """The learning rate as a device tensor: refilled between steps, read by the kernel (also from a captured graph)."""
     from mcquic_amd import optim

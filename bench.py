@@ -235,6 +235,75 @@ def _timed(fn, steps, warmup=1):
     return a.elapsed_time(b) / steps
 
 
+def neon_figures(dev, dense: bool = True, infer_batch: int = 8, train_batch: int = 4, side: int = 512):
+    """`secondary.neon`: encode + decode rate and one training step (forward + Gumbel straight-through backward, eager) of
+    Neon(32, 4096, [16, 8, 4, 2, 2], denseNorm) on `side` x `side` images, with the conv kernels' share of fp32-MFMA peak and the
+    training step's peak device memory (what the reference's `checkpoint_wrapper` on encoder / decoder is there to bound,
+    mcquic/modules/compressor.py:230-231)."""
+    from mcquic_amd import Neon
+    from mcquic_amd.autograd import backward, mse_loss
+    torch.manual_seed(3407)
+    cfg = (32, 4096, [16, 8, 4, 2, 2])
+    model = Neon(*cfg, dense).to(dev).eval()
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand((infer_batch, 3, side, side), generator=g) * 2 - 1).to(dev)
+    prof = ConvProfiler().install()
+    prof.MAX_STEPS = 2
+    prof.active = False
+    model.decode(model.encode(x))
+    prof.active = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        prof.next_step()
+        model.decode(model.encode(x))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 2 * 1e3
+    prof.remove()
+    c = prof.summary()
+    out = {"model": f"Neon{cfg} denseNorm={dense}, random-init weights", "side": side, "infer_batch": infer_batch,
+           "images_s": round(infer_batch / ms * 1e3, 2), "ms_per_step": round(ms, 3),
+           "frac_of_peak": round(c["mfma_flops"] / (c["ms"] * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+           "conv_gflop_per_image": round(c["flops"] / c["steps"] / infer_batch / 1e9, 2),
+           "whole_step_frac": round(c["flops"] / c["steps"] / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4)}
+    # training step, the reference's per-GPU batch
+    model.train()
+    xt = x[:train_batch].contiguous()
+    prof = ConvProfiler().install()                             # conv FLOPs of one training-mode forward (under no_grad: same launches' shapes)
+    prof.MAX_STEPS = 1
+    prof.next_step()
+    with torch.no_grad():
+        model(xt)
+    prof.remove()
+    fwd_flops = prof.summary()["flops"]
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        xHat = model(xt)[0]
+        loss = mse_loss(xHat, xt)
+        backward(loss)
+        return loss
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(dev)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        loss = step()
+    torch.cuda.synchronize()
+    tms = (time.perf_counter() - t0) / 3 * 1e3
+    out.update({"train_batch": train_batch, "train_step_ms": round(tms, 3), "train_loss": round(float(loss), 6),
+                "train_frac_of_peak": round(3.0 * fwd_flops / (tms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+                "train_tflop_per_step": round(3.0 * fwd_flops / 1e12, 3),
+                "train_peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                "device_memory_gb": round(torch.cuda.get_device_properties(dev).total_memory / 2 ** 30, 1),
+                "checkpoint_wrapper": "not applied: the step's peak memory without recompute is the figure above"})
+    del model, x, xt
+    torch.cuda.empty_cache()
+    return out
+
+
 def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
     """Round results the headline does not show, measured in the same run (about 40 s; every entry is independent and
     carries its own `error` if it fails -- the headline line never depends on them):
@@ -370,6 +439,12 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
         del m12, x12, c12
     except Exception as exc:                                  # noqa: BLE001
         sec["model12"] = {"error": repr(exc)[:300]}
+    # ---- Neon at the shapes the snapshot's trainer builds (mcquic/train/ddp.py:79-83, configs/neon.yaml: channel 32, k = 4096, five
+    #      levels, denseNorm; 512 x 512 crops, 4 per GPU): stride-1 stem, AttentionBlocks at full resolution, widths 32 / 64 ----------
+    try:
+        sec["neon"] = neon_figures(dev)
+    except Exception as exc:                                  # noqa: BLE001
+        sec["neon"] = {"error": repr(exc)[:300]}
     # ---- batch-1 latency, hipGraph replay ---------------------------------------------------------------------------------
     try:
         model.enableGraphs(True)

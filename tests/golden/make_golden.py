@@ -201,18 +201,22 @@ def capture_f5c_backend(RQ, chunk: int = 8):
     print(f"f5c backend: {len(flips)} reference self-flips (oneDNN vs native convolution), gaps32 {gaps}")
 
 
-def capture_neon(C, RQ, dense: bool, fname: str):
+NEON_K4096 = (32, 4096, [16, 8, 4, 2, 2])      # F13 / F14: the shapes SURVEY 8(f) row 4 names (k = 4096, d = 8, m = 1; configs/neon.yaml: five levels)
+
+
+def capture_neon(C, RQ, dense: bool, fname: str, cfg=(32, 256, [8, 4, 2, 2]), hw: int = 128, stride: int = 4, logit_stride: int = 8):
     from oracle import neon_ref as NR            # generators only
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("gloo", rank=0, world_size=1)
-    ch, k, size = 32, 256, [8, 4, 2, 2]
+    ch, k, size = cfg
+    assert hw // 16 == size[0], "the level maps are `size` itself when the image side is 16 x size[0]"
     sd = NR.make_state_dict(ch, k, size, seed=3, denseNorm=dense)
     model = C.Neon(ch, k, size, dense).eval()
     model.load_state_dict(sd, strict=True)
-    xi = R.make_images(2, 128, 128, seed=5)
+    xi = R.make_images(2, hw, hw, seed=5)
     f10 = {"config": np.array([ch, k] + size), "n_state_dict_entries": np.array([len(model.state_dict())])}
     gaps = []
     orig_distance = RQ._multiCodebookQuantization._distance
@@ -236,13 +240,13 @@ def capture_neon(C, RQ, dense: bool, fname: str):
     for lv, cd in enumerate(codes):
         f10[f"code{lv}"] = cd.numpy().astype(np.int16)
         f10[f"gap{lv}"] = gaps[lv].numpy()
-    f10["rec_strided"] = rec[..., ::4, ::4].numpy()
+    f10["rec_strided"] = rec[..., ::stride, ::stride].numpy()
     f10["rec_sha"] = np.frombuffer(bytes.fromhex(sha(rec)), dtype=np.uint8)
     f10["residual_backward_1_2"] = rb.numpy()
     f10["residual_forward_1"] = rf1.numpy()
     model.train()
     g = torch.Generator().manual_seed(9)
-    shapes = [(2, 1, 2, 2, k), (2, 1, 2, 2, k), (2, 1, 4, 4, k), (2, 1, 8, 8, k)]
+    shapes = [(2, 1, sz, sz, k) for sz in reversed(size)]         # (quantizations run from the smallest level up)
     us = [(torch.rand(sh, generator=g), torch.rand(sh, generator=g)) for sh in shapes]
     it = iter([u for pair in us for u in pair])
     orig = torch.rand_like
@@ -251,11 +255,11 @@ def capture_neon(C, RQ, dense: bool, fname: str):
         xHat, yHat, codesT, logitsT = model(xi.clone())
     finally:
         torch.rand_like = orig
-    f10["train_xHat_strided"] = xHat.detach()[..., ::4, ::4].numpy()
+    f10["train_xHat_strided"] = xHat.detach()[..., ::stride, ::stride].numpy()
     f10["train_yHat"] = yHat.detach().numpy()
     for lv in range(len(size)):
         f10[f"train_code{lv}"] = codesT[lv].numpy().astype(np.int16)
-        f10[f"train_logit{lv}_strided"] = logitsT[lv].detach()[..., ::8].numpy()
+        f10[f"train_logit{lv}_strided"] = logitsT[lv].detach()[..., ::logit_stride].numpy()
         f10[f"train_ema{lv}"] = model._quantizer._entropyCoder._freqEMA[lv].detach().numpy()
     np.savez_compressed(os.path.join(OUT, fname), **f10)
 
@@ -533,6 +537,12 @@ def main():
         capture_neon(C, RQ, False, "f10_neon.npz")
     if want("f11"):
         capture_neon(C, RQ, True, "f11_neon_dense_norm.npz")
+    # ---- F13 / F14: Neon at the shapes the snapshot's trainer builds (mcquic/train/ddp.py:79-83, configs/neon.yaml: channel 32,
+    #           k = 4096, five levels) on 2 x 256x256: stride-1 stem, AttentionBlocks at FULL resolution, widths 32 / 64 -------
+    if want("f13"):
+        capture_neon(C, RQ, False, "f13_neon_k4096.npz", NEON_K4096, hw=256, stride=8, logit_stride=128)
+    if want("f14"):
+        capture_neon(C, RQ, True, "f14_neon_k4096_dense_norm.npz", NEON_K4096, hw=256, stride=8, logit_stride=128)
 
     # ---- F12: the reference's second listed model, No. 12 = Compressor(192, 12, [8192, 2048, 512]) (README.md:306):
     #           channel 192, twelve codebooks of 16-dimensional codewords.  1 x 768x512 and 2 x 200x136 (sizes that are no multiple of 128):

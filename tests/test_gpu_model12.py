@@ -50,7 +50,7 @@ def test_model12_against_reference_vectors(dev, model12, tag):
     flips, cut = _audit_model_codes(codes, want, [z[f"{tag}_gap{lv}"] for lv in range(3)])
     near = sum(int((z[f"{tag}_gap{lv}"] < 1e-5).sum()) for lv in range(3))
     bar = MAX_FLIPS12[tag]
-    record(f"model12_reference_vectors_{tag}", first_flips=flips, near_tie_vectors_below_1e-5=near, codes=sum(c.numel() for c in want), bar=bar)
+    record(f"model12_reference_vectors_{tag}", first_flips=flips, near_tie_vectors_below_1e_5=near, codes=sum(c.numel() for c in want), bar=bar)
     assert flips <= bar, f"{flips} audited flips (bar {bar}); {near} near-tie vectors in the reference's own distances"
     rec = model.decode([c.to(dev) for c in want]).cpu()
     np.testing.assert_allclose(rec[..., ::16, ::16].numpy(), z[tag + "_rec_strided"], rtol=0, atol=1e-4)

@@ -10,34 +10,43 @@ import torch
 from oracle import mcquic_ref as R
 from oracle import neon_ref as N
 
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f10_neon.npz")
-G_DENSE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f11_neon_dense_norm.npz")     # denseNorm=True
-CFG = (32, 256, [8, 4, 2, 2])
+GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# case -> (Neon(channel, k, size), image side, pixel stride of the fixture, fixture files (plain, denseNorm))
+#   "small"  F10 / F11: Neon(32, 256, [8, 4, 2, 2]) on 128 x 128
+#   "k4096"  F13 / F14: the shapes SURVEY 8(f) row 4 names and the snapshot's trainer builds (mcquic/train/ddp.py:79-83,
+#            configs/neon.yaml: channel 32, k = 4096, five levels) on 256 x 256 -- stride-1 stem, AttentionBlocks at full resolution
+CASES = {"small": ((32, 256, [8, 4, 2, 2]), 128, 4, ("f10_neon.npz", "f11_neon_dense_norm.npz")),
+         "k4096": ((32, 4096, [16, 8, 4, 2, 2]), 256, 8, ("f13_neon_k4096.npz", "f14_neon_k4096_dense_norm.npz"))}
+CFG = CASES["small"][0]
+CASE = pytest.mark.parametrize("case", ["small", "k4096"])
+NEON_MAX_FLIPS = {"small": 0, "k4096": 4}     # first flips allowed per run (4x the measurement, profiles/r05_parity_measurements.json)
+NEAR_TIE = 1e-5          # a code may differ from the reference's only where the reference's own top-2 gap is below this
 # denseNorm -> worst relative gradient error allowed = 4x the measured value (profiles/r04_gradient_errors.json: 3.6e-6 plain; with
 # denseNorm 4.2e-4, all of it at a conv bias in front of a one-channel-per-group GroupNorm whose gradient is structurally ZERO --
 # both sides hold rounding noise there and the error is taken against 1e-3 of the model's largest gradient, see below)
-NEON_GRAD_BAR = {False: 1.5e-5, True: 1.7e-3}
+NEON_GRAD_BAR = {("small", False): 1.5e-5, ("small", True): 1.7e-3, ("k4096", False): 4e-5, ("k4096", True): 5e-3}
 DENSE = pytest.mark.parametrize("dense", [False, True], ids=["plain", "denseNorm"])
 
 
-def _golden(dense):
-    return np.load(G_DENSE if dense else G)
+def _golden(dense, case="small"):
+    return np.load(os.path.join(GDIR, CASES[case][3][1 if dense else 0]))
 
 
-def _uniforms(k, seed=9):
+def _uniforms(k, seed=9, size=(8, 4, 2, 2)):
     g = torch.Generator().manual_seed(seed)
-    shapes = [(2, 1, 2, 2, k), (2, 1, 2, 2, k), (2, 1, 4, 4, k), (2, 1, 8, 8, k)]
+    shapes = [(2, 1, sz, sz, k) for sz in reversed(size)]           # (quantizations run from the smallest level up)
     return [(torch.rand(s, generator=g), torch.rand(s, generator=g)) for s in shapes]
 
 
+@CASE
 @DENSE
-def test_neon_oracle_matches_reference_vectors(dense):
-    z = _golden(dense)
-    ch, k, size = CFG
+def test_neon_oracle_matches_reference_vectors(dense, case):
+    z = _golden(dense, case)
+    (ch, k, size), hw, st, _ = CASES[case]
     assert [int(v) for v in z["config"]] == [ch, k] + size
     sd = N.make_state_dict(ch, k, size, seed=3, denseNorm=dense)
     assert len(sd) == int(z["n_state_dict_entries"][0])
-    x = R.make_images(2, 128, 128, seed=5)
+    x = R.make_images(2, hw, hw, seed=5)
     codes = N.encode(sd, x)
     for lv, c in enumerate(codes):
         assert torch.equal(c, torch.from_numpy(z[f"code{lv}"].astype(np.int64))), lv
@@ -45,14 +54,14 @@ def test_neon_oracle_matches_reference_vectors(dense):
     #  vectors captured in the build container, the plain variant 0)
     tol, tol_t = (5e-5, 1e-4) if dense else (2e-6, 5e-6)
     rec = N.decode(sd, codes)
-    np.testing.assert_allclose(rec[..., ::4, ::4].numpy(), z["rec_strided"], rtol=0, atol=tol)
+    np.testing.assert_allclose(rec[..., ::st, ::st].numpy(), z["rec_strided"], rtol=0, atol=tol)
     np.testing.assert_allclose(N.residual_backward(sd, codes[1], 2).numpy(), z["residual_backward_1_2"], rtol=0, atol=tol)
     rf = N.residual_forward(sd, codes[1], N.residual_forward(sd, codes[0], None, 0), 1)
     np.testing.assert_allclose(rf.numpy(), z["residual_forward_1"], rtol=0, atol=tol)
-    xHat, yHat, codesT, logits, _ = N.forward_train(sd, x, _uniforms(k))
-    np.testing.assert_allclose(xHat[..., ::4, ::4].numpy(), z["train_xHat_strided"], rtol=0, atol=tol_t)
+    xHat, yHat, codesT, logits, _ = N.forward_train(sd, x, _uniforms(k, size=size))
+    np.testing.assert_allclose(xHat[..., ::st, ::st].numpy(), z["train_xHat_strided"], rtol=0, atol=tol_t)
     np.testing.assert_allclose(yHat.numpy(), z["train_yHat"], rtol=0, atol=tol_t)
-    for lv in range(4):
+    for lv in range(len(size)):
         assert torch.equal(codesT[lv], torch.from_numpy(z[f"train_code{lv}"].astype(np.int64)))
 
 
@@ -78,9 +87,9 @@ def test_various_m_coder_round_trip_and_errors():
     assert torch.allclose(coder._freqEMA[1], R.freq_ema_update(before, counts, ema=0.998), atol=1e-7)
 
 
-def _model(dev, dense=False):
+def _model(dev, dense=False, case="small"):
     from mcquic_amd import Neon
-    ch, k, size = CFG
+    ch, k, size = CASES[case][0]
     sd = N.make_state_dict(ch, k, size, seed=3, denseNorm=dense)
     model = Neon(ch, k, size, dense)
     model.load_state_dict(sd, strict=True)
@@ -88,24 +97,36 @@ def _model(dev, dense=False):
 
 
 @pytest.mark.gpu
+@CASE
 @DENSE
-def test_neon_hip_against_oracle_and_reference_vectors(dev, dense):
-    z = _golden(dense)
-    model, sd = _model(dev, dense)
+def test_neon_hip_against_oracle_and_reference_vectors(dev, dense, case):
+    from _record import record
+    z = _golden(dense, case)
+    (ch, k, size), hw, st, _ = CASES[case]
+    model, sd = _model(dev, dense, case)
     model.eval()
-    x = R.make_images(2, 128, 128, seed=5)
+    x = R.make_images(2, hw, hw, seed=5)
     codes = [c.cpu() for c in model.encode(x.to(dev))]
+    # near-tie protocol on the reference's own top-2 gaps: a code may differ only where that gap is below
+    # NEAR_TIE; the image's later quantizations (LARGER levels here: Neon codes small -> large) then see another residual
     alive = torch.ones(2, dtype=torch.bool)
-    for lv, c in enumerate(codes):                                     # near-tie protocol on the reference's gaps
+    flips, widest, near = 0, 0.0, 0
+    for lv, c in enumerate(codes):
         want = torch.from_numpy(z[f"code{lv}"].astype(np.int64))
+        gap = torch.from_numpy(z[f"gap{lv}"])
+        near += int((gap < NEAR_TIE).sum())
         bad = (c != want) & alive[:, None, None, None]
         if bad.any():
-            assert float(torch.from_numpy(z[f"gap{lv}"])[bad].max()) < 1e-5, f"level {lv}"
+            flips += int(bad.sum())
+            widest = max(widest, float(gap[bad].max()))
             alive &= ~bad.flatten(1).any(1)
-    assert alive.all(), "a near-tie flipped on this small fixture (none observed when the test was written)"
-    want_codes = [torch.from_numpy(z[f"code{lv}"].astype(np.int64)).to(dev) for lv in range(4)]
+    record(f"neon_codes[{case},denseNorm={bool(dense)}]", first_flips=flips, widest_reference_gap_at_a_flip=widest,
+           near_tie_vectors_below_1e_5=near, codes=sum(c.numel() for c in codes), bar_gap=NEAR_TIE, bar_flips=NEON_MAX_FLIPS[case])
+    assert widest < NEAR_TIE, f"a code differs where the reference's own gap is {widest:.3e}"
+    assert flips <= NEON_MAX_FLIPS[case], f"{flips} first flips ({near} near-tie vectors in the reference's own distances)"
+    want_codes = [torch.from_numpy(z[f"code{lv}"].astype(np.int64)).to(dev) for lv in range(len(size))]
     rec = model.decode(want_codes).cpu()
-    np.testing.assert_allclose(rec[..., ::4, ::4].numpy(), z["rec_strided"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(rec[..., ::st, ::st].numpy(), z["rec_strided"], rtol=0, atol=1e-4)
     assert float((rec - N.decode(sd, [c.cpu() for c in want_codes])).abs().max()) <= 1e-4
     rb = model.residual_backward(want_codes[1], 2).cpu()
     np.testing.assert_allclose(rb.numpy(), z["residual_backward_1_2"], rtol=0, atol=1e-4)
@@ -116,24 +137,25 @@ def test_neon_hip_against_oracle_and_reference_vectors(dev, dense):
     # byte streams (raw int64, like the reference's VariousMCoder) and the crop-back of decompress
     xs = R.make_images(2, 100, 120, seed=6).to(dev)
     cds, binaries, headers = model.compress(xs)
-    assert headers[0].CodeSize.m == [1, 1, 1, 1] and headers[0].ImageSize.height == 100
+    assert headers[0].CodeSize.m == [1] * len(size) and headers[0].ImageSize.height == 100
     out = model.decompress(binaries, headers)
     assert tuple(out.shape) == (2, 3, 100, 120)
     assert torch.equal(out, R.aligned_crop_back(model.decode(cds), 100, 120))
 
 
 @pytest.mark.gpu
+@CASE
 @DENSE
-def test_neon_training_forward_and_gradients(dev, dense):
+def test_neon_training_forward_and_gradients(dev, dense, case):
     """Training-mode forward against the reference's vectors (F10; F11 with denseNorm=True: GroupNorm forward and backward on
     csrc/norm.hip) and every parameter gradient against CPU autograd through the oracle (same weights, same uniform draws,
     loss = <xHat, G>)."""
-    z = _golden(dense)
-    ch, k, size = CFG
-    model, sd = _model(dev, dense)
+    z = _golden(dense, case)
+    (ch, k, size), hw, st, _ = CASES[case]
+    model, sd = _model(dev, dense, case)
     model.train()
-    x = R.make_images(2, 128, 128, seed=5)
-    us = _uniforms(k)
+    x = R.make_images(2, hw, hw, seed=5)
+    us = _uniforms(k, size=size)
     leaf = {key: (v.clone().requires_grad_() if v.is_floating_point() and "reparam" not in key and "_bound" not in key and "_freqEMA" not in key else v)
             for key, v in sd.items()}
     cb = leaf["_quantizer._quantizers.0._codebook"]
@@ -147,7 +169,7 @@ def test_neon_training_forward_and_gradients(dev, dense):
     for lv in range(len(size)):
         assert torch.equal(out[2][lv].cpu(), codes[lv]), f"codes level {lv}"
         assert torch.equal(out[2][lv].cpu(), torch.from_numpy(z[f"train_code{lv}"].astype(np.int64)))
-    np.testing.assert_allclose(out[0].detach().cpu()[..., ::4, ::4].numpy(), z["train_xHat_strided"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out[0].detach().cpu()[..., ::st, ::st].numpy(), z["train_xHat_strided"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(out[1].detach().cpu().numpy(), z["train_yHat"], rtol=0, atol=1e-4)
     for lv in range(len(size)):
         np.testing.assert_allclose(model._quantizer._entropyCoder._freqEMA[lv].detach().cpu().numpy(), z[f"train_ema{lv}"], rtol=0, atol=1e-7)
@@ -173,6 +195,6 @@ def test_neon_training_forward_and_gradients(dev, dense):
         if rel > worst[1]:
             worst = (name, rel)
     from _record import record
-    bar = NEON_GRAD_BAR[bool(dense)]
-    record(f"neon_training_step[denseNorm={bool(dense)}]", worst_rel_grad_err=worst[1], at=worst[0], bar=bar)
+    bar = NEON_GRAD_BAR[(case, bool(dense))]
+    record(f"neon_training_step[{case},denseNorm={bool(dense)}]", worst_rel_grad_err=worst[1], at=worst[0], bar=bar)
     assert worst[1] < bar, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"

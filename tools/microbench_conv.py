@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--batch1", action="store_true", help="the 3x3 shapes of one 768x512 image (batch-1 latency)")
     ap.add_argument("--c192", action="store_true", help="the 3x3 shapes of model No. 12 (channel 192) at 16 images: 64-row bands (0x22) against the 128-row tile (0x42)")
     ap.add_argument("--train", action="store_true", help="the 3x3 shapes of the config-#5 training step (8 images of 128x128 ... 4x4)")
+    ap.add_argument("--neon", action="store_true", help="the 3x3 shapes of Neon(32, ...) at 4 x 512x512 (widths 32 / 64 / 8 at full resolution ... 32x32 maps): "
+                                                    "32- and 64-row tiles, one / two / four pixel blocks per wave")
     ap.add_argument("--tiles", default=None, help="comma-separated hex tile codes instead of the full list, e.g. 0,0x1f,0x11")
     args = ap.parse_args()
     tiles = TILES if args.tiles is None else [int(t, 16) for t in args.tiles.split(",")]
@@ -54,7 +56,12 @@ def main():
     train = [(8, 128, 128, s, s, 3, 1) for s in (128, 64, 32, 16, 8, 4)]
     batch1 = [(1, 128, 128, hh, ww, 3, 1) for hh, ww in ((384, 256), (192, 128), (96, 64), (48, 32), (24, 16), (12, 8))]
     c192 = [(16, 192, 192, hh, ww, 3, 1) for hh, ww in ((384, 256), (192, 128), (96, 64), (48, 32), (24, 16), (12, 8))]
-    for (n, cin, cout, h, w, ks, stride) in c192 if args.c192 else train if args.train else batch1 if args.batch1 else (SHAPES[3:6] if args.small else SHAPES[:2] if args.big else SHAPES[6:] if args.k1 else SHAPES[:7]):
+    neon = [(4, 32, 32, s_, s_, 3, 1) for s_ in (512, 256, 128, 64)] + [(4, 32, 64, 64, 64, 3, 1), (4, 64, 64, 64, 64, 3, 1), (4, 64, 8, 64, 64, 3, 1),
+                                                                      (4, 8, 32, 64, 64, 3, 1), (4, 32, 32, 32, 32, 3, 1), (4, 32, 32, 16, 16, 3, 1), (4, 3, 32, 512, 512, 3, 1),
+                                                                      (4, 32, 3, 512, 512, 3, 1)]
+    if args.neon and args.tiles is None:
+        tiles = [0, 0x11, 0x12, 0x14, 0x21, 0x22, 0x111, 0x112, 0x121]
+    for (n, cin, cout, h, w, ks, stride) in neon if args.neon else c192 if args.c192 else train if args.train else batch1 if args.batch1 else (SHAPES[3:6] if args.small else SHAPES[:2] if args.big else SHAPES[6:] if args.k1 else SHAPES[:7]):
         x = torch.randn(n, cin, h, w, device=dev)
         res = torch.randn(n, cout, h // stride, w // stride, device=dev)
         packs = [ops.PackedConv(torch.randn(cout, cin, ks, ks, device=dev) * 0.03, torch.randn(cout, device=dev), winograd=2 if args.winograd else None)
@@ -62,7 +69,7 @@ def main():
         flops = 2.0 * n * (h // stride) * (w // stride) * cout * cin * ks * ks
         row = []
         for tile in tiles:
-            if h * w > 100 * 64 and tile not in (0, 0x42, 0x41, 0x22, 0x11) and not args.train and not args.batch1 and args.tiles is None:
+            if h * w > 100 * 64 and tile not in (0, 0x42, 0x41, 0x22, 0x11) and not args.train and not args.batch1 and not args.neon and args.tiles is None:
                 continue
             kw = dict(tile=tile)
             if args.winograd:

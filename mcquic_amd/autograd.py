@@ -559,6 +559,27 @@ def _gdn_operands(module, beta_p, gamma_p, bounds):
     return cached[1], cached[2]
 
 
+def _gdn_forward(module, x, beta_p, gamma_p, inverse: bool):
+    """(y, forward operand stream, input-gradient operand stream, (beta bound, gamma bound)) of a GDN / IGDN layer."""
+    bb, be, gb, ge = _gdn_bounds(module)
+    packed, back = _gdn_operands(module, beta_p, gamma_p, (bb, be, gb, ge))
+    y = ops.conv2d(x, packed, square_in=True, igdn_mul=x) if inverse else ops.conv2d(x, packed, square_in=True, gdn_mul=x)
+    return y, packed, back, (bb, gb)
+
+
+def _gdn_backward(x, packed, back, bounds, beta_p, gamma_p, dy, inverse: bool):
+    """(dx, d beta_p, d gamma_p): 5 launches -- the recomputed s-launch with the element-wise part in its epilogue, the 1x1
+    input-gradient launch, the 1x1 weight gradient on x^2 (+ its reduce) and both re-parametrisation gradients in one."""
+    if _GDN_BWD_FUSED:
+        dxd, ds = ops.conv2d_gdn_bwd(x, packed, dy, inverse)      # s = beta + gamma @ x^2 recomputed, dy f(s) and dy x f'(s) from its epilogue
+    else:                                                          # (A/B switch: the round-3 form, s stored and read back)
+        dxd, ds = ops.gdn_bwd_prep(x, ops.conv2d(x, packed, square_in=True), dy, inverse)
+    dx = ops.conv2d(ds, back, mul=x, res=dxd)                      # dy f(s) + 2 x (gamma^T ds)
+    dgamma, dbeta = ops.conv2d_wgrad(x, ds, 1, 1, square_x=True, want_bias=True)
+    dbeta_p, dgamma_p = ops.nonneg_reparam_bwd2(beta_p, dbeta, bounds[0], gamma_p, dgamma[:, :, 0, 0], bounds[1])
+    return dx, dbeta_p, dgamma_p
+
+
 class GdnFn(torch.autograd.Function):
     """y = x * f(beta + gamma @ x^2) with the non-negative re-parametrisation of beta [C], gamma [C, C] INSIDE the node
     (mcquic/nn/gdn.py:67-91, mcquic/nn/base.py:17-29,81-84): folding, the 1x1 launch, and in backward the two input-gradient
@@ -567,26 +588,92 @@ class GdnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, beta_p, gamma_p, module, inverse):
-        bb, be, gb, ge = _gdn_bounds(module)
-        packed, back = _gdn_operands(module, beta_p, gamma_p, (bb, be, gb, ge))
-        y = ops.conv2d(x, packed, square_in=True, igdn_mul=x) if inverse else ops.conv2d(x, packed, square_in=True, gdn_mul=x)
+        y, packed, back, bounds = _gdn_forward(module, x, beta_p, gamma_p, inverse)
         ctx.save_for_backward(x, beta_p, gamma_p)
-        ctx.packed, ctx.back, ctx.inverse, ctx.bounds = packed, back, inverse, (bb, gb)
+        ctx.packed, ctx.back, ctx.inverse, ctx.bounds = packed, back, inverse, bounds
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, beta_p, gamma_p = ctx.saved_tensors
-        dy = dy.contiguous()
-        if _GDN_BWD_FUSED:
-            dxd, ds = ops.conv2d_gdn_bwd(x, ctx.packed, dy, ctx.inverse)      # s = beta + gamma @ x^2 recomputed, dy f(s) and dy x f'(s) from its epilogue
-        else:                                                                  # (A/B switch: the round-3 form, s stored and read back)
-            dxd, ds = ops.gdn_bwd_prep(x, ops.conv2d(x, ctx.packed, square_in=True), dy, ctx.inverse)
-        dx = ops.conv2d(ds, ctx.back, mul=x, res=dxd)                          # dy f(s) + 2 x (gamma^T ds)
-        dgamma, dbeta = ops.conv2d_wgrad(x, ds, 1, 1, square_x=True, want_bias=True)
-        bb, gb = ctx.bounds
-        dbeta_p, dgamma_p = ops.nonneg_reparam_bwd2(beta_p, dbeta, bb, gamma_p, dgamma[:, :, 0, 0], gb)    # both in one launch
+        dx, dbeta_p, dgamma_p = _gdn_backward(x, ctx.packed, ctx.back, ctx.bounds, beta_p, gamma_p, dy.contiguous(), ctx.inverse)
         return dx, dbeta_p, dgamma_p, None, None
+
+
+class ScaleBlockFn(torch.autograd.Function):
+    """ResidualBlockWithStride (`up` False: SiLU, conv3 s2, GDN, conv3, + conv3 s2 skip; mcquic/nn/blocks.py:98-122) and
+    ResidualBlockShuffle (`up` True: SiLU, pixelShuffle3x3, IGDN, conv3, + pixelShuffle3x3 skip; :141-159) as ONE autograd node:
+    forward = the four launches of the op-by-op graph; backward keeps those launches too, except that the gradient reaching x
+    along the branch (through the first convolution and the SiLU) and the one along the skip convolution MEET IN THE EPILOGUE of
+    the branch's input-gradient launch (* silu'(x) + d_skip; through the PixelShuffle store for the strided block) instead of in a
+    SiLU-backward launch plus an add -- one launch and three tensor passes less per block.
+    Parameter order: conv1 (w, b), GDN (beta, gamma), conv2 (w, b), skip (w, b)."""
+
+    @staticmethod
+    def forward(ctx, x, sx, w1, b1, beta_p, gamma_p, w2, b2, ws, bs, block, up):
+        c1, gdn_m, c2, cs = _scale_block_layers(block, up)
+        stride = 1 if up else 2
+        t = ops.conv2d(sx, c1.packed(), stride, shuffle2=up)
+        u, packed, back, bounds = _gdn_forward(gdn_m, t, beta_p, gamma_p, up)
+        skip = ops.conv2d(x, cs.packed(), stride, shuffle2=up)
+        y = ops.conv2d(u, c2.packed(), res=skip, dual_silu=True)       # (+ silu(y) for the block that follows)
+        sy = ops.silu_twin(y)
+        ctx.save_for_backward(x, sx, t, u, beta_p, gamma_p, w1, w2, ws)
+        ctx.block, ctx.up, ctx.packed, ctx.back, ctx.bounds = block, up, packed, back, bounds
+        ctx.mark_non_differentiable(sy)
+        ctx.set_materialize_grads(False)
+        return y, sy
+
+    @staticmethod
+    def backward(ctx, dy, _dsy):
+        x, sx, t, u, beta_p, gamma_p, w1, w2, ws = ctx.saved_tensors
+        up = ctx.up
+        c1, gdn_m, c2, cs = _scale_block_layers(ctx.block, up)
+        stride = 1 if up else 2
+        dy = dy.contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        d_u = ops.conv2d(dy, _dgrad_packed(c2, w2))
+        dw2, db2 = ops.conv2d_wgrad(u, dy, 3, 1, want_bias=True)
+        dyc = ops.pixel_unshuffle2(dy) if up else dy
+        dx_skip = None
+        if need_dx:
+            dx_skip = ops.conv2d(dyc, _dgrad_packed(cs, ws)) if up else _crop_like(ops.conv2d(dyc, _dgrad_packed(cs, ws), shuffle2=True), x)
+        dws, dbs = ops.conv2d_wgrad(x, dyc, 3, stride, want_bias=True)
+        d_t, dbeta_p, dgamma_p = _gdn_backward(t, ctx.packed, ctx.back, ctx.bounds, beta_p, gamma_p, d_u, up)
+        d_tc = ops.pixel_unshuffle2(d_t) if up else d_t
+        dx = None
+        if need_dx:
+            wt1 = _dgrad_packed(c1, w1)
+            if up:
+                dx = ops.conv2d(d_tc, wt1, dsilu_mul=x, res=dx_skip)
+            elif x.shape[-2] == 2 * d_tc.shape[-2] and x.shape[-1] == 2 * d_tc.shape[-1]:
+                dx = ops.conv2d(d_tc, wt1, shuffle2=True, dsilu_mul=x, res=dx_skip)
+            else:                                                  # (odd maps: the sub-pixel form over-covers by a row / column)
+                dx = ops.silu_bwd(x, _crop_like(ops.conv2d(d_tc, wt1, shuffle2=True), x), dx_skip)
+        dw1, db1 = ops.conv2d_wgrad(sx, d_tc, 3, stride, want_bias=True)
+        return dx, None, dw1, db1, dbeta_p, dgamma_p, dw2, db2, dws, dbs, None, None
+
+
+def _scale_block_layers(block, up: bool):
+    """(first conv, GDN / IGDN, closing conv, skip conv) of a strided / shuffle block (the shuffle convs sit inside their Sequential)."""
+    c1, cs = block._branch[1], block._skip
+    if up:
+        c1, cs = c1[0], cs[0]
+    return c1, block._branch[2], block._branch[3], cs
+
+
+def _crop_like(t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    if t.shape[-2] != x.shape[-2] or t.shape[-1] != x.shape[-1]:
+        t = t[..., :x.shape[-2], :x.shape[-1]].contiguous()
+    return t
+
+
+def scale_block(x, block, up: bool):
+    """ResidualBlockWithStride / ResidualBlockShuffle in the training graph (ScaleBlockFn); the result carries its SiLU twin."""
+    c1, gdn_m, c2, cs = _scale_block_layers(block, up)
+    y, sy = ScaleBlockFn.apply(x, _silu_of(x), c1.weight, c1.bias, gdn_m.beta, gdn_m.gamma, c2.weight, c2.bias, cs.weight, cs.bias, block, up)
+    ops.set_silu_twin(y, sy)
+    return y
 
 
 class GroupNormFn(torch.autograd.Function):

@@ -83,6 +83,9 @@ struct ConvK {
 };
 
 constexpr int PRO_NONE = 0, PRO_SILU = 1, PRO_SQUARE = 2;
+#ifndef MCQ_SHUFFLE_SIDE
+#define MCQ_SHUFFLE_SIDE 1      // build switch (A/B of the dominant instance's register allocation): 0 = the PixelShuffle store takes no side tensors
+#endif
 // 128-row Winograd instance: the epilogue flag set instance `id` (the kernel's PRO slot) is compiled for; 0 = any (run-time flags)
 constexpr unsigned wino_epilogue_flags(int id) {
     return id == 1 ? 0u : id == 2 ? MCQ_CONV_SILU_OUT : id == 3 ? MCQ_CONV_RESIDUAL : id == 4 ? (MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU)
@@ -604,8 +607,22 @@ next_tile:
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
                         const unsigned so = ((co_row0 >> 2) + 2u * (unsigned)rq) * HoWo * 16u;
-                        mcq_buffer_store2_s(f32x2v{v[rq * 4 + 0], v[rq * 4 + 1]}, yr[nb], pvo[nb], so);
-                        mcq_buffer_store2_s(f32x2v{v[rq * 4 + 2], v[rq * 4 + 3]}, yr[nb], pvo[nb], so + W2b);
+                        f32x2v top = f32x2v{v[rq * 4 + 0], v[rq * 4 + 1]}, bot = f32x2v{v[rq * 4 + 2], v[rq * 4 + 3]};
+                        // (round 5) the input-gradient launch of a stride-2 convolution stores through the shuffle; when that convolution
+                        // sits behind a SiLU and beside a skip path (ResidualBlockWithStride) the two side operations of the plain
+                        // input-gradient launches apply here too, at the shuffled addresses: * silu'(mul), + res
+                        if (MCQ_SHUFFLE_SIDE && (f & MCQ_CONV_DSILU_MUL)) {
+                            const f32x2v mt = mcq_buffer_load2_s(mr[nb], pvo[nb], so), mb2 = mcq_buffer_load2_s(mr[nb], pvo[nb], so + W2b);
+                            top = f32x2v{top[0] * mcq_dsilu(mt[0]), top[1] * mcq_dsilu(mt[1])};
+                            bot = f32x2v{bot[0] * mcq_dsilu(mb2[0]), bot[1] * mcq_dsilu(mb2[1])};
+                        }
+                        if (MCQ_SHUFFLE_SIDE && (f & MCQ_CONV_RESIDUAL)) {
+                            const f32x2v rt = mcq_buffer_load2_s(rr_[nb], pvo[nb], so), rb = mcq_buffer_load2_s(rr_[nb], pvo[nb], so + W2b);
+                            top = f32x2v{top[0] + p.res_scale * rt[0], top[1] + p.res_scale * rt[1]};
+                            bot = f32x2v{bot[0] + p.res_scale * rb[0], bot[1] + p.res_scale * rb[1]};
+                        }
+                        mcq_buffer_store2_s(top, yr[nb], pvo[nb], so);
+                        mcq_buffer_store2_s(bot, yr[nb], pvo[nb], so + W2b);
                     }
                     continue;
                 }
@@ -1447,7 +1464,10 @@ int conv_validate(const mcq_conv_desc* d) {
     }
     if ((fl & MCQ_CONV_SILU_IN) && (fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;
     if (fl & MCQ_CONV_SHUFFLE2) {
-        if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN | MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D | MCQ_CONV_WINOGRAD2D16))) return MCQ_EINVAL;
+        if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN | MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D | MCQ_CONV_WINOGRAD2D16 |
+                                               MCQ_CONV_DSILU_MUL | MCQ_CONV_RESIDUAL))) return MCQ_EINVAL;
+        if ((fl & (MCQ_CONV_DSILU_MUL | MCQ_CONV_RESIDUAL)) && (!MCQ_SHUFFLE_SIDE || (fl & (MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D | MCQ_CONV_WINOGRAD2D16))))
+            return MCQ_EINVAL;
     }
     // one image's input slab plus the prefetch rings' over-read (up to 8 channels) must stay below 2 GiB: byte offsets and
     // the descriptors' shrinking num_records are 32-bit (signed in the scalar arithmetic of the k-loop)

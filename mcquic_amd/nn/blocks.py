@@ -33,6 +33,7 @@ __all__ = ["ResidualBlockWithStride", "ResidualBlockShuffle", "ResidualBlock", "
 # branch's workgroups, and the launch-latency-bound small levels run two kernels at once.  MCQUIC_AMD_BRANCH_STREAMS=0
 # turns it off (single stream, same results).
 _BRANCH_STREAMS = os.environ.get("MCQUIC_AMD_BRANCH_STREAMS", "1") != "0"
+_BLOCK_NODES = os.environ.get("MCQUIC_AMD_BLOCK_NODES", "1") != "0"      # A/B switch: 0 = strided / shuffle blocks op by op in the training graph
 _side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
 _MULTI_MAX_PIXELS = int(os.environ.get("MCQUIC_AMD_MULTI_MAX_PIXELS", str(64 * 1024)))   # N * H * W up to which AttentionBlock stacks share launches
 # ... and below this many pixels nothing is forked at all: a launch that does not fill the chip for several rounds has no tail worth
@@ -140,6 +141,8 @@ class ResidualBlockWithStride(_residulBlock):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
+            if _BLOCK_NODES and self._branch[1].bias is not None:
+                return AG.scale_block(x, self, up=False)                       # the whole block as one autograd node
             sx, x = AG.silu_fork(x)                                           # (the branch's and the skip's gradients meet in one launch)
             t = self._branch[2](self._branch[1](sx))
             return self._branch[3](t, res=self._skip(x), dual_silu=True)      # (+ silu(out) for the block that follows)
@@ -161,6 +164,8 @@ class ResidualBlockShuffle(_residulBlock):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
+            if _BLOCK_NODES and self._branch[1][0].bias is not None:
+                return AG.scale_block(x, self, up=True)
             sx, x = AG.silu_fork(x)
             t = self._branch[2](self._branch[1](sx))
             return self._branch[3](t, res=self._skip(x), dual_silu=True)

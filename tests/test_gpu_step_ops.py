@@ -215,3 +215,53 @@ def test_gate_backward_from_the_recomputed_1x1_launch(dev, shape):
     both = ops.conv2d_gate_bwd([b, b2], [pk, pk], [a, a2], [dout, d2])
     (da2, ds2), = ops.conv2d_gate_bwd([b2], [pk], [a2], [d2])
     assert torch.equal(both[0][0], da) and torch.equal(both[0][1], ds) and torch.equal(both[1][0], da2) and torch.equal(both[1][1], ds2)
+
+
+@pytest.mark.parametrize("shape", [(8, 128, 32, 32), (2, 128, 64, 64), (3, 32, 9, 7), (1, 8, 4, 4), (2, 192, 16, 12)])
+def test_pixel_shuffle_store_with_side_tensors(dev, shape):
+    """MCQ_CONV_SHUFFLE2 | DSILU_MUL | RESIDUAL (the input-gradient launch of a strided block's first convolution: * silu'(x) + d_skip
+    through the shuffle) against the shuffle store followed by the stand-alone kernels; each side operation alone as well."""
+    from mcquic_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c * h)
+    x = torch.randn((n, c, h, w), generator=g).to(dev)
+    wt = (torch.randn((4 * c, c, 3, 3), generator=g) / (3 * c ** 0.5)).to(dev)
+    pk = ops.PackedConv(wt, None)
+    m, r = [torch.randn((n, c, 2 * h, 2 * w), generator=g).to(dev) for _ in range(2)]
+    plain = ops.conv2d(x, pk, shuffle2=True)
+    for kw, want in ((dict(dsilu_mul=m, res=r), ops.silu_bwd(m, plain, r)), (dict(dsilu_mul=m), ops.silu_bwd(m, plain)), (dict(res=r), plain + r)):
+        got = ops.conv2d(x, pk, shuffle2=True, **kw)
+        err = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-12)
+        assert err <= 2e-6, (sorted(kw), err)
+
+
+@pytest.mark.parametrize("up", [False, True])
+@pytest.mark.parametrize("shape", [(2, 32, 16, 16), (1, 128, 8, 8), (2, 8, 7, 9)])
+def test_scale_block_node_equals_op_by_op_graph(dev, up, shape):
+    """ScaleBlockFn (strided / shuffle block as one autograd node, gradients meeting in a conv epilogue) against the op-by-op
+    autograd graph of the same block: outputs bit-equal, every gradient within 4e-6 of the largest entry."""
+    from mcquic_amd.nn import blocks
+    n, c, h, w = shape
+    torch.manual_seed(c + h)
+    blk = (blocks.ResidualBlockShuffle(c, c) if up else blocks.ResidualBlockWithStride(c, c)).to(dev).train()
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn((n, c, h, w), generator=g).to(dev)
+    res = {}
+    for mode in (True, False):
+        blocks._BLOCK_NODES = mode
+        try:
+            for p in blk.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_()
+            y = blk(x * 1.0)
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+            (y * gy).sum().backward()
+            res[mode] = (y.detach(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None})
+        finally:
+            blocks._BLOCK_NODES = True
+    assert torch.equal(res[True][0], res[False][0])
+    pairs = [("dx", res[True][1], res[False][1])] + [(k, res[True][2][k], res[False][2][k]) for k in res[False][2]]
+    assert set(res[True][2]) == set(res[False][2])
+    for name, a, b in pairs:
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+        assert err <= 4e-6, (name, err)

@@ -274,6 +274,7 @@ def neon_figures(dev, dense: bool = True, infer_batch: int = 8, train_batch: int
     prof.next_step()
     with torch.no_grad():
         model(xt)
+    torch.cuda.synchronize()
     prof.remove()
     fwd_flops = prof.summary()["flops"]
 

@@ -1642,6 +1642,22 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         // <= 32 output channels (the 12-channel head, the tiny fixture models): one weight load feeds NB MFMAs, so the
         // widest pixel tile that still leaves >= 2048 waves amortises it best (head conv 2.34 -> 2.05 ms with NB = 4)
         MB = 1; NB = (tb * nprob >= 4 * 2048) ? 4 : 2;
+        // Neon's 32-wide layers (channel 32, stride-1 stem: 256 x 256 ... 16 x 16 maps; round 5, tools/microbench_conv.py --neon,
+        // profiles/r05_neon_tile_sweep.txt): with <= 32 input channels a k-loop is 144 steps and the epilogue weighs as much as the
+        // weights' amortisation -- two pixel blocks per wave only where the launch has waves to spare (4 x 512x512: 218 us against
+        // 237 / 221 for one / four), one below that (256x256 49.9 vs 53.8 us, 128x128 16.0 vs 26.9, 64x64 11.5 vs 14.8), split over
+        // two waves when even that leaves SIMDs idle (4 x 64 -> 8 at 64x64: 11.6 us against 22.4)
+        if (d->Cin <= 64) {
+            NB = (tb * nprob >= 16384) ? 2 : 1;
+            while (ksl < 3 && (((tb + NB - 1) / NB * nprob) << ksl) < 1024) ++ksl;
+        }
+    }
+    else if (co32 == 2 && ((tb + 1) / 2) * nprob < 2048 && d->ksize == 3) {
+        // 64 output channels on maps that leave the 64 x 64 tile short of waves (Neon's 64-wide layers live on 64 x 64 maps):
+        // one wave per 32 x 32 tile, unsplit, instead of the larger tile split 4 / 8 ways through LDS (4 x 64 -> 64 at 64x64:
+        // 14.7 us against 21.4; 32 -> 64: 11.6 against 17.0)
+        MB = 1; NB = 1;
+        while (ksl < 3 && ((tb * co32 * nprob) << ksl) < 1024) ++ksl;
     }
     else {
         // (the 128 x 32 tile <4, 1> is instantiated and reachable through `tile`; an automatic rule preferring it on

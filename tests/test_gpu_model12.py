@@ -24,8 +24,10 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODEL12 = (192, 12, [8192, 2048, 512])
 # index bars = 4x what profiles/r05_parity_measurements.json records for these cases (never below 1): set after the measurement
-MAX_FLIPS12 = {"kodak": 1, "ragged": 1}
-MAX_DIFF12 = 12
+# (measured in round 5: kodak 1 first flip of 24 192 codes with 6 vectors below 1e-5 in the reference's own distances, ragged 0 of 8 064
+#  with 3; the four-image oracle batch 0 differing codes in 0 images)
+MAX_FLIPS12 = {"kodak": 4, "ragged": 1}
+MAX_DIFF_IMAGES12 = 1
 TOL192 = 4e-6          # sums of 192 x 9 = 1728 products (2e-6 holds for the 1152 of channel 128: measured 3.2e-6 here)
 
 
@@ -70,8 +72,9 @@ def test_model12_against_oracle_batch(dev, model12):
     total = sum(c.numel() for c in want)
     diff = sum(int((a != b).sum()) for a, b in zip(got, want))
     images = sum(int(any(bool((a[i] != b[i]).any()) for a, b in zip(got, want))) for i in range(x.shape[0]))
-    record("model12_oracle_batch", differing_codes=diff, images_with_a_difference=images, codes=total, bar=MAX_DIFF12)
-    assert diff <= MAX_DIFF12, f"{diff} of {total} codes differ from the oracle's (bar {MAX_DIFF12}: near-ties explain a handful per image)"
+    record("model12_oracle_batch", differing_codes=diff, images_with_a_difference=images, codes=total, bar_images=MAX_DIFF_IMAGES12)
+    # (a first flip changes the residual every deeper level of THAT image quantizes, so differences are counted in images)
+    assert images <= MAX_DIFF_IMAGES12, f"{images} of 4 images differ from the oracle's codes somewhere ({diff} of {total} codes; bar {MAX_DIFF_IMAGES12} image)"
     rec = model.decode([c.to(dev) for c in want]).cpu()
     ref = R.decode(sd, want)
     assert float((rec - ref).abs().max()) <= 1e-4

@@ -19,12 +19,14 @@ CASES = {"small": ((32, 256, [8, 4, 2, 2]), 128, 4, ("f10_neon.npz", "f11_neon_d
          "k4096": ((32, 4096, [16, 8, 4, 2, 2]), 256, 8, ("f13_neon_k4096.npz", "f14_neon_k4096_dense_norm.npz"))}
 CFG = CASES["small"][0]
 CASE = pytest.mark.parametrize("case", ["small", "k4096"])
-NEON_MAX_FLIPS = {"small": 0, "k4096": 4}     # first flips allowed per run (4x the measurement, profiles/r05_parity_measurements.json)
+NEON_MAX_FLIPS = {"small": 0, "k4096": 1}     # first flips allowed per run: 0 were measured on both (profiles/r05_parity_measurements.json);
+                                              # k4096 has one vector below 1e-5 in the reference's own distances, hence one
 NEAR_TIE = 1e-5          # a code may differ from the reference's only where the reference's own top-2 gap is below this
 # denseNorm -> worst relative gradient error allowed = 4x the measured value (profiles/r04_gradient_errors.json: 3.6e-6 plain; with
 # denseNorm 4.2e-4, all of it at a conv bias in front of a one-channel-per-group GroupNorm whose gradient is structurally ZERO --
 # both sides hold rounding noise there and the error is taken against 1e-3 of the model's largest gradient, see below)
-NEON_GRAD_BAR = {("small", False): 1.5e-5, ("small", True): 1.7e-3, ("k4096", False): 4e-5, ("k4096", True): 5e-3}
+# (k4096, round 5: 3.4e-5 plain at a decoder bias, 2.2e-4 with denseNorm at the same structurally-zero kind of bias)
+NEON_GRAD_BAR = {("small", False): 1.5e-5, ("small", True): 1.7e-3, ("k4096", False): 1.4e-4, ("k4096", True): 8.7e-4}
 DENSE = pytest.mark.parametrize("dense", [False, True], ids=["plain", "denseNorm"])
 
 

@@ -284,7 +284,7 @@ def neon_figures(dev, dense: bool = True, infer_batch: int = 8, train_batch: int
         xHat = model(xt)[0]
         loss = mse_loss(xHat, xt)
         backward(loss)
-        return loss
+        return loss.detach()                                    # (no handle on the autograd graph outlives the step: a later capture needs that)
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -294,10 +294,34 @@ def neon_figures(dev, dense: bool = True, infer_batch: int = 8, train_batch: int
         loss = step()
     torch.cuda.synchronize()
     tms = (time.perf_counter() - t0) / 3 * 1e3
+    peak_bytes = torch.cuda.max_memory_allocated(dev)
+    # ... and the same step as one hipGraph (what parallel.GraphedTrainStep replays; the eager figure is bound by the host)
+    gms = None
+    from mcquic_amd.nn import blocks as _blocks
+    streams = _blocks._BRANCH_STREAMS
+    try:
+        _blocks._BRANCH_STREAMS = False                        # (nested stream forks crash hipGraph capture on ROCm 7.2)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        for p in model.parameters():
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        gms = _timed(graph.replay, 5, warmup=1)
+        del graph
+    except Exception as exc:                                    # noqa: BLE001
+        out["train_graph_error"] = repr(exc)[:200]
+    finally:
+        _blocks._BRANCH_STREAMS = streams
+    if gms is not None:
+        out["train_step_graph_ms"] = round(gms, 3)
+        out["train_graph_frac_of_peak"] = round(3.0 * fwd_flops / (gms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4)
     out.update({"train_batch": train_batch, "train_step_ms": round(tms, 3), "train_loss": round(float(loss), 6),
                 "train_frac_of_peak": round(3.0 * fwd_flops / (tms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
                 "train_tflop_per_step": round(3.0 * fwd_flops / 1e12, 3),
-                "train_peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                "train_peak_memory_gb": round(peak_bytes / 2 ** 30, 2),
                 "device_memory_gb": round(torch.cuda.get_device_properties(dev).total_memory / 2 ** 30, 1),
                 "checkpoint_wrapper": "not applied: the step's peak memory without recompute is the figure above"})
     del model, x, xt

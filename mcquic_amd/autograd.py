@@ -148,6 +148,40 @@ class SubPassFn(torch.autograd.Function):
         return dr, ops.axpby(db2.contiguous(), dr, 1.0, -1.0)
 
 
+class ForkFn(torch.autograd.Function):
+    """k aliases of x for k consumers: their gradients are summed by this library's add kernels (one launch for two or three
+    consumers) instead of by adds the autograd engine issues itself."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *ds):
+        ds = [d.contiguous() for d in ds if d is not None]
+        if not ds:
+            return None, None
+        dx = ds[0]
+        i = 1
+        while i + 1 < len(ds):
+            dx = ops.add3(dx, ds[i], ds[i + 1])
+            i += 2
+        if i < len(ds):
+            dx = ops.add(dx, ds[i])
+        return dx, None
+
+
+def fork(x, k: int):
+    """k aliases of x (ForkFn), each carrying x's SiLU twin."""
+    tx = ops.silu_twin(x)
+    outs = ForkFn.apply(x, k)
+    if tx is not None:
+        for o in outs:
+            ops.set_silu_twin(o, tx)
+    return outs
+
+
 class MseFn(torch.autograd.Function):
     """F.mse_loss(a, b) (mcquic/loss/__init__.py:62) from this library's own reduction: no library memset inside a captured step."""
 
@@ -484,10 +518,14 @@ class GateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, x):
         ctx.save_for_backward(a, b)
-        return ops.gate(a, b, x)
+        out = ops.gate(a, b, x, dual_silu=True)                  # (+ silu(out): the block that follows starts with an activation)
+        sout = ops.silu_twin(out)
+        ctx.mark_non_differentiable(sout)
+        ctx.set_materialize_grads(False)
+        return out, sout
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dsout=None):
         a, b = ctx.saved_tensors
         dout = dout.contiguous()
         da, db = ops.gate_bwd(a, b, dout)
@@ -743,7 +781,7 @@ def residual_block(x, block):
 
 
 def gate(a, b, x):
-    return GateFn.apply(a, b, x)
+    return _with_twin(*GateFn.apply(a, b, x))
 
 
 def _with_twin(out, sout):

@@ -118,8 +118,10 @@ class _multiCodebookQuantization(nn.Module):
         """[n, m*d, h, w] -> int64 [n, m, h, w] = argmin_k ((x2 + c2) - 2 x.c), first index on ties (:144-179)."""
         return ops.vq_assign(x, self._cache[0].get(self._codebook))
 
-    def forward(self, x: torch.Tensor, freqEMA: torch.Tensor, uniforms=None, step=None):
+    def forward(self, x: torch.Tensor, freqEMA: torch.Tensor, uniforms=None, step=None, codebook=None):
         """Training-mode forward (:181-239), forward values only (no autograd graph yet).
+        `codebook`: an alias of `self._codebook` to differentiate through (a quantizer whose codebook is shared by several levels
+        hands every level its own alias so that their gradients are summed by one node, autograd.fork).
 
         logit = (-dist / sqrt(k)) * max(temperature, eps); random drop against the level's frequency EMA;
         gumbelSoftmax(hard=True); code = argmax(logit).  The straight-through sample y_hard - y_soft + y_soft is
@@ -144,7 +146,7 @@ class _multiCodebookQuantization(nn.Module):
             rng = None
         if torch.is_grad_enabled():
             from ..autograd import SoftQuantizeFn
-            deq, code, logit, sdeq = SoftQuantizeFn.apply(x, self._codebook, self._temperature, freqEMA.detach(), uniforms[0], uniforms[1],
+            deq, code, logit, sdeq = SoftQuantizeFn.apply(x, self._codebook if codebook is None else codebook, self._temperature, freqEMA.detach(), uniforms[0], uniforms[1],
                                                           exponent, cb, float(EPS), rng, counts)
             ops.set_silu_twin(deq, sdeq)
             return deq, code, logit           # the sample is represented by its (differentiable) dequantisation
@@ -520,6 +522,8 @@ class ResidualBackwardQuantizer(VariousMQuantizer):
         quantizeds, codes, logits = [], [], []
         current = None
         st = self._stepPrologue(x, uniforms)          # (the j-th quantization reads `_entropyCoder._freqEMA[j]`, see __init__)
+        # ONE codebook under every level: each level differentiates through its own alias and one node sums the gradients
+        cbs = AG.fork(self._quantizers[0]._codebook, len(self._quantizers)) if grad else [None] * len(self._quantizers)
         for j, (quantizer, dequantizer, backward, latent) in enumerate(zip(self._quantizers[::-1], self._dequantizers[::-1],
                                                                            self._backwards[::-1], latents[::-1])):
             if current is None:
@@ -527,12 +531,14 @@ class ResidualBackwardQuantizer(VariousMQuantizer):
             else:
                 residual = AG.sub(latent, current) if grad else ops.axpby(latent, current, 1.0, -1.0)
             sample, code, logit = quantizer(residual, quantizer._freqEMA, None if uniforms is None else uniforms[j],
-                                            None if st is None else st.level(j))
+                                            None if st is None else st.level(j), cbs[j])
             quantized = dequantizer(sample)
+            # (two consumers: the decoder side and the `backward` stack -- or, behind the last level's identity, the next residual)
+            quantized, forBackward = AG.fork(quantized, 2) if grad else (quantized, quantized)
             quantizeds.append(quantized)
             codes.append(code)
             logits.append(logit)
-            current = backward(quantized)
+            current = backward(forBackward)
         formerLevel = None
         for decoder, quantized in zip(self._decoders[::-1], quantizeds):
             if formerLevel is None:

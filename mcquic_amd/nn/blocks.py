@@ -118,9 +118,10 @@ class ResidualBlock(_residulBlock):
         if self.training and torch.is_grad_enabled():
             if self._skip is None and not self.denseNorm:         # training graph: two fused launches each way
                 return AG.residual_block(x, self)
-            t = self._branch[1](AG.silu(x))                       # (width-changing / normalised blocks: op-by-op autograd)
+            sx, x = AG.silu_fork(x)                               # (width-changing / normalised blocks: op-by-op autograd; x's two
+            t = self._branch[1](sx)                               #  gradients -- through the activation and along the skip -- meet in one launch)
             t = self._branch[2](t) if self.denseNorm else AG.silu(t)
-            return self._branch[3](t, res=x if self._skip is None else self._skip(x))
+            return self._branch[3](t, res=x if self._skip is None else self._skip(x), dual_silu=True)
         if self.denseNorm:
             t = self._branch[2](self._branch[1](x, silu_in=True))     # GroupNorm(conv1(silu(x))): no activation in front of conv2
         else:
@@ -189,7 +190,8 @@ class AttentionBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
             if self.denseNorm:                                    # normalised blocks: op-by-op autograd
-                return AG.gate(self._mainBranch(x), self._sideBranch(x), x)
+                xa, xb, xc = AG.fork(x, 3)                        # (three consumers: their gradients summed by one launch of ours)
+                return AG.gate(self._mainBranch(xa), self._sideBranch(xb), xc)
             return AG.attention_block(x, self)
         if ops._MULTI and not self.denseNorm and x.shape[0] * x.shape[2] * x.shape[3] <= _MULTI_MAX_PIXELS:
             # the two stacks apply the same layer shapes to different tensors: layer by layer they share a launch

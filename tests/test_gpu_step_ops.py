@@ -144,7 +144,8 @@ _NO_LAUNCH = ("empty", "empty_like", "empty_strided", "new_empty", "new_empty_st
               "unbind", "split", "chunk", "narrow", "contiguous", "result_type", "is_pinned", "set_", "record_stream", "is_nonzero_meta")
 
 
-def test_training_step_issues_no_aten_kernels(dev):
+@pytest.mark.parametrize("kind", ["compressor", "neon", "neon_dense_norm"])
+def test_training_step_issues_no_aten_kernels(dev, kind):
     """One training step (forward + backward) of a Compressor dispatches NO ATen operator that launches a kernel: every launch is
     this library's (VERDICT r4 counted 98 `at::native::*` launches per replay of the captured qp=2 step: the soft assignment's
     bookkeeping, the frequency EMA, LowerBound's rule, the autograd engine's own gradient sums and the root gradient's fill).
@@ -168,13 +169,17 @@ def test_training_step_issues_no_aten_kernels(dev):
     blocks._BRANCH_STREAMS = False
     try:
         torch.manual_seed(3407)
-        model = Compressor(16, 2, [64, 32, 16]).to(dev).train()
+        if kind == "compressor":
+            model = Compressor(16, 2, [64, 32, 16]).to(dev).train()
+        else:
+            from mcquic_amd import Neon
+            model = Neon(32, 256, [8, 4, 2, 2], kind == "neon_dense_norm").to(dev).train()
         x = (torch.rand((2, 3, 128, 128), generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
 
         def step():
             for p in model.parameters():
                 p.grad = None
-            xHat, _, _, _ = model(x)
+            xHat = model(x)[0]
             loss = mse_loss(xHat, x)
             backward(loss)
             return loss

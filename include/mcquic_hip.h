@@ -466,11 +466,16 @@ int mcq_pack_conv_weight_winograd16_f32(const float* w, int32_t Cout, int32_t Ci
  * rstd = 1 / sqrt(var + eps): nn.GroupNorm(groups, C) as the reference's ResidualBlock inserts it in place of its second
  * activation when denseNorm is set (mcquic/nn/blocks.py:179-200).  gamma / beta may be NULL (1 / 0).  y_silu (NULL = none)
  * receives silu(y).  mean_out / rstd_out [N * groups] (both or neither): what the backward pass needs. */
+/* `workspace` (round 5; mcq_group_norm_workspace_floats floats, 0 = none needed, NULL = take the one-workgroup-per-run kernel):
+ * runs of 32 k floats and more -- Neon's GroupNorm(32, 32) on 512 x 512 maps -- are cut into 8192-float chunks, one workgroup
+ * each, whose (mean, M2) pairs are merged in chunk order. */
+size_t mcq_group_norm_workspace_floats(int32_t N, int32_t C, int32_t HW, int32_t groups);
 int mcq_group_norm_f32(const float* x, const float* gamma, const float* beta, float* y, float* y_silu, float* mean_out,
-                       float* rstd_out, int32_t N, int32_t C, int32_t HW, int32_t groups, float eps, void* stream);
+                       float* rstd_out, float* workspace /* or NULL */, int32_t N, int32_t C, int32_t HW, int32_t groups, float eps,
+                       void* stream);
 /* Backward of the above: dx [N, C, HW], dgamma / dbeta [C] (NULL = not wanted) from x, dy and the forward's mean / rstd.
- * workspace: mcq_group_norm_bwd_workspace_floats(N, C) floats.  Deterministic (no atomics). */
-size_t mcq_group_norm_bwd_workspace_floats(int32_t N, int32_t C);
+ * workspace: mcq_group_norm_bwd_workspace_floats(N, C, HW, groups) floats.  Deterministic (no atomics). */
+size_t mcq_group_norm_bwd_workspace_floats(int32_t N, int32_t C, int32_t HW, int32_t groups);
 int mcq_group_norm_bwd_f32(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx,
                            float* dgamma, float* dbeta, float* workspace, int32_t N, int32_t C, int32_t HW, int32_t groups,
                            void* stream);

@@ -132,8 +132,9 @@ SYMBOLS = {
     "mcq_ms_ssim_u8": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_ms_ssim_window": (None, [c_void_p]),
     "mcq_sqdiff_sum_u8": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
-    "mcq_group_norm_f32": (c_int32, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
-    "mcq_group_norm_bwd_workspace_floats": (c_size_t, [c_int32, c_int32]),
+    "mcq_group_norm_workspace_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "mcq_group_norm_f32": (c_int32, [c_void_p] * 8 + [c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "mcq_group_norm_bwd_workspace_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "mcq_group_norm_bwd_f32": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_selftest_launch_failure": (c_int32, [c_void_p]),
     "mcq_version": (c_char_p, []),

@@ -152,20 +152,222 @@ __global__ void group_norm_bwd_params_kernel(const float* __restrict__ mean, con
     if (dbeta) dbeta[ch] = b;
 }
 
+
+// ---- large runs (round 5): many workgroups per (image, group) ---------------------------------------------------------------------
+// One workgroup per run is fine while a run is a few thousand floats (the 4x4 ... 32x32 maps of the qp = 2 shapes); Neon puts
+// GroupNorm(32, 32) on 512 x 512 maps -- a run is one 1 MB plane, 4 images are 128 workgroups on 256 CUs each walking its plane three
+// times with 4-byte loads, and the backward sums ran one WAVE per plane: a captured Neon training step spent 57 of its 92 ms here.
+// Chunked form: a plane is cut into chunks of GN_CHUNK floats, one workgroup each.
+//   forward   gn_chunk_stats_kernel  per chunk (mean_c, M2_c) two-pass over the chunk's own values (registers)
+//             gn_chunk_apply_kernel  every workgroup merges its run's chunk statistics in chunk order (Chan's pairwise update: no
+//                                    E[x^2] - E[x]^2 cancellation, deterministic), then normalises its chunk
+//   backward  gn_chunk_bwd_sums_kernel / gn_chunk_bwd_dx_kernel the same way for (sum dy, sum dy x)
+constexpr int GN_CHUNK = 8192;          // floats per chunk: 32 floats (8 x 16 bytes) per thread
+constexpr int GN_CHUNK_MIN_RUN = 4 * GN_CHUNK;      // runs below this stay on the one-workgroup kernels
+
+struct GnChunkK {
+    const float* x; const float* dy; const float* gamma; const float* beta;
+    float* y; float* y_silu; float* mean_out; float* rstd_out; float* dx;
+    const float* mean; const float* rstd;
+    float* stats;            // forward: [planes][chunks][2] (mean_c, M2_c); backward: [planes][chunks][2] (sum dy, sum dy x)
+    float* sum_dy; float* sum_dyx;      // backward: per-plane totals for the parameter kernel
+    int C, HW, groups, chunks;
+    float eps;
+};
+
+// the chunk's values, 8 float4 per thread (zero beyond the plane), and how many of them are real
+__device__ __forceinline__ int gn_load_chunk(const float* __restrict__ p, int HW, int chunk, f32x4v (&v)[GN_CHUNK / (4 * kThreads)]) {
+    const int first = chunk * GN_CHUNK;
+    const int n = HW - first < GN_CHUNK ? HW - first : GN_CHUNK;
+    const bool vec = (((uintptr_t)(p + first) & 15) == 0);
+#pragma unroll
+    for (int e = 0; e < GN_CHUNK / (4 * kThreads); ++e) {
+        const int i = (e * kThreads + (int)threadIdx.x) * 4;
+        if (vec && i + 3 < n) v[e] = *reinterpret_cast<const f32x4v*>(p + first + i);
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[e][q] = i + q < n ? p[first + i + q] : 0.0f;
+        }
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(kThreads) void gn_chunk_stats_kernel(GnChunkK k) {
+    __shared__ float slots[4];
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    const float* xp = k.x + (size_t)plane * k.HW;
+    f32x4v v[GN_CHUNK / (4 * kThreads)];
+    const int n = gn_load_chunk(xp, k.HW, chunk, v);
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < GN_CHUNK / (4 * kThreads); ++e) s += (v[e][0] + v[e][1]) + (v[e][2] + v[e][3]);
+    const float mean = block_sum(s, slots) / (float)n;
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < GN_CHUNK / (4 * kThreads); ++e) {
+        const int i = (e * kThreads + (int)threadIdx.x) * 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float a = i + t < n ? v[e][t] - mean : 0.0f;
+            q += a * a;
+        }
+    }
+    const float m2 = block_sum(q, slots);
+    if (threadIdx.x == 0) {
+        float* st = k.stats + ((size_t)plane * k.chunks + chunk) * 2;
+        st[0] = mean; st[1] = m2;
+    }
+}
+
+// (mean, rstd) of run `ng` from its chunk statistics, merged in (plane, chunk) order; every thread computes the same values
+__device__ __forceinline__ void gn_merge_stats(const GnChunkK& k, int ng, float& mean, float& rstd) {
+    const int cg = k.C / k.groups;
+    const int n_img = ng / k.groups, g = ng % k.groups;
+    const float* st = k.stats + ((size_t)(n_img * k.C + g * cg) * k.chunks) * 2;
+    float cnt = 0.0f, mu = 0.0f, m2 = 0.0f;
+    for (int pc = 0; pc < cg * k.chunks; ++pc) {
+        const int chunk = pc % k.chunks;
+        const int first = chunk * GN_CHUNK;
+        const float nb = (float)(k.HW - first < GN_CHUNK ? k.HW - first : GN_CHUNK);
+        const float mb = st[2 * pc], qb = st[2 * pc + 1];
+        const float tot = cnt + nb, delta = mb - mu;
+        mu = mu + delta * (nb / tot);
+        m2 = m2 + qb + delta * delta * (cnt * nb / tot);
+        cnt = tot;
+    }
+    mean = mu;
+    rstd = 1.0f / sqrtf(m2 / cnt + k.eps);
+}
+
+__global__ __launch_bounds__(kThreads) void gn_chunk_apply_kernel(GnChunkK k) {
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    const int n_img = plane / k.C, ch = plane % k.C;
+    const int cg = k.C / k.groups;
+    const int ng = n_img * k.groups + ch / cg;
+    float mean, rstd;
+    gn_merge_stats(k, ng, mean, rstd);
+    if (threadIdx.x == 0 && chunk == 0 && ch % cg == 0 && k.mean_out) { k.mean_out[ng] = mean; k.rstd_out[ng] = rstd; }
+    const float scale = rstd * (k.gamma ? k.gamma[ch] : 1.0f);
+    const float shift = __builtin_fmaf(-scale, mean, k.beta ? k.beta[ch] : 0.0f);
+    const float* xp = k.x + (size_t)plane * k.HW;
+    f32x4v v[GN_CHUNK / (4 * kThreads)];
+    const int n = gn_load_chunk(xp, k.HW, chunk, v);
+    const int first = chunk * GN_CHUNK;
+    float* yp = k.y + (size_t)plane * k.HW + first;
+    float* sp = k.y_silu ? k.y_silu + (size_t)plane * k.HW + first : nullptr;
+    const bool vec = (((uintptr_t)yp & 15) == 0);
+#pragma unroll
+    for (int e = 0; e < GN_CHUNK / (4 * kThreads); ++e) {
+        const int i = (e * kThreads + (int)threadIdx.x) * 4;
+        f32x4v o, so;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { o[t] = __builtin_fmaf(v[e][t], scale, shift); so[t] = sp ? mcq_silu(o[t]) : 0.0f; }
+        if (vec && i + 3 < n) {
+            *reinterpret_cast<f32x4v*>(yp + i) = o;
+            if (sp) *reinterpret_cast<f32x4v*>(sp + i) = so;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (i + t < n) { yp[i + t] = o[t]; if (sp) sp[i + t] = so[t]; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void gn_chunk_bwd_sums_kernel(GnChunkK k) {
+    __shared__ float slots[8];
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    f32x4v xv[GN_CHUNK / (4 * kThreads)], dv[GN_CHUNK / (4 * kThreads)];
+    gn_load_chunk(k.x + (size_t)plane * k.HW, k.HW, chunk, xv);
+    gn_load_chunk(k.dy + (size_t)plane * k.HW, k.HW, chunk, dv);          // (zero beyond the plane: those terms add nothing)
+    float a = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int e = 0; e < GN_CHUNK / (4 * kThreads); ++e)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { a += dv[e][t]; b += dv[e][t] * xv[e][t]; }
+    a = block_sum(a, slots);
+    b = block_sum(b, slots + 4);
+    if (threadIdx.x == 0) {
+        float* st = k.stats + ((size_t)plane * k.chunks + chunk) * 2;
+        st[0] = a; st[1] = b;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void gn_chunk_bwd_dx_kernel(GnChunkK k) {
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    const int n_img = plane / k.C, ch = plane % k.C;
+    const int cg = k.C / k.groups;
+    const int g = ch / cg, ng = n_img * k.groups + g;
+    // the run's sums: chunks in order per plane, planes in order (every thread, same order)
+    float ds = 0.0f, db = 0.0f, own_dy = 0.0f, own_dyx = 0.0f;
+    for (int c = 0; c < cg; ++c) {
+        const int pl = n_img * k.C + g * cg + c;
+        const float* st = k.stats + (size_t)pl * k.chunks * 2;
+        float a = 0.0f, b = 0.0f;
+        for (int q = 0; q < k.chunks; ++q) { a += st[2 * q]; b += st[2 * q + 1]; }
+        const float gm = k.gamma ? k.gamma[g * cg + c] : 1.0f;
+        ds += gm * b;
+        db += gm * a;
+        if (pl == plane) { own_dy = a; own_dyx = b; }
+    }
+    if (threadIdx.x == 0 && chunk == 0) { k.sum_dy[plane] = own_dy; k.sum_dyx[plane] = own_dyx; }
+    const float mu = k.mean[ng], rs = k.rstd[ng];
+    const float inv = 1.0f / (float)((long long)cg * k.HW);
+    const float c2 = (db * mu - ds) * rs * rs * rs * inv;
+    const float c3 = -c2 * mu - db * rs * inv;
+    const float c1 = rs * (k.gamma ? k.gamma[ch] : 1.0f);
+    f32x4v xv[GN_CHUNK / (4 * kThreads)], dv[GN_CHUNK / (4 * kThreads)];
+    const int n = gn_load_chunk(k.x + (size_t)plane * k.HW, k.HW, chunk, xv);
+    gn_load_chunk(k.dy + (size_t)plane * k.HW, k.HW, chunk, dv);
+    const int first = chunk * GN_CHUNK;
+    float* op = k.dx + (size_t)plane * k.HW + first;
+    const bool vec = (((uintptr_t)op & 15) == 0);
+#pragma unroll
+    for (int e = 0; e < GN_CHUNK / (4 * kThreads); ++e) {
+        const int i = (e * kThreads + (int)threadIdx.x) * 4;
+        f32x4v o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = c1 * dv[e][t] + c2 * xv[e][t] + c3;
+        if (vec && i + 3 < n) *reinterpret_cast<f32x4v*>(op + i) = o;
+        else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (i + t < n) op[i + t] = o[t];
+        }
+    }
+}
+
+inline int gn_chunks(int HW) { return (HW + GN_CHUNK - 1) / GN_CHUNK; }
+inline bool gn_chunked(int C, int HW, int groups) { return (long long)(C / groups) * HW >= GN_CHUNK_MIN_RUN && HW >= GN_CHUNK; }
+
 }  // namespace
 
+extern "C" size_t mcq_group_norm_workspace_floats(int32_t N, int32_t C, int32_t HW, int32_t groups) {
+    if (N <= 0 || C <= 0 || HW <= 0 || groups <= 0 || C % groups != 0) return 0;
+    return gn_chunked(C, HW, groups) ? (size_t)N * C * gn_chunks(HW) * 2 : 0;
+}
+
 extern "C" int mcq_group_norm_f32(const float* x, const float* gamma, const float* beta, float* y, float* y_silu, float* mean_out,
-                                  float* rstd_out, int32_t N, int32_t C, int32_t HW, int32_t groups, float eps, void* stream) {
+                                  float* rstd_out, float* workspace, int32_t N, int32_t C, int32_t HW, int32_t groups, float eps, void* stream) {
     if (!x || !y || N <= 0 || C <= 0 || HW <= 0 || groups <= 0 || C % groups != 0 || !(eps >= 0.0f)) return MCQ_EINVAL;
     if ((mean_out == nullptr) != (rstd_out == nullptr)) return MCQ_EINVAL;
     if ((long long)(C / groups) * HW > 0x7fffffffLL || (long long)N * groups > 0x7fffffffLL) return MCQ_ETOOLARGE;
+    if (workspace && gn_chunked(C, HW, groups) && (long long)N * C <= 65535) {        // many workgroups per run (see above)
+        GnChunkK k = {};
+        k.x = x; k.gamma = gamma; k.beta = beta; k.y = y; k.y_silu = y_silu; k.mean_out = mean_out; k.rstd_out = rstd_out;
+        k.stats = workspace; k.C = C; k.HW = HW; k.groups = groups; k.chunks = gn_chunks(HW); k.eps = eps;
+        const dim3 grid((unsigned)k.chunks, (unsigned)(N * C));
+        hipLaunchKernelGGL(gn_chunk_stats_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, k);
+        hipLaunchKernelGGL(gn_chunk_apply_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, k);
+        return mcq_check_launch();
+    }
     hipLaunchKernelGGL(group_norm_fwd_kernel, dim3((unsigned)(N * groups)), dim3(kThreads), 0, (hipStream_t)stream, x, gamma, beta, y,
                        y_silu, mean_out, rstd_out, C, HW, groups, eps);
     return mcq_check_launch();
 }
 
-extern "C" size_t mcq_group_norm_bwd_workspace_floats(int32_t N, int32_t C) {
-    return N > 0 && C > 0 ? (size_t)2 * N * C : 0;
+extern "C" size_t mcq_group_norm_bwd_workspace_floats(int32_t N, int32_t C, int32_t HW, int32_t groups) {
+    if (N <= 0 || C <= 0 || HW <= 0 || groups <= 0 || C % groups != 0) return 0;
+    return (size_t)2 * N * C + (gn_chunked(C, HW, groups) ? (size_t)N * C * gn_chunks(HW) * 2 : 0);
 }
 
 extern "C" int mcq_group_norm_bwd_f32(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd,
@@ -177,6 +379,19 @@ extern "C" int mcq_group_norm_bwd_f32(const float* x, const float* dy, const flo
     float* sum_dy = workspace;
     float* sum_dyx = workspace + (size_t)N * C;
     const int planes = N * C;
+    if (gn_chunked(C, HW, groups) && (long long)N * C <= 65535) {
+        GnChunkK k = {};
+        k.x = x; k.dy = dy; k.gamma = gamma; k.mean = mean; k.rstd = rstd; k.dx = dx;
+        k.stats = workspace + (size_t)2 * N * C; k.sum_dy = sum_dy; k.sum_dyx = sum_dyx;
+        k.C = C; k.HW = HW; k.groups = groups; k.chunks = gn_chunks(HW);
+        const dim3 grid((unsigned)k.chunks, (unsigned)planes);
+        hipLaunchKernelGGL(gn_chunk_bwd_sums_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, k);
+        hipLaunchKernelGGL(gn_chunk_bwd_dx_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, k);
+        if (dgamma || dbeta)
+            hipLaunchKernelGGL(group_norm_bwd_params_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, (hipStream_t)stream, mean, rstd,
+                               sum_dy, sum_dyx, dgamma, dbeta, N, C, groups);
+        return mcq_check_launch();
+    }
     hipLaunchKernelGGL(group_norm_bwd_sums_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, x, dy,
                        sum_dy, sum_dyx, planes, HW);
     hipLaunchKernelGGL(group_norm_bwd_dx_kernel, dim3((unsigned)(N * groups)), dim3(kThreads), 0, (hipStream_t)stream, x, dy, gamma, mean,

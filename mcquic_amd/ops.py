@@ -894,9 +894,12 @@ def group_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[t
     y2 = torch.empty_like(x) if dual_silu else None
     mean = torch.empty(n * groups, dtype=torch.float32, device=x.device) if want_stats else None
     rstd = torch.empty_like(mean) if want_stats else None
+    lib = _lib.load()
+    nws = lib.mcq_group_norm_workspace_floats(n, c, h * w, groups)       # > 0: large runs, many workgroups per (image, group)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
     with _guard(x.device):
-        check(_lib.load().mcq_group_norm_f32(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(y2), _ptr(mean), _ptr(rstd), n, c, h * w,
-                                             groups, float(eps), _stream()), "mcq_group_norm_f32")
+        check(lib.mcq_group_norm_f32(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(y2), _ptr(mean), _ptr(rstd), _ptr(ws), n, c, h * w,
+                                     groups, float(eps), _stream()), "mcq_group_norm_f32")
     if y2 is not None:
         set_silu_twin(y, y2)
     return (y, mean, rstd) if want_stats else y
@@ -909,7 +912,7 @@ def group_norm_bwd(x: torch.Tensor, dy: torch.Tensor, weight: Optional[torch.Ten
     n, c, h, w = x.shape
     weight = None if weight is None else _dev(weight.detach(), "weight")
     lib = _lib.load()
-    ws = torch.empty(lib.mcq_group_norm_bwd_workspace_floats(n, c), dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.mcq_group_norm_bwd_workspace_floats(n, c, h * w, groups), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     dw = torch.empty(c, dtype=torch.float32, device=x.device) if want_params else None
     db = torch.empty(c, dtype=torch.float32, device=x.device) if want_params else None

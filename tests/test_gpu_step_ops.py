@@ -291,3 +291,31 @@ def test_scale_block_node_equals_op_by_op_graph(dev, up, shape):
     for name, a, b in pairs:
         err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
         assert err <= 4e-6, (name, err)
+
+
+@pytest.mark.parametrize("shape,groups", [((2, 32, 192, 192), 32), ((1, 8, 128, 128), 1), ((2, 4, 97, 101), 2), ((3, 32, 512, 64), 32),
+                                          ((2, 32, 16, 16), 32), ((2, 8, 8, 8), 1)])
+def test_group_norm_large_runs(dev, shape, groups):
+    """nn.GroupNorm forward (+ SiLU twin) and backward on runs long enough for the chunked kernels (many workgroups per
+    (image, group): Neon's GroupNorm(32, 32) on 512 x 512 maps) and, for comparison, on the short runs the one-workgroup kernels
+    keep -- against torch's CPU GroupNorm in float64."""
+    from mcquic_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c * h + groups)
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3)
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    dy = torch.randn(shape, generator=g)
+    xr = x.double().requires_grad_()
+    gr, br = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    ref = torch.nn.functional.group_norm(xr, groups, gr, br, 1e-5)
+    ref.backward(dy.double())
+    y, mean, rstd = ops.group_norm(x.to(dev), gamma.to(dev), beta.to(dev), groups, 1e-5, dual_silu=True, want_stats=True)
+    assert float((y.cpu().double() - ref.detach()).abs().max()) <= 5e-6 * max(1.0, float(ref.detach().abs().max()))
+    assert torch.equal(ops.silu_twin(y), ops.silu(y))
+    dx, dw, db = ops.group_norm_bwd(x.to(dev), dy.to(dev), gamma.to(dev), mean, rstd, groups)
+    for got, want, name in ((dx, xr.grad, "dx"), (dw, gr.grad, "dgamma"), (db, br.grad, "dbeta")):
+        err = float((got.cpu().double() - want).abs().max()) / max(float(want.abs().max()), 1e-12)
+        assert err <= 2e-5, (name, err)
+    # deterministic: a second run gives the same bits
+    y2 = ops.group_norm(x.to(dev), gamma.to(dev), beta.to(dev), groups, 1e-5)
+    assert torch.equal(y, y2)

@@ -459,9 +459,15 @@ class ResidualBackwardQuantizer(VariousMQuantizer):
 
     def _latents(self, x: torch.Tensor) -> List[torch.Tensor]:
         latents = []
-        for encoder in self._encoders:
+        grad = self.training and torch.is_grad_enabled()
+        for i, encoder in enumerate(self._encoders):
             x = encoder(x)
-            latents.append(x)
+            if grad and i + 1 < len(self._encoders):
+                from .. import autograd as AG
+                x, keep = AG.fork(x, 2)            # (a level's latent feeds the next level AND its own residual: one node sums the two gradients)
+                latents.append(keep)
+            else:
+                latents.append(x)
         return latents
 
     def encode(self, x: torch.Tensor) -> List[torch.Tensor]:

@@ -18,9 +18,14 @@ from mcquic_amd.autograd import mse_loss
 def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(3407)
-    model = Compressor(128, 2, [8192, 2048, 512]).to(dev).train()
-    x = (torch.rand((8, 3, 256, 256)) * 2 - 1).to(dev)
-    xHat, yHat, codes, logits = model(x)
+    if "--neon" in sys.argv or "--neon-dense" in sys.argv:
+        from mcquic_amd import Neon
+        model = Neon(32, 256, [8, 4, 2, 2], "--neon-dense" in sys.argv).to(dev).train()
+        x = (torch.rand((2, 3, 128, 128)) * 2 - 1).to(dev)
+    else:
+        model = Compressor(128, 2, [8192, 2048, 512]).to(dev).train()
+        x = (torch.rand((8, 3, 256, 256)) * 2 - 1).to(dev)
+    xHat = model(x)[0]
     loss = mse_loss(xHat, x)
     consumers = collections.defaultdict(list)
     seen, stack = set(), [loss.grad_fn]

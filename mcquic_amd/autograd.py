@@ -219,25 +219,39 @@ def mse_loss(a, b):
 
 
 # ---- ResidualBlock / AttentionBlock as whole autograd nodes ---------------------------------------------------------
+# `denseNorm` blocks (mcquic/nn/blocks.py:179-200: nn.GroupNorm where the second activation was; what configs/neon.yaml trains) take
+# the same nodes: the middle of the block is  t1 -> GroupNorm -> u  instead of  t1 -> SiLU -> s1  (the SiLU rode in conv1's epilogue;
+# the normalisation is launches of its own, csrc/norm.hip), everything around it -- multi-problem launches, the input gradient's
+# `* silu'(x) + dy` epilogue, grouped weight gradients -- is shared.  A normalised block's tape entry carries six tensors
+# (x, sx, t1, u, mean, rstd) where a plain one carries four (x, sx, t1, s1); its parameters are (w1, b1, w2, b2, gamma, beta).
+def _rb_norm(block):
+    """The block's GroupNorm module, or None for a plain block."""
+    return block._branch[2] if getattr(block, "denseNorm", False) else None
+
+
+def _rb_nsaved(block) -> int:
+    return 6 if _rb_norm(block) is not None else 4
+
+
+def _rb_params(block):
+    c1, c2 = block._branch[1], block._branch[3]
+    ps = [c1.weight, c1.bias, c2.weight, c2.bias]
+    gn = _rb_norm(block)
+    if gn is not None:
+        ps += [gn.weight, gn.bias]
+    return ps
+
+
 def _rb_forward(block, x, sx):
-    """y = conv2(silu(conv1(silu(x)))) + x in two fused launches; returns (y, silu(y), what backward needs)."""
-    c1, c2 = block._branch[1], block._branch[3]
-    t1 = ops.conv2d(sx, c1.packed(), dual_silu=True)           # t1 and silu(t1) from one launch
-    s1 = ops.silu_twin(t1)
-    y = ops.conv2d(s1, c2.packed(), res=x, dual_silu=True)      # + x; silu(y) for the next block
-    return y, ops.silu_twin(y), (x, sx, t1, s1)
+    """y = conv2(act2(conv1(silu(x)))) + x, act2 = SiLU (two fused launches) or GroupNorm; returns (y, silu(y), what backward needs)."""
+    ys, sys_, saved = _rb_forward_multi([block], [x], [sx])
+    return ys[0], sys_[0], saved[0]
 
 
-def _rb_backward(block, saved, dy, pairs, need_dx: bool = True):
-    """Input gradient of a ResidualBlock in two fused launches; the two weight-gradient operand pairs are appended to
-    `pairs` for a grouped launch:  d_t1 = conv(dy, W2^T) * silu'(t1);  dx = conv(d_t1, W1^T) * silu'(x) + dy."""
-    x, sx, t1, s1 = saved
-    c1, c2 = block._branch[1], block._branch[3]
-    d_t1 = ops.conv2d(dy, _dgrad_packed(c2, c2.weight), dsilu_mul=t1)
-    dx = ops.conv2d(d_t1, _dgrad_packed(c1, c1.weight), dsilu_mul=x, res=dy) if need_dx else None
-    pairs.append((sx, d_t1))
-    pairs.append((s1, dy))
-    return dx
+def _rb_backward(block, saved, dy, pairs, need_dx: bool = True, norm_grads=None):
+    """Input gradient of a ResidualBlock; the two weight-gradient operand pairs are appended to `pairs` for a grouped launch:
+    d_t1 = conv(dy, W2^T) * silu'(t1);  dx = conv(d_t1, W1^T) * silu'(x) + dy   (normalised: d_t1 = GroupNorm'(conv(dy, W2^T)))."""
+    return _rb_backward_multi([block], [saved], [dy], pairs, norm_grads=norm_grads, need_dx=need_dx)[0]
 
 
 def _wgrads(pairs):
@@ -245,8 +259,55 @@ def _wgrads(pairs):
     return ops.conv2d_wgrad_group([a for a, _ in pairs], [b for _, b in pairs], want_bias=True)
 
 
+def _rb_forward_multi(blocks, xs, sxs):
+    """Several ResidualBlocks of one shape side by side: each of the two layers is ONE launch for all of them."""
+    norm = _rb_norm(blocks[0]) is not None
+    t1s = ops.conv2d_multi(sxs, [blk._branch[1].packed() for blk in blocks], dual_silu=not norm)
+    if norm:
+        mids, stats = [], []
+        for blk, t1 in zip(blocks, t1s):
+            gn = blk._branch[2]
+            u, mean, rstd = ops.group_norm(t1, gn.weight, gn.bias, gn.num_groups, gn.eps, want_stats=True)
+            mids.append(u)
+            stats.append((mean, rstd))
+    else:
+        mids = [ops.silu_twin(t) for t in t1s]
+    ys = ops.conv2d_multi(mids, [blk._branch[3].packed() for blk in blocks], per_problem=[dict(res=x) for x in xs], dual_silu=True)
+    if norm:
+        saved = [(x, sx, t1, u, st[0], st[1]) for x, sx, t1, u, st in zip(xs, sxs, t1s, mids, stats)]
+    else:
+        saved = [(x, sx, t1, s1) for x, sx, t1, s1 in zip(xs, sxs, t1s, mids)]
+    return ys, [ops.silu_twin(y) for y in ys], saved
+
+
+def _rb_backward_multi(blocks, saveds, dys, pairs, norm_grads=None, need_dx: bool = True):
+    """Input gradients of several ResidualBlocks of one shape, two launches in all (+ the normalisations' own); operand pairs
+    appended per block as (conv1 pair, conv2 pair); a normalised block's (d gamma, d beta) go into `norm_grads` (one entry per block)."""
+    c1s, c2s = [blk._branch[1] for blk in blocks], [blk._branch[3] for blk in blocks]
+    norm = _rb_norm(blocks[0]) is not None
+    if norm:
+        d_us = ops.conv2d_multi(dys, [_dgrad_packed(c, c.weight) for c in c2s])
+        d_t1s = []
+        for blk, sv, d_u in zip(blocks, saveds, d_us):
+            gn = blk._branch[2]
+            d_t1, dgw, dgb = ops.group_norm_bwd(sv[2], d_u, gn.weight, sv[4], sv[5], gn.num_groups, want_params=True)
+            d_t1s.append(d_t1)
+            if norm_grads is not None:
+                norm_grads.append((dgw, dgb))
+    else:
+        d_t1s = ops.conv2d_multi(dys, [_dgrad_packed(c, c.weight) for c in c2s], per_problem=[dict(dsilu_mul=sv[2]) for sv in saveds])
+    dxs = [None] * len(blocks)
+    if need_dx:
+        dxs = ops.conv2d_multi(d_t1s, [_dgrad_packed(c, c.weight) for c in c1s],
+                               per_problem=[dict(dsilu_mul=sv[0], res=dy) for sv, dy in zip(saveds, dys)])
+    for sv, d_t1, dy in zip(saveds, d_t1s, dys):
+        pairs.append((sv[1], d_t1))
+        pairs.append((sv[3], dy))
+    return dxs
+
+
 class ResidualBlockFn(torch.autograd.Function):
-    """y = conv2(silu(conv1(silu(x)))) + x  (mcquic/nn/blocks.py:179-200) as two fused launches each way:
+    """y = conv2(act2(conv1(silu(x)))) + x  (mcquic/nn/blocks.py:179-200) as two fused launches each way:
          forward   t1, silu(t1) = conv1(silu(x))                      (SiLU twin stored by the producing launch)
                    y,  silu(y)  = conv2(silu(t1)) + x
          backward  d_t1 = conv(dy, W2^T) * silu'(t1)                   (MCQ_CONV_DSILU_MUL epilogue)
@@ -254,10 +315,11 @@ class ResidualBlockFn(torch.autograd.Function):
                    dW1, db1, dW2, db2: ONE grouped weight-gradient launch over (silu(x), d_t1) and (silu(t1), dy)
        No stand-alone SiLU / SiLU-backward / add kernels, no channel-major copies.  `sx` = silu(x) is an input so that a
        producer's twin is reused; the second output silu(y) is the next block's `sx` (no gradient flows through it: every
-       consumer differentiates through y itself)."""
+       consumer differentiates through y itself).  `denseNorm`: act2 = GroupNorm (see above), parameters + (gamma, beta)."""
 
     @staticmethod
-    def forward(ctx, x, sx, w1, b1, w2, b2, block):
+    def forward(ctx, x, sx, *rest):
+        block = rest[-1]
         y, sy, saved = _rb_forward(block, x, sx)
         ctx.save_for_backward(*saved)
         ctx.block = block
@@ -267,31 +329,11 @@ class ResidualBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dsy):
-        pairs = []
-        dx = _rb_backward(ctx.block, ctx.saved_tensors, dy.contiguous(), pairs, ctx.needs_input_grad[0])
+        pairs, ng = [], []
+        dx = _rb_backward(ctx.block, ctx.saved_tensors, dy.contiguous(), pairs, ctx.needs_input_grad[0], norm_grads=ng)
         (dw1, db1), (dw2, db2) = _wgrads(pairs)
-        return dx, None, dw1, db1, dw2, db2, None
-
-
-def _rb_forward_multi(blocks, xs, sxs):
-    """Several ResidualBlocks of one shape side by side: each of the two layers is ONE launch for all of them."""
-    t1s = ops.conv2d_multi(sxs, [blk._branch[1].packed() for blk in blocks], dual_silu=True)
-    s1s = [ops.silu_twin(t) for t in t1s]
-    ys = ops.conv2d_multi(s1s, [blk._branch[3].packed() for blk in blocks], per_problem=[dict(res=x) for x in xs], dual_silu=True)
-    return ys, [ops.silu_twin(y) for y in ys], [(x, sx, t1, s1) for x, sx, t1, s1 in zip(xs, sxs, t1s, s1s)]
-
-
-def _rb_backward_multi(blocks, saveds, dys, pairs):
-    """Input gradients of several ResidualBlocks of one shape, two launches in all; operand pairs appended per block as
-    (conv1 pair, conv2 pair)."""
-    c1s, c2s = [blk._branch[1] for blk in blocks], [blk._branch[3] for blk in blocks]
-    d_t1s = ops.conv2d_multi(dys, [_dgrad_packed(c, c.weight) for c in c2s], per_problem=[dict(dsilu_mul=sv[2]) for sv in saveds])
-    dxs = ops.conv2d_multi(d_t1s, [_dgrad_packed(c, c.weight) for c in c1s],
-                           per_problem=[dict(dsilu_mul=sv[0], res=dy) for sv, dy in zip(saveds, dys)])
-    for sv, d_t1, dy in zip(saveds, d_t1s, dys):
-        pairs.append((sv[1], d_t1))
-        pairs.append((sv[3], dy))
-    return dxs
+        extra = list(ng[0]) if ng else []
+        return (dx, None, dw1, db1, dw2, db2, *extra, None)
 
 
 class AttentionBlockFn(torch.autograd.Function):
@@ -299,7 +341,7 @@ class AttentionBlockFn(torch.autograd.Function):
     The two stacks apply the same layer shapes to different tensors: layer by layer they share a launch (mcq_conv2d_multi_f32),
     in both directions -- on the 16x16 ... 4x4 maps of a training crop a launch is latency, not work --, every ResidualBlock
     is two fused launches each way, and the twelve 3x3 weight gradients of the block leave in ONE grouped launch.
-    Parameter order: main RB 0..2 then side RB 0..2, each (w1, b1, w2, b2), then the 1x1 conv's (w, b)."""
+    Parameter order: main RB 0..2 then side RB 0..2, each (w1, b1, w2, b2[, gamma, beta]), then the 1x1 conv's (w, b)."""
 
     @staticmethod
     def forward(ctx, x, sx, *rest):
@@ -325,16 +367,20 @@ class AttentionBlockFn(torch.autograd.Function):
         block = ctx.block
         a, b = ctx.saved_tensors[:2]
         saved = ctx.saved_tensors[2:]
-        main = [saved[8 * i: 8 * i + 4] for i in range(3)]
-        side = [saved[8 * i + 4: 8 * i + 8] for i in range(3)]
+        ns = _rb_nsaved(block._mainBranch[0])
+        main = [saved[2 * ns * i: 2 * ns * i + ns] for i in range(3)]
+        side = [saved[2 * ns * i + ns: 2 * ns * i + 2 * ns] for i in range(3)]
         dout = dout.contiguous()
         c11 = block._sideBranch[3]
         (h, dbb), = ops.conv2d_gate_bwd([b], [c11.packed()], [a], [dout])     # d a, d (conv1x1 output)
         g = ops.conv2d(dbb, _dgrad_packed(c11, c11.weight))
         dw11, db11 = ops.conv2d_wgrad(b, dbb, 1, 1, want_bias=True)
         pairs = []                                               # appended RB 2, 1, 0; per RB: main (conv1, conv2), side (conv1, conv2)
+        norms = {}                                               # RB index -> [(d gamma, d beta) of main, of side]
         for i in (2, 1, 0):
-            h, g = _rb_backward_multi([block._mainBranch[i], block._sideBranch[i]], [main[i], side[i]], [h, g], pairs)
+            ng = []
+            h, g = _rb_backward_multi([block._mainBranch[i], block._sideBranch[i]], [main[i], side[i]], [h, g], pairs, norm_grads=ng)
+            norms[i] = ng
         dx = ops.add3(h, g, dout)
         grads = _wgrads(pairs)
         by_rb = {i: grads[4 * k: 4 * k + 4] for k, i in enumerate((2, 1, 0))}
@@ -343,6 +389,8 @@ class AttentionBlockFn(torch.autograd.Function):
             for i in range(3):
                 (dw1, db1), (dw2, db2) = by_rb[i][2 * stack], by_rb[i][2 * stack + 1]
                 flat.extend([dw1, db1, dw2, db2])
+                if norms[i]:
+                    flat.extend(norms[i][stack])
         return (dx, None, *flat, dw11, db11, None)
 
 
@@ -764,8 +812,7 @@ def attention_block(x, block):
     params = []
     for stack in (block._mainBranch, block._sideBranch):
         for i in range(3):
-            c1, c2 = stack[i]._branch[1], stack[i]._branch[3]
-            params.extend([c1.weight, c1.bias, c2.weight, c2.bias])
+            params.extend(_rb_params(stack[i]))
     c11 = block._sideBranch[3]
     out, sout = AttentionBlockFn.apply(x, _silu_of(x), *params, c11.weight, c11.bias, block)
     ops.set_silu_twin(out, sout)
@@ -774,8 +821,7 @@ def attention_block(x, block):
 
 def residual_block(x, block):
     """ResidualBlock in the training graph (ResidualBlockFn); the result carries silu(result) as its twin."""
-    c1, c2 = block._branch[1], block._branch[3]
-    y, sy = ResidualBlockFn.apply(x, _silu_of(x), c1.weight, c1.bias, c2.weight, c2.bias, block)
+    y, sy = ResidualBlockFn.apply(x, _silu_of(x), *_rb_params(block), block)
     ops.set_silu_twin(y, sy)
     return y
 

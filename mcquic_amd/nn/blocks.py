@@ -33,6 +33,7 @@ __all__ = ["ResidualBlockWithStride", "ResidualBlockShuffle", "ResidualBlock", "
 # branch's workgroups, and the launch-latency-bound small levels run two kernels at once.  MCQUIC_AMD_BRANCH_STREAMS=0
 # turns it off (single stream, same results).
 _BRANCH_STREAMS = os.environ.get("MCQUIC_AMD_BRANCH_STREAMS", "1") != "0"
+_NORM_NODES = os.environ.get("MCQUIC_AMD_NORM_NODES", "1") != "0"        # A/B switch: 0 = `denseNorm` blocks op by op in the training graph
 _BLOCK_NODES = os.environ.get("MCQUIC_AMD_BLOCK_NODES", "1") != "0"      # A/B switch: 0 = strided / shuffle blocks op by op in the training graph
 _side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
 _MULTI_MAX_PIXELS = int(os.environ.get("MCQUIC_AMD_MULTI_MAX_PIXELS", str(64 * 1024)))   # N * H * W up to which AttentionBlock stacks share launches
@@ -116,7 +117,7 @@ class ResidualBlock(_residulBlock):
 
     def forward(self, x: torch.Tensor, res2: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
-            if self._skip is None and not self.denseNorm:         # training graph: two fused launches each way
+            if self._skip is None and (_NORM_NODES or not self.denseNorm):      # training graph: the block as one autograd node
                 return AG.residual_block(x, self)
             sx, x = AG.silu_fork(x)                               # (width-changing / normalised blocks: op-by-op autograd; x's two
             t = self._branch[1](sx)                               #  gradients -- through the activation and along the skip -- meet in one launch)
@@ -189,7 +190,7 @@ class AttentionBlock(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
-            if self.denseNorm:                                    # normalised blocks: op-by-op autograd
+            if self.denseNorm and not _NORM_NODES:                # (A/B: normalised blocks op by op)
                 xa, xb, xc = AG.fork(x, 3)                        # (three consumers: their gradients summed by one launch of ours)
                 return AG.gate(self._mainBranch(xa), self._sideBranch(xb), xc)
             return AG.attention_block(x, self)

@@ -467,8 +467,8 @@ int mcq_pack_conv_weight_winograd16_f32(const float* w, int32_t Cout, int32_t Ci
  * activation when denseNorm is set (mcquic/nn/blocks.py:179-200).  gamma / beta may be NULL (1 / 0).  y_silu (NULL = none)
  * receives silu(y).  mean_out / rstd_out [N * groups] (both or neither): what the backward pass needs. */
 /* `workspace` (round 5; mcq_group_norm_workspace_floats floats, 0 = none needed, NULL = take the one-workgroup-per-run kernel):
- * runs of 32 k floats and more -- Neon's GroupNorm(32, 32) on 512 x 512 maps -- are cut into 8192-float chunks, one workgroup
- * each, whose (mean, M2) pairs are merged in chunk order. */
+ * planes of 256 pixels and more are cut into 8192-float chunks, one workgroup each, whose (mean, M2) pairs are merged in
+ * (plane, chunk) order -- Neon's GroupNorm(32, 32) on 512 x 512 maps is 32 chunks per run instead of one workgroup. */
 size_t mcq_group_norm_workspace_floats(int32_t N, int32_t C, int32_t HW, int32_t groups);
 int mcq_group_norm_f32(const float* x, const float* gamma, const float* beta, float* y, float* y_silu, float* mean_out,
                        float* rstd_out, float* workspace /* or NULL */, int32_t N, int32_t C, int32_t HW, int32_t groups, float eps,

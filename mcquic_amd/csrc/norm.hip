@@ -154,7 +154,7 @@ __global__ void group_norm_bwd_params_kernel(const float* __restrict__ mean, con
 
 
 // ---- large runs (round 5): many workgroups per (image, group) ---------------------------------------------------------------------
-// One workgroup per run is fine while a run is a few thousand floats (the 4x4 ... 32x32 maps of the qp = 2 shapes); Neon puts
+// One workgroup per run is fine while a run is a few hundred floats (4x4 ... 8x8 maps); Neon puts
 // GroupNorm(32, 32) on 512 x 512 maps -- a run is one 1 MB plane, 4 images are 128 workgroups on 256 CUs each walking its plane three
 // times with 4-byte loads, and the backward sums ran one WAVE per plane: a captured Neon training step spent 57 of its 92 ms here.
 // Chunked form: a plane is cut into chunks of GN_CHUNK floats, one workgroup each.
@@ -163,7 +163,7 @@ __global__ void group_norm_bwd_params_kernel(const float* __restrict__ mean, con
 //                                    E[x^2] - E[x]^2 cancellation, deterministic), then normalises its chunk
 //   backward  gn_chunk_bwd_sums_kernel / gn_chunk_bwd_dx_kernel the same way for (sum dy, sum dy x)
 constexpr int GN_CHUNK = 8192;          // floats per chunk: 32 floats (8 x 16 bytes) per thread
-constexpr int GN_CHUNK_MIN_RUN = 4 * GN_CHUNK;      // runs below this stay on the one-workgroup kernels
+constexpr int GN_CHUNK_MIN_HW = 256;    // planes below this stay on the one-workgroup-per-run kernels (a chunk would be mostly padding)
 
 struct GnChunkK {
     const float* x; const float* dy; const float* gamma; const float* beta;
@@ -337,7 +337,9 @@ __global__ __launch_bounds__(kThreads) void gn_chunk_bwd_dx_kernel(GnChunkK k) {
 }
 
 inline int gn_chunks(int HW) { return (HW + GN_CHUNK - 1) / GN_CHUNK; }
-inline bool gn_chunked(int C, int HW, int groups) { return (long long)(C / groups) * HW >= GN_CHUNK_MIN_RUN && HW >= GN_CHUNK; }
+// (every plane of >= 256 pixels: even where a plane is one partial chunk -- 64 x 64 maps -- a workgroup that reads its values once
+//  with 16-byte loads and keeps them in registers beats the one-workgroup kernels' three scalar passes: 128 x 128 planes 245 -> ~20 us)
+inline bool gn_chunked(int C, int HW, int groups) { (void)C; (void)groups; return HW >= GN_CHUNK_MIN_HW; }
 
 }  // namespace
 

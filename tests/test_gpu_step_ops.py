@@ -294,7 +294,7 @@ def test_scale_block_node_equals_op_by_op_graph(dev, up, shape):
 
 
 @pytest.mark.parametrize("shape,groups", [((2, 32, 192, 192), 32), ((1, 8, 128, 128), 1), ((2, 4, 97, 101), 2), ((3, 32, 512, 64), 32),
-                                          ((2, 32, 16, 16), 32), ((2, 8, 8, 8), 1)])
+                                          ((2, 32, 16, 16), 32), ((2, 8, 8, 8), 1), ((4, 32, 64, 64), 32), ((2, 32, 17, 15), 4), ((1, 8, 32, 32), 1)])
 def test_group_norm_large_runs(dev, shape, groups):
     """nn.GroupNorm forward (+ SiLU twin) and backward on runs long enough for the chunked kernels (many workgroups per
     (image, group): Neon's GroupNorm(32, 32) on 512 x 512 maps) and, for comparison, on the short runs the one-workgroup kernels

@@ -146,6 +146,11 @@ int mcq_conv2d_multi_f32(const mcq_conv_desc* descs, int32_t n, void* stream);
  * (mcquic/nn/base.py:81-84 NonNegativeParametrizer.forward). */
 int mcq_nonneg_reparam_f32(const float* p, float bound, float pedestal, float* out, int64_t n,
                            void* stream);
+/* The same for up to mcq_nonneg_reparam_max_multi() parameters in ONE launch (host arrays of `count` entries): every GDN layer's
+ * beta and gamma after an optimizer step (round 5; 20 launches per step of the qp = 2 model before). */
+int32_t mcq_nonneg_reparam_max_multi(void);
+int mcq_nonneg_reparam_multi_f32(const float* const* p, float* const* out, const int64_t* n, const float* bound, const float* pedestal,
+                                 int32_t count, void* stream);
 
 /* ---- multi-codebook quantizer ------------------------------------------------------------- */
 

@@ -59,6 +59,8 @@ SYMBOLS = {
     "mcq_conv2d_max_multi": (c_int32, []),
     "mcq_conv2d_multi_f32": (c_int32, [POINTER(ConvDesc), c_int32, c_void_p]),
     "mcq_nonneg_reparam_f32": (c_int32, [c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
+    "mcq_nonneg_reparam_max_multi": (c_int32, []),
+    "mcq_nonneg_reparam_multi_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "mcq_packed_codebook_floats": (c_size_t, [c_int32, c_int32, c_int32]),
     "mcq_vq_pack_codebook_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "mcq_vq_assign_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,

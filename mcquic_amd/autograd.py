@@ -645,6 +645,45 @@ def _gdn_operands(module, beta_p, gamma_p, bounds):
     return cached[1], cached[2]
 
 
+def refresh_gdn_operands(modules) -> int:
+    """Bring the training operands of all GDN / IGDN `modules` whose parameters changed up to date in grouped launches: ONE launch
+    for every stale layer's two re-parametrisations, one grouped pack for the forward streams, one for the input-gradient streams
+    (2 gamma^T) -- what `_gdn_operands` does layer by layer with 4 launches each (40 per step of the qp = 2 model after an optimizer
+    update).  Everything is written in place: the folded tensors and both operand streams keep their addresses (a captured step holds
+    them).  Returns the number of layers refreshed.  Layers of one channel count share the launches."""
+    stale = []
+    for m in modules:
+        key = (ops.tensor_version(m.beta), m.beta.data_ptr(), ops.tensor_version(m.gamma), m.gamma.data_ptr())
+        cached = m.__dict__.get("_trainOperands")
+        if cached is None or cached[0] != key:
+            stale.append((m, key))
+    if not stale:
+        return 0
+    by_shape = {}
+    for m, key in stale:
+        by_shape.setdefault((tuple(m.gamma.shape), m.gamma.device), []).append((m, key))
+    for group in by_shape.values():
+        ps, outs, bounds, peds = [], [], [], []
+        for m, _ in group:
+            fold = m.__dict__.get("_trainFold")
+            if fold is None or fold[0].device != m.beta.device:
+                fold = m.__dict__["_trainFold"] = (torch.empty_like(m.beta.detach()), torch.empty_like(m.gamma.detach()))
+            bb, be, gb, ge = _gdn_bounds(m)
+            ps += [m.beta, m.gamma]
+            outs += [fold[0], fold[1]]
+            bounds += [bb, gb]
+            peds += [be, ge]
+        ops.nonneg_reparam_multi_(ps, outs, bounds, peds)
+        gammas = [m.__dict__["_trainFold"][1][..., None, None] for m, _ in group]
+        betas = [m.__dict__["_trainFold"][0] for m, _ in group]
+        old = [m.__dict__.get("_trainOperands") for m, _ in group]
+        fwd = ops.pack_convs(gammas, betas, into=[None if o is None else o[1] for o in old])
+        back = ops.pack_convs(gammas, dgrad=True, stride=1, scale=2.0, into=[None if o is None else o[2] for o in old])
+        for (m, key), f, b in zip(group, fwd, back):
+            m.__dict__["_trainOperands"] = (key, f, b)
+    return len(stale)
+
+
 def _gdn_forward(module, x, beta_p, gamma_p, inverse: bool):
     """(y, forward operand stream, input-gradient operand stream, (beta bound, gamma bound)) of a GDN / IGDN layer."""
     bb, be, gb, ge = _gdn_bounds(module)

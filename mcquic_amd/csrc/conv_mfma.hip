@@ -998,7 +998,7 @@ inline void sec_note(const mcq_conv_desc* descs, int nprob, unsigned bit) {
     for (int c = 0; c < nprob; ++c) g_sec_used[descs[c].w_packed] |= bit;
 }
 
-constexpr int PACK_MAX_MULTI = 16;
+constexpr int PACK_MAX_MULTI = 64;       // (round 5: 16 -> 64; the qp=2 model's ~150 convolutions of one shape re-pack in 3 launches instead of 10)
 constexpr int MCQ_TAIL_STEPS = 16;
 struct PackTable { const float* w[PACK_MAX_MULTI]; float* out[PACK_MAX_MULTI]; unsigned char mask[PACK_MAX_MULTI]; };
 // (mask: sections to write -- bit 0 the 128-row copy, 1 the 64-row, 2 the 32-row, 3 the 16x16-tile order; mcq_pack_conv_weight_multi_masked_f32)
@@ -1152,6 +1152,21 @@ __global__ void nonneg_reparam_kernel(const float* __restrict__ p, float bound, 
                                       int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
+        const float v = fmaxf(p[i], bound);
+        out[i] = v * v - pedestal;
+    }
+}
+
+// several parameters in one launch (the beta [C] and gamma [C, C] of every GDN layer after an optimizer step: 20 launches -> 1)
+constexpr int REPARAM_MAX_MULTI = 64;
+struct ReparamTable { const float* p[REPARAM_MAX_MULTI]; float* out[REPARAM_MAX_MULTI]; long long n[REPARAM_MAX_MULTI]; float bound[REPARAM_MAX_MULTI];
+                      float pedestal[REPARAM_MAX_MULTI]; };
+__global__ void nonneg_reparam_multi_kernel(ReparamTable t) {
+    const float* p = t.p[0]; float* out = t.out[0]; long long n = t.n[0]; float bound = t.bound[0], pedestal = t.pedestal[0];
+#pragma unroll
+    for (int c = 1; c < REPARAM_MAX_MULTI; ++c)
+        if ((int)blockIdx.y == c) { p = t.p[c]; out = t.out[c]; n = t.n[c]; bound = t.bound[c]; pedestal = t.pedestal[c]; }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float v = fmaxf(p[i], bound);
         out[i] = v * v - pedestal;
     }
@@ -1436,6 +1451,25 @@ int pack_multi(const float* const* w, float* const* out, const uint8_t* masks, i
     return mcq_check_launch();
 }
 }  // namespace
+
+extern "C" int32_t mcq_nonneg_reparam_max_multi(void) { return REPARAM_MAX_MULTI; }
+
+extern "C" int mcq_nonneg_reparam_multi_f32(const float* const* p, float* const* out, const int64_t* n, const float* bound, const float* pedestal,
+                                            int32_t count, void* stream) {
+    if (!p || !out || !n || !bound || !pedestal || count < 1 || count > REPARAM_MAX_MULTI) return MCQ_EINVAL;
+    ReparamTable t;
+    long long most = 0;
+    for (int c = 0; c < REPARAM_MAX_MULTI; ++c) {
+        const int k = c < count ? c : 0;
+        if (!p[k] || !out[k] || n[k] <= 0) return MCQ_EINVAL;
+        t.p[c] = p[k]; t.out[c] = out[k]; t.n[c] = n[k]; t.bound[c] = bound[k]; t.pedestal[c] = pedestal[k];
+        if (n[k] > most) most = n[k];
+    }
+    long long blocks = (most + 255) / 256;
+    if (blocks > 256) blocks = 256;                          // (grid-stride loop inside)
+    hipLaunchKernelGGL(nonneg_reparam_multi_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, (hipStream_t)stream, t);
+    return mcq_check_launch();
+}
 
 extern "C" int mcq_nonneg_reparam_f32(const float* p, float bound, float pedestal, float* out, int64_t n, void* stream) {
     if (!p || !out || n <= 0) return MCQ_EINVAL;

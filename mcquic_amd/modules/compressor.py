@@ -181,6 +181,13 @@ class BaseCompressor(nn.Module):
             convs = self.__dict__["_convList"] = [m for m in self.modules() if isinstance(m, Conv2d)]
         from ..nn.convs import Conv2d
         Conv2d.repack_stale(convs, self.__dict__.get("_packMasks"))     # (_packMasks: only while parallel.GraphedTrainStep captures)
+        gdns = self.__dict__.get("_gdnList")
+        if gdns is None:
+            from ..nn.gdn import GenDivNorm
+            gdns = self.__dict__["_gdnList"] = [m for m in self.modules() if isinstance(m, GenDivNorm)]
+        if gdns:
+            from .. import autograd as AG
+            AG.refresh_gdn_operands(gdns)                               # the GDN layers' folded parameters and operand streams, grouped too
 
     def reAssignCodebook(self) -> torch.Tensor:
         return self._quantizer.reAssignCodebook()

@@ -561,6 +561,26 @@ def nonneg_reparam(p: torch.Tensor, bound: float, pedestal: float) -> torch.Tens
     return out
 
 
+def nonneg_reparam_multi_(ps, outs, bounds, pedestals) -> None:
+    """outs[i] = max(ps[i], bounds[i])^2 - pedestals[i] for many parameters in ceil(n / 64) launches (mcq_nonneg_reparam_multi_f32);
+    `outs` are written in place (their addresses are what packed operand streams and captured graphs hold)."""
+    lib = _lib.load()
+    ps = [_dev(p.detach(), "p") for p in ps]
+    for o, p in zip(outs, ps):
+        if o.shape != p.shape or o.dtype != torch.float32 or not o.is_contiguous() or o.device != p.device:
+            raise ValueError("nonneg_reparam_multi_: every output must be a contiguous float32 tensor of its parameter's shape")
+    cap = lib.mcq_nonneg_reparam_max_multi()
+    with _guard(ps[0].device):
+        for lo in range(0, len(ps), cap):
+            k = min(cap, len(ps) - lo)
+            src = (ctypes.c_void_p * k)(*[p.data_ptr() for p in ps[lo:lo + k]])
+            dst = (ctypes.c_void_p * k)(*[o.data_ptr() for o in outs[lo:lo + k]])
+            ns = (ctypes.c_int64 * k)(*[p.numel() for p in ps[lo:lo + k]])
+            bd = (ctypes.c_float * k)(*[float(b) for b in bounds[lo:lo + k]])
+            pd = (ctypes.c_float * k)(*[float(b) for b in pedestals[lo:lo + k]])
+            check(lib.mcq_nonneg_reparam_multi_f32(src, dst, ns, bd, pd, k, _stream()), "mcq_nonneg_reparam_multi_f32")
+
+
 def nonneg_reparam_bwd(p: torch.Tensor, dfolded: torch.Tensor, bound: float) -> torch.Tensor:
     """Gradient of max(p, bound)^2 - pedestal w.r.t. p under LowerBound's rule (mcq_nonneg_reparam_bwd_f32)."""
     p, dfolded = _dev(p.detach(), "p"), _dev(dfolded, "dfolded")

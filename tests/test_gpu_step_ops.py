@@ -319,3 +319,34 @@ def test_group_norm_large_runs(dev, shape, groups):
     # deterministic: a second run gives the same bits
     y2 = ops.group_norm(x.to(dev), gamma.to(dev), beta.to(dev), groups, 1e-5)
     assert torch.equal(y, y2)
+
+
+def test_grouped_gdn_operand_refresh_equals_layer_by_layer(dev):
+    """autograd.refresh_gdn_operands (one re-parametrisation launch + two grouped packs for all stale GDN layers) leaves the same
+    folded parameters and operand streams as the per-layer path, in place (addresses kept) when the parameters change again."""
+    from mcquic_amd import autograd as AG
+    from mcquic_amd.nn.gdn import GenDivNorm, InvGenDivNorm
+    torch.manual_seed(4)
+    layers = [GenDivNorm(128).to(dev), InvGenDivNorm(128).to(dev), GenDivNorm(32).to(dev), GenDivNorm(128).to(dev)]
+    with torch.no_grad():
+        for m in layers:
+            m.gamma.add_(torch.randn_like(m.gamma) * 0.01)
+            m.beta.add_(torch.rand_like(m.beta))
+    assert AG.refresh_gdn_operands(layers) == 4
+    assert AG.refresh_gdn_operands(layers) == 0                     # nothing stale: nothing launched
+    addr = [(m.__dict__["_trainOperands"][1].wp.data_ptr(), m.__dict__["_trainOperands"][2].wp.data_ptr()) for m in layers]
+    for rnd in range(2):
+        for m in layers:
+            grouped = m.__dict__["_trainOperands"]
+            m2 = type(m)(m.beta.numel()).to(dev)
+            with torch.no_grad():
+                m2.beta.copy_(m.beta)
+                m2.gamma.copy_(m.gamma)
+            f, b = AG._gdn_operands(m2, m2.beta, m2.gamma, AG._gdn_bounds(m2))
+            assert torch.equal(grouped[1].wp, f.wp) and torch.equal(grouped[1].bias, f.bias) and torch.equal(grouped[2].wp, b.wp)
+        with torch.no_grad():                                       # an "optimizer step": versions move, the refresh is in place
+            for m in layers[:3]:
+                m.gamma.mul_(1.01)
+                m.beta.add_(0.001)
+        assert AG.refresh_gdn_operands(layers) == 3
+        assert addr == [(m.__dict__["_trainOperands"][1].wp.data_ptr(), m.__dict__["_trainOperands"][2].wp.data_ptr()) for m in layers]

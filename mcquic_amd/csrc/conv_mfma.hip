@@ -1069,11 +1069,11 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
 
 __global__ void pack_conv_weight_multi_kernel(PackTable t, int Cout, int Cin, int ks, int S, int TP, size_t sec4, size_t sec2, size_t total,
                                               int mode, int Co, int Ci, float scale) {
-    const float* w = t.w[0];
-    float* out = t.out[0];
-#pragma unroll
-    for (int c = 1; c < PACK_MAX_MULTI; ++c)
-        if ((int)blockIdx.y == c) { w = t.w[c]; out = t.out[c]; }
+    // (a uniform dynamic index into the by-value table: scalar loads from the kernel-argument segment -- a compare chain over 64
+    //  entries cost every thread ~190 vector instructions)
+    const int c = (int)blockIdx.y;
+    const float* w = t.w[c];
+    float* out = t.out[c];
     pack_conv_weight_body(w, Cout, Cin, ks, S, TP, out, sec4, sec2, total, mode, Co, Ci, scale);
 }
 
@@ -1139,12 +1139,10 @@ __global__ void pack_conv_weight_runs_kernel(const float* __restrict__ w, int Co
 }
 
 __global__ void pack_conv_weight_runs_multi_kernel(PackTable t, int Cout, int Cin, int S, int TP, int mode, int Co, int Ci, float scale, unsigned n16) {
-    const float* w = t.w[0];
-    float* out = t.out[0];
-    unsigned mask = t.mask[0];
-#pragma unroll
-    for (int c = 1; c < PACK_MAX_MULTI; ++c)
-        if ((int)blockIdx.y == c) { w = t.w[c]; out = t.out[c]; mask = t.mask[c]; }
+    const int c = (int)blockIdx.y;
+    const float* w = t.w[c];
+    float* out = t.out[c];
+    const unsigned mask = t.mask[c];
     pack_conv_weight_runs_body(w, Cout, Cin, S, TP, out, mode, Co, Ci, scale, n16, mask);
 }
 
@@ -1162,10 +1160,8 @@ constexpr int REPARAM_MAX_MULTI = 64;
 struct ReparamTable { const float* p[REPARAM_MAX_MULTI]; float* out[REPARAM_MAX_MULTI]; long long n[REPARAM_MAX_MULTI]; float bound[REPARAM_MAX_MULTI];
                       float pedestal[REPARAM_MAX_MULTI]; };
 __global__ void nonneg_reparam_multi_kernel(ReparamTable t) {
-    const float* p = t.p[0]; float* out = t.out[0]; long long n = t.n[0]; float bound = t.bound[0], pedestal = t.pedestal[0];
-#pragma unroll
-    for (int c = 1; c < REPARAM_MAX_MULTI; ++c)
-        if ((int)blockIdx.y == c) { p = t.p[c]; out = t.out[c]; n = t.n[c]; bound = t.bound[c]; pedestal = t.pedestal[c]; }
+    const int c = (int)blockIdx.y;                              // (uniform index into the kernel-argument table)
+    const float* p = t.p[c]; float* out = t.out[c]; const long long n = t.n[c]; const float bound = t.bound[c], pedestal = t.pedestal[c];
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float v = fmaxf(p[i], bound);
         out[i] = v * v - pedestal;

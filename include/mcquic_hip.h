@@ -466,6 +466,16 @@ int mcq_sqdiff_sum_u8(const uint8_t* x, const uint8_t* y, int64_t* out, int64_t 
 size_t mcq_packed_conv_winograd16_floats(int32_t Cout, int32_t Cin);
 int mcq_pack_conv_weight_winograd16_f32(const float* w, int32_t Cout, int32_t Cin, float* out, void* stream);
 
+/* ---- the weight gradients' reduce passes, batched (round 5) ----------------------------------------------------------------------------
+ * mcq_wgrad_defer(1): from now on the mcq_conv2d_wgrad*_nchw* entry points record their second pass (the fixed-order sum of the
+ * partial tiles in `workspace` -> dW in OIHW order, db) instead of launching it; mcq_wgrad_flush(0, stream) launches everything
+ * recorded, 72 convolutions per launch, and empties the record (discard != 0: empties it without launching, after an error).
+ * Until the flush the caller keeps every workspace alive and reads no dW / db.  Same sums in the same order as the one-by-one pass.
+ * mcq_wgrad_pending(): convolutions recorded and not yet flushed.  Process-wide switch: one backward pass at a time uses it. */
+void mcq_wgrad_defer(int32_t on);
+int32_t mcq_wgrad_pending(void);
+int mcq_wgrad_flush(int32_t discard, void* stream);
+
 /* ---- GroupNorm (`denseNorm=True`) ------------------------------------------------------------------------------------
  * y = (x - mean) * rstd * gamma[c] + beta[c] over each (image, group) of C / groups adjacent channels, biased variance,
  * rstd = 1 / sqrt(var + eps): nn.GroupNorm(groups, C) as the reference's ResidualBlock inserts it in place of its second

@@ -100,6 +100,9 @@ SYMBOLS = {
     "mcq_conv2d_wgrad1x1_nchw_workspace_floats": (c_size_t, [c_int32] * 5),
     "mcq_conv2d_wgrad1x1_nchw_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                                c_int32, c_int32, c_void_p]),
+    "mcq_wgrad_defer": (None, [c_int32]),
+    "mcq_wgrad_pending": (c_int32, []),
+    "mcq_wgrad_flush": (c_int32, [c_int32, c_void_p]),
     "mcq_nchw_to_nhwc_pair_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32,
                                             c_int32, c_void_p]),
     "mcq_channel_sum_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),

@@ -202,13 +202,22 @@ _ONES = {}
 
 
 def backward(loss: torch.Tensor) -> None:
-    """`loss.backward()` with the root gradient taken from a cached 1.0 on the loss's device: the engine otherwise allocates and
-    FILLS one per call -- the one ATen launch left in a captured training step."""
+    """`loss.backward()` with the root gradient taken from a cached 1.0 on the loss's device (the engine otherwise allocates and
+    FILLS one per call -- the one ATen launch left in a captured training step) and with the weight gradients' reduce passes of the
+    whole pass run in a few launches at its end (ops.wgrad_deferral).  NOT for a backward pass something else listens to (torch DDP
+    reads gradients from bucket hooks while the pass is still running): there, call `loss.backward()` as usual."""
     key = (loss.device, loss.dtype)
     one = _ONES.get(key)
     if one is None:
         one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
-    loss.backward(one if loss.dim() == 0 else None)
+    with ops.wgrad_deferral():                                  # (this pass is ours end to end: the weight gradients' reduce passes run batched)
+        loss.backward(one if loss.dim() == 0 else None)
+
+
+def run_backward(tensors, grad_tensors) -> None:
+    """torch.autograd.backward(tensors, grad_tensors) with the weight gradients' reduce passes batched (see `backward`)."""
+    with ops.wgrad_deferral():
+        torch.autograd.backward(tensors, grad_tensors)
 
 
 def mse_loss(a, b):
@@ -700,7 +709,8 @@ def _gdn_backward(x, packed, back, bounds, beta_p, gamma_p, dy, inverse: bool):
     else:                                                          # (A/B switch: the round-3 form, s stored and read back)
         dxd, ds = ops.gdn_bwd_prep(x, ops.conv2d(x, packed, square_in=True), dy, inverse)
     dx = ops.conv2d(ds, back, mul=x, res=dxd)                      # dy f(s) + 2 x (gamma^T ds)
-    dgamma, dbeta = ops.conv2d_wgrad(x, ds, 1, 1, square_x=True, want_bias=True)
+    with ops.wgrad_now():                                          # (read right below: no deferred reduce for this one)
+        dgamma, dbeta = ops.conv2d_wgrad(x, ds, 1, 1, square_x=True, want_bias=True)
     dbeta_p, dgamma_p = ops.nonneg_reparam_bwd2(beta_p, dbeta, bounds[0], gamma_p, dgamma[:, :, 0, 0], bounds[1])
     return dx, dbeta_p, dgamma_p
 

@@ -18,7 +18,9 @@
 //   workgroup   = 4 waves of one tile, summed through LDS in a fixed tree before the partials leave the CU
 //   second pass = wgrad_rows_reduce_kernel: fixed-order sum over the workgroups' partials -> dW in OIHW order, db
 // Deterministic: no atomics anywhere.
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "mcq_common.h"
 #include "../../include/mcquic_hip.h"
@@ -373,6 +375,76 @@ __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(WgRowsReduceK p)
     const int co = (int)(r % Cout);
     const int tap = (int)(r / Cout);
     dw[((size_t)co * Cin + ci) * p.taps + tap] = s;
+}
+
+// ---- the reduce passes of a whole backward pass in a few launches (round 5) ------------------------------------------------------
+// A captured training step held 56 reduce launches, 44 of them 5-9 us of latency for microseconds of traffic.  While deferral is
+// on (mcq_wgrad_defer; mcquic_amd.autograd.backward switches it on around a backward pass it owns) the entry points below record
+// their reduce pass per convolution instead of launching it, and mcq_wgrad_flush launches all recorded passes, up to
+// REDUCE_BATCH per launch: blockIdx.x walks the jobs' 64-output blocks back to back.  Same sums in the same order as the
+// one-by-one kernel.  The caller keeps every workspace alive until the flush and reads no weight gradient before it.
+constexpr int REDUCE_BATCH = 72;
+struct ReduceJob { const float* part; const float* bias_part; float* dw; float* dbias; int groups, Cout, Cin, taps; };
+struct ReduceBatch { ReduceJob job[REDUCE_BATCH]; unsigned first[REDUCE_BATCH + 1]; int njobs; };
+
+__global__ __launch_bounds__(256) void wgrad_rows_reduce_batch_kernel(ReduceBatch b) {
+    __shared__ float red[4][64];
+    int j = 0;
+    while (j + 1 < b.njobs && blockIdx.x >= b.first[j + 1]) ++j;          // (uniform: scalar compares over the kernel-argument table)
+    const ReduceJob q = b.job[j];
+    const int Cout = q.Cout, Cin = q.Cin;
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const size_t i = (size_t)(blockIdx.x - b.first[j]) * 64 + lane;
+    const size_t per = (size_t)q.taps * Cout * Cin;
+    const bool is_bias = i >= per;
+    const size_t co_b = i - per;
+    const bool live = is_bias ? (q.dbias != nullptr && co_b < (size_t)Cout) : true;
+    const int count = is_bias ? q.groups * 4 : q.groups;
+    const int per_slice = (count + 3) / 4;
+    const int s0 = slice * per_slice, s1 = s0 + per_slice < count ? s0 + per_slice : count;
+    const float* src = is_bias ? q.bias_part + co_b : q.part + i;
+    const size_t stride = is_bias ? (size_t)Cout : per;
+    float s = 0.0f;
+    if (live) {
+        int g = s0;
+        for (; g + 8 <= s1; g += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(g + k) * stride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; g < s1; ++g) s += src[(size_t)g * stride];
+    }
+    red[slice][lane] = s;
+    __syncthreads();
+    if (slice != 0 || !live) return;
+    s = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (is_bias) { q.dbias[co_b] = s; return; }
+    const int ci = (int)(i % Cin);
+    const size_t r = i / Cin;
+    const int co = (int)(r % Cout);
+    const int tap = (int)(r / Cout);
+    q.dw[((size_t)co * Cin + ci) * q.taps + tap] = s;
+}
+
+std::mutex g_defer_mu;
+bool g_defer = false;
+std::vector<ReduceJob> g_jobs;
+
+// the second pass of a weight-gradient launch: now, or recorded per convolution for mcq_wgrad_flush
+inline void reduce_pass(const WgRowsReduceK& q, unsigned gx, unsigned nconv, hipStream_t s) {
+    {
+        std::lock_guard<std::mutex> lock(g_defer_mu);
+        if (g_defer) {
+            const size_t per = (size_t)q.taps * q.Cout * q.Cin;
+            for (unsigned c = 0; c < nconv; ++c)
+                g_jobs.push_back(ReduceJob{q.part + (size_t)c * q.groups * per, q.bias_part ? q.bias_part + (size_t)c * q.groups * 4 * q.Cout : nullptr,
+                                           q.dw[c], q.dbias[c], q.groups, q.Cout, q.Cin, q.taps});
+            return;
+        }
+    }
+    hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3(gx, nconv), dim3(256), 0, s, q);
 }
 
 // ---- 3x3 stride-2 convolutions (ResidualBlockWithStride's two convs, the 3-channel stem) --------------------------------
@@ -791,7 +863,7 @@ extern "C" int mcq_conv2d_wgrad_nchw_group_f32(const float* const* x, const floa
         else hipLaunchKernelGGL((conv_wgrad_rows_kernel<false, 4>), grid, dim3(256), 0, s, p);
     }
     const size_t per = (size_t)9 * Cout * Cin + (any_bias ? (size_t)Cout : 0);
-    hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3((unsigned)((per + 63) / 64), (unsigned)nconv), dim3(256), 0, s, q);
+    reduce_pass(q, (unsigned)((per + 63) / 64), (unsigned)nconv, s);
     return mcq_check_launch();
 }
 
@@ -846,7 +918,7 @@ extern "C" int mcq_conv2d_wgrad1x1_nchw_f32(const float* x, const float* dy, flo
     }
 #undef MCQ_LAUNCH_ROWS1
     const size_t per = (size_t)Cout * Cin + (dbias ? (size_t)Cout : 0);
-    hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3((unsigned)((per + 63) / 64), 1u), dim3(256), 0, s, q);
+    reduce_pass(q, (unsigned)((per + 63) / 64), 1u, s);
     return mcq_check_launch();
 }
 
@@ -875,7 +947,40 @@ extern "C" int mcq_conv2d_wgrad_s2_nchw_f32(const float* x, const float* dy, flo
     if (dbias) hipLaunchKernelGGL(conv_wgrad_rows_s2_kernel<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(conv_wgrad_rows_s2_kernel<false>, grid, dim3(256), 0, s, p);
     const size_t per = (size_t)9 * Cout * Cin + (dbias ? (size_t)Cout : 0);
-    hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3((unsigned)((per + 63) / 64), 1u), dim3(256), 0, s, q);
+    reduce_pass(q, (unsigned)((per + 63) / 64), 1u, s);
     return mcq_check_launch();
 }
 
+extern "C" void mcq_wgrad_defer(int32_t on) {
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    g_defer = on != 0;
+}
+
+extern "C" int32_t mcq_wgrad_pending(void) {
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    return (int32_t)g_jobs.size();
+}
+
+extern "C" int mcq_wgrad_flush(int32_t discard, void* stream) {
+    std::vector<ReduceJob> jobs;
+    {
+        std::lock_guard<std::mutex> lock(g_defer_mu);
+        jobs.swap(g_jobs);
+    }
+    if (discard || jobs.empty()) return MCQ_OK;
+    for (size_t at = 0; at < jobs.size(); at += REDUCE_BATCH) {
+        ReduceBatch b;
+        const int n = (int)(jobs.size() - at < (size_t)REDUCE_BATCH ? jobs.size() - at : (size_t)REDUCE_BATCH);
+        unsigned blocks = 0;
+        for (int j = 0; j < REDUCE_BATCH; ++j) {
+            const ReduceJob& q = jobs[at + (j < n ? j : 0)];
+            b.job[j] = q;
+            b.first[j] = blocks;
+            if (j < n) blocks += (unsigned)(((size_t)q.taps * q.Cout * q.Cin + (q.dbias ? (size_t)q.Cout : 0) + 63) / 64);
+        }
+        b.first[REDUCE_BATCH] = blocks;
+        b.njobs = n;
+        hipLaunchKernelGGL(wgrad_rows_reduce_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    return mcq_check_launch();
+}

@@ -997,6 +997,63 @@ def nchw_to_nhwc(x: torch.Tensor, square: bool = False) -> torch.Tensor:
 
 _WGRAD_ROWS = os.environ.get("MCQUIC_AMD_WGRAD_ROWS", "1") != "0"      # A/B switch: 0 = always the NHWC weight-gradient kernel
 
+# ---- the weight gradients' reduce passes, batched over a backward pass (mcq_wgrad_defer / mcq_wgrad_flush) -------------------------------
+_WGRAD_DEFER = os.environ.get("MCQUIC_AMD_WGRAD_DEFER", "1") != "0"    # A/B switch: 0 = every weight-gradient launch reduces right away
+_defer = {"on": False, "keep": []}
+
+
+class wgrad_deferral:
+    """`with ops.wgrad_deferral():` around a backward pass this library owns end to end (autograd.backward, parallel.GraphedTrainStep):
+    inside, weight-gradient launches leave their partial tiles in their workspaces and record the reduce pass; on exit ALL recorded
+    passes run in a few launches (a captured training step: 56 reduce launches -> 3).  Nothing may read a weight gradient before the
+    exit -- torch DDP's bucket hooks do, which is why a plain `loss.backward()` never defers.  Workspaces are kept alive until then."""
+
+    def __enter__(self):
+        self.active = _WGRAD_DEFER and not _defer["on"]
+        if self.active:
+            _defer["on"] = True
+            _lib.load().mcq_wgrad_defer(1)
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if not self.active:
+            return False
+        lib = _lib.load()
+        lib.mcq_wgrad_defer(0)
+        _defer["on"] = False
+        try:
+            if exc_type is None and lib.mcq_wgrad_pending():
+                dev = _defer["keep"][0].device if _defer["keep"] else torch.device("cuda", torch.cuda.current_device())
+                with _guard(dev):
+                    check(lib.mcq_wgrad_flush(0, _stream()), "mcq_wgrad_flush")
+            else:
+                lib.mcq_wgrad_flush(1, None)
+        finally:
+            del _defer["keep"][:]
+        return False
+
+
+class wgrad_now:
+    """Inside a `wgrad_deferral`: the weight gradients of this block are reduced right away (their values are read next)."""
+
+    def __enter__(self):
+        self.was = _defer["on"]
+        if self.was:
+            _lib.load().mcq_wgrad_defer(0)
+            _defer["on"] = False
+        return self
+
+    def __exit__(self, *exc):
+        if self.was:
+            _lib.load().mcq_wgrad_defer(1)
+            _defer["on"] = True
+        return False
+
+
+def _keep(ws: torch.Tensor) -> None:
+    if _defer["on"]:
+        _defer["keep"].append(ws)
+
 
 def conv2d_wgrad_group(xs, dys, want_bias: bool = True):
     """Weight (and bias) gradients of several 3x3 stride-1 convolutions of ONE shape in one launch pair
@@ -1030,6 +1087,7 @@ def conv2d_wgrad_group(xs, dys, want_bias: bool = True):
                                                       table(*[t.data_ptr() for t in dws]),
                                                       table(*[t.data_ptr() for t in dbs]) if want_bias else None, k, _ptr(ws),
                                                       n, cin, h, w, cout, _stream()), "mcq_conv2d_wgrad_nchw_group_f32")
+        _keep(ws)
         out.extend(zip(dws, dbs if want_bias else [None] * k))
     return out
 
@@ -1051,6 +1109,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
             with _guard(x.device):
                 check(lib.mcq_conv2d_wgrad_nchw_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream()),
                       "mcq_conv2d_wgrad_nchw_f32")
+            _keep(ws)
             return (dw, db) if want_bias else dw
     if ksize == 3 and stride == 2 and not square_x and _WGRAD_ROWS and (ho, wo) == (h // 2, w // 2):
         nws = lib.mcq_conv2d_wgrad_s2_nchw_workspace_floats(n, cin, h, w, cout)
@@ -1061,6 +1120,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
             with _guard(x.device):
                 check(lib.mcq_conv2d_wgrad_s2_nchw_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream()),
                       "mcq_conv2d_wgrad_s2_nchw_f32")
+            _keep(ws)
             return (dw, db) if want_bias else dw
     if ksize == 1 and stride == 1 and _WGRAD_ROWS:
         nws = lib.mcq_conv2d_wgrad1x1_nchw_workspace_floats(n, cin, h, w, cout)
@@ -1071,6 +1131,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
             with _guard(x.device):
                 check(lib.mcq_conv2d_wgrad1x1_nchw_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout,
                                                        int(square_x), _stream()), "mcq_conv2d_wgrad1x1_nchw_f32")
+            _keep(ws)
             return (dw, db) if want_bias else dw
     xt = torch.empty((n, h, w, cin), dtype=torch.float32, device=x.device)
     dyt = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)

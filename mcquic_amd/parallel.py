@@ -478,10 +478,12 @@ class GraphedTrainStep:
                 if torch.is_tensor(leaf) and leaf is not lg and leaf.grad is not None:
                     outs.append(lg)
                     grads.append(leaf.grad)
-            torch.autograd.backward(outs, grads)              # quantizer parameters, d y
+            from .autograd import run_backward
+            run_backward(outs, grads)                         # quantizer parameters, d y
         else:
             y, yl = self._carry[0], self._carry[1]
-            y.backward(yl.grad)                               # encoder parameters
+            from .autograd import run_backward
+            run_backward([y], [yl.grad])                      # encoder parameters
             self._carry = None
 
     def _forward_backward(self):

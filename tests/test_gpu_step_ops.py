@@ -350,3 +350,35 @@ def test_grouped_gdn_operand_refresh_equals_layer_by_layer(dev):
                 m.beta.add_(0.001)
         assert AG.refresh_gdn_operands(layers) == 3
         assert addr == [(m.__dict__["_trainOperands"][1].wp.data_ptr(), m.__dict__["_trainOperands"][2].wp.data_ptr()) for m in layers]
+
+
+@pytest.mark.parametrize("kind", ["compressor", "neon_dense_norm"])
+def test_deferred_reduce_passes_give_the_same_gradients(dev, kind):
+    """autograd.backward (weight-gradient reduce passes recorded and run batched at the end of the pass) against a plain
+    loss.backward() (every launch reduces right away): every parameter gradient bit for bit -- same partial tiles, same order."""
+    from mcquic_amd import Compressor, Neon, ops
+    from mcquic_amd.autograd import backward, mse_loss
+    torch.manual_seed(3407)
+    model = (Compressor(32, 2, [64, 32, 16]) if kind == "compressor" else Neon(32, 256, [8, 4, 2, 2], True)).to(dev).train()
+    x = (torch.rand((4, 3, 128, 128), generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
+    us = None
+    if kind == "compressor":
+        g = torch.Generator().manual_seed(1)
+        us = [(torch.rand((4, 2, s, s, k), generator=g).to(dev), torch.rand((4, 2, s, s, k), generator=g).to(dev)) for s, k in ((8, 64), (4, 32), (2, 16))]
+    else:
+        g = torch.Generator().manual_seed(1)
+        us = [(torch.rand((4, 1, s, s, 256), generator=g).to(dev), torch.rand((4, 1, s, s, 256), generator=g).to(dev)) for s in (2, 2, 4, 8)]
+    grads = {}
+    for mode in ("plain", "deferred"):
+        for p in model.parameters():
+            p.grad = None
+        loss = mse_loss(model(x, uniforms=us)[0], x)
+        if mode == "plain":
+            loss.backward()
+        else:
+            backward(loss)
+        assert ops._lib.load().mcq_wgrad_pending() == 0
+        grads[mode] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert set(grads["plain"]) == set(grads["deferred"]) and len(grads["plain"]) > 50
+    for n in grads["plain"]:
+        assert torch.equal(grads["plain"][n], grads["deferred"][n]), n

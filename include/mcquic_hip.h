@@ -469,7 +469,7 @@ int mcq_pack_conv_weight_winograd16_f32(const float* w, int32_t Cout, int32_t Ci
 /* ---- the weight gradients' reduce passes, batched (round 5) ----------------------------------------------------------------------------
  * mcq_wgrad_defer(1): from now on the mcq_conv2d_wgrad*_nchw* entry points record their second pass (the fixed-order sum of the
  * partial tiles in `workspace` -> dW in OIHW order, db) instead of launching it; mcq_wgrad_flush(0, stream) launches everything
- * recorded, 72 convolutions per launch, and empties the record (discard != 0: empties it without launching, after an error).
+ * recorded, 80 convolutions per launch, and empties the record (discard != 0: empties it without launching, after an error).
  * Until the flush the caller keeps every workspace alive and reads no dW / db.  Same sums in the same order as the one-by-one pass.
  * mcq_wgrad_pending(): convolutions recorded and not yet flushed.  Process-wide switch: one backward pass at a time uses it. */
 void mcq_wgrad_defer(int32_t on);

@@ -381,21 +381,22 @@ __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(WgRowsReduceK p)
 // A captured training step held 56 reduce launches, 44 of them 5-9 us of latency for microseconds of traffic.  While deferral is
 // on (mcq_wgrad_defer; mcquic_amd.autograd.backward switches it on around a backward pass it owns) the entry points below record
 // their reduce pass per convolution instead of launching it, and mcq_wgrad_flush launches all recorded passes, up to
-// REDUCE_BATCH per launch: blockIdx.x walks the jobs' 64-output blocks back to back.  Same sums in the same order as the
+// REDUCE_BATCH per launch (blockIdx.y = the convolution).  Same sums in the same order as the
 // one-by-one kernel.  The caller keeps every workspace alive until the flush and reads no weight gradient before it.
-constexpr int REDUCE_BATCH = 72;
+constexpr int REDUCE_BATCH = 80;
 struct ReduceJob { const float* part; const float* bias_part; float* dw; float* dbias; int groups, Cout, Cin, taps; };
-struct ReduceBatch { ReduceJob job[REDUCE_BATCH]; unsigned first[REDUCE_BATCH + 1]; int njobs; };
+struct ReduceBatch { ReduceJob job[REDUCE_BATCH]; };
 
+// grid (blocks of the largest job, jobs): a job's surplus blocks leave at once.  (The first form put the jobs' blocks back to back
+// on blockIdx.x and searched a prefix table: 72 dependent scalar loads per workgroup, 3 us each -- four times the one-by-one passes.)
 __global__ __launch_bounds__(256) void wgrad_rows_reduce_batch_kernel(ReduceBatch b) {
     __shared__ float red[4][64];
-    int j = 0;
-    while (j + 1 < b.njobs && blockIdx.x >= b.first[j + 1]) ++j;          // (uniform: scalar compares over the kernel-argument table)
-    const ReduceJob q = b.job[j];
+    const ReduceJob q = b.job[blockIdx.y];                              // (uniform index into the kernel-argument table)
     const int Cout = q.Cout, Cin = q.Cin;
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const size_t i = (size_t)(blockIdx.x - b.first[j]) * 64 + lane;
     const size_t per = (size_t)q.taps * Cout * Cin;
+    if ((size_t)blockIdx.x * 64 >= per + (q.dbias ? (size_t)Cout : 0)) return;      // (workgroup-uniform)
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
     const bool is_bias = i >= per;
     const size_t co_b = i - per;
     const bool live = is_bias ? (q.dbias != nullptr && co_b < (size_t)Cout) : true;
@@ -971,16 +972,14 @@ extern "C" int mcq_wgrad_flush(int32_t discard, void* stream) {
     for (size_t at = 0; at < jobs.size(); at += REDUCE_BATCH) {
         ReduceBatch b;
         const int n = (int)(jobs.size() - at < (size_t)REDUCE_BATCH ? jobs.size() - at : (size_t)REDUCE_BATCH);
-        unsigned blocks = 0;
+        unsigned most = 0;
         for (int j = 0; j < REDUCE_BATCH; ++j) {
             const ReduceJob& q = jobs[at + (j < n ? j : 0)];
             b.job[j] = q;
-            b.first[j] = blocks;
-            if (j < n) blocks += (unsigned)(((size_t)q.taps * q.Cout * q.Cin + (q.dbias ? (size_t)q.Cout : 0) + 63) / 64);
+            const unsigned blocks = (unsigned)(((size_t)q.taps * q.Cout * q.Cin + (q.dbias ? (size_t)q.Cout : 0) + 63) / 64);
+            if (j < n && blocks > most) most = blocks;
         }
-        b.first[REDUCE_BATCH] = blocks;
-        b.njobs = n;
-        hipLaunchKernelGGL(wgrad_rows_reduce_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+        hipLaunchKernelGGL(wgrad_rows_reduce_batch_kernel, dim3(most, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
     }
     return mcq_check_launch();
 }

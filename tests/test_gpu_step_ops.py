@@ -369,9 +369,13 @@ def test_deferred_reduce_passes_give_the_same_gradients(dev, kind):
         g = torch.Generator().manual_seed(1)
         us = [(torch.rand((4, 1, s, s, 256), generator=g).to(dev), torch.rand((4, 1, s, s, 256), generator=g).to(dev)) for s in (2, 2, 4, 8)]
     grads = {}
+    ema0 = [f.detach().clone() for f in model._quantizer._entropyCoder._freqEMA]
     for mode in ("plain", "deferred"):
         for p in model.parameters():
             p.grad = None
+        with torch.no_grad():                                       # (the forward moves the frequency EMA, which the random drop reads)
+            for f, f0 in zip(model._quantizer._entropyCoder._freqEMA, ema0):
+                f.copy_(f0)
         loss = mse_loss(model(x, uniforms=us)[0], x)
         if mode == "plain":
             loss.backward()

@@ -18,6 +18,7 @@
 //   workgroup   = 4 waves of one tile, summed through LDS in a fixed tree before the partials leave the CU
 //   second pass = wgrad_rows_reduce_kernel: fixed-order sum over the workgroups' partials -> dW in OIHW order, db
 // Deterministic: no atomics anywhere.
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -969,17 +970,20 @@ extern "C" int mcq_wgrad_flush(int32_t discard, void* stream) {
         jobs.swap(g_jobs);
     }
     if (discard || jobs.empty()) return MCQ_OK;
-    for (size_t at = 0; at < jobs.size(); at += REDUCE_BATCH) {
+    // a launch's grid.x is its LARGEST job's block count: jobs go largest first, and a launch ends where the next job would leave
+    // more than a quarter of its row of blocks empty (the first form mixed 128 -> 512 shuffle convolutions with 1x1 ones:
+    // three quarters of 738 k workgroups were dispatched to leave at once, 233 us)
+    auto blocks_of = [](const ReduceJob& q) { return (unsigned)(((size_t)q.taps * q.Cout * q.Cin + (q.dbias ? (size_t)q.Cout : 0) + 63) / 64); };
+    std::stable_sort(jobs.begin(), jobs.end(), [&](const ReduceJob& a, const ReduceJob& b) { return blocks_of(a) > blocks_of(b); });
+    size_t at = 0;
+    while (at < jobs.size()) {
         ReduceBatch b;
-        const int n = (int)(jobs.size() - at < (size_t)REDUCE_BATCH ? jobs.size() - at : (size_t)REDUCE_BATCH);
-        unsigned most = 0;
-        for (int j = 0; j < REDUCE_BATCH; ++j) {
-            const ReduceJob& q = jobs[at + (j < n ? j : 0)];
-            b.job[j] = q;
-            const unsigned blocks = (unsigned)(((size_t)q.taps * q.Cout * q.Cin + (q.dbias ? (size_t)q.Cout : 0) + 63) / 64);
-            if (j < n && blocks > most) most = blocks;
-        }
+        const unsigned most = blocks_of(jobs[at]);
+        int n = 0;
+        while (n < REDUCE_BATCH && at + n < jobs.size() && 4u * blocks_of(jobs[at + n]) >= 3u * most) ++n;
+        for (int j = 0; j < REDUCE_BATCH; ++j) b.job[j] = jobs[at + (j < n ? j : 0)];
         hipLaunchKernelGGL(wgrad_rows_reduce_batch_kernel, dim3(most, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
+        at += n;
     }
     return mcq_check_launch();
 }

@@ -371,6 +371,13 @@ int mcq_mse_bwd_f32(const float* a, const float* b, const float* dloss, float* d
 int mcq_sumsq_f32(const float* x, float* out, void* workspace, int64_t n, void* stream);
 int mcq_clip_by_norm_f32(float* x, const float* sumsq, float max_norm, float eps, float* norm_out /* or NULL */, int64_t n, void* stream);
 
+/* Many tensors -> their slices of one flat buffer in ONE launch (the gradients of a captured training step into the buffer the
+ * all-reduce and the optimizer read; torch.cat moves 666 tensors in six launches): device tables as for mcq_adam_step_f32 --
+ * `src_ptrs` [ntensors] addresses, `dst_offsets` / `numel` [ntensors] in floats, and one (tensor, first element) entry per
+ * mcq_adam_chunk()-element chunk in `blk_tensor` / `blk_first` [nblocks]. */
+int mcq_gather_flat_f32(const void* src_ptrs, float* flat, const int64_t* dst_offsets, const int64_t* numel, const int32_t* blk_tensor,
+                        const int64_t* blk_first, int32_t nblocks, void* stream);
+
 /* Adam / AdamW over a whole model in ONE launch (the `self._optimizer.step()` of mcquic/train/trainer.py:283 with the reference's
  * `Adam`, configs/a800_8.yaml:20-25; arithmetic of torch.optim.Adam / AdamW: lerp of exp_avg, mul + addcmul of exp_avg_sq, bias
  * corrections from the step count, param -= lr / bc1 * exp_avg / (sqrt(exp_avg_sq) / sqrt(bc2) + eps); L2 or decoupled decay).

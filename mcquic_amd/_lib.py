@@ -118,6 +118,7 @@ SYMBOLS = {
     "mcq_mse_workspace_bytes": (c_size_t, [c_int64]),
     "mcq_mse_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_mse_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mcq_gather_flat_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "mcq_adam_chunk": (c_int32, []),
     "mcq_adam_step_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
                                     c_double, c_int32, c_int32, c_void_p, c_void_p]),

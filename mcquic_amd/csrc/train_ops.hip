@@ -684,6 +684,28 @@ extern "C" int mcq_mse_bwd_f32(const float* a, const float* b, const float* dlos
     return mcq_check_launch();
 }
 
+// many tensors -> their slices of one flat buffer in ONE launch: workgroup b copies chunk blk_first[b] of tensor blk_tensor[b]
+// (device tables like the optimizer's: the tensor list does not travel as kernel arguments, 4 KB at a time)
+__global__ __launch_bounds__(256) void gather_flat_kernel(const unsigned long long* __restrict__ src_ptrs, float* __restrict__ flat,
+                                                          const long long* __restrict__ dst_off, const long long* __restrict__ numel,
+                                                          const int* __restrict__ blk_tensor, const long long* __restrict__ blk_first) {
+    const int t = blk_tensor[blockIdx.x];
+    const long long first = blk_first[blockIdx.x];
+    const float* __restrict__ src = (const float*)src_ptrs[t];
+    float* __restrict__ dst = flat + dst_off[t];
+    const long long n = numel[t];
+    const long long end = first + ADAM_CHUNK < n ? first + ADAM_CHUNK : n;
+    for (long long i = first + threadIdx.x; i < end; i += 256) dst[i] = src[i];
+}
+
+extern "C" int mcq_gather_flat_f32(const void* src_ptrs, float* flat, const int64_t* dst_offsets, const int64_t* numel, const int32_t* blk_tensor,
+                                   const int64_t* blk_first, int32_t nblocks, void* stream) {
+    if (!src_ptrs || !flat || !dst_offsets || !numel || !blk_tensor || !blk_first || nblocks <= 0) return MCQ_EINVAL;
+    hipLaunchKernelGGL(gather_flat_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)src_ptrs, flat,
+                       (const long long*)dst_offsets, (const long long*)numel, (const int*)blk_tensor, (const long long*)blk_first);
+    return mcq_check_launch();
+}
+
 extern "C" int32_t mcq_adam_chunk(void) { return ADAM_CHUNK; }
 
 extern "C" int mcq_adam_step_f32(const void* ptr_tables, int32_t ntensors, const int64_t* numel, const int32_t* blk_tensor, const int64_t* blk_first,

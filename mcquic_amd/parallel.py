@@ -349,7 +349,7 @@ class GraphedTrainStep:
                 with torch.cuda.graph(g, pool=pool, stream=self._stream, **mode):
                     self._segment(k)
                     if self.live_groups[k]:
-                        torch.cat([p.grad.reshape(-1) for p in self.live_groups[k]], out=self.slices[k])
+                        self._gather(k)
                     if k == 0:
                         sinks = [c.countSink() for c in self.coders]
                         # (one coder per model: its count buffer itself -- the sampling kernels add into it, nothing is copied)
@@ -383,6 +383,42 @@ class GraphedTrainStep:
                 torch.cuda.synchronize()
                 self.post = None
                 self._restore_optimizer_state(before)        # (host-side counters may have moved before the capture gave up)
+
+    def _gather(self, k: int):
+        """Segment k's gradients into its slice of the flat buffer: ONE launch over device tables (mcq_gather_flat_f32) instead of
+        torch.cat's six.  Called inside the capture: the gradients' addresses (allocations of the captured backward pass, the same
+        on every replay) reach the device table through a copy node from a pinned host tensor this object keeps alive."""
+        from . import _lib
+        from .ops import check, _guard, _stream
+        params = self.live_groups[k]
+        lib = _lib.load()
+        chunk = lib.mcq_adam_chunk()
+        dev = self.flat.device
+        if not hasattr(self, "_gatherTables"):
+            self._gatherTables = {}
+        tb = self._gatherTables.get(k)
+        if tb is None:
+            sizes = [p.numel() for p in params]
+            offs, at = [], 0
+            for n in sizes:
+                offs.append(at)
+                at += n
+            blk_t, blk_f = [], []
+            for i, n in enumerate(sizes):
+                for first in range(0, n, chunk):
+                    blk_t.append(i)
+                    blk_f.append(first)
+            tb = self._gatherTables[k] = dict(
+                host=torch.empty(len(params), dtype=torch.int64, pin_memory=True), ptrs=torch.empty(len(params), dtype=torch.int64, device=dev),
+                offs=torch.tensor(offs, dtype=torch.int64).to(dev), numel=torch.tensor(sizes, dtype=torch.int64).to(dev),
+                blk_t=torch.tensor(blk_t, dtype=torch.int32).to(dev), blk_f=torch.tensor(blk_f, dtype=torch.int64).to(dev), nblocks=len(blk_t))
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in params]
+        tb["grads"] = grads                                   # (alive as long as the tables point at them)
+        tb["host"].copy_(torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64))
+        tb["ptrs"].copy_(tb["host"], non_blocking=True)       # (a copy NODE inside the capture: re-read from the pinned tensor on every replay)
+        with _guard(dev):
+            check(lib.mcq_gather_flat_f32(tb["ptrs"].data_ptr(), self.slices[k].data_ptr(), tb["offs"].data_ptr(), tb["numel"].data_ptr(),
+                                          tb["blk_t"].data_ptr(), tb["blk_f"].data_ptr(), tb["nblocks"], _stream()), "mcq_gather_flat_f32")
 
     # ---- replica state ---------------------------------------------------------------------------------------------------
     def _broadcast_state(self):

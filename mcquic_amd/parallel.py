@@ -335,6 +335,7 @@ class GraphedTrainStep:
                 n = sum(p.numel() for p in g)
                 self.slices.append(self.flat[off: off + n])
                 off += n
+            self._gather_tables()
             self._init_optimizer_state()
             torch.cuda.synchronize()
             with torch.no_grad():
@@ -392,12 +393,26 @@ class GraphedTrainStep:
         from .ops import check, _guard, _stream
         params = self.live_groups[k]
         lib = _lib.load()
-        chunk = lib.mcq_adam_chunk()
         dev = self.flat.device
-        if not hasattr(self, "_gatherTables"):
-            self._gatherTables = {}
-        tb = self._gatherTables.get(k)
-        if tb is None:
+        tb = self._gatherTables[k]
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in params]
+        tb["grads"] = grads                                   # (alive as long as the tables point at them)
+        tb["host"].copy_(torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64))
+        tb["ptrs"].copy_(tb["host"], non_blocking=True)       # (a copy NODE inside the capture: re-read from the pinned tensor on every replay)
+        with _guard(dev):
+            check(lib.mcq_gather_flat_f32(tb["ptrs"].data_ptr(), self.slices[k].data_ptr(), tb["offs"].data_ptr(), tb["numel"].data_ptr(),
+                                          tb["blk_t"].data_ptr(), tb["blk_f"].data_ptr(), tb["nblocks"], _stream()), "mcq_gather_flat_f32")
+
+    def _gather_tables(self):
+        """The static side of `_gather` (sizes, offsets, chunk tables, the pinned pointer buffer), built OUTSIDE the captures: host-to-device
+        copies from pageable memory invalidate a capture."""
+        from . import _lib
+        chunk = _lib.load().mcq_adam_chunk()
+        dev = self.flat.device
+        self._gatherTables = {}
+        for k, params in enumerate(self.live_groups):
+            if not params:
+                continue
             sizes = [p.numel() for p in params]
             offs, at = [], 0
             for n in sizes:
@@ -408,17 +423,11 @@ class GraphedTrainStep:
                 for first in range(0, n, chunk):
                     blk_t.append(i)
                     blk_f.append(first)
-            tb = self._gatherTables[k] = dict(
+            self._gatherTables[k] = dict(
                 host=torch.empty(len(params), dtype=torch.int64, pin_memory=True), ptrs=torch.empty(len(params), dtype=torch.int64, device=dev),
                 offs=torch.tensor(offs, dtype=torch.int64).to(dev), numel=torch.tensor(sizes, dtype=torch.int64).to(dev),
                 blk_t=torch.tensor(blk_t, dtype=torch.int32).to(dev), blk_f=torch.tensor(blk_f, dtype=torch.int64).to(dev), nblocks=len(blk_t))
-        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in params]
-        tb["grads"] = grads                                   # (alive as long as the tables point at them)
-        tb["host"].copy_(torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64))
-        tb["ptrs"].copy_(tb["host"], non_blocking=True)       # (a copy NODE inside the capture: re-read from the pinned tensor on every replay)
-        with _guard(dev):
-            check(lib.mcq_gather_flat_f32(tb["ptrs"].data_ptr(), self.slices[k].data_ptr(), tb["offs"].data_ptr(), tb["numel"].data_ptr(),
-                                          tb["blk_t"].data_ptr(), tb["blk_f"].data_ptr(), tb["nblocks"], _stream()), "mcq_gather_flat_f32")
+        torch.cuda.synchronize()
 
     # ---- replica state ---------------------------------------------------------------------------------------------------
     def _broadcast_state(self):

@@ -201,7 +201,7 @@ class MseFn(torch.autograd.Function):
 _ONES = {}
 
 
-def backward(loss: torch.Tensor) -> None:
+def backward(loss: torch.Tensor, defer_reduce: bool = True) -> None:
     """`loss.backward()` with the root gradient taken from a cached 1.0 on the loss's device (the engine otherwise allocates and
     FILLS one per call -- the one ATen launch left in a captured training step) and with the weight gradients' reduce passes of the
     whole pass run in a few launches at its end (ops.wgrad_deferral).  NOT for a backward pass something else listens to (torch DDP
@@ -210,6 +210,9 @@ def backward(loss: torch.Tensor) -> None:
     one = _ONES.get(key)
     if one is None:
         one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    if not defer_reduce:                                        # (something reads gradients DURING the pass, e.g. torch DDP's bucket hooks)
+        loss.backward(one if loss.dim() == 0 else None)
+        return
     with ops.wgrad_deferral():                                  # (this pass is ours end to end: the weight gradients' reduce passes run batched)
         loss.backward(one if loss.dim() == 0 else None)
 

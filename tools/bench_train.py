@@ -86,7 +86,7 @@ def main():
             p.grad = None
         xHat, yHat, codes, logits = net(x)
         loss = mse_loss(xHat, x)                            # plain MSE through this library's reduction (no memset node in a capture)
-        backward(loss)
+        backward(loss, defer_reduce=net is model)          # (under torch DDP the bucket hooks read gradients while the pass runs)
         if opt is not None:
             opt.step()
         return loss

@@ -682,6 +682,28 @@ def seed_rng(seed: int, device=None) -> None:
         st.copy_(val)
 
 
+def get_rng_state(device=None) -> torch.Tensor:
+    """{seed, offset} of the in-kernel generator of `device` as a CPU int64[2] tensor -- what a checkpoint stores beside
+    torch.cuda.get_rng_state() (the soft assignment's draws are NOT torch's stream, so torch's state does not cover them)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = _rng_states.get(dev.index)
+    if st is None:
+        seed_rng(torch.initial_seed(), dev)
+        st = _rng_states[dev.index]
+    return st.detach().cpu().clone()
+
+
+def set_rng_state(state: torch.Tensor, device=None) -> None:
+    """Restore a state returned by get_rng_state (in place: a captured step keeps reading the same device tensor)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    state = torch.as_tensor(state, dtype=torch.int64).reshape(2)
+    st = _rng_states.get(dev.index)
+    if st is None:
+        _rng_states[dev.index] = state.to(dev)
+    else:
+        st.copy_(state)
+
+
 def rng_snapshot(device) -> torch.Tensor:
     """{seed, offset} for ONE pair of draws (a fresh int64[2] device tensor), after which the generator's offset moves on -- both
     on the device and in stream order, so the sequence is captured by a hipGraph and advances on every replay.  Seeded from

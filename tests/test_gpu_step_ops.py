@@ -386,3 +386,18 @@ def test_deferred_reduce_passes_give_the_same_gradients(dev, kind):
     assert set(grads["plain"]) == set(grads["deferred"]) and len(grads["plain"]) > 50
     for n in grads["plain"]:
         assert torch.equal(grads["plain"][n], grads["deferred"][n]), n
+
+
+def test_generator_state_round_trip(dev):
+    """ops.get_rng_state / set_rng_state: a run resumed from the saved state draws what the uninterrupted run drew."""
+    from mcquic_amd import ops
+    ops.seed_rng(77, dev)
+    ops.rng_snapshot(dev)
+    saved = ops.get_rng_state(dev)
+    a = [ops.hash_uniform(ops.rng_snapshot(dev), 1, (1000,)) for _ in range(3)]
+    ops.seed_rng(5, dev)                                            # (something else re-seeds in between)
+    ops.set_rng_state(saved, dev)
+    b = [ops.hash_uniform(ops.rng_snapshot(dev), 1, (1000,)) for _ in range(3)]
+    assert saved.device.type == "cpu" and saved.tolist() == [77, 1]
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

@@ -80,9 +80,38 @@ struct ConvK {
     int tiles_log2;    // (1 << tiles_log2) output tiles per workgroup
     int total_wgs;     // (persistent Winograd instance) workgroups' worth of tiles along x; the grid may be smaller
     unsigned flags; float res_scale;
+    int xlds;          // GDN / IGDN 1x1 launches whose multiplier IS the input: the k-loop parks the loaded x in LDS for the epilogue
 };
 
 constexpr int PRO_NONE = 0, PRO_SILU = 1, PRO_SQUARE = 2;
+#ifndef MCQ_GDN_XLDS
+#define MCQ_GDN_XLDS 0          // build switch: 0 = the GDN / IGDN epilogue re-reads x from memory (rounds 1-4: 2.0x the read traffic)
+#endif
+#ifndef MCQ_FAST_RSQRT
+#define MCQ_FAST_RSQRT 0        // build switch: 1 = the GDN / IGDN epilogue forms 1/sqrt(s) and sqrt(s) from v_rsq_f32 + one Newton step
+#endif
+// s = beta + sum gamma x^2 >= beta > 0 and far from the denormal range (the reparametrised beta is bounded below by 2^-18^2 ... ~1e-6),
+// so none of sqrtf's / the division's range handling is needed: v_rsq_f32 (1 ulp) corrected once is within 1 ulp of the exact value
+__device__ __forceinline__ float mcq_rsqrt_pos(float s) {
+    if (!MCQ_FAST_RSQRT) return 1.0f / sqrtf(s);
+    const float y = __builtin_amdgcn_rsqf(s);
+    const float e = fmaf(-s * y, y, 1.0f);
+    return fmaf(0.5f * y, e, y);
+}
+__device__ __forceinline__ float mcq_sqrt_pos(float s) {
+    if (!MCQ_FAST_RSQRT) return sqrtf(s);
+    const float y = __builtin_amdgcn_rsqf(s);
+    const float r = s * y;
+    const float e = fmaf(-r, r, s);
+    return fmaf(0.5f * y, e, r);
+}
+#ifndef MCQ_XLDS_STEPS
+#define MCQ_XLDS_STEPS 64       // k-steps (channel pairs) parked; below 64 the later channels are re-read from memory (step MCQ_XLDS_STEPS is a dump slot)
+#endif
+constexpr int XLDS_WAVE_FLOATS = (MCQ_XLDS_STEPS < 64 ? MCQ_XLDS_STEPS + 1 : 64) * 64;
+#ifndef MCQ_XLDS_TILES_LOG2
+#define MCQ_XLDS_TILES_LOG2 2   // waves per workgroup of such a launch (log2): 16 KB of LDS per wave bounds the waves resident on a CU
+#endif
 #ifndef MCQ_SHUFFLE_SIDE
 #define MCQ_SHUFFLE_SIDE 1      // build switch (A/B of the dominant instance's register allocation): 0 = the PixelShuffle store takes no side tensors
 #endif
@@ -408,6 +437,8 @@ next_tile:
 #pragma unroll
     for (int i = 0; i < PGV; ++i) Vn[i] = 0.0f;
     if (WINO && active) wino_transform(0, Vn);
+    // (this wave's 64 x 64 floats of the parking area, at its own lane)
+    float* const xpark = mcq_lds + (size_t)wave * XLDS_WAVE_FLOATS + lane;
     auto kbody = [&](const int sp) __attribute__((always_inline)) {
         // Every VALU instruction between two MFMAs costs the matrix pipe ~10 cycles (tools/probes/mfma_issue.hip), so
         // the k-loop has none: the channel-pair offset of an activation load lives in its buffer descriptor -- one per
@@ -450,6 +481,12 @@ next_tile:
 #pragma unroll
                 for (int nb = 0; nb < NBG; ++nb) {
                     float v = B[sb][nb];
+                    // (round 5) y = x f(beta + gamma x^2): the closing multiply needs the very x values this loop streams through --
+                    // lane (hi, j) loads channel 2 s + hi of pixel j at k-step s.  They are parked in LDS ([k-step][lane], 16 KB per
+                    // wave at 128 channels, no other wave reads them) instead of being read from memory a second time: these launches
+                    // are HBM-bound (3.9 TB/s at 3 x the tensor) with the matrix pipe 93 % idle, so the 64 ds_write cost nothing
+                    if (MCQ_GDN_XLDS && TAPS == 1 && PRO == PRO_SQUARE && NB == 1 && p.xlds)
+                        xpark[(size_t)(MCQ_XLDS_STEPS < 64 ? min(sp + u, MCQ_XLDS_STEPS) : sp + u) * 64] = v;
                     if (PRO == PRO_SILU) v = mcq_silu(v);
                     if (PRO == PRO_SQUARE) v = v * v;
                     bv[nb] = v;
@@ -665,14 +702,22 @@ next_tile:
                 }
                 if (f & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL | MCQ_CONV_DSILU_MUL)) {
                     float m[16];
+                    if (MCQ_GDN_XLDS && TAPS == 1 && PRO == PRO_SQUARE && NB == 1 && p.xlds && (MCQ_XLDS_STEPS >= 64 || co_row0 < 2u * MCQ_XLDS_STEPS)) {
+                        // row c = co_row0 + (r & 3) + 8 (r >> 2) + 4 hi of pixel j went through the k-loop at step c >> 1, in the half-wave
+                        // c & 1: each half-wave reads 32 consecutive floats
+                        const float* xw = mcq_lds + (size_t)wave * XLDS_WAVE_FLOATS + (co_row0 >> 1) * 64u + (unsigned)hi * 128u + (unsigned)j;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m[r] = mcq_buffer_load_s(mr[nb], pvo[nb], so[r]);
+                        for (int r = 0; r < 16; ++r) m[r] = xw[(mcq_drow(r, 0) >> 1) * 64 + (mcq_drow(r, 0) & 1) * 32];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) m[r] = mcq_buffer_load_s(mr[nb], pvo[nb], so[r]);
+                    }
                     if (f & MCQ_CONV_GDN) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = m[r] * (1.0f / sqrtf(v[r]));
+                        for (int r = 0; r < 16; ++r) v[r] = m[r] * mcq_rsqrt_pos(v[r]);
                     } else if (f & MCQ_CONV_IGDN) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = m[r] * sqrtf(v[r]);
+                        for (int r = 0; r < 16; ++r) v[r] = m[r] * mcq_sqrt_pos(v[r]);
                     } else if (f & MCQ_CONV_MUL) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) v[r] = m[r] * v[r];
@@ -1203,8 +1248,10 @@ int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2
     k.ks_log2 = ksplit_log2;
     k.slice_pairs = k.S >> ksplit_log2;
     k.tiles_log2 = ksplit_log2 >= 2 ? 0 : 2 - ksplit_log2;           // 4 waves per workgroup, 8 for 8-way split
+    if (!(MCQ_GDN_XLDS && NB == 1 && ksplit_log2 == 0 && k.ks == 1 && pro == PRO_SQUARE)) k.xlds = 0;
+    if (k.xlds) k.tiles_log2 = MCQ_XLDS_TILES_LOG2;
     const int waves = 1 << (k.ks_log2 + k.tiles_log2);
-    const size_t lds = ksplit_log2 ? (size_t)waves * NB * 1024 * sizeof(float) : 0;
+    const size_t lds = ksplit_log2 ? (size_t)waves * NB * 1024 * sizeof(float) : k.xlds ? (size_t)waves * XLDS_WAVE_FLOATS * sizeof(float) : 0;
     const dim3 grid((unsigned)((tiles + (1 << k.tiles_log2) - 1) >> k.tiles_log2), (unsigned)co_tiles, (unsigned)k.nprob);
     const dim3 block(64 * waves);
     // (round 4, measured and removed: `s_setprio 2` for the first-dispatched workgroup of every CU in single-round launches, so that
@@ -1528,6 +1575,10 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     k.TP = steps_padded(d->Cin, d->ksize);
     k.flags = fl; k.res_scale = d->res_scale;
     k.nprob = nprob;
+    // GDN / IGDN whose multiplier is the launch's own input, all channels of it inside one k-loop of <= 64 steps (launch_tile
+    // clears this again for the tiles without the LDS parking area)
+    k.xlds = (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN)) && d->ksize == 1 && d->stride == 1 && d->Cin == d->Cout && d->Cin <= 128;
+    for (int c = 0; c < nprob; ++c) if (descs[c].mul != descs[c].x) k.xlds = 0;
     for (int c = 1; c < MCQ_CONV_MAX_MULTI; ++c) {
         const mcq_conv_desc* e = descs + (c < nprob ? c : 0);
         ConvPtrs& a = k.alt[c - 1];

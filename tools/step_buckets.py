@@ -21,7 +21,7 @@ def bucket(name: str) -> str:
         return "1x1 conv"
     if "wgrad_rows_kernel" in n:
         return "wgrad row walk"
-    if "wgrad_rows_reduce_kernel" in n or "wgrad_reduce_kernel" in n:
+    if "wgrad_rows_reduce" in n or "wgrad_reduce_kernel" in n:      # (incl. wgrad_rows_reduce_batch_kernel, round 5)
         return "wgrad reduce passes"
     if "wgrad_rows_s2" in n:
         return "wgrad stride 2"

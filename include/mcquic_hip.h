@@ -81,7 +81,9 @@ typedef struct mcq_conv_desc {
     int32_t stride;        /* 1 or 2                                                               */
     uint32_t flags;
     float   res_scale;     /* +1 or -1                                                             */
-    int32_t tile;          /* 0 = auto; else (log2 split-K << 8) | (MB << 4) | NB forces the wave tile (testing / tuning) */
+    int32_t tile;          /* 0 = auto; else (log2 split-K << 8) | (MB << 4) | NB forces the wave tile (testing / tuning);
+                            * bit 0x400: the 128 x 64 tile of a 3x3 stride-1 layer over pixel PAIRS (same bits, wide epilogue accesses;
+                            * even output width, flags within SiLU / twin / residual / silu' / PixelShuffle), bit 0x800: never */
 } mcq_conv_desc;
 
 /* Number of floats mcq_pack_conv_weight_f32 writes for a [Cout, Cin, ks, ks] weight. */

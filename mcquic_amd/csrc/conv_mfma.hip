@@ -87,6 +87,9 @@ constexpr int PRO_NONE = 0, PRO_SILU = 1, PRO_SQUARE = 2;
 #ifndef MCQ_GDN_XLDS
 #define MCQ_GDN_XLDS 0          // build switch: 0 = the GDN / IGDN epilogue re-reads x from memory (rounds 1-4: 2.0x the read traffic)
 #endif
+#ifndef MCQ_PAIR
+#define MCQ_PAIR 0              // build switch: 1 = 3x3 stride-1 layers on the 128 x 64 tile run over pixel PAIRS (conv_mfma_kernel<..., PAIR = true>)
+#endif
 #ifndef MCQ_FAST_RSQRT
 #define MCQ_FAST_RSQRT 0        // build switch: 1 = the GDN / IGDN epilogue forms 1/sqrt(s) and sqrt(s) from v_rsq_f32 + one Newton step
 #endif
@@ -154,7 +157,7 @@ template <> __device__ __forceinline__ float mcq_wload<1>(__amdgpu_buffer_rsrc_t
 }
 
 
-template <int MB, int NB, int PRO, int PFA, int PFB, int TAPS, int OCC>
+template <int MB, int NB, int PRO, int PFA, int PFB, int TAPS, int OCC, bool PAIR = false>
 __global__ __launch_bounds__(TAPS >= 12 ? 256 : 512, OCC) void conv_mfma_kernel(ConvK p) {
     static_assert(TAPS == 1 ? PFA == PFB : ((TAPS % PFA == 0 || PFA % TAPS == 0) && PFB % TAPS == 0 && PFB % PFA == 0),
                   "ring depths must tile the unrolled body");
@@ -170,6 +173,12 @@ __global__ __launch_bounds__(TAPS >= 12 ? 256 : 512, OCC) void conv_mfma_kernel(
     // form).  Sixteen accumulator tiles per 32-row band: the instance takes ONE band per wave (MB = 1; the four waves of a
     // workgroup are the four bands of 128 output channels over the same tiles, so the input patches hit L1 three times out of
     // four), accumulators again in hand-numbered AGPRs; the epilogue sees NB = 4 pixel blocks (oy, ox).
+    // PAIR (round 5; direct 3x3 stride 1, NB = 2): the two pixel blocks of a wave are the EVEN and the ODD pixels of 32 horizontally
+    // adjacent pairs (the Winograd form's geometry without its arithmetic).  Per channel pair and filter row a lane loads the four
+    // inputs under its pair once (x = 2 xp - 1 .. 2 xp + 2) and feeds them to the six (tap, pixel) MFMA groups that read them -- 12
+    // activation loads per channel pair instead of 18 -- and every output-shaped access of the epilogue is one 64-bit access per row
+    // for both pixels (even widths) instead of two 32-bit ones.
+    static_assert(!PAIR || (TAPS == 9 && NB == 2 && PRO == 0 && PFB % 9 == 0), "PAIR: the direct 3x3 form with two pixel blocks");
     constexpr bool W2D = TAPS == 16;
     constexpr bool WINO = TAPS == 12 || W2D;
     constexpr int PG = W2D ? 16 : 4;                // transform positions = k-steps per group of operand loads
@@ -179,7 +188,8 @@ __global__ __launch_bounds__(TAPS >= 12 ? 256 : 512, OCC) void conv_mfma_kernel(
     //  epilogue is compiled for -- one set per kernel instance: dispatching on the flags inside the persistent tile loop left
     //  every instance's temporaries live around the loop and pushed the compiler into the AGPRs)
     constexpr unsigned WEF = wino_epilogue_flags(PRO);
-    constexpr int NBG = WINO ? 1 : NB;              // pixel blocks the operand stream walks (pair blocks for WINO)
+    constexpr int NBG = (WINO || PAIR) ? 1 : NB;    // pixel blocks the operand stream walks (pair blocks for WINO / PAIR)
+    constexpr int LT = PAIR ? 12 : TAPS;            // activation loads per channel pair and pixel block
     constexpr int NACC = WINO ? PG : NB;            // accumulator tiles per 32-row band
     // The 128-row Winograd instance has 4 x 4 accumulator tiles = 256 registers: the whole AGPR half of a one-wave-per-SIMD
     // register file.  hipcc's allocator cannot work with that (it parks other values in AGPRs that do not exist and splits
@@ -242,10 +252,10 @@ next_tile:
     bool valid[NB];
     __amdgpu_buffer_rsrc_t rsrc[NB];
     const char* xb[NB];                             // (wave-uniform) first byte of the block's image
-    unsigned voff[NBG][TAPS];                       // per-tap byte offset of this lane's pixel, or the OOB marker
+    unsigned voff[NBG][LT];                       // per-tap byte offset of this lane's pixel, or the OOB marker
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        int pb = WINO ? gw : gw * NB + nb;
+        int pb = (WINO || PAIR) ? gw : gw * NB + nb;
         const bool pbv = pb < p.total_blocks;
         if (!pbv) pb = p.total_blocks - 1;
         const int per_img = p.nby * p.nbx;
@@ -255,19 +265,19 @@ next_tile:
         const int bx = rem - by * p.nbx;
         img[nb] = n;
         yo[nb] = W2D ? 2 * (by * BH + ly) + (nb >> 1) : by * BH + ly;
-        xo[nb] = W2D ? 2 * (bx * BW + lx) + (nb & 1) : WINO ? 2 * (bx * BW + lx) + nb : bx * BW + lx;
+        xo[nb] = W2D ? 2 * (bx * BW + lx) + (nb & 1) : (WINO || PAIR) ? 2 * (bx * BW + lx) + nb : bx * BW + lx;
         valid[nb] = pbv && yo[nb] < p.Ho && xo[nb] < p.Wo;
         xb[nb] = reinterpret_cast<const char*>(mcq_uniform_ptr(P_x + (size_t)n * p.Cin * HW));
         rsrc[nb] = mcq_make_rsrc(xb[nb], plane_bytes);
-        if (WINO && nb > 0) continue;
+        if ((WINO || PAIR) && nb > 0) continue;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            // (WINO: tap = 4 dy + position under the pair, x = 2 xp - 1 + position)
-            const int dy = TAPS == 9 ? tap / 3 : WINO ? tap / 4 : 0, dx = TAPS == 9 ? tap % 3 : WINO ? tap % 4 : 0;
+        for (int tap = 0; tap < LT; ++tap) {
+            // (WINO / PAIR: tap = 4 dy + position under the pair, x = 2 xp - 1 + position)
+            const int dy = PAIR ? tap / 4 : TAPS == 9 ? tap / 3 : WINO ? tap / 4 : 0, dx = PAIR ? tap % 4 : TAPS == 9 ? tap % 3 : WINO ? tap % 4 : 0;
             const int yi = yo[nb] * p.stride + dy - pad;
             const int xi = xo[nb] * p.stride + dx - pad;
             const bool inb = valid[nb] && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
-            voff[WINO ? 0 : nb][tap] = inb ? (unsigned)(yi * p.W + xi + hi * HW) * 4u : MCQ_OOB;
+            voff[(WINO || PAIR) ? 0 : nb][tap] = inb ? (unsigned)(yi * p.W + xi + hi * HW) * 4u : MCQ_OOB;
         }
     }
 
@@ -280,7 +290,8 @@ next_tile:
     constexpr int PAIRS_PER_ITER = TAPS != 1 ? U / TAPS : U;
     typedef typename AVec<MB>::T avec_t;
     avec_t A[PFA];
-    float B[PFB][NBG];
+    constexpr int BSLOTS = PAIR ? PFB / 9 * 12 : PFB;     // (PAIR: the ring holds loads, 12 per channel pair, not k-steps)
+    float B[BSLOTS][NBG];
     const int tile128 = co_base >> 7, q0 = (co_base & 127) >> 5;
     const int s0 = kslice * p.slice_pairs;          // first channel pair of this wave's slice
     // weights: the copy packed for this tile height, so that a wave-wide load is one dense run of 64 * MB floats
@@ -415,9 +426,9 @@ next_tile:
             wso += 256 * MB;
         }
 #pragma unroll
-        for (int st = 0; st < PFB; ++st) {          // activations of steps 0 .. PFB-1
-            const int tap = TAPS != 1 ? st % TAPS : 0;
-            const unsigned so = soff + (unsigned)(TAPS != 1 ? st / TAPS : st) * step_bytes;
+        for (int st = 0; st < BSLOTS; ++st) {       // activations of steps 0 .. PFB-1
+            const int tap = TAPS != 1 ? st % LT : 0;
+            const unsigned so = soff + (unsigned)(TAPS != 1 ? st / LT : st) * step_bytes;
 #pragma unroll
             for (int nb = 0; nb < NBG; ++nb) B[st][nb] = mcq_buffer_load(rsrc[nb], voff[nb][tap] + so);
         }
@@ -459,6 +470,24 @@ next_tile:
         for (int u = 0; u < U; ++u) {
             if (TAPS != 1 && u > 0 && u % TAPS == 0 && sp + u / TAPS >= npairs) break;   // the slice ends inside the body
             const int sa = u % PFA, sb = u % PFB;
+            if constexpr (PAIR) {
+                // k-step (channel pair q of the body, filter row dy, tap dx): the even pixel reads load `dx` of the row, the odd one
+                // load `dx + 1`; load `dx` is dead after the even pixel's MFMAs (the odd pixel used it one step ago), load 3 after
+                // the odd pixel's last tap -- each is refilled there with the same load two channel pairs on
+                const int q = u / 9, t9 = u % 9, dy = t9 / 3, dx = t9 % 3, base = q * 12 + dy * 4;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<MB>(A[sa], mb), B[base + dx + nb][0], acc[mb][nb], 0, 0, 0);
+                    if (nb == 0) B[base + dx][0] = mcq_buffer_load(rB[0][q], voff[0][dy * 4 + dx]);
+                    else if (dx == 2) B[base + 3][0] = mcq_buffer_load(rB[0][q], voff[0][dy * 4 + 3]);
+                }
+                A[sa] = mcq_wload<MB>(wr, wlane, wso);
+                wso += 256 * MB;
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             float bv[NBG];
             if (WINO) {
                 // four loads of one (channel pair, filter row) -> the B operands of four k-steps, formed one group AHEAD (during
@@ -586,17 +615,29 @@ next_tile:
 #pragma unroll
                 for (int nb0 = 0; nb0 < NB; nb0 += EB) {
                     float vv[EB][16], rvv[EB][16], tw[EB][16];
+                    // (PAIR: the two blocks are the even and the odd pixel of a lane's pair -- 8 adjacent, 8-byte aligned bytes of every
+                    //  output-shaped tensor, the width being even: one 64-bit access per row for both)
                     if (EF & MCQ_CONV_DSILU_MUL) {              // (tw is free here: no SiLU twin in a gradient launch)
+                        if constexpr (PAIR && EB == 2) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { const f32x2v t2 = mcq_buffer_load2_s(mr[0], pvo[0], sob[r]); tw[0][r] = t2[0]; tw[1][r] = t2[1]; }
+                        } else {
 #pragma unroll
                         for (int e = 0; e < EB; ++e)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) tw[e][r] = mcq_buffer_load_s(mr[nb0 + e], pvo[nb0 + e], sob[r]);
+                        }
                     }
                     if (EF & MCQ_CONV_RESIDUAL) {
+                        if constexpr (PAIR && EB == 2) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { const f32x2v t2 = mcq_buffer_load2_s(rr_[0], pvo[0], sob[r]); rvv[0][r] = t2[0]; rvv[1][r] = t2[1]; }
+                        } else {
 #pragma unroll
                         for (int e = 0; e < EB; ++e)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) rvv[e][r] = mcq_buffer_load_s(rr_[nb0 + e], pvo[nb0 + e], sob[r]);
+                        }
                     }
 #pragma unroll
                     for (int e = 0; e < EB; ++e) {
@@ -620,6 +661,14 @@ next_tile:
                             for (int r = 0; r < 16; ++r) tw[e][r] = mcq_silu(vv[e][r]);
                         }
                     }
+                    if constexpr (PAIR && EB == 2) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mcq_buffer_store2_s(f32x2v{vv[0][r], vv[1][r]}, yr[0], pvo[0], sob[r]);
+                        if (EF & MCQ_CONV_DUAL_SILU) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mcq_buffer_store2_s(f32x2v{tw[0][r], tw[1][r]}, y2r[0], pvo[0], sob[r]);
+                        }
+                    } else {
 #pragma unroll
                     for (int e = 0; e < EB; ++e) {
 #pragma unroll
@@ -629,6 +678,66 @@ next_tile:
                             for (int r = 0; r < 16; ++r) mcq_buffer_store_s(tw[e][r], y2r[nb0 + e], pvo[nb0 + e], sob[r]);
                         }
                     }
+                    }
+                }
+                continue;
+            }
+            if constexpr (PAIR) {
+                // every other flag set the launcher sends here (subsets of SiLU / twin / residual / * silu'(.), PixelShuffle store): both
+                // pixels of the pair together, 64-bit accesses (128-bit through the shuffle: a pair's cells are four adjacent floats)
+                float v0[16], v1[16];
+                get_acc(mi, 0, v0);
+                get_acc(mi, 1, v1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { v0[r] = v0[r] + bias16[r]; v1[r] = v1[r] + bias16[r]; }
+                if (f & MCQ_CONV_SHUFFLE2) {
+                    const unsigned W2b = 2u * (unsigned)p.Wo * 4u;
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const unsigned so = ((co_row0 >> 2) + 2u * (unsigned)rq) * HoWo * 16u;
+                        f32x4v top = f32x4v{v0[rq * 4 + 0], v0[rq * 4 + 1], v1[rq * 4 + 0], v1[rq * 4 + 1]};
+                        f32x4v bot = f32x4v{v0[rq * 4 + 2], v0[rq * 4 + 3], v1[rq * 4 + 2], v1[rq * 4 + 3]};
+                        if (MCQ_SHUFFLE_SIDE && (f & MCQ_CONV_DSILU_MUL)) {
+                            const f32x4v mt = mcq_buffer_load4_s(mr[0], pvo[0], so), mb2 = mcq_buffer_load4_s(mr[0], pvo[0], so + W2b);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { top[e] = top[e] * mcq_dsilu(mt[e]); bot[e] = bot[e] * mcq_dsilu(mb2[e]); }
+                        }
+                        if (MCQ_SHUFFLE_SIDE && (f & MCQ_CONV_RESIDUAL)) {
+                            const f32x4v rt = mcq_buffer_load4_s(rr_[0], pvo[0], so), rb = mcq_buffer_load4_s(rr_[0], pvo[0], so + W2b);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { top[e] = top[e] + p.res_scale * rt[e]; bot[e] = bot[e] + p.res_scale * rb[e]; }
+                        }
+                        mcq_buffer_store4_s(top, yr[0], pvo[0], so);
+                        mcq_buffer_store4_s(bot, yr[0], pvo[0], so + W2b);
+                    }
+                    continue;
+                }
+                unsigned so[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) so[r] = (co_row0 + (unsigned)mcq_drow(r, 0)) * HoWo * 4u;
+                if (f & MCQ_CONV_DSILU_MUL) {
+                    f32x2v m2[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m2[r] = mcq_buffer_load2_s(mr[0], pvo[0], so[r]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { v0[r] = v0[r] * mcq_dsilu(m2[r][0]); v1[r] = v1[r] * mcq_dsilu(m2[r][1]); }
+                }
+                if (f & MCQ_CONV_RESIDUAL) {
+                    f32x2v r2[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) r2[r] = mcq_buffer_load2_s(rr_[0], pvo[0], so[r]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { v0[r] = v0[r] + p.res_scale * r2[r][0]; v1[r] = v1[r] + p.res_scale * r2[r][1]; }
+                }
+                if (f & MCQ_CONV_SILU_OUT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { v0[r] = mcq_silu(v0[r]); v1[r] = mcq_silu(v1[r]); }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mcq_buffer_store2_s(f32x2v{v0[r], v1[r]}, yr[0], pvo[0], so[r]);
+                if (f & MCQ_CONV_DUAL_SILU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mcq_buffer_store2_s(f32x2v{mcq_silu(v0[r]), mcq_silu(v1[r])}, y2r[0], pvo[0], so[r]);
                 }
                 continue;
             }
@@ -1237,7 +1346,7 @@ inline size_t general_floats(int Cout, int Cin, int ks) {
 }
 
 template <int MB, int NB, int PF3A, int PF3B, int PF1>
-int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2, hipStream_t s) {
+int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2, hipStream_t s, bool pair = false) {
     // split-K: one 32-row band per owner wave (KS >= MB), whole channel pairs per slice, slices of >= 8 pairs of a
     // 3x3 conv (1x1 convs, 64 steps in all, are never split)
     if (ksplit_log2 > 0 && (1 << ksplit_log2) < MB) ksplit_log2 = MB == 4 ? 2 : 1;
@@ -1257,6 +1366,14 @@ int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2
     // (round 4, measured and removed: `s_setprio 2` for the first-dispatched workgroup of every CU in single-round launches, so that
     //  one of the two waves of a SIMD finishes its k-loop early and its epilogue runs under the other's MFMAs -- the captured
     //  training step 22.32 vs 22.34 ms, the 32-image step 123.3 vs 123.4 ms: two epilogues side by side cost what one does)
+    if (pair) {
+        if constexpr (MB == 4 && NB == 2) {
+            if (ksplit_log2 != 0 || pro != PRO_NONE || k.ks != 3) return MCQ_EINVAL;
+            hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF3A, PF3B, 9, OCC, true>), grid, block, lds, s, k);
+            return mcq_check_launch();
+        }
+        return MCQ_EINVAL;
+    }
     if (k.ks == 3) {
         if (pro == PRO_SILU) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF3A, PF3B, 9, OCC>), grid, block, lds, s, k);
         else if (pro == PRO_NONE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF3A, PF3B, 9, OCC>), grid, block, lds, s, k);
@@ -1717,6 +1834,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     // a tile are split over 2/4/8 waves of one workgroup and reduced through LDS.
     const int co32 = (d->Cout + 31) / 32;
     int MB, NB, ksl = 0;
+    bool dsilu41 = false;                 // the 128 x 32 tile chosen over the 128 x 64 one for an input-gradient epilogue (see below)
     const int forced = d->tile & 0xff;
     if (forced) { MB = forced >> 4; NB = forced & 15; ksl = (d->tile >> 8) & 3; }
     else if (co32 == 1) {
@@ -1783,7 +1901,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         // input-gradient launches of the training step (* silu'(.) [+ dy]): their epilogue carries one more output-shaped side
         // read and a sigmoid per element; the 128 x 32 tile has a band-wise instance of it (the 128 x 64 tile has no registers
         // left for one) and at three waves per SIMD hides it better (8 x 128 x 128 x 128: 300-311 -> 270-277 us)
-        else if (MB == 4 && NB == 2 && ksl == 0 && (fl & MCQ_CONV_DSILU_MUL) && d->ksize == 3) NB = 1;
+        else if (MB == 4 && NB == 2 && ksl == 0 && (fl & MCQ_CONV_DSILU_MUL) && d->ksize == 3) { NB = 1; dsilu41 = true; }
         // 1x1 layers (GDN / IGDN, the AttentionBlock gate): 64 k-steps per tile against an epilogue that reads and writes an
         // output-shaped tensor each -- HBM time, not matrix time.  One pixel block per wave (half the epilogue per wave, three
         // waves per SIMD to hide it) wins wherever the launch still fills the chip without a split: 32 x 128 x 384x256 GDN
@@ -1800,14 +1918,37 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     }
     if (fl & MCQ_CONV_GATE_BWD) { NB = 1; ksl = 0; }        // (likewise)
     const int pro = (fl & MCQ_CONV_SILU_IN) ? PRO_SILU : (fl & MCQ_CONV_SQUARE_IN) ? PRO_SQUARE : PRO_NONE;
-    const long long ptiles = (tb + NB - 1) / NB;
+    long long ptiles = (tb + NB - 1) / NB;
+    // (round 5) the 128 x 64 tile of a 3x3 stride-1 layer over 32 PAIRS of horizontally adjacent pixels (tile bit 0x400 forces it,
+    // 0x800 forbids it): pair blocks shaped (32 >> b) rows x (1 << b) pairs, b by the fewest wasted lanes
+    const bool pair_ok = MB == 4 && (NB == 2 || dsilu41) && ksl == 0 && d->ksize == 3 && d->stride == 1 && pro == PRO_NONE && (k.Wo & 1) == 0 &&
+                         !(fl & ~(unsigned)(MCQ_CONV_SILU_OUT | MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU | MCQ_CONV_DSILU_MUL | MCQ_CONV_SHUFFLE2));
+    // on its own it takes the launches whose pair tiles are ONE round of the chip (1536 < waves <= 2048, two per SIMD: 8 x 128 x 128 x 128,
+    // 8 x 128 -> 512 x 64 x 64): with nothing behind a wave to hide its prologue and epilogue the shorter instruction streams pay
+    // (isolated 280-299 us against 301-332 for the best other tile); in multi-round launches they do not (B32: -0.7 % without a twin,
+    // +1 % with residual + twin)
+    bool pair = false;
+    if (pair_ok) {
+        const int Wp = k.Wo / 2;
+        int bl = 5; double bu = -1.0;
+        for (int lg = 5; lg >= 2; --lg) {
+            const int bw2 = 1 << lg, bh2 = 32 >> lg;
+            const double cover = (double)((k.Ho + bh2 - 1) / bh2 * bh2) * (double)((Wp + bw2 - 1) / bw2 * bw2);
+            const double util = (double)k.Ho * Wp / cover;
+            if (util > bu + 1e-9) { bu = util; bl = lg; }
+        }
+        const int pnbx = (Wp + (1 << bl) - 1) >> bl, pnby = (k.Ho + (32 >> bl) - 1) / (32 >> bl);
+        const long long pt = (long long)k.N * pnbx * pnby, pair_waves = pt * ((co32 + 3) / 4) * nprob;
+        pair = (d->tile & 0x400) || (MCQ_PAIR && !(d->tile & 0x800) && pair_waves > 1536 && pair_waves <= 2048);
+        if (pair) { NB = 2; k.bw_log2 = bl; k.nbx = pnbx; k.nby = pnby; ptiles = pt; k.total_blocks = (int)pt; }
+    }
     const int co_tiles = (co32 + MB - 1) / MB;
     // the epilogue addresses one image of the output (and of every side input) through a 32-bit buffer offset,
     // rows of the last cout tile included
     if ((uint64_t)co_tiles * 32u * (unsigned)MB * (uint64_t)k.Ho * k.Wo * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
     hipStream_t s = (hipStream_t)stream;
     sec_note(descs, nprob, MB == 4 ? 1u : MB == 2 ? 2u : 4u);
-    if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42A, MCQ_PF42B, 4>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42A, MCQ_PF42B, 4>(k, pro, ptiles, co_tiles, ksl, s, pair);
     if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 2) return launch_tile<2, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
     if (MB == 2 && NB == 1) return launch_tile<2, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);

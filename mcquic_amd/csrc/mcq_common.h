@@ -114,6 +114,14 @@ __device__ __forceinline__ void mcq_buffer_store2_s(f32x2v v, __amdgpu_buffer_rs
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), r, (int)voff, (int)soff, 0);
 }
 
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mcq_buffer_load4_s(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void mcq_buffer_store4_s(f32x4v v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, (int)voff, (int)soff, 0);
+}
+
 // Uniform (SGPR) 64-bit pointer from a possibly lane-tainted one.
 template <typename T>
 __device__ __forceinline__ T* mcq_uniform_ptr(T* p) {

@@ -80,6 +80,54 @@ def test_conv_without_bias_and_ragged_cout(dev, case):
         _close(ops.silu_twin(got), F.silu(want + res), 2e-6, f"nobias+twin{case} tile={tile:#x}")
 
 
+PAIR_CASES = [(2, 128, 128, 24, 32), (1, 128, 128, 13, 38), (3, 64, 128, 12, 8), (1, 128, 256, 7, 6), (2, 126, 128, 33, 70), (1, 128, 128, 40, 2)]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_conv_pixel_pair_tile_is_bit_equal(dev, case):
+    """tile bit 0x400: the 128 x 64 tile over 32 horizontally adjacent pixel PAIRS (conv_mfma_kernel<..., PAIR = true>) -- every
+    accumulator sees the same MFMA sequence as in the 0x42 tile, so the results are the same bits, for every epilogue."""
+    from mcquic_amd import ops
+    n, cin, cout, h, w = case
+    x = _rand((n, cin, h, w), 11).to(dev)
+    wt = _rand((cout, cin, 3, 3), 12, 1.0 / np.sqrt(cin * 9))
+    b = _rand((cout,), 13, 0.1)
+    res = _rand((n, cout, h, w), 14).to(dev)
+    pk = ops.PackedConv(wt.to(dev), b.to(dev))
+    want = F.conv2d(x.cpu(), wt, b, padding=1)
+    for kw in ({}, dict(silu_out=True), dict(res=res, dual_silu=True), dict(res=res), dict(dual_silu=True), dict(dsilu_mul=res, res=res)):
+        a = ops.conv2d(x, pk, 1, tile=0x42, **kw)
+        g = ops.conv2d(x, pk, 1, tile=0x442, **kw)
+        assert torch.equal(a, g), f"pair tile differs from the 0x42 tile: {case} {sorted(kw)}"
+        if "dual_silu" in kw:
+            assert torch.equal(ops.silu_twin(a), ops.silu_twin(g)), f"pair tile twin: {case} {sorted(kw)}"
+    _close(ops.conv2d(x, pk, 1, tile=0x442), want, 2e-6, f"pair conv{case}")
+    if cout % 4 == 0:
+        assert torch.equal(ops.conv2d(x, pk, 1, tile=0x42, shuffle2=True), ops.conv2d(x, pk, 1, tile=0x442, shuffle2=True))
+
+
+def test_conv_pixel_pair_tile_stays_inside_its_output(dev):
+    import ctypes
+    from mcquic_amd import _lib, ops
+    n, cin, cout, h, w = 2, 16, 70, 9, 14
+    x = _rand((n, cin, h, w), 8).to(dev)
+    wt = _rand((cout, cin, 3, 3), 9, 0.1)
+    pk = ops.PackedConv(wt.to(dev), None)
+    want = F.conv2d(x.cpu(), wt, None, padding=1)
+    guard, numel = 1 << 16, n * cout * h * w
+    buf = torch.full((guard + numel + guard,), 7.5, device=dev)
+    twin = torch.full((guard + numel + guard,), -3.25, device=dev)
+    y, y2 = buf[guard:guard + numel], twin[guard:guard + numel]
+    d = _lib.ConvDesc(x.data_ptr(), pk.wp.data_ptr(), None, y.data_ptr(), y2.data_ptr(), None, None, None,
+                      n, cin, h, w, cout, 3, 1, ops.CONV_DUAL_SILU, 1.0, 0x442)
+    assert _lib.load().mcq_conv2d_f32(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    _close(y.view(n, cout, h, w), want, 2e-6, "guarded pair conv")
+    _close(y2.view(n, cout, h, w), F.silu(want), 2e-6, "guarded pair twin")
+    for t, fill in ((buf, 7.5), (twin, -3.25)):
+        assert bool((t[:guard] == fill).all()) and bool((t[guard + numel:] == fill).all()), "pair tile: guard band written"
+
+
 def test_conv_never_writes_outside_its_output(dev):
     """Raw C-ABI call with the output placed inside a guard band: rows of the last cout tile past Cout, pixels past the
     image and the second image's slab are all addressed through range-checked buffer stores."""

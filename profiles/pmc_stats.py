@@ -51,4 +51,12 @@ for r in rows[:24]:
     wr = r.get("WRITE_SIZE", float("nan")) * 1024 / 1e6
     util = r.get("SQ_VALU_MFMA_BUSY_CYCLES", float("nan")) / (r.get("GRBM_GUI_ACTIVE", float("nan")) * 1024)
     print(f"{r['kernel']:34s} {r['wgs']:6d} {r['gy']:2d} {r['launches']:4d} {r.get('_dur_ns', 0) / 1e3:9.1f} {rd:17.1f} {wr:9.1f} {util:21.3f}")
+# any further counter of the passes (e.g. SQ_INSTS_VALU, SQ_INSTS_MFMA: instruction counts per launch, summed over the chip)
+KNOWN = {"FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "_dur_ns", "kernel", "wgs", "gy", "launches"}
+extra = sorted({c for r in rows for c in r if c not in KNOWN})
+if extra:
+    print()
+    print(f"{'kernel':34s} {'wgs':>6} {'gy':>2} " + " ".join(f"{c:>28s}" for c in extra))
+    for r in rows[:24]:
+        print(f"{r['kernel']:34s} {r['wgs']:6d} {r['gy']:2d} " + " ".join(f"{r.get(c, float('nan')):28.0f}" for c in extra))
 json.dump(rows, open("/tmp/pmc_rows.json", "w"))

@@ -106,6 +106,19 @@ def test_conv_pixel_pair_tile_is_bit_equal(dev, case):
         assert torch.equal(ops.conv2d(x, pk, 1, tile=0x42, shuffle2=True), ops.conv2d(x, pk, 1, tile=0x442, shuffle2=True))
 
 
+def test_conv_pixel_pair_tile_multi_problem(dev):
+    """Two problems in one launch (the AttentionBlock stacks' form) through the pair tile: each equals its own single launch."""
+    from mcquic_amd import ops
+    n, c, h, w = 2, 128, 20, 24
+    xs = [_rand((n, c, h, w), 21 + i).to(dev) for i in range(2)]
+    rs = [_rand((n, c, h, w), 31 + i).to(dev) for i in range(2)]
+    pks = [ops.PackedConv(_rand((c, c, 3, 3), 41 + i, 1.0 / np.sqrt(c * 9)).to(dev), _rand((c,), 51 + i, 0.1).to(dev)) for i in range(2)]
+    ys = ops.conv2d_multi(xs, pks, 1, per_problem=[dict(res=r) for r in rs], dual_silu=True, tile=0x442)
+    for i in range(2):
+        one = ops.conv2d(xs[i], pks[i], 1, res=rs[i], dual_silu=True, tile=0x42)
+        assert torch.equal(ys[i], one) and torch.equal(ops.silu_twin(ys[i]), ops.silu_twin(one)), f"problem {i}"
+
+
 def test_conv_pixel_pair_tile_stays_inside_its_output(dev):
     import ctypes
     from mcquic_amd import _lib, ops

@@ -30,7 +30,7 @@ extern "C" {
  * compares it with mcq_abi_version() of the library it loaded before calling anything else: a stale .so under new
  * prototypes (or the reverse) misaligns arguments silently otherwise.  3 = round 3 (mcq_rans_*_with_indexes take cdf_lens,
  * mcq_gate_f32 takes out_silu -- both changed in round 2 without a bump --, GroupNorm / logits-gradient entry points). */
-#define MCQ_ABI_VERSION   7
+#define MCQ_ABI_VERSION   8
 
 #define MCQ_OK            0
 #define MCQ_EINVAL       -1   /* NULL pointer / non-positive dimension / unsupported combination */
@@ -57,6 +57,10 @@ extern "C" {
                                       * y = res * sigmoid(s) (d a), y_silu = res * mul * sigmoid(s) (1 - sigmoid(s)) (d s); res = d out, mul = a.
                                       * What torch.autograd derives for mcquic/nn/blocks.py:286-287; the forward keeps no s (the gate is the 1x1
                                       * launch's MCQ_CONV_GATE epilogue in training as in inference). */
+#define MCQ_CONV_TAPS_LR    0x20000u /* (round 5) a PROMISE about w_packed, not an operation: the 3x3 stride-1 filter is zero outside its lower-right
+                                      * 2 x 2 taps (dy, dx in {0, +1}) -- what mcq_pack_conv_dgrad_weight_f32 writes for a stride-2 layer
+                                      * ([4 Cin, Cout, 3, 3] through MCQ_CONV_SHUFFLE2: torch.autograd's conv_transpose2d of mcquic/nn/convs.py:132-153
+                                      * conv3x3(stride=2)).  The launch then walks 4 of the 9 taps; same sums.  No input prologue, no Winograd form. */
 #define MCQ_CONV_DUAL_SILU  0x100u /* also store silu(y) to y_silu: the next block's act1(x), computed once per element */
 #define MCQ_CONV_WINOGRAD2D 0x1000u /* OPT-IN like MCQ_CONV_WINOGRAD: F(2x2, 3x3), 4/9 of the multiplications; w_packed from   */
                                     /* mcq_pack_conv_weight_winograd2d_f32; Cout % 128 == 0, Cin % 8 == 0                                */

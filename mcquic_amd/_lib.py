@@ -23,6 +23,7 @@ CONV_WINOGRAD2D = 0x1000
 CONV_WINOGRAD2D16 = 0x2000
 CONV_GDN_BWD, CONV_IGDN_BWD = 0x4000, 0x8000
 CONV_GATE_BWD = 0x10000
+CONV_TAPS_LR = 0x20000
 
 
 class ConvDesc(Structure):
@@ -147,7 +148,7 @@ SYMBOLS = {
     "mcq_abi_version": (c_int32, []),
 }
 
-ABI_VERSION = 7          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
+ABI_VERSION = 8          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
 
 _lib = None
 

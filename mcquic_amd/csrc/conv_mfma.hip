@@ -87,6 +87,9 @@ constexpr int PRO_NONE = 0, PRO_SILU = 1, PRO_SQUARE = 2;
 #ifndef MCQ_GDN_XLDS
 #define MCQ_GDN_XLDS 0          // build switch: 0 = the GDN / IGDN epilogue re-reads x from memory (rounds 1-4: 2.0x the read traffic)
 #endif
+#ifndef MCQ_TAPS_LR
+#define MCQ_TAPS_LR 1           // build switch: 0 = MCQ_CONV_TAPS_LR launches walk all nine taps (rounds 1-4: 5 / 9 of their MFMAs multiply zeros)
+#endif
 #ifndef MCQ_PAIR
 #define MCQ_PAIR 0              // build switch: 1 = 3x3 stride-1 layers on the 128 x 64 tile run over pixel PAIRS (conv_mfma_kernel<..., PAIR = true>)
 #endif
@@ -179,6 +182,12 @@ __global__ __launch_bounds__(TAPS >= 12 ? 256 : 512, OCC) void conv_mfma_kernel(
     // activation loads per channel pair instead of 18 -- and every output-shaped access of the epilogue is one 64-bit access per row
     // for both pixels (even widths) instead of two 32-bit ones.
     static_assert(!PAIR || (TAPS == 9 && NB == 2 && PRO == 0 && PFB % 9 == 0), "PAIR: the direct 3x3 form with two pixel blocks");
+    // TAPS == 4 (round 5): a 3x3 stride-1 layer whose filter is zero outside its lower-right 2 x 2 taps (MCQ_CONV_TAPS_LR: the
+    // input-gradient convolution of a stride-2 layer, [4 Cin, Cout, 3, 3] through the PixelShuffle store -- output pixel 2 q + i
+    // reads dY[q] and, for i = 1, dY[q + 1]: rows / columns -1 of the window never).  The operand stream stays the dense 9-tap one;
+    // the k-loop walks taps 4, 5, 7, 8 of every channel pair only: 4 / 9 of the MFMAs and activation loads, the same sums.
+    constexpr bool LR4 = TAPS == 4;
+    constexpr int WT = LR4 ? 9 : TAPS;              // k-steps per channel pair in the packed weights
     constexpr bool W2D = TAPS == 16;
     constexpr bool WINO = TAPS == 12 || W2D;
     constexpr int PG = W2D ? 16 : 4;                // transform positions = k-steps per group of operand loads
@@ -244,7 +253,7 @@ next_tile:
     const int ly = j >> p.bw_log2, lx = j & (BW - 1);
     const int BH = 32 >> p.bw_log2;
     const int HW = p.H * p.W + tile_zero;
-    const int pad = TAPS == 1 ? 0 : 1;
+    const int pad = (TAPS == 1 || LR4) ? 0 : 1;
     const unsigned plane_bytes = (unsigned)p.Cin * (unsigned)HW * 4u;
 
     // ---- geometry of the NB pixel blocks this wave owns -------------------------------------
@@ -273,7 +282,8 @@ next_tile:
 #pragma unroll
         for (int tap = 0; tap < LT; ++tap) {
             // (WINO / PAIR: tap = 4 dy + position under the pair, x = 2 xp - 1 + position)
-            const int dy = PAIR ? tap / 4 : TAPS == 9 ? tap / 3 : WINO ? tap / 4 : 0, dx = PAIR ? tap % 4 : TAPS == 9 ? tap % 3 : WINO ? tap % 4 : 0;
+            const int dy = PAIR ? tap / 4 : TAPS == 9 ? tap / 3 : WINO ? tap / 4 : LR4 ? tap / 2 : 0,
+                      dx = PAIR ? tap % 4 : TAPS == 9 ? tap % 3 : WINO ? tap % 4 : LR4 ? tap % 2 : 0;
             const int yi = yo[nb] * p.stride + dy - pad;
             const int xi = xo[nb] * p.stride + dx - pad;
             const bool inb = valid[nb] && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
@@ -299,12 +309,16 @@ next_tile:
     // four / two times the cache lines and made a 12x8-level launch 30 instead of 21 us)
     // -- as a wave-uniform base plus a constant per-lane offset, read through a buffer load whose running offset is
     // the scalar soffset (no per-lane pointer arithmetic in the k-loop)
-    const float* wbu = MB == 4 ? P_wp + ((size_t)tile128 * p.TP + (size_t)s0 * TAPS) * 256 + q0
-                     : MB == 2 ? P_wp64 + ((size_t)(co_base >> 6) * p.TP + (size_t)s0 * TAPS) * 128
-                               : P_wp32 + ((size_t)(co_base >> 5) * p.TP + (size_t)s0 * TAPS) * 64;
+    const float* wbu = MB == 4 ? P_wp + ((size_t)tile128 * p.TP + (size_t)s0 * WT) * 256 + q0
+                     : MB == 2 ? P_wp64 + ((size_t)(co_base >> 6) * p.TP + (size_t)s0 * WT) * 128
+                               : P_wp32 + ((size_t)(co_base >> 5) * p.TP + (size_t)s0 * WT) * 64;
     const __amdgpu_buffer_rsrc_t wr = mcq_make_rsrc(wbu, 0x7fffffffu);   // (the packed copies end in a zero tail: over-reads are in bounds)
     const unsigned wlane = (unsigned)lane * (unsigned)(4 * MB);
-    unsigned wso = 0;
+    // (LR4: the live taps of a channel pair are steps 4, 5, 7, 8 of its nine -- the distance to the next live step by position)
+    auto winc = [](const int live_step) constexpr -> unsigned {
+        return !LR4 ? 1u : (live_step & 3) == 0 ? 1u : (live_step & 3) == 1 ? 2u : (live_step & 3) == 2 ? 1u : 5u;
+    };
+    unsigned wso = LR4 ? 4u * 256u * MB : 0u;
     const unsigned step_bytes = 2u * (unsigned)HW * 4u;     // one channel pair further
     unsigned soff = (unsigned)s0 * step_bytes;
 
@@ -423,7 +437,7 @@ next_tile:
 #pragma unroll
         for (int st = 0; st < PFA; ++st) {          // weights of steps 0 .. PFA-1 of the slice
             A[st] = mcq_wload<MB>(wr, wlane, wso);
-            wso += 256 * MB;
+            wso += 256 * MB * winc(st);
         }
 #pragma unroll
         for (int st = 0; st < BSLOTS; ++st) {       // activations of steps 0 .. PFB-1
@@ -542,7 +556,7 @@ next_tile:
                 B[sb][nb] = mcq_buffer_load(rB[nb][ds - PFBP], voff[nb][tl]);
             }
             A[sa] = mcq_wload<MB>(wr, wlane, wso);
-            wso += 256 * MB;
+            wso += 256 * MB * winc(u + PFA);
             // keep the software pipeline as written: without this fence the scheduler sinks the loads of all U
             // steps to the end of the (branch-free) body and waits for them one step later
             __builtin_amdgcn_sched_barrier(0);
@@ -1346,7 +1360,7 @@ inline size_t general_floats(int Cout, int Cin, int ks) {
 }
 
 template <int MB, int NB, int PF3A, int PF3B, int PF1>
-int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2, hipStream_t s, bool pair = false) {
+int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2, hipStream_t s, bool pair = false, bool lr4 = false) {
     // split-K: one 32-row band per owner wave (KS >= MB), whole channel pairs per slice, slices of >= 8 pairs of a
     // 3x3 conv (1x1 convs, 64 steps in all, are never split)
     if (ksplit_log2 > 0 && (1 << ksplit_log2) < MB) ksplit_log2 = MB == 4 ? 2 : 1;
@@ -1373,6 +1387,11 @@ int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2
             return mcq_check_launch();
         }
         return MCQ_EINVAL;
+    }
+    if (lr4) {              // (the rings in live steps: weights 8 ahead, activations 16 = four channel pairs)
+        if (pro != PRO_NONE || k.ks != 3) return MCQ_EINVAL;
+        hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, 8, 16, 4, OCC>), grid, block, lds, s, k);
+        return mcq_check_launch();
     }
     if (k.ks == 3) {
         if (pro == PRO_SILU) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF3A, PF3B, 9, OCC>), grid, block, lds, s, k);
@@ -1644,7 +1663,9 @@ int conv_validate(const mcq_conv_desc* d) {
     if (!d || !d->x || !d->w_packed || !d->y) return MCQ_EINVAL;
     if (d->N <= 0 || d->Cin <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return MCQ_EINVAL;
     if ((d->ksize != 1 && d->ksize != 3) || (d->stride != 1 && d->stride != 2)) return MCQ_EINVAL;
-    const unsigned fl = d->flags;
+    if ((d->flags & MCQ_CONV_TAPS_LR) && (d->ksize != 3 || d->stride != 1 || (d->flags & (MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D | MCQ_CONV_WINOGRAD2D16 |
+                                                                                    MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN)))) return MCQ_EINVAL;
+    const unsigned fl = d->flags & ~(unsigned)MCQ_CONV_TAPS_LR;      // (a promise about the weights, not an operation)
     if ((fl & MCQ_CONV_RESIDUAL) && !d->res) return MCQ_EINVAL;
     if ((fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL | MCQ_CONV_DSILU_MUL)) && !d->mul) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_GATE) && !d->gate_id) return MCQ_EINVAL;
@@ -1677,7 +1698,8 @@ bool t16_takes(int N, int Cin, int H, int W, int Cout, int ksize, int stride, un
 
 int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     const mcq_conv_desc* d = descs;
-    const unsigned fl = d->flags;
+    const unsigned fl = d->flags & ~(unsigned)MCQ_CONV_TAPS_LR;
+    const bool lr4 = MCQ_TAPS_LR && (d->flags & MCQ_CONV_TAPS_LR);      // only the filter's lower-right 2 x 2 taps are non-zero
     ConvK k;
     k.x = d->x; k.wp = d->w_packed;
     k.wp64 = k.wp + section_floats(d->Cout, d->Cin, d->ksize, 4);
@@ -1921,7 +1943,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     long long ptiles = (tb + NB - 1) / NB;
     // (round 5) the 128 x 64 tile of a 3x3 stride-1 layer over 32 PAIRS of horizontally adjacent pixels (tile bit 0x400 forces it,
     // 0x800 forbids it): pair blocks shaped (32 >> b) rows x (1 << b) pairs, b by the fewest wasted lanes
-    const bool pair_ok = MB == 4 && (NB == 2 || dsilu41) && ksl == 0 && d->ksize == 3 && d->stride == 1 && pro == PRO_NONE && (k.Wo & 1) == 0 &&
+    const bool pair_ok = !lr4 && MB == 4 && (NB == 2 || dsilu41) && ksl == 0 && d->ksize == 3 && d->stride == 1 && pro == PRO_NONE && (k.Wo & 1) == 0 &&
                          !(fl & ~(unsigned)(MCQ_CONV_SILU_OUT | MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU | MCQ_CONV_DSILU_MUL | MCQ_CONV_SHUFFLE2));
     // on its own it takes the launches whose pair tiles are ONE round of the chip (1536 < waves <= 2048, two per SIMD: 8 x 128 x 128 x 128,
     // 8 x 128 -> 512 x 64 x 64): with nothing behind a wave to hide its prologue and epilogue the shorter instruction streams pay
@@ -1948,13 +1970,13 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     if ((uint64_t)co_tiles * 32u * (unsigned)MB * (uint64_t)k.Ho * k.Wo * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
     hipStream_t s = (hipStream_t)stream;
     sec_note(descs, nprob, MB == 4 ? 1u : MB == 2 ? 2u : 4u);
-    if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42A, MCQ_PF42B, 4>(k, pro, ptiles, co_tiles, ksl, s, pair);
-    if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 2 && NB == 2) return launch_tile<2, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 2 && NB == 1) return launch_tile<2, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 1 && NB == 4) return launch_tile<1, 4, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 1 && NB == 2) return launch_tile<1, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s);
-    if (MB == 1 && NB == 1) return launch_tile<1, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s);
+    if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42A, MCQ_PF42B, 4>(k, pro, ptiles, co_tiles, ksl, s, pair, lr4);
+    if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s, false, lr4);
+    if (MB == 2 && NB == 2) return launch_tile<2, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s, false, lr4);
+    if (MB == 2 && NB == 1) return launch_tile<2, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s, false, lr4);
+    if (MB == 1 && NB == 4) return launch_tile<1, 4, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s, false, lr4);
+    if (MB == 1 && NB == 2) return launch_tile<1, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s, false, lr4);
+    if (MB == 1 && NB == 1) return launch_tile<1, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s, false, lr4);
     return MCQ_EINVAL;
 }
 

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import (CONV_DSILU_MUL, CONV_DUAL_SILU, CONV_MUL, CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN,
-                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, CONV_WINOGRAD2D, CONV_WINOGRAD2D16, CONV_GDN_BWD, CONV_IGDN_BWD, CONV_GATE_BWD, ConvDesc, check)
+                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, CONV_WINOGRAD2D, CONV_WINOGRAD2D16, CONV_GDN_BWD, CONV_IGDN_BWD, CONV_GATE_BWD, CONV_TAPS_LR, ConvDesc, check)
 
 # OPT-IN fast path, never the default and never the headline bench: large 3x3 stride-1 layers in the Winograd F(2, 3) form
 # along x (mcq_pack_conv_weight_winograd_f32 + MCQ_CONV_WINOGRAD): 2/3 of the multiplications, float32 throughout, but not
@@ -139,7 +139,9 @@ def _ptr(t: Optional[torch.Tensor]):
 class PackedConv:
     """A conv weight re-laid for the MFMA operand stream (+ its bias), see mcq_pack_conv_weight_f32."""
 
-    __slots__ = ("wp", "bias", "cout", "cin", "ksize", "wino", "wino2d", "wino16")
+    __slots__ = ("wp", "bias", "cout", "cin", "ksize", "wino", "wino2d", "wino16", "lr_taps")
+    # lr_taps: the packed 3x3 filter is zero outside its lower-right 2 x 2 taps (the input-gradient stream of a stride-2 layer): launches
+    # say so (MCQ_CONV_TAPS_LR) and walk 4 of the 9 taps
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], copy_bias: bool = True, winograd: Optional[bool] = None):
         weight = _dev(weight.detach(), "weight")
@@ -155,6 +157,7 @@ class PackedConv:
         self.bias = None if bias is None else (_dev(bias.detach(), "bias").clone() if copy_bias else _dev(bias.detach(), "bias"))
         self.cout, self.cin, self.ksize = cout, cin, kh
         self.wino = self.wino2d = self.wino16 = None
+        self.lr_taps = False
         level = (2 if _WINOGRAD_2D else 1) if _WINOGRAD else 0
         if winograd is not None:
             level = 1 if winograd is True else int(winograd)
@@ -218,6 +221,7 @@ class PackedConv:
         self.bias = None
         self.cout, self.cin, self.ksize = co_d.value, ci_d.value, kh
         self.wino = self.wino2d = self.wino16 = None
+        self.lr_taps = stride == 2 and kh == 3
         if (winograd if winograd is not None else _WINOGRAD) and kh == 3 and stride == 1 and scale == 1.0 and cin % 64 == 0:
             self.wino = torch.empty(lib.mcq_packed_conv_winograd_floats(cin, cout), dtype=torch.float32, device=weight.device)
             with _guard(weight.device):
@@ -284,6 +288,7 @@ def pack_convs(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Option
         pk.bias = None if dgrad or biases is None or biases[i] is None else _dev(biases[i].detach(), "bias")
         pk.cout, pk.cin, pk.ksize = co, ci, kh
         pk.wino = pk.wino2d = pk.wino16 = None
+        pk.lr_taps = bool(dgrad) and stride == 2 and kh == 3
         out.append(pk)
     return out
 
@@ -370,6 +375,8 @@ def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool
             wp = w.wino
         elif winograd:
             raise ValueError("winograd=True needs a 3x3 stride-1 layer with Cout % 64 == 0, packed with winograd=True, and no input prologue")
+    if _TAPS_LR and getattr(w, "lr_taps", False) and stride == 1 and wp is w.wp and not (flags & (CONV_SILU_IN | CONV_SQUARE_IN)):
+        flags |= CONV_TAPS_LR
     d = ConvDesc(_ptr(x), _ptr(wp), _ptr(w.bias), _ptr(y), _ptr(y2), _ptr(res), _ptr(mul), _ptr(gate_id),
                  n, cin, h, wd, w.cout, w.ksize, stride, flags, float(res_scale), tile)
     return d, y, y2, (x, res, mul, gate_id)
@@ -526,6 +533,7 @@ def conv2d_gate_bwd(bs, ws, as_, douts):
 
 
 _MULTI = os.environ.get("MCQUIC_AMD_MULTI_CONV", "1") != "0"      # A/B switch: 0 = one launch per convolution
+_TAPS_LR = os.environ.get("MCQUIC_AMD_TAPS_LR", "1") != "0"        # A/B switch: 0 = stride-2 input-gradient launches walk all nine taps (5 of them zeros)
 
 
 def conv2d_multi(xs, ws, stride: int = 1, per_problem=None, **shared):

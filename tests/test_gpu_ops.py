@@ -80,6 +80,36 @@ def test_conv_without_bias_and_ragged_cout(dev, case):
         _close(ops.silu_twin(got), F.silu(want + res), 2e-6, f"nobias+twin{case} tile={tile:#x}")
 
 
+@pytest.mark.parametrize("case", [(2, 128, 128, 24, 32), (1, 64, 128, 13, 10), (8, 128, 128, 8, 8), (2, 96, 64, 17, 21), (1, 128, 128, 64, 64)])
+def test_stride2_input_gradient_walks_four_taps(dev, case):
+    """MCQ_CONV_TAPS_LR: the input-gradient stream of a stride-2 layer is a [4 Cin, Cout, 3, 3] filter with zeros outside its lower-right
+    2 x 2 taps; the launch that is told so walks 4 of the 9 taps and leaves the SAME bits as the one that multiplies the zeros, for every
+    tile and split, and both equal autograd's gradient of F.conv2d(stride=2)."""
+    from mcquic_amd import ops
+    n, cin, cout, h, w = case                                  # (h, w: the stride-2 layer's OUTPUT map; its input is 2h x 2w)
+    wt = _rand((cout, cin, 3, 3), 61, 1.0 / np.sqrt(cin * 9))
+    dy = _rand((n, cout, h, w), 62)
+    xin = _rand((n, cin, 2 * h, 2 * w), 63).requires_grad_(True)
+    F.conv2d(xin, wt, None, stride=2, padding=1).backward(dy)
+    pk = ops.PackedConv.dgrad(wt.to(dev), 2)
+    assert pk.lr_taps and (pk.cout, pk.cin) == (4 * cin, cout)
+    side = _rand((n, cin, 2 * h, 2 * w), 64).to(dev)
+    keep = ops._TAPS_LR
+    try:
+        for tile in (0, 0x42, 0x41, 0x22, 0x21, 0x12, 0x11, 0x142, 0x242, 0x241, 0x311):
+            if tile and ((tile >> 4) & 15) * 32 > 4 * cin:
+                continue
+            for kw in ({}, dict(res=side, dsilu_mul=side)):
+                ops._TAPS_LR = False
+                a = ops.conv2d(dy.to(dev), pk, 1, shuffle2=True, tile=tile, **kw)
+                ops._TAPS_LR = True
+                b = ops.conv2d(dy.to(dev), pk, 1, shuffle2=True, tile=tile, **kw)
+                assert torch.equal(a, b), f"four-tap walk differs: {case} tile={tile:#x} {sorted(kw)}"
+            _close(b if not kw else ops.conv2d(dy.to(dev), pk, 1, shuffle2=True, tile=tile), xin.grad, 2e-6, f"stride-2 dgrad{case} tile={tile:#x}")
+    finally:
+        ops._TAPS_LR = keep
+
+
 PAIR_CASES = [(2, 128, 128, 24, 32), (1, 128, 128, 13, 38), (3, 64, 128, 12, 8), (1, 128, 256, 7, 6), (2, 126, 128, 33, 70), (1, 128, 128, 40, 2)]
 
 

@@ -99,7 +99,7 @@ def main():
     torch.cuda.synchronize()
 
     FL = {0x1: "silu_in", 0x2: "sq_in", 0x4: "silu_out", 0x8: "res", 0x10: "gdn", 0x20: "igdn", 0x40: "gate", 0x80: "shuf", 0x100: "twin",
-          0x200: "mul", 0x400: "dsilu", 0x800: "wino", 0x1000: "wino2d"}
+          0x200: "mul", 0x400: "dsilu", 0x800: "wino", 0x1000: "wino2d", 0x20000: "4taps"}
     rows = []
     for sig, count in sigs.items():
         kind, n, cin, hh, ww, cout, ks, stride, flags, res_scale, nprob = sig
@@ -110,6 +110,10 @@ def main():
         if kind == "conv":
             xs = [torch.randn((n, cin, hh, ww), device=dev) for _ in range(nprob)]
             packs = [ops.PackedConv(torch.randn((cout, cin, ks, ks), device=dev) * 0.03, torch.randn(cout, device=dev)) for _ in range(nw * nprob)]
+            if flags & 0x20000:                # MCQ_CONV_TAPS_LR (the input-gradient stream of a stride-2 layer): 4 of the 9 taps carry work
+                flops *= 4.0 / 9.0
+                for pk in packs:
+                    pk.lr_taps = True
             shuf = bool(flags & 0x80)
             oshape = (n, cout // 4, 2 * ho, 2 * wo) if shuf else (n, cout, ho, wo)
             side = torch.randn(oshape, device=dev)

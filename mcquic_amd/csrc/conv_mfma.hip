@@ -1167,7 +1167,7 @@ inline void sec_note(const mcq_conv_desc* descs, int nprob, unsigned bit) {
 }
 
 constexpr int PACK_MAX_MULTI = 64;       // (round 5: 16 -> 64; the qp=2 model's ~150 convolutions of one shape re-pack in 3 launches instead of 10)
-constexpr int MCQ_TAIL_STEPS = 16;
+constexpr int MCQ_TAIL_STEPS = 32;       // (16 until ABI 8: the four-tap walk's weight ring runs 8 LIVE steps = up to 26 dense steps ahead)
 struct PackTable { const float* w[PACK_MAX_MULTI]; float* out[PACK_MAX_MULTI]; unsigned char mask[PACK_MAX_MULTI]; };
 // (mask: sections to write -- bit 0 the 128-row copy, 1 the 64-row, 2 the 32-row, 3 the 16x16-tile order; mcq_pack_conv_weight_multi_masked_f32)
 

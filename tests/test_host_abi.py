@@ -33,9 +33,9 @@ def test_size_queries_run_without_a_gpu():
     from mcquic_amd import _lib
     lib = _lib.load()
     # the operand stream exists once per tile height (128 / 64 / 32 rows = 4 / 2 / 1 bands of 64 lanes), each copy with
-    # 16 zero tail steps; 128 -> 128 3x3 has 576 k-steps
+    # 32 zero tail steps (16 until ABI 8); 128 -> 128 3x3 has 576 k-steps
     def sections(cout, steps):
-        return sum(((cout + 32 * b - 1) // (32 * b) * steps + 16) * 64 * b for b in (4, 2, 1))
+        return sum(((cout + 32 * b - 1) // (32 * b) * steps + 32) * 64 * b for b in (4, 2, 1))
     # 3x3 layers with 64 / 128 input channels and Cout % 16 == 0 (>= 32): + the 16-row copy of the small-launch kernel
     # (csrc/conv_t16.h), Cin / 4 channel quads x 9 taps = 288 k-steps of four channels per 16-row tile, no tail
     def small(cout, cin):

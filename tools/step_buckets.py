@@ -13,9 +13,12 @@ def bucket(name: str) -> str:
     n = name
     if "at::native" in n or "rocclr" in n or "elementwise_kernel_with_index" in n:
         return "glue: ATen / runtime"
-    if "conv_mfma_kernel<4, 2, 0, 9" in n or "conv_mfma_kernel<4, 1, 0, 9" in n or "conv_head16" in n:
+    # (", 8, 16, 4," = the four-tap walk of a stride-2 layer's input gradient, round 5: a 3x3 launch like the nine-tap one it replaces)
+    if "conv_mfma_kernel<4, 2, 0, 9" in n or "conv_mfma_kernel<4, 1, 0, 9" in n or "conv_head16" in n or \
+            "conv_mfma_kernel<4, 2, 0, 8, 16, 4," in n or "conv_mfma_kernel<4, 1, 0, 8, 16, 4," in n:
         return "3x3 conv, maps >= 32x32"
-    if "conv_mfma_kernel<1, 1, 0, 9" in n or "conv_t16" in n or "conv_mfma_kernel<2, 1, 0, 9" in n or "conv_mfma_kernel<2, 2, 0, 9" in n:
+    if "conv_mfma_kernel<1, 1, 0, 9" in n or "conv_t16" in n or "conv_mfma_kernel<2, 1, 0, 9" in n or "conv_mfma_kernel<2, 2, 0, 9" in n or \
+            ", 0, 8, 16, 4," in n:
         return "3x3 conv, maps <= 16x16"
     if "conv_mfma_kernel" in n:
         return "1x1 conv"

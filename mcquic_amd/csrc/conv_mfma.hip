@@ -85,7 +85,7 @@ struct ConvK {
 
 constexpr int PRO_NONE = 0, PRO_SILU = 1, PRO_SQUARE = 2;
 #ifndef MCQ_GDN_XLDS
-#define MCQ_GDN_XLDS 0          // build switch: 0 = the GDN / IGDN epilogue re-reads x from memory (rounds 1-4: 2.0x the read traffic)
+#define MCQ_GDN_XLDS 0          // build switch: 1 = GDN / IGDN launches keep the streamed x in LDS for the epilogue instead of re-reading it (no gain, see the k-loop)
 #endif
 #ifndef MCQ_TAPS_LR
 #define MCQ_TAPS_LR 1           // build switch: 0 = MCQ_CONV_TAPS_LR launches walk all nine taps (rounds 1-4: 5 / 9 of their MFMAs multiply zeros)
@@ -95,6 +95,7 @@ constexpr int PRO_NONE = 0, PRO_SILU = 1, PRO_SQUARE = 2;
 #endif
 #ifndef MCQ_FAST_RSQRT
 #define MCQ_FAST_RSQRT 0        // build switch: 1 = the GDN / IGDN epilogue forms 1/sqrt(s) and sqrt(s) from v_rsq_f32 + one Newton step
+                                // (-10 % on the isolated launch, nothing inside the 32-image step, other bits: left off, docs/experiments.md 10.6)
 #endif
 // s = beta + sum gamma x^2 >= beta > 0 and far from the denormal range (the reparametrised beta is bounded below by 2^-18^2 ... ~1e-6),
 // so none of sqrtf's / the division's range handling is needed: v_rsq_f32 (1 ulp) corrected once is within 1 ulp of the exact value
@@ -524,10 +525,12 @@ next_tile:
 #pragma unroll
                 for (int nb = 0; nb < NBG; ++nb) {
                     float v = B[sb][nb];
-                    // (round 5) y = x f(beta + gamma x^2): the closing multiply needs the very x values this loop streams through --
-                    // lane (hi, j) loads channel 2 s + hi of pixel j at k-step s.  They are parked in LDS ([k-step][lane], 16 KB per
-                    // wave at 128 channels, no other wave reads them) instead of being read from memory a second time: these launches
-                    // are HBM-bound (3.9 TB/s at 3 x the tensor) with the matrix pipe 93 % idle, so the 64 ds_write cost nothing
+                    // (round 5, -DMCQ_GDN_XLDS=1, measured and left OFF) y = x f(beta + gamma x^2): the closing multiply needs the very x
+                    // values this loop streams through -- lane (hi, j) loads channel 2 s + hi of pixel j at k-step s -- so they can be
+                    // parked in LDS ([k-step][lane], 16 KB per wave at 128 channels, read back by the same wave) instead of being read a
+                    // second time.  It buys nothing: that second read is served by L2 (PMC counts it, HBM does not see it), and 64 KB of
+                    // LDS per workgroup costs the third resident workgroup -- 1198-1211 -> 1229-1237 us at 32 x 128 x 384x256; with 48 of
+                    // the 64 steps parked (three workgroups stay) 1191-1200, headline unchanged (docs/experiments.md 10.6)
                     if (MCQ_GDN_XLDS && TAPS == 1 && PRO == PRO_SQUARE && NB == 1 && p.xlds)
                         xpark[(size_t)(MCQ_XLDS_STEPS < 64 ? min(sp + u, MCQ_XLDS_STEPS) : sp + u) * 64] = v;
                     if (PRO == PRO_SILU) v = mcq_silu(v);

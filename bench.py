@@ -483,14 +483,24 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
         model.enableGraphs(False)
     # ---- VQ distance + argmin, BASELINE configs[3] --------------------------------------------------------------------
     try:
-        g = torch.Generator().manual_seed(0)
-        lat = (torch.randn((32, 4 * 256, 48, 32), generator=g) * 0.1).to(dev)
-        cb = ops.PackedCodebook((torch.randn((4, 4096, 256), generator=g) * (2 / (5 * 256)) ** 0.5).to(dev))
+        from mcquic_amd.utils import synthetic as SY
+        lat_c, cb_c = SY.vq_case("config4")                   # (seed 0: latents, then the codebook -- the tensors fixture F2b was captured on)
+        lat = lat_c.to(dev)
+        cb = ops.PackedCodebook(cb_c.to(dev))
         ms = _timed(lambda: ops.vq_assign(lat, cb), 10, warmup=2)
         flops = 2.0 * 4 * 32 * 48 * 32 * 4096 * 256
         sec["vq_config4"] = {"ms": round(ms, 4), "tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                              "frac_of_peak": round(flops / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
                              "workload": "M=4 K=4096 D=256, 49152 vectors per codebook (412.3 GFLOP)"}
+        # the codes of the timed launch against the REAL reference's (fixture F2b: per-image hashes captured from
+        # mcquic/modules/quantizer.py:144-179 on these very tensors)
+        f2b = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "f2b_vq_fullsize.npz")
+        if os.path.exists(f2b):
+            import numpy as _np
+            want = _np.load(f2b)["config4_code_hash"]
+            codes = ops.vq_assign(lat, cb).cpu()
+            same = sum(int(SY.code_hash(codes[i]) == want[i].tobytes()) for i in range(codes.shape[0]))
+            sec["vq_config4"]["images_bit_equal_to_reference"] = f"{same}/{codes.shape[0]}"
         del lat, cb
     except Exception as exc:                                  # noqa: BLE001
         sec["vq_config4"] = {"error": repr(exc)[:300]}

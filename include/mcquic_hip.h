@@ -30,7 +30,7 @@ extern "C" {
  * compares it with mcq_abi_version() of the library it loaded before calling anything else: a stale .so under new
  * prototypes (or the reverse) misaligns arguments silently otherwise.  3 = round 3 (mcq_rans_*_with_indexes take cdf_lens,
  * mcq_gate_f32 takes out_silu -- both changed in round 2 without a bump --, GroupNorm / logits-gradient entry points). */
-#define MCQ_ABI_VERSION   8
+#define MCQ_ABI_VERSION   9
 
 #define MCQ_OK            0
 #define MCQ_EINVAL       -1   /* NULL pointer / non-positive dimension / unsupported combination */
@@ -249,7 +249,9 @@ int mcq_vq_soft_bwd_f32(const float* ddist, const float* rowsum, const float* x,
                         float* dcodebook, int32_t N, int32_t m, int32_t d, int32_t h, int32_t w, int32_t k, void* stream);
 
 /* ---- per-step bookkeeping of the training quantizer (round 5; csrc/step_ops.hip) ------------------------------ */
-#define MCQ_VQ_MAX_LEVELS 8
+#define MCQ_VQ_MAX_LEVELS 32   /* (8 until ABI 9; the reference's generator configs run 17 levels) */
+/* the cap a binding chunks by (returns MCQ_VQ_MAX_LEVELS of the library it loaded) */
+int32_t mcq_vq_max_levels(void);
 /* ONE launch in front of the level cascade of a training forward (host arrays of `levels` <= MCQ_VQ_MAX_LEVELS entries):
  *   exponents[l] = -(log2 k_l - 1) * usage_l^2 + log2 k_l,  usage_l = mean(freq_ema_l > eps) clamped to [0, 1]
  *                  -- the exponent of _randomDrop (mcquic/modules/quantizer.py:194-198), rounded op by op like torch;
@@ -484,7 +486,10 @@ int mcq_pack_conv_weight_winograd16_f32(const float* w, int32_t Cout, int32_t Ci
  * partial tiles in `workspace` -> dW in OIHW order, db) instead of launching it; mcq_wgrad_flush(0, stream) launches everything
  * recorded, 80 convolutions per launch, and empties the record (discard != 0: empties it without launching, after an error).
  * Until the flush the caller keeps every workspace alive and reads no dW / db.  Same sums in the same order as the one-by-one pass.
- * mcq_wgrad_pending(): convolutions recorded and not yet flushed.  Process-wide switch: one backward pass at a time uses it. */
+ * mcq_wgrad_pending(): convolutions recorded and not yet flushed ON THE CALLING THREAD'S CURRENT DEVICE.  The switch is process-wide
+ * (the autograd engine records from its own per-device thread): one backward pass at a time uses it; the record is kept per
+ * device (ABI 9), a flush launches the current device's jobs on `stream` and a discard empties every device's.
+ * The caller also keeps every dW / db alive until the flush (a dropped one would be written over whatever took its memory). */
 void mcq_wgrad_defer(int32_t on);
 int32_t mcq_wgrad_pending(void);
 int mcq_wgrad_flush(int32_t discard, void* stream);

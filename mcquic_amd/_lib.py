@@ -74,6 +74,7 @@ SYMBOLS = {
                                     c_int32, c_void_p]),
     "mcq_vq_gumbel_sample_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "mcq_vq_max_levels": (c_int32, []),
     "mcq_vq_step_prologue_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mcq_vq_temperature_grad_f32": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "mcq_freq_ema_update_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_double, c_void_p]),
@@ -148,7 +149,7 @@ SYMBOLS = {
     "mcq_abi_version": (c_int32, []),
 }
 
-ABI_VERSION = 8          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
+ABI_VERSION = 9          # MCQ_ABI_VERSION of include/mcquic_hip.h these prototypes were written against
 
 _lib = None
 

@@ -201,16 +201,40 @@ class MseFn(torch.autograd.Function):
 _ONES = {}
 
 
+def _leaves_take_by_stealing(roots) -> bool:
+    """Deferring the weight gradients' reduce passes hands the autograd engine dW / db tensors whose values only exist after the
+    flush.  That is sound only if nothing LOOKS at them before: every parameter the pass reaches must take its gradient by stealing
+    the tensor -- `.grad is None` (a second backward() without zero_grad would run `p.grad += dW` on unreduced memory) and no tensor
+    hook / post-accumulate hook on it (they would be called with it).  Walks the graph under `roots` once (a few hundred nodes).
+    (Hooks put on the AccumulateGrad nodes themselves from C++ -- torch DDP's reducer -- are invisible from here: with DDP use
+    `loss.backward()`, see `backward`.)"""
+    seen, stack = set(), [t.grad_fn for t in roots if t is not None and t.grad_fn is not None]
+    while stack:
+        fn = stack.pop()
+        if fn in seen:
+            continue
+        seen.add(fn)
+        v = getattr(fn, "variable", None)
+        if v is not None:                                       # an AccumulateGrad node
+            if v.grad is not None or getattr(v, "_backward_hooks", None) or getattr(v, "_post_accumulate_grad_hooks", None):
+                return False
+            continue
+        stack.extend(nf for nf, _ in fn.next_functions if nf is not None)
+    return True
+
+
 def backward(loss: torch.Tensor, defer_reduce: bool = True) -> None:
     """`loss.backward()` with the root gradient taken from a cached 1.0 on the loss's device (the engine otherwise allocates and
     FILLS one per call -- the one ATen launch left in a captured training step) and with the weight gradients' reduce passes of the
-    whole pass run in a few launches at its end (ops.wgrad_deferral).  NOT for a backward pass something else listens to (torch DDP
+    whole pass run in a few launches at its end (ops.wgrad_deferral) -- when that is sound: every parameter reached has `.grad is
+    None` and no hooks (`_leaves_take_by_stealing`; gradient accumulation over several backward passes, hooks: the reduce passes run
+    one by one as the launches are made, same values).  NOT for a backward pass something else listens to from C++ (torch DDP
     reads gradients from bucket hooks while the pass is still running): there, call `loss.backward()` as usual."""
     key = (loss.device, loss.dtype)
     one = _ONES.get(key)
     if one is None:
         one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
-    if not defer_reduce:                                        # (something reads gradients DURING the pass, e.g. torch DDP's bucket hooks)
+    if not defer_reduce or not _leaves_take_by_stealing([loss]):    # (something reads gradients DURING the pass)
         loss.backward(one if loss.dim() == 0 else None)
         return
     with ops.wgrad_deferral():                                  # (this pass is ours end to end: the weight gradients' reduce passes run batched)
@@ -219,6 +243,9 @@ def backward(loss: torch.Tensor, defer_reduce: bool = True) -> None:
 
 def run_backward(tensors, grad_tensors) -> None:
     """torch.autograd.backward(tensors, grad_tensors) with the weight gradients' reduce passes batched (see `backward`)."""
+    if not _leaves_take_by_stealing(list(tensors)):
+        torch.autograd.backward(tensors, grad_tensors)
+        return
     with ops.wgrad_deferral():
         torch.autograd.backward(tensors, grad_tensors)
 

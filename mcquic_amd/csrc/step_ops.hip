@@ -198,6 +198,8 @@ __global__ __launch_bounds__(STEP_T) void nonneg_reparam_bwd2_kernel(Reparam2K q
 
 }  // namespace
 
+extern "C" int32_t mcq_vq_max_levels(void) { return MCQ_VQ_MAX_LEVELS; }
+
 extern "C" int mcq_vq_step_prologue_f32(const float* const* freq_ema, const int32_t* m, const int32_t* k, int32_t levels, float eps,
                                         float* exponents, uint64_t* rng_state, uint64_t* rng_snaps, int64_t* counts, int64_t counts_n,
                                         void* stream) {

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <mutex>
 #include <type_traits>
+#include <unordered_map>
 #include <vector>
 
 #include "mcq_common.h"
@@ -432,7 +433,9 @@ __global__ __launch_bounds__(256) void wgrad_rows_reduce_batch_kernel(ReduceBatc
 
 std::mutex g_defer_mu;
 bool g_defer = false;
-std::vector<ReduceJob> g_jobs;
+// recorded reduce passes, per device (a job is only ever flushed onto a stream of the device its buffers live on)
+std::unordered_map<int, std::vector<ReduceJob>> g_jobs;
+inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 
 // the second pass of a weight-gradient launch: now, or recorded per convolution for mcq_wgrad_flush
 inline void reduce_pass(const WgRowsReduceK& q, unsigned gx, unsigned nconv, hipStream_t s) {
@@ -440,8 +443,9 @@ inline void reduce_pass(const WgRowsReduceK& q, unsigned gx, unsigned nconv, hip
         std::lock_guard<std::mutex> lock(g_defer_mu);
         if (g_defer) {
             const size_t per = (size_t)q.taps * q.Cout * q.Cin;
+            std::vector<ReduceJob>& mine = g_jobs[current_device()];
             for (unsigned c = 0; c < nconv; ++c)
-                g_jobs.push_back(ReduceJob{q.part + (size_t)c * q.groups * per, q.bias_part ? q.bias_part + (size_t)c * q.groups * 4 * q.Cout : nullptr,
+                mine.push_back(ReduceJob{q.part + (size_t)c * q.groups * per, q.bias_part ? q.bias_part + (size_t)c * q.groups * 4 * q.Cout : nullptr,
                                            q.dw[c], q.dbias[c], q.groups, q.Cout, q.Cin, q.taps});
             return;
         }
@@ -960,16 +964,19 @@ extern "C" void mcq_wgrad_defer(int32_t on) {
 
 extern "C" int32_t mcq_wgrad_pending(void) {
     std::lock_guard<std::mutex> lock(g_defer_mu);
-    return (int32_t)g_jobs.size();
+    const auto it = g_jobs.find(current_device());
+    return it == g_jobs.end() ? 0 : (int32_t)it->second.size();
 }
 
 extern "C" int mcq_wgrad_flush(int32_t discard, void* stream) {
     std::vector<ReduceJob> jobs;
     {
         std::lock_guard<std::mutex> lock(g_defer_mu);
-        jobs.swap(g_jobs);
+        if (discard) { g_jobs.clear(); return MCQ_OK; }            // (every device's: the pass they belonged to is gone)
+        const auto it = g_jobs.find(current_device());
+        if (it != g_jobs.end()) { jobs.swap(it->second); g_jobs.erase(it); }
     }
-    if (discard || jobs.empty()) return MCQ_OK;
+    if (jobs.empty()) return MCQ_OK;
     // a launch's grid.x is its LARGEST job's block count: jobs go largest first, and a launch ends where the next job would leave
     // more than a quarter of its row of blocks empty (the first form mixed 128 -> 512 shuffle convolutions with 1x1 ones:
     // three quarters of 738 k workgroups were dispatched to leave at once, 233 us)

@@ -307,10 +307,11 @@ class BaseQuantizer(nn.Module):
 
     def _stepPrologue(self, x: torch.Tensor, uniforms):
         """The per-step bookkeeping of all levels in ONE launch (ops.vq_step_prologue): every level's drop exponent and generator
-        snapshot, and the zeroed code-count buffer of the entropy coder that the sampling kernels add into.  None on the CPU
-        (module-level fallbacks: the levels then make their own)."""
+        snapshot, and the zeroed code-count buffer of the entropy coder that the sampling kernels add into.  HIP devices only:
+        the training forward has no CPU / PyTorch path (a level run on its own makes its own prologue launch, equally on the device)."""
         if not x.is_cuda:
-            return None
+            raise NotImplementedError(f"mcquic_amd: the training forward of {type(self).__name__} runs on a HIP device only (input on "
+                                      f"{x.device}); there is no CPU / PyTorch fallback -- move the model and the batch to cuda")
         coder = self._entropyCoder
         want_rng = uniforms is None and not _TORCH_RAND
         return ops.vq_step_prologue(list(coder._freqEMA), EPS, want_rng, coder.countBuffer(x.device))

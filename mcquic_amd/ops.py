@@ -765,10 +765,21 @@ def vq_step_prologue(freqs: Sequence[torch.Tensor], eps: float, want_rng: bool, 
         st.counts = _dev(counts, "counts", torch.int64)
         if st.counts.numel() != sum(st.sizes):
             raise ValueError("vq_step_prologue: the count buffer must hold sum(m_l * k_l) entries")
-    ptrs = (ctypes.c_void_p * levels)(*[f.data_ptr() for f in fs])
+    # (the library's tables hold mcq_vq_max_levels() levels per launch -- 32; the reference's generator configs run 17 -- and
+    #  anything beyond goes chunk by chunk: the generator's offset advances by each chunk's level count on the device, so the
+    #  snapshots are the ones a single launch would hand out; the count buffer is zeroed whole by the first chunk)
+    cap = int(lib.mcq_vq_max_levels())
     with _guard(dev):
-        check(lib.mcq_vq_step_prologue_f32(ptrs, ms, ks, levels, float(eps), _ptr(st.exponents), _ptr(state), _ptr(st.snaps), _ptr(st.counts),
-                                           0 if st.counts is None else st.counts.numel(), _stream()), "mcq_vq_step_prologue_f32")
+        for l0 in range(0, levels, cap):
+            nl = min(cap, levels - l0)
+            ptrs = (ctypes.c_void_p * nl)(*[f.data_ptr() for f in fs[l0: l0 + nl]])
+            ms_c = (ctypes.c_int32 * nl)(*ms[l0: l0 + nl])
+            ks_c = (ctypes.c_int32 * nl)(*ks[l0: l0 + nl])
+            first = l0 == 0 and st.counts is not None
+            check(lib.mcq_vq_step_prologue_f32(ptrs, ms_c, ks_c, nl, float(eps), _ptr(st.exponents[l0: l0 + nl]), _ptr(state),
+                                               None if st.snaps is None else _ptr(st.snaps[l0: l0 + nl]),
+                                               _ptr(st.counts) if first else None, st.counts.numel() if first else 0, _stream()),
+                  "mcq_vq_step_prologue_f32")
     return st
 
 
@@ -798,9 +809,19 @@ def freq_ema_update_(freqs: Sequence[torch.Tensor], counts: torch.Tensor, ema: f
         raise ValueError("freq_ema_update_: `counts` must hold sum(m_l * k_l) entries")
     ms = (ctypes.c_int32 * levels)(*[int(f.shape[0]) for f in fs])
     ks = (ctypes.c_int32 * levels)(*[int(f.shape[1]) for f in fs])
-    ptrs = (ctypes.c_void_p * levels)(*[f.data_ptr() for f in fs])
+    lib = _lib.load()
+    cap = int(lib.mcq_vq_max_levels())
     with _guard(counts.device):
-        check(_lib.load().mcq_freq_ema_update_f32(ptrs, ms, ks, levels, _ptr(counts), float(ema), _stream()), "mcq_freq_ema_update_f32")
+        off = 0
+        for l0 in range(0, levels, cap):                     # (a launch's tables hold `cap` levels; see vq_step_prologue)
+            nl = min(cap, levels - l0)
+            ptrs = (ctypes.c_void_p * nl)(*[f.data_ptr() for f in fs[l0: l0 + nl]])
+            ms_c = (ctypes.c_int32 * nl)(*ms[l0: l0 + nl])
+            ks_c = (ctypes.c_int32 * nl)(*ks[l0: l0 + nl])
+            size = sum(int(f.numel()) for f in fs[l0: l0 + nl])
+            check(lib.mcq_freq_ema_update_f32(ptrs, ms_c, ks_c, nl, _ptr(counts[off: off + size]), float(ema), _stream()),
+                  "mcq_freq_ema_update_f32")
+            off += size
 
 
 def hash_uniform(rng: torch.Tensor, stream_id: int, shape) -> torch.Tensor:
@@ -1080,9 +1101,12 @@ class wgrad_now:
         return False
 
 
-def _keep(ws: torch.Tensor) -> None:
+def _keep(*tensors) -> None:
+    """Workspace AND outputs of a deferred weight-gradient launch stay alive until the flush has written them: a dW the autograd
+    engine drops (a frozen weight: requires_grad False) would otherwise be handed to another tensor and the flush would write
+    over that one."""
     if _defer["on"]:
-        _defer["keep"].append(ws)
+        _defer["keep"].extend(t for t in tensors if t is not None)
 
 
 def conv2d_wgrad_group(xs, dys, want_bias: bool = True):
@@ -1117,7 +1141,7 @@ def conv2d_wgrad_group(xs, dys, want_bias: bool = True):
                                                       table(*[t.data_ptr() for t in dws]),
                                                       table(*[t.data_ptr() for t in dbs]) if want_bias else None, k, _ptr(ws),
                                                       n, cin, h, w, cout, _stream()), "mcq_conv2d_wgrad_nchw_group_f32")
-        _keep(ws)
+        _keep(ws, *dws, *(dbs or []))
         out.extend(zip(dws, dbs if want_bias else [None] * k))
     return out
 
@@ -1139,7 +1163,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
             with _guard(x.device):
                 check(lib.mcq_conv2d_wgrad_nchw_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream()),
                       "mcq_conv2d_wgrad_nchw_f32")
-            _keep(ws)
+            _keep(ws, dw, db)
             return (dw, db) if want_bias else dw
     if ksize == 3 and stride == 2 and not square_x and _WGRAD_ROWS and (ho, wo) == (h // 2, w // 2):
         nws = lib.mcq_conv2d_wgrad_s2_nchw_workspace_floats(n, cin, h, w, cout)
@@ -1150,7 +1174,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
             with _guard(x.device):
                 check(lib.mcq_conv2d_wgrad_s2_nchw_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream()),
                       "mcq_conv2d_wgrad_s2_nchw_f32")
-            _keep(ws)
+            _keep(ws, dw, db)
             return (dw, db) if want_bias else dw
     if ksize == 1 and stride == 1 and _WGRAD_ROWS:
         nws = lib.mcq_conv2d_wgrad1x1_nchw_workspace_floats(n, cin, h, w, cout)
@@ -1161,7 +1185,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
             with _guard(x.device):
                 check(lib.mcq_conv2d_wgrad1x1_nchw_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout,
                                                        int(square_x), _stream()), "mcq_conv2d_wgrad1x1_nchw_f32")
-            _keep(ws)
+            _keep(ws, dw, db)
             return (dw, db) if want_bias else dw
     xt = torch.empty((n, h, w, cin), dtype=torch.float32, device=x.device)
     dyt = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)

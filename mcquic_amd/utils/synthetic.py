@@ -42,3 +42,20 @@ def code_hash(code_img: torch.Tensor) -> bytes:
 
 def state_dict_sha(sd: Dict[str, torch.Tensor]) -> str:
     return hashlib.sha256(b"".join(sd[k].detach().cpu().contiguous().numpy().tobytes() for k in sorted(sd))).hexdigest()
+
+
+# ---- BASELINE configs[3]: the VQ distance / argmin kernel in isolation ------------------------------------
+#   latents x ~ N(0, 0.1^2) [32, m * d, 48, 32], codebook ~ N(0, 2 / (5 d)) [m, k, d] (the init law of mcquic/modules/quantizer.py:398),
+#   both from ONE torch.Generator seeded 0, latents drawn first -- the tensors bench.py's `vq_config4` leg times, the golden capture
+#   F2b (tests/golden/make_golden.py f2b) runs the reference on, and tests/test_gpu_fullsize.py checks every code of.
+VQ_CASES = {"config4": dict(m=4, k=4096, d=256, n=32, h=48, w=32, seed=0),       # BASELINE.json configs[3], 49 152 vectors per codebook
+            "qp2_l0": dict(m=2, k=8192, d=64, n=32, h=48, w=32, seed=1)}        # the qp=2 model's level 0 at configs[1]'s batch
+
+
+def vq_case(tag: str):
+    """(latents [n, m * d, h, w], codebook [m, k, d]) of VQ_CASES[tag] on the CPU."""
+    c = VQ_CASES[tag]
+    g = torch.Generator(device="cpu").manual_seed(c["seed"])
+    lat = torch.randn((c["n"], c["m"] * c["d"], c["h"], c["w"]), generator=g) * 0.1
+    cb = torch.randn((c["m"], c["k"], c["d"]), generator=g) * (2 / (5 * c["d"])) ** 0.5
+    return lat, cb

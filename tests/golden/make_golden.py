@@ -319,6 +319,43 @@ def main():
             vq[tag + "_deq_sha"] = np.frombuffer(bytes.fromhex(sha(deq)), dtype=np.uint8)
         np.savez_compressed(os.path.join(OUT, "f2_vq.npz"), **vq)
 
+    # ---- F2b: the VQ kernel's own configuration at FULL size (BASELINE configs[3]) --------------------------
+    # the reference's _multiCodebookQuantization.encode (mcquic/modules/quantizer.py:144-179) on bench.py's `vq_config4` tensors
+    # and on the qp=2 model's level-0 shape at batch 32: per-image code hashes + every near-tie (top-2 gap < F5C_NEAR in the
+    # reference's own float32 distances) with both candidates -- the F5c format, a few KB.  Two images per call (the [n, m, h, w, k]
+    # distance tensor of the whole batch would be 3.2 GB).
+    if want("f2b"):
+        from mcquic_amd.utils.synthetic import VQ_CASES, vq_case
+        f2b = {"near_threshold": np.array([F5C_NEAR])}
+        for tag in VQ_CASES:
+            lat, cb = vq_case(tag)
+            q = RQ._multiCodebookQuantization(torch.nn.Parameter(cb), 0.0)
+            hashes, near, near_gap = [], [], []
+            smallest = np.inf
+            for lo in range(0, lat.shape[0], 2):
+                xs = lat[lo:lo + 2]
+                with torch.inference_mode():
+                    dist = q._distance(xs)
+                    code = q.encode(xs)
+                top2 = torch.topk(dist, 2, dim=-1, largest=False)
+                gap = top2.values[..., 1] - top2.values[..., 0]
+                second = torch.where(top2.indices[..., 0] == code, top2.indices[..., 1], top2.indices[..., 0])
+                smallest = min(smallest, float(gap.min()))
+                for i in range(len(xs)):
+                    hashes.append(code_hash(code[i]))
+                for (i, g, yy, xx) in (gap < F5C_NEAR).nonzero().tolist():
+                    near.append((lo + i, g, yy, xx, int(code[i, g, yy, xx]), int(second[i, g, yy, xx])))
+                    near_gap.append(float(gap[i, g, yy, xx]))
+                print(f"f2b {tag}: images {lo}..{lo + len(xs) - 1}  near-ties {len(near)}", flush=True)
+            c = VQ_CASES[tag]
+            f2b[tag + "_shape"] = np.array([c["m"], c["k"], c["d"], c["n"], c["h"], c["w"], c["seed"]])
+            f2b[tag + "_code_hash"] = np.stack(hashes)
+            f2b[tag + "_near"] = np.array(near, dtype=np.int32).reshape(-1, 6)
+            f2b[tag + "_near_gap"] = np.array(near_gap, dtype=np.float32)
+            f2b[tag + "_smallest_gap"] = np.array([smallest], dtype=np.float32)
+            f2b[tag + "_input_sha"] = np.frombuffer(bytes.fromhex(sha(lat)) + bytes.fromhex(sha(cb)), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, "f2b_vq_fullsize.npz"), **f2b)
+
     # ---- F4: the full small model Compressor(8, 2, [32, 16, 8]) ----------------------------------------
     if want("f4"):
         small = {}

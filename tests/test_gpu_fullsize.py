@@ -1,5 +1,8 @@
 """GPU, BASELINE's full sizes (batch 32 of 768x512, qp=2 model): size-independent properties, since the CPU oracle
 would take minutes here.  (The oracle itself is compared at full image size on two images by bench.py's parity leg.)"""
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -77,3 +80,48 @@ def test_vq_codes_are_the_nearest_codewords_at_full_size(dev):
         top2 = torch.topk(dist, 2, dim=1, largest=False).values
         gap = (top2[:, 1] - top2[:, 0]).reshape(h, w)[bad]
         assert gap.max().item() < 1e-5
+
+
+F2B = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f2b_vq_fullsize.npz")
+F2B_GAP_BAR = 2e-6        # a code may differ from the reference's only below this gap in the reference's own distances
+F2B_MAX_FLIPS = {"config4": 8, "qp2_l0": 8}     # measured in round 6: see profiles/r06_parity_measurements.json (bars = the config[2] census's)
+
+
+@pytest.mark.parametrize("tag", ["config4", "qp2_l0"])
+def test_vq_full_size_against_the_reference(dev, tag):
+    """BASELINE configs[3] at its OWN size against the REAL reference: every one of the 196 608 codes of
+    `vq_assign_kernel<128, true>` (d = 256: the XLDS instance) -- and the 98 304 of the qp=2 level-0 shape at batch 32 -- against
+    fixture F2b, captured from mcquic/modules/quantizer.py:144-179 on the same seeded tensors (tests/golden/make_golden.py f2b):
+    per-image hashes of the reference's codes plus every vector whose top-2 gap in the reference's own float32 distances is below
+    2e-5, with both candidates.  An image whose hash differs must become hash-equal once the codes that sit at a recorded near-tie
+    AND hold the reference's runner-up are put back to its winner: a code may differ nowhere else, and only below F2B_GAP_BAR."""
+    from mcquic_amd import ops
+    from mcquic_amd.utils import synthetic as S
+    from _record import record
+    z = np.load(F2B)
+    lat, cb = S.vq_case(tag)
+    m, k, d, n, h, w, _ = [int(v) for v in z[tag + "_shape"]]
+    assert tuple(lat.shape) == (n, m * d, h, w) and tuple(cb.shape) == (m, k, d)
+    codes = ops.vq_assign(lat.to(dev), ops.PackedCodebook(cb.to(dev))).cpu()
+    assert codes.dtype == torch.int64 and tuple(codes.shape) == (n, m, h, w)
+    near = {}
+    for row, gap in zip(z[tag + "_near"], z[tag + "_near_gap"]):
+        near.setdefault(int(row[0]), []).append((int(row[1]), int(row[2]), int(row[3]), int(row[4]), int(row[5]), float(gap)))
+    flips, widest, equal = 0, 0.0, 0
+    for i in range(n):
+        if S.code_hash(codes[i]) == z[tag + "_code_hash"][i].tobytes():
+            equal += 1
+            continue
+        fixed = codes[i].clone()
+        for g, yy, xx, best, second, gap in near.get(i, []):
+            if int(fixed[g, yy, xx]) == second:
+                fixed[g, yy, xx] = best
+                flips += 1
+                widest = max(widest, gap)
+        assert S.code_hash(fixed) == z[tag + "_code_hash"][i].tobytes(), \
+            f"image {i}: codes differ from the reference's away from its recorded near-ties (or choose neither of its two candidates)"
+    record(f"vq_fullsize_vs_reference[{tag}]", images_bit_equal=equal, images=n, flips=flips, widest_reference_gap_at_a_flip=widest,
+           near_ties_below_2e_5=int(len(z[tag + "_near"])), smallest_reference_gap=float(z[tag + "_smallest_gap"][0]), codes=int(codes.numel()),
+           bar_flips=F2B_MAX_FLIPS[tag], bar_gap=F2B_GAP_BAR)
+    assert widest < F2B_GAP_BAR, f"a code differs where the reference's own gap is {widest:.3e}"
+    assert flips <= F2B_MAX_FLIPS[tag], f"{flips} codes at near-ties differ (bar {F2B_MAX_FLIPS[tag]})"

@@ -28,6 +28,7 @@ MODEL12 = (192, 12, [8192, 2048, 512])
 #  with 3; the four-image oracle batch 0 differing codes in 0 images)
 MAX_FLIPS12 = {"kodak": 4, "ragged": 1}
 MAX_DIFF_IMAGES12 = 1
+MAX_FIRST_FLIPS12 = 2      # codes that may differ at the FIRST level an image differs at (deeper levels quantize another residual)
 TOL192 = 4e-6          # sums of 192 x 9 = 1728 products (2e-6 holds for the 1152 of channel 128: measured 3.2e-6 here)
 
 
@@ -75,6 +76,14 @@ def test_model12_against_oracle_batch(dev, model12):
     record("model12_oracle_batch", differing_codes=diff, images_with_a_difference=images, codes=total, bar_images=MAX_DIFF_IMAGES12)
     # (a first flip changes the residual every deeper level of THAT image quantizes, so differences are counted in images)
     assert images <= MAX_DIFF_IMAGES12, f"{images} of 4 images differ from the oracle's codes somewhere ({diff} of {total} codes; bar {MAX_DIFF_IMAGES12} image)"
+    # ... and inside such an image only the levels BELOW its first flip may differ freely: at the first level that differs at most
+    # MAX_FIRST_FLIPS12 codes do (an image with every code wrong must not pass as "one image")
+    for i in range(x.shape[0]):
+        for lv, (a, b) in enumerate(zip(got, want)):
+            first = int((a[i] != b[i]).sum())
+            if first:
+                assert first <= MAX_FIRST_FLIPS12, f"image {i}: {first} codes differ at level {lv}, the first level that differs (bar {MAX_FIRST_FLIPS12})"
+                break
     rec = model.decode([c.to(dev) for c in want]).cpu()
     ref = R.decode(sd, want)
     assert float((rec - ref).abs().max()) <= 1e-4

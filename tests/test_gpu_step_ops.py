@@ -388,6 +388,70 @@ def test_deferred_reduce_passes_give_the_same_gradients(dev, kind):
         assert torch.equal(grads["plain"][n], grads["deferred"][n]), n
 
 
+def test_deferral_steps_aside_for_accumulation_hooks_and_frozen_weights(dev):
+    """the deferred reduce passes hand the engine dW tensors that are only written by the flush.  (1) a second
+    backward() onto existing .grad (gradient accumulation) must add REDUCED values: autograd.backward then reduces launch by
+    launch; (2) the same with a tensor hook on a parameter (the hook must see the real gradient); (3) a frozen conv weight's
+    dW is dropped by the engine -- its memory must not be handed out before the flush writes it."""
+    from mcquic_amd import Compressor
+    from mcquic_amd.autograd import backward, mse_loss, _leaves_take_by_stealing
+    torch.manual_seed(3407)
+    model = Compressor(32, 2, [64, 32, 16]).to(dev).train()
+    x = (torch.rand((4, 3, 128, 128), generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
+    g = torch.Generator().manual_seed(1)
+    us = [(torch.rand((4, 2, s, s, k), generator=g).to(dev), torch.rand((4, 2, s, s, k), generator=g).to(dev)) for s, k in ((8, 64), (4, 32), (2, 16))]
+    ema0 = [f.detach().clone() for f in model._quantizer._entropyCoder._freqEMA]
+
+    def loss_of():
+        with torch.no_grad():
+            for f, f0 in zip(model._quantizer._entropyCoder._freqEMA, ema0):
+                f.copy_(f0)
+        return mse_loss(model(x, uniforms=us)[0], x)
+
+    def grads():
+        return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    for p in model.parameters():
+        p.grad = None
+    loss_of().backward()
+    once = grads()
+    # (1) accumulation: two passes through autograd.backward without clearing
+    for p in model.parameters():
+        p.grad = None
+    l1 = loss_of()
+    assert _leaves_take_by_stealing([l1])
+    backward(l1)
+    l2 = loss_of()
+    assert not _leaves_take_by_stealing([l2])
+    backward(l2)
+    for n, v in grads().items():
+        assert torch.equal(v, once[n] + once[n]), n
+    # (2) a hook on one conv weight sees the reduced gradient
+    for p in model.parameters():
+        p.grad = None
+    w = model._encoder[1]._branch[1].weight
+    seen = []
+    h = w.register_hook(lambda gr: seen.append(gr.clone()))
+    backward(loss_of())
+    h.remove()
+    assert len(seen) == 1 and torch.equal(seen[0], once["_encoder.1._branch.1.weight"])
+    # (3) frozen weights: every other gradient unchanged, nothing written over a live tensor
+    for p in model.parameters():
+        p.grad = None
+    frozen = [model._encoder[1]._branch[1].weight, model._decoder[0]._branch[3].weight, model._encoder[2]._branch[2].gamma]
+    for p in frozen:
+        p.requires_grad_(False)
+    backward(loss_of())
+    torch.cuda.synchronize()
+    got = grads()
+    for p in frozen:
+        p.requires_grad_(True)
+    skipped = {"_encoder.1._branch.1.weight", "_decoder.0._branch.3.weight", "_encoder.2._branch.2.gamma"}
+    assert skipped.isdisjoint(got)
+    for n, v in got.items():
+        assert torch.equal(v, once[n]), n
+
+
 def test_generator_state_round_trip(dev):
     """ops.get_rng_state / set_rng_state: a run resumed from the saved state draws what the uninterrupted run drew."""
     from mcquic_amd import ops

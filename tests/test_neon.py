@@ -200,3 +200,43 @@ def test_neon_training_forward_and_gradients(dev, dense, case):
     bar = NEON_GRAD_BAR[(case, bool(dense))]
     record(f"neon_training_step[{case},denseNorm={bool(dense)}]", worst_rel_grad_err=worst[1], at=worst[0], bar=bar)
     assert worst[1] < bar, f"worst gradient mismatch {worst[1]:.3e} at {worst[0]}"
+
+
+@pytest.mark.gpu
+def test_neon_training_forward_with_seventeen_levels(dev):
+    """The level count of the reference's generator configs (configs/neon_gen.yaml: a 17-entry size list, i.e. 17 quantizations
+    through ResidualBackwardQuantizer): the per-step bookkeeping launches (mcq_vq_step_prologue_f32, mcq_freq_ema_update_f32)
+    carry tables of mcq_vq_max_levels() levels and anything beyond is chunked by ops.py -- codes, reconstruction and every
+    level's frequency EMA against the CPU oracle, with the cap's own chunking exercised by a second run under a cap of 4."""
+    from mcquic_amd import Neon, ops, _lib
+    size = [16, 8, 8, 8, 8, 4, 4, 4, 4, 2, 2, 2, 2, 1, 1, 1, 1]
+    ch, k = 32, 64
+    sd = N.make_state_dict(ch, k, size, seed=4)
+    x = R.make_images(2, 256, 256, seed=8)
+    us = _uniforms(k, seed=11, size=size)
+    want = N.forward_train({key: v.clone() for key, v in sd.items()}, x, us)
+    lib = _lib.load()
+    assert lib.mcq_vq_max_levels() >= 17
+
+    class _Capped:                                   # the library behind a cap of 4: five chunks of levels
+        def __getattr__(self, name):
+            return (lambda: 4) if name == "mcq_vq_max_levels" else getattr(lib, name)
+
+    for capped in (False, True):
+        model = Neon(ch, k, size)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(dev).train()
+        real = _lib.load
+        if capped:
+            ops._lib.load = lambda: _Capped()
+        try:
+            out = model(x.to(dev), uniforms=[(a.to(dev), b.to(dev)) for a, b in us])
+        finally:
+            ops._lib.load = real
+        for lv in range(len(size)):
+            assert torch.equal(out[2][lv].cpu(), want[2][lv]), f"codes level {lv} (capped={capped})"
+        assert float((out[0].detach().cpu() - want[0].detach()).abs().max()) <= 1e-4
+        for j in range(len(size)):                    # (the j-th quantization's histogram -> _entropyCoder._freqEMA[j], EMA 0.998)
+            got = model._quantizer._entropyCoder._freqEMA[j].detach().cpu()
+            ref = R.freq_ema_update(torch.ones((1, k)) / k, want[4][j], ema=0.998)
+            assert torch.allclose(got, ref, atol=1e-7), f"freqEMA of quantization {j} (capped={capped})"

@@ -56,6 +56,23 @@ def test_vq_matches_reference():
         assert (_sha(deq) == z[tag + "_deq_sha"]).all()
 
 
+@pytest.mark.parametrize("tag", ["config4", "qp2_l0"])
+def test_vq_full_size_fixture_oracle_side(tag):
+    """F2b (BASELINE configs[3] at its own size, captured from the reference): the oracle's codes for the first two images hash to
+    the reference's, and the fixture's inputs are the tensors mcquic_amd.utils.synthetic.vq_case makes."""
+    import hashlib
+    from mcquic_amd.utils import synthetic as S
+    z = np.load(os.path.join(G, "f2b_vq_fullsize.npz"))
+    lat, cb = S.vq_case(tag)
+    sha2 = hashlib.sha256(lat.contiguous().numpy().tobytes()).digest() + hashlib.sha256(cb.contiguous().numpy().tobytes()).digest()
+    assert sha2 == z[tag + "_input_sha"].tobytes()
+    code = R.vq_encode(lat[:2], cb)
+    for i in range(2):
+        assert S.code_hash(code[i]) == z[tag + "_code_hash"][i].tobytes()
+    near = z[tag + "_near"]
+    assert (z[tag + "_near_gap"] < float(z["near_threshold"][0])).all() and (near[:, 4] != near[:, 5]).all()
+
+
 @pytest.mark.parametrize("tag", ["pad", "aligned"])
 def test_small_model_matches_reference(tag):
     z = np.load(os.path.join(G, "f4_small_model.npz"))

@@ -100,6 +100,8 @@ class ConvProfiler:
             ho = (h + 2 * pad - w.ksize) // stride + 1
             wo = (wd + 2 * pad - w.ksize) // stride + 1
             flops = 2.0 * n * ho * wo * w.cout * cin * w.ksize * w.ksize
+            if any(kw.get(key) is not None for key in ("post_gdn", "post_igdn", "post_gate")):
+                flops += 2.0 * y.numel() * y.shape[1]       # the [128, 128] 1x1 layer that runs inside this launch (MCQ_CONV_POST_*)
             # algorithmic HBM bytes of the fused op: input and output once, plus every output-shaped side tensor its
             # contract needs (residual / multiplier / gate reads, the SiLU twin write)
             sides = sum(1 for key in ("res", "gdn_mul", "igdn_mul", "gate_mul", "gate_id", "mul") if kw.get(key) is not None)

@@ -61,6 +61,16 @@ extern "C" {
                                       * 2 x 2 taps (dy, dx in {0, +1}) -- what mcq_pack_conv_dgrad_weight_f32 writes for a stride-2 layer
                                       * ([4 Cin, Cout, 3, 3] through MCQ_CONV_SHUFFLE2: torch.autograd's conv_transpose2d of mcquic/nn/convs.py:132-153
                                       * conv3x3(stride=2)).  The launch then walks 4 of the 9 taps; same sums.  No input prologue, no Winograd form. */
+#define MCQ_CONV_POST_GDN   0x40000u  /* (round 6) the 1x1 layer that FOLLOWS this 3x3 convolution runs inside its launch, on the wave's fresh 128-channel
+                                      * tile: v = conv(x) + bias, s = post_w @ v^2 + post_bias, y = v / sqrt(s)  (ResidualBlockWithStride: conv3x3 s2 -> GenDivNorm,
+                                      * mcquic/nn/blocks.py:98-122, mcquic/nn/gdn.py:67-79).  Cout == 128, ksize 3; post_w from mcq_pack_post1x1_weight_f32. */
+#define MCQ_CONV_POST_IGDN  0x80000u  /* the same with y = v * sqrt(s) (ResidualBlockShuffle: pixelShuffle3x3 -> InvGenDivNorm, blocks.py:141-159, gdn.py:81-91).
+                                      * With MCQ_CONV_SHUFFLE2: Cout == 512 and w_packed / bias packed from the weight with its rows in SUB-PIXEL-MAJOR order
+                                      * (row 128 T + c = conv channel 4 c + T: the 128 rows of tile T are the 128 shuffled channels of sub-pixel T = 2 dy + dx),
+                                      * so that a wave holds all channels the normalisation mixes; the store goes to pixel (2 y + dy, 2 x + dx). */
+#define MCQ_CONV_POST_GATE  0x100000u /* v = conv(x) + bias + res_scale * res, s = post_w @ v + post_bias, y = mul * sigmoid(s) + gate_id  (AttentionBlock:
+                                      * the side stack's last convolution -> conv1x1 -> gate, blocks.py:281-288).  Cout == 128; DUAL_SILU allowed. */
+#define MCQ_CONV_POST_MASK  (MCQ_CONV_POST_GDN | MCQ_CONV_POST_IGDN | MCQ_CONV_POST_GATE)
 #define MCQ_CONV_DUAL_SILU  0x100u /* also store silu(y) to y_silu: the next block's act1(x), computed once per element */
 #define MCQ_CONV_WINOGRAD2D 0x1000u /* OPT-IN like MCQ_CONV_WINOGRAD: F(2x2, 3x3), 4/9 of the multiplications; w_packed from   */
                                     /* mcq_pack_conv_weight_winograd2d_f32; Cout % 128 == 0, Cin % 8 == 0                                */
@@ -88,7 +98,20 @@ typedef struct mcq_conv_desc {
     int32_t tile;          /* 0 = auto; else (log2 split-K << 8) | (MB << 4) | NB forces the wave tile (testing / tuning);
                             * bit 0x400: the 128 x 64 tile of a 3x3 stride-1 layer over pixel PAIRS (same bits, wide epilogue accesses;
                             * even output width, flags within SiLU / twin / residual / silu' / PixelShuffle), bit 0x800: never */
+    const float* post_w;    /* MCQ_CONV_POST_*: the following 1x1 layer's [128, 128] weight from mcq_pack_post1x1_weight_f32 (else NULL; ABI 9) */
+    const float* post_bias; /* MCQ_CONV_POST_*: its bias [128] (GDN / IGDN: the folded beta) or NULL                                         */
 } mcq_conv_desc;
+
+/* (round 6) Operand stream of a [128, 128] 1x1 layer for the MCQ_CONV_POST_* epilogues: the contraction runs over the wave's OWN
+ * accumulator registers, so its k-order is the accumulator order -- k-step t = 16 mb + r pairs channel 32 mb + (r & 3) + 8 (r >> 2)
+ * (lanes 0..31) with that channel + 4 (lanes 32..63): out[(t * 64 + lane) * 4 + q] = w[32 q + (lane & 31)][that channel], followed by
+ * a zero tail.  mcq_packed_post1x1_floats() floats. */
+size_t mcq_packed_post1x1_floats(void);
+int mcq_pack_post1x1_weight_f32(const float* w /* [128, 128] (1x1 OIHW) */, float* out, void* stream);
+/* 0 if this geometry / flag set has no fused form (MCQ_CONV_POST_* in `flags`), else the number of 128 x 32 wave tiles the launch
+ * would have: from 2048 (two per SIMD) mcq_conv2d_f32 takes it on its own; below that it refuses unless the caller forces the
+ * unsplit tile (tile 0x41) -- small maps, whose 3x3 layer is otherwise split over waves, run the 1x1 layer as its own launch. */
+int32_t mcq_conv2d_post_ok(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, uint32_t flags);
 
 /* Number of floats mcq_pack_conv_weight_f32 writes for a [Cout, Cin, ks, ks] weight. */
 size_t mcq_packed_conv_weight_floats(int32_t Cout, int32_t Cin, int32_t ksize);

@@ -24,6 +24,7 @@ CONV_WINOGRAD2D16 = 0x2000
 CONV_GDN_BWD, CONV_IGDN_BWD = 0x4000, 0x8000
 CONV_GATE_BWD = 0x10000
 CONV_TAPS_LR = 0x20000
+CONV_POST_GDN, CONV_POST_IGDN, CONV_POST_GATE = 0x40000, 0x80000, 0x100000     # (round 6) the following 1x1 layer inside the 3x3 launch
 
 
 class ConvDesc(Structure):
@@ -32,7 +33,7 @@ class ConvDesc(Structure):
                 ("mul", c_void_p), ("gate_id", c_void_p),
                 ("N", c_int32), ("Cin", c_int32), ("H", c_int32), ("W", c_int32), ("Cout", c_int32),
                 ("ksize", c_int32), ("stride", c_int32), ("flags", c_uint32), ("res_scale", c_float),
-                ("tile", c_int32)]
+                ("tile", c_int32), ("post_w", c_void_p), ("post_bias", c_void_p)]
 
 
 # every symbol include/mcquic_hip.h declares: name -> (restype, argtypes)
@@ -43,6 +44,9 @@ SYMBOLS = {
     "mcq_pack_conv_dgrad_weight_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p]),
     "mcq_nonneg_reparam_bwd_f32": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "mcq_conv2d_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
+    "mcq_packed_post1x1_floats": (c_size_t, []),
+    "mcq_pack_post1x1_weight_f32": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "mcq_conv2d_post_ok": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint32]),
     "mcq_packed_conv_winograd_floats": (c_size_t, [c_int32, c_int32]),
     "mcq_pack_conv_weight_winograd_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "mcq_pack_conv_dgrad_weight_winograd_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

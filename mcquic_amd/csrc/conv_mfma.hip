@@ -81,6 +81,8 @@ struct ConvK {
     int total_wgs;     // (persistent Winograd instance) workgroups' worth of tiles along x; the grid may be smaller
     unsigned flags; float res_scale;
     int xlds;          // GDN / IGDN 1x1 launches whose multiplier IS the input: the k-loop parks the loaded x in LDS for the epilogue
+    const float* post_w; const float* post_b;   // MCQ_CONV_POST_*: the following 1x1 layer (accumulator-order operand stream, bias)
+    int post_sub;      // MCQ_CONV_POST_IGDN through the PixelShuffle store: the four waves of a workgroup are the four sub-pixel row tiles of ONE pixel tile
 };
 
 constexpr int PRO_NONE = 0, PRO_SILU = 1, PRO_SQUARE = 2;
@@ -161,8 +163,17 @@ template <> __device__ __forceinline__ float mcq_wload<1>(__amdgpu_buffer_rsrc_t
 }
 
 
-template <int MB, int NB, int PRO, int PFA, int PFB, int TAPS, int OCC, bool PAIR = false>
+constexpr int POST_STEPS = 64;          // k-steps of the fused 1x1 layer: 128 channels, two per step
+constexpr int POST_TAIL = 8;            // zero steps behind them (the weight ring's over-read)
+constexpr int POST_PF = 4;              // its weight ring, in k-steps (a step is four MFMAs = 256 cycles; the stream is L2-resident)
+
+// POST (round 6): 0 = none; 1 = GDN / IGDN, 2 = AttentionBlock gate -- the 1x1 layer behind this 3x3 convolution inside the same launch
+// (MCQ_CONV_POST_*), see the section behind the k-loop
+template <int MB, int NB, int PRO, int PFA, int PFB, int TAPS, int OCC, bool PAIR = false, int POST = 0>
 __global__ __launch_bounds__(TAPS >= 12 ? 256 : 512, OCC) void conv_mfma_kernel(ConvK p) {
+    // (NB == 1: with two pixel blocks the 128 + 64 accumulators left the compiler 50-80 spilled registers -- outside the k-loop, but a
+    //  kernel with scratch ran 0.4-0.6 % slower IN the 32-image step than the two-launch form it replaces, profiles/r06_post_ab.txt)
+    static_assert(POST == 0 || (MB == 4 && TAPS == 9 && !PAIR && NB == 1), "the fused 1x1 layer needs all 128 channels of a pixel in one wave");
     static_assert(TAPS == 1 ? PFA == PFB : ((TAPS % PFA == 0 || PFA % TAPS == 0) && PFB % TAPS == 0 && PFB % PFA == 0),
                   "ring depths must tile the unrolled body");
     // TAPS == 12: the Winograd F(2, 3) form of a 3x3 stride-1 convolution along x (opt-in, MCQ_CONV_WINOGRAD).  A lane owns a
@@ -224,7 +235,8 @@ __global__ __launch_bounds__(TAPS >= 12 ? 256 : 512, OCC) void conv_mfma_kernel(
             }
     }
     const int KS = 1 << p.ks_log2;
-    const int tile_in_wg = W2D ? 0 : wave >> p.ks_log2;       // which output tile of this workgroup (W2D: all waves share it)
+    const bool post_sub = POST == 1 && p.post_sub;  // (wave-uniform) the workgroup's waves are the four sub-pixel row tiles of one pixel tile
+    const int tile_in_wg = (W2D || post_sub) ? 0 : wave >> p.ks_log2;       // which output tile of this workgroup (W2D: all waves share it)
     const int kslice = wave & (KS - 1);             // which slice of the k-steps
     // XCD-aware tile order: the dispatcher deals workgroups round-robin to the 8 XCDs (linear id % 8), each with its own
     // L2.  Taking the id as is, vertically adjacent pixel rows -- which share two of their three input rows -- always sit
@@ -248,7 +260,7 @@ next_tile:
     const int gw = (int)(wg << p.tiles_log2) + tile_in_wg;       // tile index along the pixel-block axis
     const bool active = gw * NBG < p.total_blocks;  // wave-uniform
     if (KS == 1 && !active) return;                 // (split-K waves stay for the barriers)
-    const int co_base = (W2D ? ((int)blockIdx.y * 4 + wave) * 32 : (int)blockIdx.y * (32 * MB)) + tile_zero;     // first output channel of this wave
+    const int co_base = (W2D ? ((int)blockIdx.y * 4 + wave) * 32 : post_sub ? wave * 128 : (int)blockIdx.y * (32 * MB)) + tile_zero;     // first output channel of this wave
     const int hi = lane >> 5, j = lane & 31;
     const int BW = 1 << p.bw_log2;
     const int ly = j >> p.bw_log2, lx = j & (BW - 1);
@@ -570,6 +582,130 @@ next_tile:
     }       // (!W2D)
 
     if (WASM) asm volatile("s_nop 15\n\ts_nop 15");       // (the last MFMAs' results must have landed before the first v_accvgpr_read)
+    if constexpr (POST != 0) {
+        // ---- the 1x1 layer that follows this convolution, on the fresh tile (MCQ_CONV_POST_*; round 6) ----------------------------------
+        // The wave holds ALL 128 output channels of its NB x 32 pixels: lane (hi, j) owns channel 32 mb + (r & 3) + 8 (r >> 2) + 4 hi of
+        // pixel j in acc[mb][nb][r] -- which is exactly the B operand of a 32x32x2 MFMA whose two k-slots are the channels (c, c + 4).  So the
+        // 1x1 layer's contraction runs over the accumulator registers in THEIR order (k-step t = 16 mb + r; mcq_pack_post1x1_weight_f32
+        // lays the weight out to match): no LDS, no exchange between lanes, no intermediate tensor.  Per pixel block: v = acc + bias
+        // (+ res), 64 k-steps of four MFMAs into s[4], then the element-wise close of the layer from v and s -- the arithmetic of the
+        // stand-alone 1x1 launch's epilogue (GDN: v * (1 / sqrt(s)), IGDN: v * sqrt(s), gate: mul * sigmoid(s) + id), whose k-order
+        // over the 128 channels is the only thing that differs.
+        const unsigned fl = p.flags;
+        const unsigned HoWo = (unsigned)(p.Ho * p.Wo);
+        const bool sub = post_sub;
+        const int T = sub ? (co_base >> 7) : 0;                         // this wave's sub-pixel 2 dy + dx
+        const unsigned OW = sub ? 2u * (unsigned)p.Wo : (unsigned)p.Wo, OHW = sub ? 4u * HoWo : HoWo;    // the output's row pitch / plane
+        const unsigned oslab_bytes = 128u * OHW * 4u;                   // (the output has 128 channels either way)
+        const __amdgpu_buffer_rsrc_t br = mcq_make_rsrc(mcq_uniform_ptr(P_bias ? P_bias : P_wp), P_bias ? (unsigned)p.Cout * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t pbr = mcq_make_rsrc(mcq_uniform_ptr(p.post_b ? p.post_b : P_wp), p.post_b ? 128u * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t pwr = mcq_make_rsrc(mcq_uniform_ptr(p.post_w), (unsigned)((POST_STEPS + POST_TAIL) * 1024));
+        const unsigned pwlane = (unsigned)lane * 16u;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {                                // v = acc + bias: both pixel blocks of a band from one set of bias loads
+            float b16[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) b16[r] = mcq_buffer_load_s(br, (unsigned)hi * 16u, (unsigned)(co_base + mb * 32 + mcq_drow(r, 0)) * 4u);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][nb][r] = acc[mb][nb][r] + b16[r];
+            __builtin_amdgcn_sched_barrier(0);                          // (band by band: 64 bias values in flight at once would not fit)
+        }
+        // the closing phase runs band by band with the NEXT band's side values requested one band ahead (bias of the 1x1 layer; the gate's
+        // multiplier and identity come from HBM), band 0's before the contraction starts; fences keep the compiler from pulling all four
+        // bands' loads to the front, which the register file has no room for next to 128 + 64 accumulators
+        auto band_so = [&](const int q, const int r) -> unsigned { return (unsigned)(q * 32 + mcq_drow(r, 0)) * OHW * 4u; };
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            __builtin_amdgcn_sched_barrier(0);
+            const size_t oslab = (size_t)img[nb] * 128u * OHW;
+            const __amdgpu_buffer_rsrc_t yr = mcq_make_rsrc(mcq_uniform_ptr(P_y + oslab), oslab_bytes);
+            const unsigned opix = sub ? (unsigned)(2 * yo[nb] + (T >> 1)) * OW + (unsigned)(2 * xo[nb] + (T & 1)) : (unsigned)(yo[nb] * p.Wo + xo[nb]);
+            const unsigned pvo = valid[nb] ? (opix + 4u * (unsigned)hi * OHW) * 4u : MCQ_OOB;
+            if constexpr (POST == 2) {
+                if (fl & MCQ_CONV_RESIDUAL) {                           // (the side stack's last ResidualBlock: + its input; conv-shaped = output-shaped here)
+                    const __amdgpu_buffer_rsrc_t rr = mcq_make_rsrc(mcq_uniform_ptr(P_res + oslab), oslab_bytes);
+                    float rv[2][16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[0][r] = mcq_buffer_load_s(rr, pvo, band_so(0, r));
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        if (mb < 3) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) rv[(mb + 1) & 1][r] = mcq_buffer_load_s(rr, pvo, band_so(mb + 1, r));
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = acc[mb][nb][r] + p.res_scale * rv[mb & 1][r];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            // s starts from the 1x1 layer's bias (beta for GDN / IGDN) instead of zero: no bias values to hold next to 128 + 64 accumulators
+            f32x16 sacc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[q][r] = mcq_buffer_load_s(pbr, (unsigned)hi * 16u, (unsigned)(q * 32 + mcq_drow(r, 0)) * 4u);
+            f32x4v AP[POST_PF];
+#pragma unroll
+            for (int st = 0; st < POST_PF; ++st) AP[st] = mcq_wload<4>(pwr, pwlane, (unsigned)st * 1024u);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < POST_STEPS; ++t) {
+                float b = acc[t >> 4][nb][t & 15];
+                if (POST == 1) b = b * b;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(AP[t % POST_PF][q], b, sacc[q], 0, 0, 0);
+                AP[t % POST_PF] = mcq_wload<4>(pwr, pwlane, (unsigned)(t + POST_PF) * 1024u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (POST == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (fl & MCQ_CONV_POST_IGDN) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[q][r] = acc[q][nb][r] * mcq_sqrt_pos(sacc[q][r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[q][r] = acc[q][nb][r] * mcq_rsqrt_pos(sacc[q][r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mcq_buffer_store_s(sacc[q][r], yr, pvo, band_so(q, r));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // the gate's multiplier and identity come from HBM: band q + 1's are requested before band q is closed (v is dead by now:
+                // its registers hold them)
+                const __amdgpu_buffer_rsrc_t mr = mcq_make_rsrc(mcq_uniform_ptr(P_mul + oslab), oslab_bytes);
+                const __amdgpu_buffer_rsrc_t gr = mcq_make_rsrc(mcq_uniform_ptr(P_gid + oslab), oslab_bytes);
+                const __amdgpu_buffer_rsrc_t y2r = mcq_make_rsrc(mcq_uniform_ptr(((fl & MCQ_CONV_DUAL_SILU) ? P_y2 : P_y) + oslab), oslab_bytes);
+                float m[2][16], gi[2][16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { m[0][r] = mcq_buffer_load_s(mr, pvo, band_so(0, r)); gi[0][r] = mcq_buffer_load_s(gr, pvo, band_so(0, r)); }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q < 3) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            m[(q + 1) & 1][r] = mcq_buffer_load_s(mr, pvo, band_so(q + 1, r));
+                            gi[(q + 1) & 1][r] = mcq_buffer_load_s(gr, pvo, band_so(q + 1, r));
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[q][r] = m[q & 1][r] * mcq_sigmoid(sacc[q][r]) + gi[q & 1][r];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mcq_buffer_store_s(sacc[q][r], yr, pvo, band_so(q, r));
+                    if (fl & MCQ_CONV_DUAL_SILU) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mcq_buffer_store_s(mcq_silu(sacc[q][r]), y2r, pvo, band_so(q, r));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue ---------------------------------------------------------------------------
     // Lane (hi, j) owns pixel j of each of its NB blocks and, per 32-row tile, the 16 output channels
     // row(r) + 4 hi, row(r) = (r & 3) + 8 (r >> 2).  Element (co, pixel) of image n sits at byte (co HoWo + pixel) 4 of
@@ -1363,7 +1499,7 @@ inline size_t general_floats(int Cout, int Cin, int ks) {
 }
 
 template <int MB, int NB, int PF3A, int PF3B, int PF1>
-int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2, hipStream_t s, bool pair = false, bool lr4 = false) {
+int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2, hipStream_t s, bool pair = false, bool lr4 = false, int post = 0) {
     // split-K: one 32-row band per owner wave (KS >= MB), whole channel pairs per slice, slices of >= 8 pairs of a
     // 3x3 conv (1x1 convs, 64 steps in all, are never split)
     if (ksplit_log2 > 0 && (1 << ksplit_log2) < MB) ksplit_log2 = MB == 4 ? 2 : 1;
@@ -1383,6 +1519,19 @@ int launch_tile(ConvK k, int pro, long long tiles, int co_tiles, int ksplit_log2
     // (round 4, measured and removed: `s_setprio 2` for the first-dispatched workgroup of every CU in single-round launches, so that
     //  one of the two waves of a SIMD finishes its k-loop early and its epilogue runs under the other's MFMAs -- the captured
     //  training step 22.32 vs 22.34 ms, the 32-image step 123.3 vs 123.4 ms: two epilogues side by side cost what one does)
+    if (post) {             // the following 1x1 layer inside the launch (MCQ_CONV_POST_*): unsplit 128-row tiles only
+        if constexpr (MB == 4 && NB == 1) {
+            if (ksplit_log2 != 0 || k.ks != 3 || pair || lr4 || k.nprob != 1 || (pro != PRO_NONE && pro != PRO_SILU)) return MCQ_EINVAL;
+            dim3 pgrid = grid, pblock = block;
+            if (k.post_sub) { k.tiles_log2 = 0; pgrid = dim3((unsigned)tiles, 1u, 1u); pblock = dim3(256); }   // one pixel tile per workgroup, its four waves = the four row tiles
+            if (post == 1 && pro == PRO_NONE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF3A, PF3B, 9, OCC, false, 1>), pgrid, pblock, 0, s, k);
+            else if (post == 1) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF3A, PF3B, 9, OCC, false, 1>), pgrid, pblock, 0, s, k);
+            else if (pro == PRO_NONE) hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_NONE, PF3A, PF3B, 9, OCC, false, 2>), pgrid, pblock, 0, s, k);
+            else hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, PRO_SILU, PF3A, PF3B, 9, OCC, false, 2>), pgrid, pblock, 0, s, k);
+            return mcq_check_launch();
+        }
+        return MCQ_EINVAL;
+    }
     if (pair) {
         if constexpr (MB == 4 && NB == 2) {
             if (ksplit_log2 != 0 || pro != PRO_NONE || k.ks != 3) return MCQ_EINVAL;
@@ -1662,6 +1811,25 @@ extern "C" int mcq_nonneg_reparam_f32(const float* p, float bound, float pedesta
 
 namespace {
 
+// does mcq_conv2d_f32 take a MCQ_CONV_POST_* launch on its own (`row_tiles` 128-row tiles per pixel block)?  From two 128 x 32 wave tiles
+// per SIMD; below that the map's 3x3 layer is normally split over waves and the 1x1 layer stays a launch (unless the caller forces tile 0x41)
+inline bool post_fills_chip(long long tb, int row_tiles) { return tb * row_tiles >= 2048; }
+
+// [128, 128] 1x1 weight -> [POST_STEPS + POST_TAIL][64 lanes][4]: k-step t = 16 mb + r holds the channels 32 mb + drow(r) (+ 4 for the
+// upper half-wave) -- the order in which a wave's own accumulator registers supply them
+__global__ void pack_post1x1_kernel(const float* __restrict__ w, float* __restrict__ out) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)((POST_STEPS + POST_TAIL) * 256)) return;
+    const unsigned q = i & 3u, lane = (i >> 2) & 63u, t = i >> 8;
+    float v = 0.0f;
+    if (t < (unsigned)POST_STEPS) {
+        const unsigned r = t & 15u;
+        const unsigned ci = 32u * (t >> 4) + (r & 3u) + 8u * (r >> 2) + 4u * (lane >> 5);
+        v = w[(32u * q + (lane & 31u)) * 128u + ci];
+    }
+    out[i] = v;
+}
+
 int conv_validate(const mcq_conv_desc* d) {
     if (!d || !d->x || !d->w_packed || !d->y) return MCQ_EINVAL;
     if (d->N <= 0 || d->Cin <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return MCQ_EINVAL;
@@ -1669,6 +1837,16 @@ int conv_validate(const mcq_conv_desc* d) {
     if ((d->flags & MCQ_CONV_TAPS_LR) && (d->ksize != 3 || d->stride != 1 || (d->flags & (MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D | MCQ_CONV_WINOGRAD2D16 |
                                                                                     MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN)))) return MCQ_EINVAL;
     const unsigned fl = d->flags & ~(unsigned)MCQ_CONV_TAPS_LR;      // (a promise about the weights, not an operation)
+    if (fl & MCQ_CONV_POST_MASK) {                           // the following 1x1 layer inside this launch
+        const unsigned post = fl & MCQ_CONV_POST_MASK;
+        if ((post & (post - 1)) || !d->post_w || d->ksize != 3 || (d->flags & MCQ_CONV_TAPS_LR)) return MCQ_EINVAL;
+        unsigned allowed = MCQ_CONV_POST_MASK | MCQ_CONV_SILU_IN;
+        if (post == MCQ_CONV_POST_IGDN) allowed |= MCQ_CONV_SHUFFLE2;
+        if (post == MCQ_CONV_POST_GATE) allowed |= MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU;
+        if (fl & ~allowed) return MCQ_EINVAL;
+        if (d->Cout != ((fl & MCQ_CONV_SHUFFLE2) ? 512 : 128)) return MCQ_EINVAL;
+        if (post == MCQ_CONV_POST_GATE && (!d->mul || !d->gate_id || d->stride != 1)) return MCQ_EINVAL;
+    }
     if ((fl & MCQ_CONV_RESIDUAL) && !d->res) return MCQ_EINVAL;
     if ((fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN | MCQ_CONV_GATE | MCQ_CONV_MUL | MCQ_CONV_DSILU_MUL)) && !d->mul) return MCQ_EINVAL;
     if ((fl & MCQ_CONV_GATE) && !d->gate_id) return MCQ_EINVAL;
@@ -1683,7 +1861,7 @@ int conv_validate(const mcq_conv_desc* d) {
     if ((fl & MCQ_CONV_SILU_IN) && (fl & MCQ_CONV_SQUARE_IN)) return MCQ_EINVAL;
     if (fl & MCQ_CONV_SHUFFLE2) {
         if ((d->Cout & 3) || (fl & ~(unsigned)(MCQ_CONV_SHUFFLE2 | MCQ_CONV_SILU_IN | MCQ_CONV_SQUARE_IN | MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D | MCQ_CONV_WINOGRAD2D16 |
-                                               MCQ_CONV_DSILU_MUL | MCQ_CONV_RESIDUAL))) return MCQ_EINVAL;
+                                               MCQ_CONV_DSILU_MUL | MCQ_CONV_RESIDUAL | MCQ_CONV_POST_IGDN))) return MCQ_EINVAL;
         if ((fl & (MCQ_CONV_DSILU_MUL | MCQ_CONV_RESIDUAL)) && (!MCQ_SHUFFLE_SIDE || (fl & (MCQ_CONV_WINOGRAD | MCQ_CONV_WINOGRAD2D | MCQ_CONV_WINOGRAD2D16))))
             return MCQ_EINVAL;
     }
@@ -1717,6 +1895,7 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     k.TP = steps_padded(d->Cin, d->ksize);
     k.flags = fl; k.res_scale = d->res_scale;
     k.nprob = nprob;
+    k.post_w = d->post_w; k.post_b = d->post_bias; k.post_sub = 0;
     // GDN / IGDN whose multiplier is the launch's own input, all channels of it inside one k-loop of <= 64 steps (launch_tile
     // clears this again for the tiles without the LDS parking area)
     k.xlds = (fl & (MCQ_CONV_GDN | MCQ_CONV_IGDN)) && d->ksize == 1 && d->stride == 1 && d->Cin == d->Cout && d->Cin <= 128;
@@ -1942,11 +2121,20 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         NB = 1; ksl = 0;
     }
     if (fl & MCQ_CONV_GATE_BWD) { NB = 1; ksl = 0; }        // (likewise)
+    int post = 0;
+    if (fl & MCQ_CONV_POST_MASK) {
+        // unsplit 128-row tiles that fill the chip, or the caller runs the 1x1 layer as its own launch (mcq_conv2d_post_ok)
+        if (nprob != 1 || lr4) return MCQ_EINVAL;
+        if (!post_fills_chip(tb, (fl & MCQ_CONV_SHUFFLE2) ? 4 : 1) && forced != 0x41) return MCQ_EINVAL;     // (tile 0x41: on any map size)
+        MB = 4; NB = 1; ksl = 0; dsilu41 = false;
+        post = (fl & MCQ_CONV_POST_GATE) ? 2 : 1;
+        k.post_sub = (fl & MCQ_CONV_SHUFFLE2) ? 1 : 0;
+    }
     const int pro = (fl & MCQ_CONV_SILU_IN) ? PRO_SILU : (fl & MCQ_CONV_SQUARE_IN) ? PRO_SQUARE : PRO_NONE;
     long long ptiles = (tb + NB - 1) / NB;
     // (round 5) the 128 x 64 tile of a 3x3 stride-1 layer over 32 PAIRS of horizontally adjacent pixels (tile bit 0x400 forces it,
     // 0x800 forbids it): pair blocks shaped (32 >> b) rows x (1 << b) pairs, b by the fewest wasted lanes
-    const bool pair_ok = !lr4 && MB == 4 && (NB == 2 || dsilu41) && ksl == 0 && d->ksize == 3 && d->stride == 1 && pro == PRO_NONE && (k.Wo & 1) == 0 &&
+    const bool pair_ok = !post && !lr4 && MB == 4 && (NB == 2 || dsilu41) && ksl == 0 && d->ksize == 3 && d->stride == 1 && pro == PRO_NONE && (k.Wo & 1) == 0 &&
                          !(fl & ~(unsigned)(MCQ_CONV_SILU_OUT | MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU | MCQ_CONV_DSILU_MUL | MCQ_CONV_SHUFFLE2));
     // on its own it takes the launches whose pair tiles are ONE round of the chip (1536 < waves <= 2048, two per SIMD: 8 x 128 x 128 x 128,
     // 8 x 128 -> 512 x 64 x 64): with nothing behind a wave to hide its prologue and epilogue the shorter instruction streams pay
@@ -1967,14 +2155,14 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
         pair = (d->tile & 0x400) || (MCQ_PAIR && !(d->tile & 0x800) && pair_waves > 1536 && pair_waves <= 2048);
         if (pair) { NB = 2; k.bw_log2 = bl; k.nbx = pnbx; k.nby = pnby; ptiles = pt; k.total_blocks = (int)pt; }
     }
-    const int co_tiles = (co32 + MB - 1) / MB;
+    const int co_tiles = post ? 1 : (co32 + MB - 1) / MB;      // (POST through the shuffle: the four row tiles are the waves of a workgroup)
     // the epilogue addresses one image of the output (and of every side input) through a 32-bit buffer offset,
     // rows of the last cout tile included
-    if ((uint64_t)co_tiles * 32u * (unsigned)MB * (uint64_t)k.Ho * k.Wo * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
+    if ((uint64_t)(post && k.post_sub ? 4 : co_tiles) * 32u * (unsigned)MB * (uint64_t)k.Ho * k.Wo * 4ull >= 0x80000000ull) return MCQ_ETOOLARGE;
     hipStream_t s = (hipStream_t)stream;
     sec_note(descs, nprob, MB == 4 ? 1u : MB == 2 ? 2u : 4u);
     if (MB == 4 && NB == 2) return launch_tile<4, 2, MCQ_PF42A, MCQ_PF42B, 4>(k, pro, ptiles, co_tiles, ksl, s, pair, lr4);
-    if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s, false, lr4);
+    if (MB == 4 && NB == 1) return launch_tile<4, 1, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s, false, lr4, post);
     if (MB == 2 && NB == 2) return launch_tile<2, 2, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s, false, lr4);
     if (MB == 2 && NB == 1) return launch_tile<2, 1, 9, MCQ_PFB, 16>(k, pro, ptiles, co_tiles, ksl, s, false, lr4);
     if (MB == 1 && NB == 4) return launch_tile<1, 4, 9, MCQ_PFB, 8>(k, pro, ptiles, co_tiles, ksl, s, false, lr4);
@@ -1991,6 +2179,35 @@ extern "C" int mcq_conv2d_f32(const mcq_conv_desc* d, void* stream) {
 }
 
 extern "C" int32_t mcq_conv2d_max_multi(void) { return MCQ_CONV_MAX_MULTI; }
+
+extern "C" size_t mcq_packed_post1x1_floats(void) { return (size_t)(POST_STEPS + POST_TAIL) * 256; }
+
+extern "C" int mcq_pack_post1x1_weight_f32(const float* w, float* out, void* stream) {
+    if (!w || !out) return MCQ_EINVAL;
+    hipLaunchKernelGGL(pack_post1x1_kernel, dim3((unsigned)(POST_STEPS + POST_TAIL)), dim3(256), 0, (hipStream_t)stream, w, out);
+    return mcq_check_launch();
+}
+
+extern "C" int32_t mcq_conv2d_post_ok(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, uint32_t flags) {
+    const unsigned post = flags & MCQ_CONV_POST_MASK;
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || ksize != 3 || (stride != 1 && stride != 2) || !post || (post & (post - 1))) return 0;
+    const bool sub = flags & MCQ_CONV_SHUFFLE2;
+    if (sub && post != MCQ_CONV_POST_IGDN) return 0;
+    if (Cout != (sub ? 512 : 128)) return 0;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    int best_log2 = 5; double best_util = -1.0;             // (the pixel-block shape conv_launch picks)
+    for (int lg = 5; lg >= 2; --lg) {
+        const int bw = 1 << lg, bh = 32 >> lg;
+        const double cover = (double)((Ho + bh - 1) / bh * bh) * (double)((Wo + bw - 1) / bw * bw);
+        const double util = (double)Ho * Wo / cover;
+        if (util > best_util + 1e-9) { best_util = util; best_log2 = lg; }
+    }
+    const long long tb = (long long)N * ((Wo + (1 << best_log2) - 1) >> best_log2) * ((Ho + (32 >> best_log2) - 1) / (32 >> best_log2));
+    // (the number of 128 x 32 wave tiles, capped: >= 2048 is what mcq_conv2d_f32 takes on its own; below that a caller may still
+    //  force the fused form with tile 0x41 where it has measured a gain -- one image's large maps)
+    const long long waves = tb * (sub ? 4 : 1);
+    return (int32_t)(waves > 0x7fffffffLL ? 0x7fffffffLL : waves);
+}
 
 extern "C" int32_t mcq_conv2d_small_launch(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride,
                                            uint32_t flags, int32_t nprob) {

@@ -150,8 +150,12 @@ class ResidualBlockWithStride(_residulBlock):
             return self._branch[3](t, res=self._skip(x), dual_silu=True)      # (+ silu(out) for the block that follows)
         with _fork(x) as f:
             identity = self._skip(x)
-        t = self._branch[1](x, silu_in=True)
-        t = self._branch[2](t)
+        c1, gdn = self._branch[1], self._branch[2]
+        fuse = ops.post_ok(x, c1.packed(), c1.stride, "gdn")
+        if fuse:
+            t = c1(x, silu_in=True, post_gdn=gdn.packed_post(), tile=0 if fuse == 1 else fuse)      # the normalisation inside the strided convolution's launch
+        else:
+            t = gdn(c1(x, silu_in=True))
         return self._branch[3](t, res=f.join(identity), dual_silu=True)
 
 
@@ -173,8 +177,14 @@ class ResidualBlockShuffle(_residulBlock):
             return self._branch[3](t, res=self._skip(x), dual_silu=True)
         with _fork(x) as f:
             identity = self._skip(x)
-        t = self._branch[1](x, silu_in=True)
-        t = self._branch[2](t)
+        up, igdn = self._branch[1][0], self._branch[2]
+        fuse = ops.post_ok(x, up.packed(), 1, "igdn", shuffle2=True)
+        if fuse:
+            # the inverse normalisation inside the up-sampling convolution's launch: row tiles in sub-pixel-major order, so that a wave
+            # holds the 128 channels the normalisation mixes; the PixelShuffle is still only the store pattern
+            t = ops.conv2d(x, up.packed_subpixel(), 1, silu_in=True, shuffle2=True, post_igdn=igdn.packed_post(), tile=0 if fuse == 1 else fuse)
+        else:
+            t = igdn(self._branch[1](x, silu_in=True))
         return self._branch[3](t, res=f.join(identity), dual_silu=True)
 
 
@@ -205,6 +215,19 @@ class AttentionBlock(nn.Module):
                 ta, tb = ops.conv2d_multi([a, b], [m[1].packed(), sd[1].packed()], silu_in=True, silu_out=True)
                 a, b = ops.conv2d_multi([ta, tb], [m[3].packed(), sd[3].packed()], per_problem=[dict(res=a), dict(res=b)], dual_silu=True)
             return self._sideBranch[3](b, gate_mul=a, gate_id=x, dual_silu=True)
+        last, gate = self._sideBranch[2], self._sideBranch[3]
+        fuse = 0 if (self.denseNorm or last._skip is not None) else ops.post_ok(x, last._branch[3].packed(), 1, "gate")
+        if fuse:
+            # conv1x1 + gate inside the launch of the side stack's LAST convolution (the tile it has just finished is the 1x1 layer's
+            # input: `b` is never stored); that launch needs `a`, so it runs on the main stream behind the main stack
+            with _fork(x) as f:
+                b = x
+                for i in range(2):
+                    b = self._sideBranch[i](b)
+                t = last._branch[1](b, silu_in=True, silu_out=True)
+            a = self._mainBranch(x)
+            f.join(b)
+            return ops.conv2d(f.join(t), last._branch[3].packed(), 1, res=b, post_gate=gate.packed_post(), gate_mul=a, gate_id=x, dual_silu=True, tile=0 if fuse == 1 else fuse)
         with _fork(x) as f:
             b = x
             for i in range(3):

@@ -49,6 +49,31 @@ class Conv2d(nn.Module):
             self._packedKey = key
         return self._packed
 
+    def packed_subpixel(self) -> ops.PackedConv:
+        """(inference) The operand streams of a pixelShuffle3x3's convolution with its rows in SUB-PIXEL-MAJOR order -- row 128 T + c =
+        channel 4 c + T, so that the 128 rows of tile T are the 128 shuffled channels of sub-pixel T = 2 dy + dx -- for the launch that
+        runs the InvGenDivNorm behind it in its own epilogue (MCQ_CONV_POST_IGDN | MCQ_CONV_SHUFFLE2; Cout = 4 x 128)."""
+        key = self._key()
+        pk = self.__dict__.get("_packedSub")
+        if pk is None or self.__dict__.get("_packedSubKey") != key:
+            with torch.no_grad():
+                c = self.outChannels // 4
+                w = self.weight.detach().reshape(c, 4, self.inChannels, self.kernelSize, self.kernelSize).transpose(0, 1).reshape(self.weight.shape).contiguous()
+                b = None if self.bias is None else self.bias.detach().reshape(c, 4).t().reshape(-1).contiguous()
+                pk = ops.PackedConv(w, b, copy_bias=False, winograd=False)
+            self.__dict__["_packedSub"], self.__dict__["_packedSubKey"] = pk, key
+        return pk
+
+    def packed_post(self) -> "ops.PackedPost":
+        """(inference) A [128, 128] 1x1 layer in the operand order of the MCQ_CONV_POST_GATE epilogue (the AttentionBlock's conv1x1)."""
+        key = self._key()
+        pk = self.__dict__.get("_packedPost")
+        if pk is None or self.__dict__.get("_packedPostKey") != key:
+            with torch.no_grad():
+                pk = ops.PackedPost(self.weight, self.bias)
+            self.__dict__["_packedPost"], self.__dict__["_packedPostKey"] = pk, key
+        return pk
+
     @staticmethod
     def repack_stale(convs, masks=None) -> int:
         """Bring the operand streams of all `convs` up to date in grouped launches (ops.pack_convs: up to 16 weights of one

@@ -56,6 +56,19 @@ class GenDivNorm(nn.Module):
         self.gamma = nn.Parameter(self.gamma_reparam.init(float(weightInit) * torch.eye(inChannels)))
         self._packed: Optional[ops.PackedConv] = None
         self._packedKey = None
+        self._post: Optional[ops.PackedPost] = None
+        self._postKey = None
+
+    def packed_post(self) -> "ops.PackedPost":
+        """The folded (gamma, beta) in the operand order of the MCQ_CONV_POST_GDN / _IGDN epilogue: the normalisation then runs inside
+        the launch of the convolution in front of it (inference; channel 128 -- ops.post_ok says when)."""
+        pk = self.packed()
+        if self._post is None or self._postKey is not self._packedKey:
+            gb, gp = self.gamma_reparam.lowerBound.bound, self.gamma_reparam.eps
+            gamma = ops.nonneg_reparam(self.gamma, float(gb), float(gp))
+            self._post = ops.PackedPost(gamma, pk.bias)
+            self._postKey = self._packedKey
+        return self._post
 
     def packed(self) -> ops.PackedConv:
         bb, gb = self.beta_reparam.lowerBound.bound, self.gamma_reparam.lowerBound.bound

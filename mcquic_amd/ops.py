@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import (CONV_DSILU_MUL, CONV_DUAL_SILU, CONV_MUL, CONV_GATE, CONV_GDN, CONV_IGDN, CONV_RESIDUAL, CONV_SHUFFLE2, CONV_SILU_IN,
-                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, CONV_WINOGRAD2D, CONV_WINOGRAD2D16, CONV_GDN_BWD, CONV_IGDN_BWD, CONV_GATE_BWD, CONV_TAPS_LR, ConvDesc, check)
+                   CONV_SILU_OUT, CONV_SQUARE_IN, CONV_WINOGRAD, CONV_WINOGRAD2D, CONV_WINOGRAD2D16, CONV_GDN_BWD, CONV_IGDN_BWD, CONV_GATE_BWD, CONV_TAPS_LR, CONV_POST_GDN, CONV_POST_IGDN, CONV_POST_GATE, ConvDesc, check)
 
 # OPT-IN fast path, never the default and never the headline bench: large 3x3 stride-1 layers in the Winograd F(2, 3) form
 # along x (mcq_pack_conv_weight_winograd_f32 + MCQ_CONV_WINOGRAD): 2/3 of the multiplications, float32 throughout, but not
@@ -230,6 +230,47 @@ class PackedConv:
         return self
 
 
+# (round 6) the 1x1 layer BEHIND a 3x3 convolution inside that convolution's launch (MCQ_CONV_POST_*: GDN / IGDN after a strided /
+# shuffle convolution, the AttentionBlock's gate after its side stack): A/B switch, 0 = always its own launch
+# ("1" = all, "0" = none, or a comma list of gdn / igdn / gate)
+_fp = os.environ.get("MCQUIC_AMD_FUSE_POST", "1")
+_FUSE_POST = {"gdn", "igdn", "gate"} if _fp == "1" else set() if _fp == "0" else set(_fp.split(","))
+# wave tiles (128 channels x 32 pixels) from which a launch is fused: the library's own rule is 2048 (two per SIMD); one image's large
+# maps gain from 768 up (tools/bench_post.py --batch1), forced through tile 0x41
+_POST_MIN_WAVES = int(os.environ.get("MCQUIC_AMD_POST_MIN_WAVES", "768"))
+
+
+class PackedPost:
+    """A [128, 128] 1x1 layer (+ bias) in the operand order of the MCQ_CONV_POST_* epilogues (mcq_pack_post1x1_weight_f32): its
+    contraction runs over the producing wave's accumulator registers, in their order."""
+
+    __slots__ = ("wp", "bias")
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        weight = _dev(weight.detach(), "weight")
+        if tuple(weight.shape[:2]) != (128, 128) or weight.numel() != 128 * 128:
+            raise ValueError("PackedPost: a [128, 128] 1x1 layer")
+        lib = _lib.load()
+        self.wp = torch.empty(lib.mcq_packed_post1x1_floats(), dtype=torch.float32, device=weight.device)
+        with _guard(weight.device):
+            check(lib.mcq_pack_post1x1_weight_f32(_ptr(weight), _ptr(self.wp), _stream()), "mcq_pack_post1x1_weight_f32")
+        self.bias = None if bias is None else _dev(bias.detach(), "bias").clone()
+
+
+def post_ok(x: torch.Tensor, w: "PackedConv", stride: int, kind: str, shuffle2: bool = False) -> int:
+    """Does the 1x1 layer `kind` ("gdn" / "igdn" / "gate") behind the 3x3 convolution `w` of `x` run inside that convolution's launch?
+    0 = no (the caller launches it on its own), else the `tile` to pass with the post_* option: 1 = the library's own choice (maps
+    that fill the chip with unsplit 128-row tiles), 0x41 = forced (fewer tiles than that, still a measured gain)."""
+    if kind not in _FUSE_POST or not x.is_cuda or w.ksize != 3 or _WINOGRAD or _band_rows(x, w, stride):
+        return 0
+    flag = {"gdn": CONV_POST_GDN, "igdn": CONV_POST_IGDN, "gate": CONV_POST_GATE}[kind] | (CONV_SHUFFLE2 if shuffle2 else 0)
+    n, cin, h, wd = x.shape
+    waves = int(_lib.load().mcq_conv2d_post_ok(n, cin, h, wd, w.cout, w.ksize, stride, flag))
+    if waves < max(_POST_MIN_WAVES, 1):
+        return 0
+    return 1 if waves >= 2048 else 0x41
+
+
 def pack_convs(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]] = None, *, dgrad: bool = False,
                stride: int = 1, scale: float = 1.0, into: Optional[Sequence[Optional[PackedConv]]] = None,
                masks: Optional[Sequence[int]] = None) -> List[PackedConv]:
@@ -310,7 +351,8 @@ def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool
                gdn_mul: Optional[torch.Tensor] = None, igdn_mul: Optional[torch.Tensor] = None,
                gate_mul: Optional[torch.Tensor] = None, gate_id: Optional[torch.Tensor] = None,
                mul: Optional[torch.Tensor] = None, dsilu_mul: Optional[torch.Tensor] = None, shuffle2: bool = False,
-               dual_silu: bool = False, tile: int = 0, winograd: Optional[bool] = None):
+               dual_silu: bool = False, tile: int = 0, winograd: Optional[bool] = None,
+               post_gdn: Optional["PackedPost"] = None, post_igdn: Optional["PackedPost"] = None, post_gate: Optional["PackedPost"] = None):
     """(mcq_conv_desc, y, y_silu or None, tensors the descriptor points at) for one fused conv launch."""
     if silu_in:
         twin = silu_twin(x)
@@ -348,7 +390,8 @@ def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool
             raise ValueError(f"residual shape {tuple(res.shape)} != output shape {tuple(y.shape)}")
     for flag, t in ((CONV_GDN, gdn_mul), (CONV_IGDN, igdn_mul), (CONV_GATE, gate_mul), (CONV_MUL, mul_in), (CONV_DSILU_MUL, dsilu_mul)):
         if t is not None:
-            flags |= flag
+            if not (flag == CONV_GATE and post_gate is not None):     # (post_gate: the gate closes the FUSED 1x1 layer, MCQ_CONV_POST_GATE)
+                flags |= flag
             mul = _dev(t, "mul")
             if mul.shape != y.shape:
                 raise ValueError(f"mul shape {tuple(mul.shape)} != output shape {tuple(y.shape)}")
@@ -356,6 +399,15 @@ def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool
         gate_id = _dev(gate_id, "gate_id")
         if gate_id.shape != y.shape:
             raise ValueError("gate identity shape mismatch")
+    post = None
+    for flag, pk in ((CONV_POST_GDN, post_gdn), (CONV_POST_IGDN, post_igdn), (CONV_POST_GATE, post_gate)):
+        if pk is not None:
+            if post is not None:
+                raise ValueError("one fused 1x1 layer per launch")
+            flags |= flag
+            post = pk
+    if post is not None:
+        winograd = False                             # (the fused 1x1 layer lives in the direct kernel's epilogue)
     wp = w.wp
     auto_2d = winograd is None and _WINOGRAD and _WINOGRAD_2D and w.wino2d is not None and n * h * wd >= _WINOGRAD_MIN_PIXELS_2D
     if winograd or auto_2d or (winograd is None and _WINOGRAD and n * h * wd >= _WINOGRAD_MIN_PIXELS):
@@ -378,8 +430,9 @@ def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool
     if _TAPS_LR and getattr(w, "lr_taps", False) and stride == 1 and wp is w.wp and not (flags & (CONV_SILU_IN | CONV_SQUARE_IN)):
         flags |= CONV_TAPS_LR
     d = ConvDesc(_ptr(x), _ptr(wp), _ptr(w.bias), _ptr(y), _ptr(y2), _ptr(res), _ptr(mul), _ptr(gate_id),
-                 n, cin, h, wd, w.cout, w.ksize, stride, flags, float(res_scale), tile)
-    return d, y, y2, (x, res, mul, gate_id)
+                 n, cin, h, wd, w.cout, w.ksize, stride, flags, float(res_scale), tile,
+                 None if post is None else _ptr(post.wp), None if post is None else _ptr(post.bias))
+    return d, y, y2, (x, res, mul, gate_id, post)
 
 
 # ---- images whose activations do not fit one launch --------------------------------------------------------------------------
@@ -1104,9 +1157,12 @@ class wgrad_now:
 def _keep(*tensors) -> None:
     """Workspace AND outputs of a deferred weight-gradient launch stay alive until the flush has written them: a dW the autograd
     engine drops (a frozen weight: requires_grad False) would otherwise be handed to another tensor and the flush would write
-    over that one."""
+    over that one.  Outputs are held through their STORAGE, never the tensor itself (nor a view of it: a view made without grad
+    mode still references its base tensor): AccumulateGrad only takes a gradient as it is while nothing else references that very
+    tensor -- with a second reference it clones it, during the pass, i.e. before the flush has written the values."""
     if _defer["on"]:
-        _defer["keep"].extend(t for t in tensors if t is not None)
+        _defer["keep"].append(tensors[0])
+        _defer["keep"].extend(t.untyped_storage() for t in tensors[1:] if t is not None)
 
 
 def conv2d_wgrad_group(xs, dys, want_bias: bool = True):

@@ -389,7 +389,17 @@ def secondary(model, x, dev, cpu_codes, cpu_pix, nb):
     try:
         from mcquic_amd import validate
         enc, dec = validate.speed(model, iters=20)
+        # the same batch through encode() / decode() alone (no byte streams): what the coder costs at THIS batch size
+        x10 = torch.rand(10, 3, 768, 512).to(dev)
+        c10 = model.encode(x10)
+        t_enc = _timed(lambda: model.encode(x10), 20, warmup=1)
+        t_dec = _timed(lambda: model.decode(c10), 20, warmup=1)
+        del x10, c10
         sec["speed_protocol"] = {"encode_mpps": round(enc, 2), "decode_mpps": round(dec, 2),
+                                 "tensor_only_batch10": {"encode_mpps": round(10 * 0.393216 / t_enc * 1e3, 2), "decode_mpps": round(10 * 0.393216 / t_dec * 1e3, 2),
+                                                         "note": "encode() / decode() of the same 10-image batch, no entropy coder: the coder's cost is the gap to THESE "
+                                                                 "(the 32-image headline's per-direction rates are another batch size)"},
+                                 "coder_overlap": os.environ.get("MCQUIC_AMD_CODER_OVERLAP", "1") != "0",
                                  "images_s_encode_decode_768x512": round(1.0 / (0.393216 / enc + 0.393216 / dec), 2),
                                  "protocol": "mcquic/validate/validator.py:60-97 with 20 instead of 50 iterations: torch.rand(10, 3, 768, 512), one "
                                              "warm-up, `compress` x 20 then `decompress` x 20 between events, host rANS coding INCLUDED",

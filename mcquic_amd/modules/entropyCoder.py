@@ -87,6 +87,19 @@ def hostThreads() -> int:
     return max(1, min(n, 32))
 
 
+CODER_OVERLAP = os.environ.get("MCQUIC_AMD_CODER_OVERLAP", "1") != "0"     # A/B switch: 0 = copy / code all levels at once (rounds 1-5)
+_POOL = None                     # ONE host thread for the level-wise coder jobs of this process (module state: models are deep-copied)
+_COPY_STREAMS = {}               # device index -> the side stream the codes leave the device on
+
+
+def _hostWorker():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mcq-rans")
+    return _POOL
+
+
 def _poolThreads(threads: int, symbols: int) -> int:
     """Threads for one batched call: never more than one per 16 K symbols.  A pool thread costs ~40 us to start and join, a
     symbol ~25 ns: ten 768x512 images (61 K symbols on level 0, 15 K and 4 K below) code fastest on 2-4 threads (0.30 ms per
@@ -288,16 +301,40 @@ class EntropyCoder(nn.Module):
                 compressed[i].append(b)
         return compressed, [CodeSize([m] * len(codes), heights, widths, list(self._k)) for _ in range(n)]
 
+    # ---- the same, overlapped with the kernels that make / use the codes (round 6) ---------------------------------------------
+    # `compress` above copies every level, waits for the whole stream, then codes on the host; `decompress` decodes every level
+    # before the first kernel of the decoder is enqueued.  But level 0's codes (3/4 of the symbols) exist long before levels 1 .. are
+    # computed, and the decoder needs the LAST level (the smallest stream) first: a level-wise interface lets the quantizer hand each
+    # level over as soon as its `vq_assign` is enqueued (copy on a side stream, coded on a host thread while the GPU works on the
+    # next level), and take decoded levels one by one, smallest first, while a host thread decodes the larger ones.  Same bytes,
+    # same codes (tests/test_gpu_entropy_coder.py).  MCQUIC_AMD_CODER_OVERLAP=0: the all-at-once forms above.
+    def _worker(self):
+        return _hostWorker()
+
+    def _copyStream(self, device):
+        st = _COPY_STREAMS.get(device.index)
+        if st is None:
+            st = _COPY_STREAMS[device.index] = torch.cuda.Stream(device=device)
+        return st
+
+    def beginCompress(self, levels: int) -> "_CompressJob":
+        self.CDFs                                              # refresh the tables if the EMA changed
+        if levels != len(self._tables):
+            raise RuntimeError(f"expected {len(self._tables)} code levels, got {levels}")
+        return _CompressJob(self)
+
+    def beginDecompress(self, binaries: List[List[bytes]], codeSizes: List[CodeSize]) -> "_DecompressJob":
+        first = self._checkHeaders(binaries, codeSizes)
+        return _DecompressJob(self, binaries, first)
+
     # what a header may ask the decoder to allocate: a side of 2^15 latent positions is a 2-megapixel-wide image 64 times over
     _MAX_SIDE = 1 << 15
     _MAX_AREA = 1 << 24          # latent positions per level and image (16 M = a 64 k x 64 k pixel image at stride 16)
     _MAX_SYMBOLS = 1 << 28       # n * m * h * w per level: what one call may stage (1 GiB of int32)
 
-    @torch.inference_mode()
-    def decompress(self, binaries: List[List[bytes]], codeSizes: List[CodeSize]) -> List[torch.Tensor]:
-        """binaries[n][level] -> level-length list of int64 [n, m, h, w] on the coder's device.  Header fields are
-        untrusted input (they come out of a `.mcq` file): m / k must be this model's, sizes positive and bounded, all
-        images of a batch alike -- checked before anything is allocated."""
+    def _checkHeaders(self, binaries: List[List[bytes]], codeSizes: List[CodeSize]) -> CodeSize:
+        """Header fields are untrusted input (they come out of a `.mcq` file): m / k must be this model's, sizes positive and
+        bounded, all images of a batch alike -- checked before anything is allocated.  Returns the batch's (common) CodeSize."""
         if len(binaries) < 1 or len(binaries) != len(codeSizes):
             raise RuntimeError("`binaries` and `codeSizes` must be non-empty and of equal length.")
         self.CDFs
@@ -321,6 +358,15 @@ class EntropyCoder(nn.Module):
             # every level halves the one before it, rounding up (stride-2 convs with padding 1: ceil(h / 2))
             if lv > 0 and (h != (int(first.heights[lv - 1]) + 1) // 2 or w != (int(first.widths[lv - 1]) + 1) // 2):
                 raise RuntimeError("The header's code sizes do not halve from level to level.")
+        return first
+
+    @torch.inference_mode()
+    def decompress(self, binaries: List[List[bytes]], codeSizes: List[CodeSize]) -> List[torch.Tensor]:
+        """binaries[n][level] -> level-length list of int64 [n, m, h, w] on the coder's device.  Header fields are
+        untrusted input (they come out of a `.mcq` file): m / k must be this model's, sizes positive and bounded, all
+        images of a batch alike -- checked before anything is allocated."""
+        first = self._checkHeaders(binaries, codeSizes)
+        levels = len(self._tables)
         device = self._freqEMA[0].device
         n = len(binaries)
         out = []
@@ -335,6 +381,89 @@ class EntropyCoder(nn.Module):
             out.append(host.to(device, non_blocking=True).to(torch.int64).reshape(n, self._m, h, w))
         return out
 
+
+
+class _CompressJob:
+    """One `compress` call taken level by level (EntropyCoder.beginCompress): submit(level, code) right after the level's codes are
+    enqueued; finish() -> (binaries[n][level], CodeSize per image)."""
+
+    def __init__(self, coder: "EntropyCoder"):
+        self.coder = coder
+        self.futures = {}
+        self.shapes = {}
+
+    def submit(self, lv: int, code: torch.Tensor) -> None:
+        coder = self.coder
+        n, m, h, w = code.shape
+        if m != coder._m:
+            raise RuntimeError("Please give codes with correct shape: `m` is inconsisitent.")
+        self.shapes[lv] = (n, m, h, w)
+        c32 = code.detach().to(torch.int32)
+        done = None
+        if c32.is_cuda:
+            main = torch.cuda.current_stream(c32.device)
+            side = coder._copyStream(c32.device)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                pinned = torch.empty(c32.shape, dtype=torch.int32, pin_memory=True)
+                pinned.copy_(c32, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(side)
+            c32.record_stream(side)
+            c32 = pinned
+        table = coder._tables[lv]
+
+        def code_level(host=c32, done=done, table=table, n=n, m=m, h=h, w=w):
+            if done is not None:
+                done.synchronize()
+            idx = np.repeat(np.arange(m, dtype=np.int32), h * w)            # group id per symbol, [m, h, w] order
+            return ransEncodeBatchWithIndexes(host.numpy().reshape(n, m * h * w), idx, table)
+        self.futures[lv] = coder._worker().submit(code_level)
+
+    def finish(self):
+        coder = self.coder
+        levels = len(coder._tables)
+        if sorted(self.futures) != list(range(levels)):
+            raise RuntimeError(f"expected {levels} code levels, got {len(self.futures)}")
+        n, m = self.shapes[0][0], self.shapes[0][1]
+        if any(self.shapes[lv][0] != n for lv in range(levels)):
+            raise RuntimeError("Please give codes with correct shape: `n` is inconsisitent.")
+        compressed: List[List[bytes]] = [[] for _ in range(n)]
+        for lv in range(levels):
+            for i, b in enumerate(self.futures[lv].result()):
+                compressed[i].append(b)
+        heights = [self.shapes[lv][2] for lv in range(levels)]
+        widths = [self.shapes[lv][3] for lv in range(levels)]
+        return compressed, [CodeSize([m] * levels, heights, widths, list(coder._k)) for _ in range(n)]
+
+
+class _DecompressJob:
+    """One `decompress` call taken level by level (EntropyCoder.beginDecompress): every level is decoded on the coder's host thread,
+    LAST level first (the order the decoder cascade consumes them in); level(lv) -> int64 [n, m, h, w] on the coder's device."""
+
+    def __init__(self, coder: "EntropyCoder", binaries: List[List[bytes]], first: CodeSize):
+        self.coder = coder
+        self.device = coder._freqEMA[0].device
+        self.n = len(binaries)
+        levels = len(coder._tables)
+        self.futures = {}
+        for lv in reversed(range(levels)):
+            h, w = int(first.heights[lv]), int(first.widths[lv])
+            streams = [binary[lv] for binary in binaries]
+            self.futures[lv] = coder._worker().submit(self._decode_level, lv, streams, h, w)
+
+    def _decode_level(self, lv, streams, h, w):
+        coder = self.coder
+        idx = np.repeat(np.arange(coder._m, dtype=np.int32), h * w)
+        host = torch.empty((self.n, idx.size), dtype=torch.int32, pin_memory=self.device.type == "cuda")
+        ransDecodeBatchWithIndexes(streams, idx, coder._tables[lv], out=host.numpy())
+        return host, h, w
+
+    def level(self, lv: int) -> torch.Tensor:
+        host, h, w = self.futures[lv].result()
+        return host.to(self.device, non_blocking=True).to(torch.int64).reshape(self.n, self.coder._m, h, w)
 
 
 class VariousMCoder(nn.Module):

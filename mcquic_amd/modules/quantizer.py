@@ -359,6 +359,35 @@ class UMGMQuantizer(BaseQuantizer):
             codes.append(code)
         return codes
 
+    def compress(self, x: torch.Tensor):
+        """`encode` + the entropy coder (mcquic/modules/entropyCoder.py:108-126) with the coder taken level by level: a level's codes
+        leave for the host (side stream, host thread) as soon as they are enqueued, while the GPU computes the levels below it --
+        level 0 holds three quarters of the symbols and is ready first.  Same codes, same bytes as encode() + coder.compress()."""
+        from .entropyCoder import CODER_OVERLAP
+        if not (CODER_OVERLAP and x.is_cuda):
+            return super().compress(x)
+        job = self._entropyCoder.beginCompress(len(self._encoders))
+        codes = []
+        for lv, encoder in enumerate(self._encoders):
+            x, code = encoder.encode(x)
+            codes.append(code)
+            job.submit(lv, code)
+        binaries, codeSize = job.finish()
+        return codes, binaries, codeSize
+
+    def decompress(self, binaries, codeSize) -> torch.Tensor:
+        """The coder's streams -> `decode` (entropyCoder.py:141-154) with the levels decoded on a host thread in the order the decoder
+        cascade consumes them -- the last (smallest) level first: its kernels are enqueued while the larger levels are still being
+        decoded."""
+        from .entropyCoder import CODER_OVERLAP
+        if not (CODER_OVERLAP and self._entropyCoder._freqEMA[0].is_cuda):
+            return super().decompress(binaries, codeSize)
+        job = self._entropyCoder.beginDecompress(binaries, codeSize)
+        formerLevel = None
+        for lv in reversed(range(len(self._decoders))):
+            formerLevel = self._decoders[lv].decode(job.level(lv), formerLevel)
+        return formerLevel
+
     def decode(self, codes: List[torch.Tensor]) -> Optional[torch.Tensor]:
         if len(codes) != len(self._decoders):
             raise RuntimeError(f"expected {len(self._decoders)} code levels, got {len(codes)}")

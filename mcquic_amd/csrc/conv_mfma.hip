@@ -53,6 +53,10 @@
 #ifndef MCQ_CONV_MAX_MULTI
 #define MCQ_CONV_MAX_MULTI 4
 #endif
+// (round 6, built and dropped: conv_c32_kernel, a persistent kernel for Neon's 32 -> 32 layers with the whole filter bank in registers
+//  and the input patch double-buffered in LDS by DMA -- bit-identical to the 32 x 32 tile below, and no faster: 185 / 192 / 260 us on
+//  4 x 32 x 512x512 plain / SiLU / residual + twin against 181 / 189 / 230 here.  Source, test and counters: tools/probes/conv_c32.h,
+//  docs/experiments.md section 11.3)
 
 namespace {
 
@@ -2040,7 +2044,10 @@ int conv_launch(const mcq_conv_desc* descs, int nprob, void* stream) {
     int MB, NB, ksl = 0;
     bool dsilu41 = false;                 // the 128 x 32 tile chosen over the 128 x 64 one for an input-gradient epilogue (see below)
     const int forced = d->tile & 0xff;
-    if (forced) { MB = forced >> 4; NB = forced & 15; ksl = (d->tile >> 8) & 3; }
+    if (forced) {
+        MB = forced >> 4; NB = forced & 15; ksl = (d->tile >> 8) & 3;
+        if ((MB != 1 && MB != 2 && MB != 4) || (NB != 1 && NB != 2 && NB != 4)) return MCQ_EINVAL;      // (no such tile: NB = 0 would divide by zero below)
+    }
     else if (co32 == 1) {
         // <= 32 output channels (the 12-channel head, the tiny fixture models): one weight load feeds NB MFMAs, so the
         // widest pixel tile that still leaves >= 2048 waves amortises it best (head conv 2.34 -> 2.05 ms with NB = 4)

@@ -857,3 +857,15 @@ def test_vq_assign_and_gather_random_shapes(dev):
         want = torch.stack([cb[g][got.cpu()[:, g]] for g in range(m)], 1)                  # [n, m, h, w, d]
         assert torch.equal(out, want.permute(0, 1, 4, 2, 3).reshape(n, m * d, h, w)), what
     assert flips <= 8, f"{flips} audited near-tie flips over 80 shapes"
+
+
+def test_forced_tiles_that_do_not_exist_are_refused(dev):
+    """mcq_conv_desc.tile names (MB << 4) | NB with MB, NB in {1, 2, 4}: anything else is MCQ_EINVAL (a pixel-block count of zero once
+    reached the launcher's tile arithmetic: an integer division by zero on the host, round 6)."""
+    from mcquic_amd import ops
+    x = _rand((1, 32, 16, 16), 1).to(dev)
+    pk = ops.PackedConv(_rand((32, 32, 3, 3), 2, 0.05).to(dev), None)
+    for tile in (0x20, 0x10, 0x03, 0x31, 0x18, 0x320):
+        with pytest.raises(RuntimeError):
+            ops.conv2d(x, pk, 1, tile=tile)
+    assert ops.conv2d(x, pk, 1, tile=0x11).shape == (1, 32, 16, 16)

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--train", action="store_true", help="the 3x3 shapes of the config-#5 training step (8 images of 128x128 ... 4x4)")
     ap.add_argument("--neon", action="store_true", help="the 3x3 shapes of Neon(32, ...) at 4 x 512x512 (widths 32 / 64 / 8 at full resolution ... 32x32 maps): "
                                                     "32- and 64-row tiles, one / two / four pixel blocks per wave")
+    ap.add_argument("--only3232", action="store_true", help="with --neon: only the 32 -> 32 shapes")
     ap.add_argument("--tiles", default=None, help="comma-separated hex tile codes instead of the full list, e.g. 0,0x1f,0x11")
     args = ap.parse_args()
     tiles = TILES if args.tiles is None else [int(t, 16) for t in args.tiles.split(",")]
@@ -59,6 +60,8 @@ def main():
     neon = [(4, 32, 32, s_, s_, 3, 1) for s_ in (512, 256, 128, 64)] + [(4, 32, 64, 64, 64, 3, 1), (4, 64, 64, 64, 64, 3, 1), (4, 64, 8, 64, 64, 3, 1),
                                                                       (4, 8, 32, 64, 64, 3, 1), (4, 32, 32, 32, 32, 3, 1), (4, 32, 32, 16, 16, 3, 1), (4, 3, 32, 512, 512, 3, 1),
                                                                       (4, 32, 3, 512, 512, 3, 1)]
+    if args.only3232:
+        neon = [sh for sh in neon if sh[1] == 32 and sh[2] == 32 and sh[3] >= 64]
     if args.neon and args.tiles is None:
         tiles = [0, 0x11, 0x12, 0x14, 0x21, 0x22, 0x111, 0x112, 0x121]
     for (n, cin, cout, h, w, ks, stride) in neon if args.neon else c192 if args.c192 else train if args.train else batch1 if args.batch1 else (SHAPES[3:6] if args.small else SHAPES[:2] if args.big else SHAPES[6:] if args.k1 else SHAPES[:7]):

@@ -32,7 +32,14 @@ struct C32K {
 };
 
 constexpr unsigned C32_FLAGS = MCQ_CONV_SILU_OUT | MCQ_CONV_RESIDUAL | MCQ_CONV_DUAL_SILU | MCQ_CONV_DSILU_MUL;
-constexpr int C32_TH = 8, C32_TW = 32;                     // output tile: two pixel rows per wave
+#ifndef MCQ_C32_TH
+#define MCQ_C32_TH 8
+#endif
+#ifndef MCQ_C32_OCC
+#define MCQ_C32_OCC 2
+#endif
+constexpr int C32_TH = MCQ_C32_TH, C32_TW = 32;            // output tile: C32_TH / 4 pixel rows per wave
+constexpr int C32_RP = C32_TH / 8;                          // row pairs per wave
 constexpr int C32_PH = C32_TH + 2, C32_PW = C32_TW + 2;    // input patch
 constexpr int C32_PLANE = C32_PH * C32_PW;                  // 340 floats per channel
 constexpr int C32_LOADS = (C32_PLANE + 63) / 64;            // wave-wide DMA pieces per channel plane: 6, the last one 20 / 64 filled
@@ -45,7 +52,7 @@ inline bool c32_shape(int Cout, int Cin, int ksize, int stride) { return Cout ==
 __shared__ float c32_buf0[C32_HALF];
 __shared__ float c32_buf1[C32_HALF];
 
-__global__ __launch_bounds__(256, 2) void conv_c32_kernel(C32K p) {
+__global__ __launch_bounds__(256, MCQ_C32_OCC) void conv_c32_kernel(C32K p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int hi = lane >> 5, j = lane & 31;
@@ -93,15 +100,14 @@ __global__ __launch_bounds__(256, 2) void conv_c32_kernel(C32K p) {
     // everything this wave has in flight has landed and every wave of the workgroup is here (LDS reads of the last half included)
     auto landed_and_met = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    f32x16 acc[2];
+    f32x16 acc[C32_RP][2];
     // one half of the contraction for this wave's two pixel rows.  Per channel pair their nine taps read 3 columns x 4 patch rows =
     // 12 values for 18 MFMAs, requested one channel pair AHEAD; tap order = the general kernel's (dy major)
     auto multiply = [&](const float* buf, const int half) __attribute__((always_inline)) {
-        // lane (hi, j): channel 2 s + hi of the half, column j + dx, patch rows 2 wave .. 2 wave + 3 -- as an LDS byte address
-        const unsigned l0 = (unsigned)reinterpret_cast<size_t>(buf + hi * C32_PLANE + j + (wave * 2) * C32_PW);
-        // Six two-address LDS reads per channel pair from ONE base register (row pairs (0, 1), (2, 3) of the three columns: dword
-        // offsets <= 104 fit the instruction's 8-bit fields), spelled out: left to itself hipcc pairs the addresses differently and
-        // pays a v_add per read -- 12 issue slots per 18 MFMAs instead of 7.  (inline asm: the wait for them is spelled out too)
+#pragma unroll
+        for (int rp = 0; rp < C32_RP; ++rp) {
+        // lane (hi, j): channel 2 s + hi of the half, column j + dx, patch rows of this row pair -- as an LDS byte address
+        const unsigned l0 = (unsigned)reinterpret_cast<size_t>(buf + hi * C32_PLANE + j + (wave * 2 * C32_RP + 2 * rp) * C32_PW);
         f32x2v V[2][3][2];
         auto request = [&](const int s) __attribute__((always_inline)) {
             const unsigned base = l0 + (unsigned)(((s >> 1) * C32_WAVE + 2 * (s & 1) * C32_PLANE) * 4);
@@ -121,10 +127,11 @@ __global__ __launch_bounds__(256, 2) void conv_c32_kernel(C32K p) {
                 const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(half * 8 + s) * 9 + tap], V[s & 1][dx][(b + dy) >> 1][(b + dy) & 1], acc[b], 0, 0, 0);
+                    acc[rp][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(half * 8 + s) * 9 + tap], V[s & 1][dx][(b + dy) >> 1][(b + dy) & 1], acc[rp][b], 0, 0, 0);
                 if (tap == 0 && s + 1 < 8) request(s + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
     };
 
@@ -132,9 +139,11 @@ __global__ __launch_bounds__(256, 2) void conv_c32_kernel(C32K p) {
     if (tile < t_end) dma(tile, 0, c32_buf0);
     for (; tile < t_end; tile += slots) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int rp = 0; rp < C32_RP; ++rp)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rp][b][r] = 0.0f;
         landed_and_met();                                    // channels 0 .. 15 are in buffer 0; nobody reads buffer 1 any more
         dma(tile, 1, c32_buf1);
         multiply(c32_buf0, 0);
@@ -148,10 +157,11 @@ __global__ __launch_bounds__(256, 2) void conv_c32_kernel(C32K p) {
         const int y0 = ty * C32_TH, x0 = tx * C32_TW;
         const size_t oslab = (size_t)n * 32 * HW;
         const __amdgpu_buffer_rsrc_t yr = mcq_make_rsrc(mcq_uniform_ptr(p.y + oslab), plane_bytes);
-        {
+#pragma unroll
+        for (int rp = 0; rp < C32_RP; ++rp) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const int yy = y0 + wave * 2 + b, xx = x0 + j;
+                const int yy = y0 + wave * 2 * C32_RP + 2 * rp + b, xx = x0 + j;
                 const unsigned pvo = (yy < p.H && xx < p.W) ? ((unsigned)(yy * p.W + xx) + 4u * (unsigned)hi * (unsigned)HW) * 4u : MCQ_OOB;
                 // (eight channels at a time: the filter bank and the four accumulator tiles leave ~40 registers for the side values)
                 const __amdgpu_buffer_rsrc_t mr = mcq_make_rsrc(mcq_uniform_ptr(((fl & MCQ_CONV_DSILU_MUL) ? p.mul : p.y) + oslab), plane_bytes);
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_c32_kernel(C32K p) {
                 for (int g = 0; g < 2; ++g) {
                     float v[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = acc[b][g * 8 + q] + mcq_buffer_load_s(br, (unsigned)hi * 16u, (unsigned)mcq_drow(g * 8 + q, 0) * 4u);
+                    for (int q = 0; q < 8; ++q) v[q] = acc[rp][b][g * 8 + q] + mcq_buffer_load_s(br, (unsigned)hi * 16u, (unsigned)mcq_drow(g * 8 + q, 0) * 4u);
                     if (fl & MCQ_CONV_DSILU_MUL) {
                         float m[8];
 #pragma unroll

@@ -15,6 +15,14 @@
 #include "../../include/mcquic_hip.h"
 #include <math.h>
 
+#ifndef VQ_TWO_LEVEL
+#define VQ_TWO_LEVEL 0          // build switch: 1 = the tile epilogue first folds a band's 16 distances to their minimum (v_min3_f32) and runs the
+                                // compare / select pairs only when some lane's band beats its running minimum.  Built and measured in round 6
+                                // (profiles/r06_vq_two_level.txt): same codes, 1-5 % SLOWER on every shape (config #4 3.05 vs 3.02 ms, qp=2 level 0
+                                // 0.922 vs 0.906 ms, d = 16 0.955 vs 0.922 ms) -- the wave-uniform skip costs the epilogue its overlap with the
+                                // next tile's MFMAs and 38 % of the bands take both paths.  Left off.
+#endif
+
 namespace {
 
 // SPC = compile-time k-steps per tile (p.Sp) for the common vector lengths, 0 = run-time loop.  With the k-steps of a
@@ -193,20 +201,33 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
             for (int r = 0; r < 16; ++r) z[r] = 0.0f;
             const f32x16 c2d = __builtin_amdgcn_mfma_f32_32x32x2f32(c2a[mb], bone, z, 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+            for (int nb = 0; nb < NB; ++nb) {
+                // (x2 + c2) - 2 * inter ; 2 * inter is exact, so the fused form rounds identically.  Two distances per
+                // instruction (v_pk_add_f32 / v_pk_fma_f32: same IEEE operations, half the issue slots)
+                float dv[16];
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    // (x2 + c2) - 2 * inter ; 2 * inter is exact, so the fused form rounds identically.  Two distances per
-                    // instruction (v_pk_add_f32 / v_pk_fma_f32: same IEEE operations, half the issue slots)
                     const f32x2v s2 = f32x2v{x2[nb], x2[nb]} + f32x2v{c2d[r], c2d[r + 1]};
                     const f32x2v dv2 = __builtin_elementwise_fma(f32x2v{-2.0f, -2.0f}, f32x2v{acc[mb][nb][r], acc[mb][nb][r + 1]}, s2);
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const float dv = dv2[e];
-                        const int word = word0 + mb * 32 + mcq_drow(r + e, hi);
-                        if (dv < best[nb]) { best[nb] = dv; bidx[nb] = word; }
-                    }
+                    dv[r] = dv2[0]; dv[r + 1] = dv2[1];
                 }
+                if (VQ_TWO_LEVEL) {
+                    // (round 6, off: see VQ_TWO_LEVEL) two levels: the band's 16 distances are first folded to their minimum (v_min3_f32: eight instructions),
+                    // and the compare / select pair per distance that finds WHICH row it was only runs when some lane of the wave has a
+                    // band that beats its running minimum -- past the first tiles that is rare (a band improves a lane's minimum with
+                    // probability ~ 1 / bands seen).  Same result: no distance below the running minimum <=> band minimum not below it,
+                    // and inside the slow path the rows are visited in index order with a strict comparison, as before.
+                    float t0 = fminf(fminf(dv[0], dv[1]), dv[2]), t1 = fminf(fminf(dv[3], dv[4]), dv[5]), t2 = fminf(fminf(dv[6], dv[7]), dv[8]),
+                          t3 = fminf(fminf(dv[9], dv[10]), dv[11]), t4 = fminf(fminf(dv[12], dv[13]), dv[14]);
+                    const float tmin = fminf(fminf(fminf(t0, t1), t2), fminf(fminf(t3, t4), dv[15]));
+                    if (__builtin_amdgcn_ballot_w64(tmin < best[nb]) == 0ull) continue;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int word = word0 + mb * 32 + mcq_drow(r, hi);
+                    if (dv[r] < best[nb]) { best[nb] = dv[r]; bidx[nb] = word; }
+                }
+            }
         }
         c2a = c2n;
     }

@@ -14,6 +14,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "sweep: the long form of a seeded sweep whose sample runs under -m gpu; only with -m 'gpu and sweep'")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` (the driver's run, bounded by a step timeout) takes the seeded SAMPLES of the long sweeps; their full forms carry the
+    `sweep` marker and run only when the marker expression names it (`-m "gpu and sweep"`)."""
+    if "sweep" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="long sweep: run with -m 'gpu and sweep'")
+    for item in items:
+        if "sweep" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

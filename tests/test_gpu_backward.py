@@ -777,16 +777,20 @@ def test_soft_assignment_backward_random_shapes(dev):
         _close(dcb, torch.from_numpy(want_dc).float(), 3e-6, "dcodebook " + what)
 
 
-def test_blocks_backward_random_shapes(dev):
+@pytest.mark.parametrize("which", [pytest.param("sample", id="sample"), pytest.param("all", id="all", marks=pytest.mark.sweep)])
+def test_blocks_backward_random_shapes(dev, which):
     """The four block types in training mode at 14 seeded random (channels, batch, map) shapes -- channel counts that are no
     multiple of 32 (GDN's 1x1 launches, the 16-row tiles), odd maps (stride-2 blocks round up, pixel-shuffle blocks double) --
-    forward and every gradient against CPU autograd through the oracle's functions."""
+    forward and every gradient against CPU autograd through the oracle's functions.  `-m gpu`: every second shape;
+    `-m "gpu and sweep"`: all fourteen."""
     import random
     from mcquic_amd import nn as N
     rng = random.Random(17)
     for it in range(14):
         c = rng.choice([8, 12, 20, 32, 48, 64, 128, 192])
         n, h, w = rng.randint(1, 4), rng.randint(2, 20), rng.randint(2, 20)
+        if which == "sample" and it % 2:
+            continue
         x = _rand((n, c, h, w), 9500 + it)
         cases = [(N.ResidualBlock(c, c), R._rb, R.residual_block), (N.ResidualBlockWithStride(c, c), R._rb_stride, R.residual_block_with_stride),
                  (N.ResidualBlockShuffle(c, c), R._rb_shuffle, R.residual_block_shuffle), (N.AttentionBlock(c), R._attn, R.attention_block)]

@@ -319,15 +319,18 @@ def test_row_band_fallback_equals_the_single_launch(dev):
     assert float((rec - banded_rec).abs().max()) <= 2e-6
 
 
-def test_random_geometries_against_the_oracle(dev):
+@pytest.mark.parametrize("which", [pytest.param("sample", id="sample"), pytest.param("all", id="all", marks=pytest.mark.sweep)])
+def test_random_geometries_against_the_oracle(dev, which):
     """Twenty-four seeded random (batch, height, width) triples -- odd sizes, the smallest sizes reflect padding admits (a side of s
     pixels is padded to the next multiple of 128, which needs both pads < s: s >= 44), sizes around the 128-pixel padding steps,
     tall and wide strips -- through two small models against the CPU oracle: codes under the near-tie protocol, pixels within
     1e-4.  The fixed shapes above pin the tiles the benchmark runs; this sweeps the tails (partial pixel blocks, padding splits,
-    levels smaller than one tile)."""
+    levels smaller than one tile).  `-m gpu` runs a sample of eight of them (four edge sizes, four free ones: the CPU oracle is
+    100 s of the full sweep), `-m "gpu and sweep"` all twenty-four."""
     import random
     rng = random.Random(20260929)
     edge = [44, 45, 63, 64, 65, 127, 128, 129, 130, 200, 255, 256, 257, 300, 383, 384, 385, 511, 512, 513]
+    take = set(range(24)) if which == "all" else {0, 1, 2, 3, 10, 11, 12, 13}
     total = 0
     for it in range(24):
         if it < 10:
@@ -335,12 +338,14 @@ def test_random_geometries_against_the_oracle(dev):
         else:
             h, w = rng.randint(44, 520), rng.randint(44, 520)
         n = rng.choice([1, 1, 2, 3, 5])
+        if it not in take:
+            continue
         if it % 2 == 0:
             mism, _ = _compare(dev, 8, 2, [32, 16, 8], n=n, h=h, w=w, seed=100 + it, pix_tol=1e-4)
         else:
             mism, _ = _compare(dev, 16, 4, [64, 16, 8], n=n, h=h, w=w, seed=100 + it, pix_tol=1e-4)
         total += mism
-    assert total <= 8, f"{total} audited near-tie mismatches over twenty-four geometries"
+    assert total <= 8, f"{total} audited near-tie mismatches over {len(take)} geometries"
 
 
 def test_sizes_reflect_padding_cannot_take_are_refused_like_the_reference(dev):

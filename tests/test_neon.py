@@ -209,10 +209,10 @@ def test_neon_training_forward_with_seventeen_levels(dev):
     carry tables of mcq_vq_max_levels() levels and anything beyond is chunked by ops.py -- codes, reconstruction and every
     level's frequency EMA against the CPU oracle, with the cap's own chunking exercised by a second run under a cap of 4."""
     from mcquic_amd import Neon, ops, _lib
-    size = [16, 8, 8, 8, 8, 4, 4, 4, 4, 2, 2, 2, 2, 1, 1, 1, 1]
+    size = [4, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1]            # (17 levels like configs/neon_gen.yaml's list, on 64 x 64 crops)
     ch, k = 32, 64
     sd = N.make_state_dict(ch, k, size, seed=4)
-    x = R.make_images(2, 256, 256, seed=8)
+    x = R.make_images(2, 64, 64, seed=8)
     us = _uniforms(k, seed=11, size=size)
     want = N.forward_train({key: v.clone() for key, v in sd.items()}, x, us)
     lib = _lib.load()

@@ -100,6 +100,17 @@ def _hostWorker():
     return _POOL
 
 
+def _forget_worker_after_fork():
+    """A forked child inherits the executor object but not its thread: the first job would wait forever.  Start over there."""
+    global _POOL
+    _POOL = None
+    _COPY_STREAMS.clear()
+
+
+if hasattr(os, "register_at_fork"):
+    os.register_at_fork(after_in_child=_forget_worker_after_fork)
+
+
 def _poolThreads(threads: int, symbols: int) -> int:
     """Threads for one batched call: never more than one per 16 K symbols.  A pool thread costs ~40 us to start and join, a
     symbol ~25 ns: ten 768x512 images (61 K symbols on level 0, 15 K and 4 K below) code fastest on 2-4 threads (0.30 ms per

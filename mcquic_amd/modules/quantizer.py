@@ -441,6 +441,91 @@ class VariousMQuantizer(BaseQuantizer):
         self._k = k
 
 
+class _plainHeadEncoder(_quantizerEncoder):
+    """`_quantizerEncoder` whose `quantizationHead` / `latentHead` are nn.Identity() (NeonQuantizer, quantizer.py:490-491): the codes
+    come straight from the latent-stage encoder's output, and EVERY level -- the last one too -- returns z - dequant(code)
+    (quantizer.py:310-318 with `latentHead` never None)."""
+
+    def encode(self, x: torch.Tensor):
+        z = self._latentStageEncoder(x)
+        code = self._quantizer.encode(z)
+        return ops.axpby(z, self._dequantizer.decode(code), 1.0, -1.0), code
+
+    def forward(self, *a, **kw):
+        raise NotImplementedError("NeonQuantizer's training forward raises in the reference snapshot too (it hands the float 0.5 to "
+                                  "_multiCodebookQuantization where the frequency EMA tensor belongs, quantizer.py:493,194-200)")
+
+
+class _plainHeadDecoder(_quantizerDecoder):
+    """`_quantizerDecoder` with nn.Identity() `dequantizationHead` / `sideHead` (quantizer.py:497-498): q + formerLevel, restoreHead."""
+
+    def decode(self, code: torch.Tensor, formerLevel: Optional[torch.Tensor]):
+        q = self._dequantizer.decode(code)
+        return self._restoreHead(q if self._sideHead is None else ops.add(q, formerLevel))
+
+    def forward(self, *a, **kw):
+        raise NotImplementedError("NeonQuantizer's training forward raises in the reference snapshot too (quantizer.py:493)")
+
+
+class NeonQuantizer(VariousMQuantizer):
+    """reference: quantizer.py:469-573 -- the one quantizer class of that file no model or config of the snapshot instantiates: a
+    32-channel cascade like UMGMQuantizer's with a group count PER LEVEL (`m[i]` codebooks of 32 / m[i] dimensions, k[i] codewords),
+    identity heads, and a latent-stage encoder / restore head per level (ResidualBlock, AttentionBlock, strided / shuffle block, a
+    bias-free 1x1 convolution).  Same module tree and state_dict keys; inference only (encode / decode / compress / decompress,
+    Codebooks, reAssignCodebook): the reference's own training forward raises (see `_plainHeadEncoder.forward`)."""
+
+    def __init__(self, m: List[int], k: List[int]):
+        if not isinstance(k, list):
+            raise AttributeError
+        from ..nn import AttentionBlock, ResidualBlock, ResidualBlockShuffle, ResidualBlockWithStride, conv1x1
+        super().__init__(m, k)
+        encoders, decoders = [], []
+        for i, (ki, mi) in enumerate(zip(k, m)):
+            codebook = nn.Parameter(nn.init.normal_(torch.empty(mi, ki, 32 // mi), std=math.sqrt(2 / (5 * 32 / float(mi)))))
+            cache = _CodebookCache()
+            quantizer = _multiCodebookQuantization(codebook, cache)
+            dequantizer = _multiCodebookDeQuantization(codebook, cache)
+            lse = nn.Sequential(ResidualBlock(32, 32), AttentionBlock(32), ResidualBlockWithStride(32, 32), conv1x1(32, 32, bias=False))
+            restore = nn.Sequential(conv1x1(32, 32, bias=False), ResidualBlockShuffle(32, 32), AttentionBlock(32), ResidualBlock(32, 32))
+            encoders.append(_plainHeadEncoder(quantizer, dequantizer, lse, nn.Identity(), nn.Identity()))
+            decoders.append(_plainHeadDecoder(dequantizer, nn.Identity(), nn.Identity() if i < len(k) - 1 else None, restore))
+        self._encoders = nn.ModuleList(encoders)
+        self._decoders = nn.ModuleList(decoders)
+
+    @property
+    def Codebooks(self):
+        return list(encoder.Codebook for encoder in self._encoders)
+
+    def encode(self, x: torch.Tensor) -> List[torch.Tensor]:
+        codes = []
+        for encoder in self._encoders:
+            x, code = encoder.encode(x)
+            codes.append(code)
+        return codes
+
+    def decode(self, codes: List[torch.Tensor]) -> Optional[torch.Tensor]:
+        if len(codes) != len(self._decoders):
+            raise RuntimeError(f"expected {len(self._decoders)} code levels, got {len(codes)}")
+        formerLevel = None
+        for decoder, code in zip(self._decoders[::-1], codes[::-1]):
+            formerLevel = decoder.decode(code, formerLevel)
+        return formerLevel
+
+    def reAssignCodebook(self) -> torch.Tensor:
+        reassigned = [encoder.reAssignCodebook(freq) for encoder, freq in zip(self._encoders, self.NormalizedFreq)]
+        return torch.cat(reassigned).float().mean()
+
+    def syncCodebook(self):
+        import torch.distributed as dist
+        dist.barrier()
+        for encoder in self._encoders:
+            encoder.syncCodebook()
+
+    def forward(self, x: torch.Tensor):
+        raise NotImplementedError("NeonQuantizer's training forward raises in the reference snapshot too (it hands the float 0.5 to "
+                                  "_multiCodebookQuantization where the frequency EMA tensor belongs, quantizer.py:493,194-200)")
+
+
 class ResidualBackwardQuantizer(VariousMQuantizer):
     """The quantizer of `Neon` (reference: quantizer.py:577-765): ONE codebook [1, k, 8] shared by all levels; every level has
     a latent-stage encoder (down), a `backward` stack and a `restoreHead` (both up); codes are produced from the SMALLEST

@@ -344,3 +344,66 @@ def _make_state_dict(channel: int, k: int, size: List[int], seed: int) -> StateD
     for j in range(levels):                                # quantizer i reads _entropyCoder._freqEMA[-(i + 1)] (:607)
         sd[f"_quantizer._entropyCoder._freqEMA.{j}"] = sd[f"_quantizer._quantizers.{levels - 1 - j}._freqEMA"]
     return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# NeonQuantizer (mcquic/modules/quantizer.py:469-573): a 32-channel cascade with a group count per level and identity heads.
+# No model of the snapshot builds it; its encode / decode run in the reference (its training forward raises), so these two are
+# what tests/golden/f15_neon_quantizer.npz pins.  Keys as in `NeonQuantizer(m, k).state_dict()` (no `_quantizer.` prefix).
+# ----------------------------------------------------------------------------------------------
+def neon_quantizer_levels(sd: StateDict) -> int:
+    lv = 0
+    while f"_encoders.{lv}._quantizer._codebook" in sd:
+        lv += 1
+    return lv
+
+
+def neon_quantizer_encode(sd: StateDict, x: torch.Tensor, collect: Optional[dict] = None) -> List[torch.Tensor]:
+    """NeonQuantizer.encode (:519-527) over _quantizerEncoder.encode (:310-318) with identity heads: every level returns z - dequant."""
+    codes = []
+    for i in range(neon_quantizer_levels(sd)):
+        pre = f"_encoders.{i}."
+        z = latent_stage_encoder(sd, pre + "_latentStageEncoder.", x)
+        cb = sd[pre + "_quantizer._codebook"]
+        if collect is not None:
+            collect.setdefault("q", []).append(z)
+        code = R.vq_encode(z, cb)
+        codes.append(code)
+        x = z - R.vq_decode(code, cb)
+    return codes
+
+
+def neon_quantizer_decode(sd: StateDict, codes: List[torch.Tensor]) -> torch.Tensor:
+    """NeonQuantizer.decode (:529-533) over _quantizerDecoder.decode (:351-357): the last level has no side head."""
+    levels = neon_quantizer_levels(sd)
+    former = None
+    for i in reversed(range(levels)):
+        q = R.vq_decode(codes[i], sd[f"_decoders.{i}._dequantizer._codebook"])
+        former = restore_stack(sd, f"_decoders.{i}._restoreHead.", q if i == levels - 1 else q + former)
+    return former
+
+
+def make_neon_quantizer_state_dict(m: List[int], k: List[int], seed: int = 0) -> StateDict:
+    sd: StateDict = {}
+    s = seed * 100000
+    for i, (mi, ki) in enumerate(zip(m, k)):
+        base = s + 300 * i
+        pre = f"_encoders.{i}._latentStageEncoder."
+        _rb(sd, pre + "0.", 32, 32, base)
+        _attn(sd, pre + "1.", 32, base + 10)
+        R._rb_stride(sd, pre + "2.", 32, base + 40)
+        _conv_nobias(sd, pre + "3.", 32, 32, base + 50)
+        g = torch.Generator().manual_seed(base + 7)
+        codebook = torch.randn((mi, ki, 32 // mi), generator=g) * math.sqrt(2 / (5 * 32 / float(mi)))
+        sd[f"_encoders.{i}._quantizer._codebook"] = codebook
+        sd[f"_encoders.{i}._quantizer._temperature"] = torch.ones((mi, 1, 1, 1))
+        sd[f"_encoders.{i}._quantizer._bound.bound"] = torch.tensor([R.EPS])
+        sd[f"_encoders.{i}._dequantizer._codebook"] = codebook
+        sd[f"_decoders.{i}._dequantizer._codebook"] = codebook
+        pre = f"_decoders.{i}._restoreHead."
+        _conv_nobias(sd, pre + "0.", 32, 32, base + 60)
+        R._rb_shuffle(sd, pre + "1.", 32, base + 61)
+        _attn(sd, pre + "2.", 32, base + 70)
+        _rb(sd, pre + "3.", 32, 32, base + 100)
+        sd[f"_entropyCoder._freqEMA.{i}"] = torch.ones((mi, ki)) / ki
+    return sd

@@ -356,6 +356,38 @@ def main():
             f2b[tag + "_input_sha"] = np.frombuffer(bytes.fromhex(sha(lat)) + bytes.fromhex(sha(cb)), dtype=np.uint8)
         np.savez_compressed(os.path.join(OUT, "f2b_vq_fullsize.npz"), **f2b)
 
+    # ---- F15: NeonQuantizer (mcquic/modules/quantizer.py:469-573), the quantizer class no model of the snapshot builds --------------
+    # encode / decode of the REAL class on a seeded 32-channel tensor: codes, the reference's own top-2 gaps, the restored tensor
+    if want("f15"):
+        from oracle import neon_ref as NR
+        m15, k15 = [2, 4, 1], [64, 32, 16]
+        sd15 = NR.make_neon_quantizer_state_dict(m15, k15, seed=5)
+        nq = RQ.NeonQuantizer(m15, k15).eval()
+        nq.load_state_dict(sd15, strict=True)
+        x15 = rand((2, 32, 48, 80), 15)
+        gaps = []
+        orig_distance = RQ._multiCodebookQuantization._distance
+
+        def rec(self, x):
+            dist = orig_distance(self, x)
+            top2 = torch.topk(dist, 2, dim=-1, largest=False).values
+            gaps.append((top2[..., 1] - top2[..., 0]).clone())
+            return dist
+        RQ._multiCodebookQuantization._distance = rec
+        try:
+            with torch.inference_mode():
+                codes15 = nq.encode(x15)
+        finally:
+            RQ._multiCodebookQuantization._distance = orig_distance
+        with torch.inference_mode():
+            rec15 = nq.decode(codes15)
+        f15 = {"m": np.array(m15), "k": np.array(k15), "x_shape": np.array(x15.shape), "rec_strided": rec15[..., ::4, ::4].numpy(), "rec_mean_abs": np.array([float(rec15.abs().mean())]),
+               "keys": np.array(sorted(nq.state_dict().keys()))}
+        for lv, c in enumerate(codes15):
+            f15[f"code{lv}"] = c.numpy().astype(np.int16)
+            f15[f"gap{lv}"] = gaps[lv].numpy()
+        np.savez_compressed(os.path.join(OUT, "f15_neon_quantizer.npz"), **f15)
+
     # ---- F4: the full small model Compressor(8, 2, [32, 16, 8]) ----------------------------------------
     if want("f4"):
         small = {}

@@ -148,3 +148,30 @@ def test_decompress_rejects_hostile_headers():
         coder.decompress(binaries, [good, CodeSize(good.m, [8, 2, 1], good.widths, good.k)])
     for a, b in zip(codes, coder.decompress(binaries, sizes)):
         assert torch.equal(a, b)
+
+
+def test_level_wise_jobs_on_the_cpu_and_after_a_fork():
+    """The level-wise coder interface (EntropyCoder.beginCompress / beginDecompress, round 6) on host tensors: the bytes of the
+    all-at-once call; and a forked child, which inherits the executor object without its thread, starts its own worker."""
+    import os
+    from mcquic_amd.modules import entropyCoder as E
+    coder = E.EntropyCoder(2, [64, 32, 16])
+    g = torch.Generator().manual_seed(0)
+    codes = [torch.randint(0, k, (3, 2, 8 >> lv, 8 >> lv), generator=g) for lv, k in enumerate([64, 32, 16])]
+    want, sizes = coder.compress(codes)
+
+    def through_jobs():
+        job = coder.beginCompress(3)
+        for lv, c in enumerate(codes):
+            job.submit(lv, c)
+        got, got_sizes = job.finish()
+        dj = coder.beginDecompress(got, got_sizes)
+        back = [dj.level(lv) for lv in reversed(range(3))][::-1]
+        return got == want and all(torch.equal(a, b) for a, b in zip(codes, back))
+    assert through_jobs()
+    if hasattr(os, "fork"):
+        pid = os.fork()
+        if pid == 0:
+            os._exit(0 if through_jobs() else 1)
+        _, status = os.waitpid(pid, 0)
+        assert os.WEXITSTATUS(status) == 0

@@ -240,3 +240,69 @@ def test_neon_training_forward_with_seventeen_levels(dev):
             got = model._quantizer._entropyCoder._freqEMA[j].detach().cpu()
             ref = R.freq_ema_update(torch.ones((1, k)) / k, want[4][j], ema=0.998)
             assert torch.allclose(got, ref, atol=1e-7), f"freqEMA of quantization {j} (capped={capped})"
+
+
+# ---- NeonQuantizer (mcquic/modules/quantizer.py:469-573): the quantizer class of that file no model of the snapshot instantiates ----
+NQ_M, NQ_K = [2, 4, 1], [64, 32, 16]
+
+
+def _nq_input():
+    g = torch.Generator().manual_seed(15)
+    return (torch.rand((2, 32, 48, 80), generator=g) * 2 - 1)
+
+
+def test_neon_quantizer_oracle_matches_reference_vectors():
+    """F15, captured from the REAL NeonQuantizer.encode / decode: the oracle's codes are the reference's, the restored tensor within
+    1e-6, and the HIP module has the reference's state_dict keys."""
+    from mcquic_amd.modules.quantizer import NeonQuantizer
+    z = np.load(os.path.join(GDIR, "f15_neon_quantizer.npz"))
+    sd = N.make_neon_quantizer_state_dict(NQ_M, NQ_K, seed=5)
+    codes = N.neon_quantizer_encode(sd, _nq_input())
+    for lv, c in enumerate(codes):
+        assert torch.equal(c, torch.from_numpy(z[f"code{lv}"].astype(np.int64))), f"level {lv}"
+    rec = N.neon_quantizer_decode(sd, codes)
+    np.testing.assert_allclose(rec[..., ::4, ::4].numpy(), z["rec_strided"], rtol=0, atol=1e-6)
+    mod = NeonQuantizer(NQ_M, NQ_K)
+    assert sorted(mod.state_dict().keys()) == list(z["keys"])
+    mod.load_state_dict(sd, strict=True)
+    assert [tuple(c.shape) for c in mod.Codebooks] == [(2, 64, 16), (4, 32, 8), (1, 16, 32)]
+    with pytest.raises(AttributeError):
+        NeonQuantizer([1], 64)                              # (the reference's own check, :471-472)
+
+
+@pytest.mark.gpu
+def test_neon_quantizer_hip_against_reference_vectors(dev):
+    """The HIP NeonQuantizer against F15: codes under the near-tie protocol, the restored tensor within 1e-4 from the reference's
+    codes, the raw-int64 byte streams of VariousMCoder round-tripping per-level group counts, and the training forward refused
+    like the reference's (which raises on the float it is handed for a frequency EMA)."""
+    from mcquic_amd.modules.quantizer import NeonQuantizer
+    z = np.load(os.path.join(GDIR, "f15_neon_quantizer.npz"))
+    sd = N.make_neon_quantizer_state_dict(NQ_M, NQ_K, seed=5)
+    mod = NeonQuantizer(NQ_M, NQ_K).eval()
+    mod.load_state_dict(sd, strict=True)
+    mod = mod.to(dev)
+    x = _nq_input().to(dev)
+    with torch.no_grad():
+        codes = [c.cpu() for c in mod.encode(x)]
+    alive = torch.ones(2, dtype=torch.bool)
+    flips = 0
+    for lv, c in enumerate(codes):
+        want = torch.from_numpy(z[f"code{lv}"].astype(np.int64))
+        assert c.dtype == torch.int64 and c.shape == want.shape
+        bad = (c != want) & alive[:, None, None, None]
+        if bad.any():
+            assert float(torch.from_numpy(z[f"gap{lv}"])[bad].max()) < NEAR_TIE, f"level {lv}: a code differs away from a near-tie of the reference"
+            flips += int(bad.sum())
+            alive &= ~bad.flatten(1).any(1)
+    assert flips <= 1
+    want_codes = [torch.from_numpy(z[f"code{lv}"].astype(np.int64)).to(dev) for lv in range(3)]
+    with torch.no_grad():
+        rec = mod.decode(want_codes).cpu()
+    np.testing.assert_allclose(rec[..., ::4, ::4].numpy(), z["rec_strided"], rtol=0, atol=1e-4)
+    assert abs(float(rec.abs().mean()) - float(z["rec_mean_abs"][0])) < 1e-5
+    with torch.no_grad():
+        cds, binaries, sizes = mod.compress(x)
+        back = mod.decompress(binaries, sizes)
+    assert sizes[0].m == NQ_M and torch.equal(back, mod.decode(cds))
+    with pytest.raises(NotImplementedError):
+        mod(x)

@@ -89,7 +89,6 @@ def hostThreads() -> int:
 
 CODER_OVERLAP = os.environ.get("MCQUIC_AMD_CODER_OVERLAP", "1") != "0"     # A/B switch: 0 = copy / code all levels at once (rounds 1-5)
 _POOL = None                     # ONE host thread for the level-wise coder jobs of this process (module state: models are deep-copied)
-_COPY_STREAMS = {}               # device index -> the side stream the codes leave the device on
 
 
 def _hostWorker():
@@ -104,7 +103,6 @@ def _forget_worker_after_fork():
     """A forked child inherits the executor object but not its thread: the first job would wait forever.  Start over there."""
     global _POOL
     _POOL = None
-    _COPY_STREAMS.clear()
 
 
 if hasattr(os, "register_at_fork"):
@@ -316,17 +314,11 @@ class EntropyCoder(nn.Module):
     # `compress` above copies every level, waits for the whole stream, then codes on the host; `decompress` decodes every level
     # before the first kernel of the decoder is enqueued.  But level 0's codes (3/4 of the symbols) exist long before levels 1 .. are
     # computed, and the decoder needs the LAST level (the smallest stream) first: a level-wise interface lets the quantizer hand each
-    # level over as soon as its `vq_assign` is enqueued (copy on a side stream, coded on a host thread while the GPU works on the
+    # level over as soon as its `vq_assign` is enqueued (copy in stream order, coded on a host thread while the GPU works on the
     # next level), and take decoded levels one by one, smallest first, while a host thread decodes the larger ones.  Same bytes,
     # same codes (tests/test_gpu_entropy_coder.py).  MCQUIC_AMD_CODER_OVERLAP=0: the all-at-once forms above.
     def _worker(self):
         return _hostWorker()
-
-    def _copyStream(self, device):
-        st = _COPY_STREAMS.get(device.index)
-        if st is None:
-            st = _COPY_STREAMS[device.index] = torch.cuda.Stream(device=device)
-        return st
 
     def beginCompress(self, levels: int) -> "_CompressJob":
         self.CDFs                                              # refresh the tables if the EMA changed
@@ -412,17 +404,14 @@ class _CompressJob:
         c32 = code.detach().to(torch.int32)
         done = None
         if c32.is_cuda:
-            main = torch.cuda.current_stream(c32.device)
-            side = coder._copyStream(c32.device)
-            ready = torch.cuda.Event()
-            ready.record(main)
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                pinned = torch.empty(c32.shape, dtype=torch.int32, pin_memory=True)
-                pinned.copy_(c32, non_blocking=True)
-                done = torch.cuda.Event()
-                done.record(side)
-            c32.record_stream(side)
+            # the copy stays on the COMPUTE stream (123 KB for ten images' level 0: a few microseconds in stream order) and an event
+            # behind it releases the host thread.  A copy stream of its own shares a hardware queue with other streams once a process
+            # has made a few (the bench's main process: side streams of the blocks, prefetch streams) and then waits behind the
+            # kernels it was meant to overlap: compress fell from 219 to 183 Mpps there (profiles/r06_speed_protocol_overlap.txt)
+            pinned = torch.empty(c32.shape, dtype=torch.int32, pin_memory=True)
+            pinned.copy_(c32, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(c32.device))
             c32 = pinned
         table = coder._tables[lv]
 

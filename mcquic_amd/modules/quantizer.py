@@ -361,7 +361,7 @@ class UMGMQuantizer(BaseQuantizer):
 
     def compress(self, x: torch.Tensor):
         """`encode` + the entropy coder (mcquic/modules/entropyCoder.py:108-126) with the coder taken level by level: a level's codes
-        leave for the host (side stream, host thread) as soon as they are enqueued, while the GPU computes the levels below it --
+        leave for the host (a copy in stream order, then a host thread) as soon as they are enqueued, while the GPU computes the levels below it --
         level 0 holds three quarters of the symbols and is ready first.  Same codes, same bytes as encode() + coder.compress()."""
         from .entropyCoder import CODER_OVERLAP
         if not (CODER_OVERLAP and x.is_cuda):

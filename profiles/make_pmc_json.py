@@ -26,7 +26,7 @@ out = {
     "csrc_sha": csrc_sha(),      # the kernel sources these passes ran on; bench.py prints traffic_stale when its own differ
     "source": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE} --kernel-trace -- "
               "python bench.py --steps 1 --warmup 1 --no-cpu-baseline (three separate passes, single stream; "
-              "tools/collect_profiles.sh, profiles/pmc_stats.py, profiles/make_pmc_json.py)",
+              "tools/collect.sh, profiles/pmc_stats.py, profiles/make_pmc_json.py)",
     "kernel": dom + " (128 co x 64 px wave tile, 3x3, no prologue)",
     "units": "bytes per launch, averaged over the launches of the kernel in the run; FETCH_SIZE/WRITE_SIZE are KiB "
              "counters; on gfx950 FETCH_SIZE tallies 64 B per 128-B request for wide coalesced reads "

@@ -13,7 +13,8 @@
 #   train    training step figures + trace + buckets
 #   tests    the GPU test suite with durations
 #   ab VAR A B [runs]   alternating `VAR=A` / `VAR=B` headline runs on this box (bench.py --steps 8 --no-secondary): in-step A/B of a switch
-# Outputs: gpurun_out/<round>_<what>/ (merged back by gpurun); the summaries worth keeping are copied into profiles/ HERE by the script
+# Outputs: gpurun_out/<round>_<what>/ (merged back by gpurun; what the script copies into profiles/ on the BOX only serves the same call --
+# bench.py reads profiles/rNN_pmc.json -- and is copied from gpurun_out/ into profiles/ again by hand after the call)
 # (kernel traces and counter databases are deleted: too large to travel).  Earlier rounds' one-off scripts: git history (tools/collect_r0*.sh).
 set -u
 WHAT=${1:-final}; shift || true

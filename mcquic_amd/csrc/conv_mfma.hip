@@ -53,12 +53,6 @@
 #ifndef MCQ_CONV_MAX_MULTI
 #define MCQ_CONV_MAX_MULTI 4
 #endif
-// (round 6, measured inside the 32-image step and not kept -- docs/experiments.md section 11.7:
-//  * accumulators of the residual (+ twin) launches STARTED from the residual, so that the epilogue holds no output-shaped load:
-//    259.9 -> 257.5 images/s, isolated 1626 -> 1663 us on the 192x128 layer -- the first MFMAs then wait for 128 HBM loads that sit in
-//    front of the operand rings;
-//  * the 64 x 64 tile budgeted for two waves per SIMD instead of three (no spills: its 20 spilled registers live in the epilogue):
-//    259.2 -> 258.4; with a 9-step activation ring at three waves per SIMD: 259.1, no difference)
 // (round 6, built and dropped: conv_c32_kernel, a persistent kernel for Neon's 32 -> 32 layers with the whole filter bank in registers
 //  and the input patch double-buffered in LDS by DMA -- bit-identical to the 32 x 32 tile below, and no faster: 185 / 192 / 260 us on
 //  4 x 32 x 512x512 plain / SiLU / residual + twin against 181 / 189 / 230 here.  Source, test and counters: tools/probes/conv_c32.h,

@@ -1103,7 +1103,72 @@ _WGRAD_ROWS = os.environ.get("MCQUIC_AMD_WGRAD_ROWS", "1") != "0"      # A/B swi
 
 # ---- the weight gradients' reduce passes, batched over a backward pass (mcq_wgrad_defer / mcq_wgrad_flush) -------------------------------
 _WGRAD_DEFER = os.environ.get("MCQUIC_AMD_WGRAD_DEFER", "1") != "0"    # A/B switch: 0 = every weight-gradient launch reduces right away
-_defer = {"on": False, "keep": []}
+_defer = {"on": False, "keep": [], "queue": [], "small": None, "main": None, "side": None, "forked": False, "split": None}
+# Round 6, measured and left OFF (MCQUIC_AMD_WGRAD_SIDE=1 turns it on): inside a deferral nothing reads a weight gradient before the
+# flush, so the weight-gradient LAUNCHES need not stand in the chain of input gradients either.  They are queued (outputs allocated at
+# once, operands held) and issued in batches on ONE side stream: when the backward pass moves from chip-filling maps to the few-pixel
+# ones (or back) everything queued so far goes to the side stream behind one fork edge; one join at the flush.  Eager step on one
+# MI355X 22.09 -> 21.56 ms (the host is the bound there and the side stream hides some of it); a captured step LOSES: as a second
+# branch inside one hipGraph 36.8 ms against 21.2 (~85 edges: 35.5), as hipGraphs of their own beside the main stream's
+# (tools/probes/split_capture.py) 22.6 -- the row walks hold every wave slot and each launch of the latency-bound chain over the
+# 16x16 ... 4x4 maps waits for one.  Inside a plain capture the queue is therefore issued in line.  docs/experiments.md section 11.8.
+_WGRAD_SIDE = os.environ.get("MCQUIC_AMD_WGRAD_SIDE", "0") == "1"
+_WGRAD_SMALL_PIXELS = 4096                                          # images x output pixels up to which a launch counts as few-pixel
+_wgrad_streams = {}
+
+
+def _queue_wgrad(small: bool, operands, launch) -> None:
+    """One weight-gradient call of a deferred pass: `launch()` runs later, on the side stream or at the flush."""
+    dev = operands[0].device
+    main = torch.cuda.current_stream(dev)
+    if _defer["main"] is None:
+        key = (dev.index, main.cuda_stream)
+        side = _wgrad_streams.get(key)
+        if side is None:
+            side = _wgrad_streams[key] = torch.cuda.Stream(device=dev)
+        _defer["main"], _defer["side"], _defer["forked"] = main, side, False
+    elif main != _defer["main"]:                                    # (a launch from another stream than the pass began on: in line)
+        launch()
+        return
+    if _defer["small"] is not None and small != _defer["small"] and _defer["queue"]:
+        _issue_wgrads(side=True)
+    _defer["small"] = small
+    _defer["queue"].append(launch)
+    _defer["keep"].extend(operands)                                 # (the side stream reads them: not the allocator's to hand out before the join)
+
+
+def _issue_wgrads(side: bool) -> None:
+    queue, _defer["queue"] = _defer["queue"], []
+    if not queue:
+        return
+    main = _defer["main"]
+    if side and _defer["split"] is not None:
+        # a capture that knows about the fork (tools/probes/split_capture.py): the batch becomes a hipGraph of its own, replayed on
+        # the side stream beside the main stream's next graph
+        _defer["split"].fork(queue)
+        _defer["forked"] = True
+    elif side and not torch.cuda.is_current_stream_capturing():
+        _defer["side"].wait_stream(main)
+        _defer["forked"] = True
+        with torch.cuda.stream(_defer["side"]):
+            for launch in queue:
+                launch()
+    else:                                                           # (in line: the flush's rest, or a plain capture)
+        with torch.cuda.stream(main):
+            for launch in queue:
+                launch()
+
+
+def _join_wgrad_side() -> None:
+    main, side, forked = _defer["main"], _defer["side"], _defer["forked"]
+    _defer["main"] = _defer["side"] = _defer["small"] = None
+    _defer["forked"] = False
+    del _defer["queue"][:]
+    if forked:
+        if _defer["split"] is not None:
+            _defer["split"].join()
+        else:
+            main.wait_stream(side)
 
 
 class wgrad_deferral:
@@ -1123,9 +1188,14 @@ class wgrad_deferral:
         if not self.active:
             return False
         lib = _lib.load()
-        lib.mcq_wgrad_defer(0)
-        _defer["on"] = False
         try:
+            if exc_type is None:
+                _issue_wgrads(side=False)                           # (what is still queued: in line, beside whatever the side stream still holds)
+        finally:
+            lib.mcq_wgrad_defer(0)
+            _defer["on"] = False
+        try:
+            _join_wgrad_side()                                      # (the reduce passes read what the side stream's launches left)
             if exc_type is None and lib.mcq_wgrad_pending():
                 dev = _defer["keep"][0].device if _defer["keep"] else torch.device("cuda", torch.cuda.current_device())
                 with _guard(dev):
@@ -1165,7 +1235,47 @@ def _keep(*tensors) -> None:
         _defer["keep"].extend(t.untyped_storage() for t in tensors[1:] if t is not None)
 
 
+class _Later:
+    """An output of a queued launch, held WITHOUT a reference to the tensor the caller got (AccumulateGrad takes a gradient as it is
+    only while nothing else references that very tensor; with a second reference it clones it -- before the launch has run)."""
+
+    def __init__(self, t: Optional[torch.Tensor]):
+        self.storage, self.shape = (t.untyped_storage(), tuple(t.shape)) if t is not None else (None, None)
+
+    def tensor(self) -> Optional[torch.Tensor]:
+        if self.storage is None:
+            return None
+        return torch.empty(0, dtype=torch.float32, device=self.storage.device).set_(self.storage, 0, self.shape)
+
+
+def _wgrad_outputs(x, dy, ksize: int, want_bias: bool):
+    dw = torch.empty((dy.shape[1], x.shape[1], ksize, ksize), dtype=torch.float32, device=x.device)
+    return dw, (torch.empty((dy.shape[1],), dtype=torch.float32, device=x.device) if want_bias else None)
+
+
 def conv2d_wgrad_group(xs, dys, want_bias: bool = True):
+    if not (_defer["on"] and _WGRAD_SIDE):
+        return _conv2d_wgrad_group(xs, dys, want_bias)
+    xs, dys = [_dev(t, "x") for t in xs], [_dev(t, "dy") for t in dys]
+    outs = [_wgrad_outputs(x, dy, 3, want_bias) for x, dy in zip(xs, dys)]
+    small = xs[0].shape[0] * dys[0].shape[2] * dys[0].shape[3] <= _WGRAD_SMALL_PIXELS
+    later = [(_Later(dw), _Later(db)) for dw, db in outs]
+    _queue_wgrad(small, xs + dys, lambda: _conv2d_wgrad_group(xs, dys, want_bias, [(a.tensor(), b.tensor()) for a, b in later]))
+    return outs
+
+
+def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, square_x: bool = False, want_bias: bool = False):
+    if not (_defer["on"] and _WGRAD_SIDE):
+        return _conv2d_wgrad(x, dy, ksize, stride, square_x, want_bias)
+    x, dy = _dev(x, "x"), _dev(dy, "dy")
+    out = _wgrad_outputs(x, dy, ksize, want_bias)
+    small = x.shape[0] * dy.shape[2] * dy.shape[3] <= _WGRAD_SMALL_PIXELS
+    later = (_Later(out[0]), _Later(out[1]))
+    _queue_wgrad(small, [x, dy], lambda: _conv2d_wgrad(x, dy, ksize, stride, square_x, want_bias, (later[0].tensor(), later[1].tensor())))
+    return out if want_bias else out[0]
+
+
+def _conv2d_wgrad_group(xs, dys, want_bias: bool = True, outs=None):
     """Weight (and bias) gradients of several 3x3 stride-1 convolutions of ONE shape in one launch pair
     (mcq_conv2d_wgrad_nchw_group_f32).  Returns [(dW, db or None), ...]; shapes the row-walk kernel does not take, or a
     single pair, go through conv2d_wgrad one by one."""
@@ -1176,8 +1286,8 @@ def conv2d_wgrad_group(xs, dys, want_bias: bool = True):
     nws = lib.mcq_conv2d_wgrad_nchw_workspace_floats(n, cin, h, w, cout) if (_WGRAD_ROWS and same and tuple(dys[0].shape[2:]) == (h, w)) else 0
     if not nws or len(xs) == 1:
         out = []
-        for x, dy in zip(xs, dys):
-            r = conv2d_wgrad(x, dy, 3, 1, want_bias=want_bias)
+        for i, (x, dy) in enumerate(zip(xs, dys)):
+            r = _conv2d_wgrad(x, dy, 3, 1, want_bias=want_bias, out=outs[i] if outs else None)
             out.append(r if want_bias else (r, None))
         return out
     out = []
@@ -1189,8 +1299,11 @@ def conv2d_wgrad_group(xs, dys, want_bias: bool = True):
         gd = [_dev(t, "dy") for t in dys[lo:lo + cap]]
         k = len(gx)
         ws = torch.empty(nws * k, dtype=torch.float32, device=gx[0].device)
-        dws = [torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=gx[0].device) for _ in range(k)]
-        dbs = [torch.empty((cout,), dtype=torch.float32, device=gx[0].device) for _ in range(k)] if want_bias else None
+        if outs:
+            dws, dbs = [o[0] for o in outs[lo:lo + k]], ([o[1] for o in outs[lo:lo + k]] if want_bias else None)
+        else:
+            dws = [torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=gx[0].device) for _ in range(k)]
+            dbs = [torch.empty((cout,), dtype=torch.float32, device=gx[0].device) for _ in range(k)] if want_bias else None
         table = ctypes.c_void_p * k
         with _guard(gx[0].device):
             check(lib.mcq_conv2d_wgrad_nchw_group_f32(table(*[t.data_ptr() for t in gx]), table(*[t.data_ptr() for t in gd]),
@@ -1202,7 +1315,8 @@ def conv2d_wgrad_group(xs, dys, want_bias: bool = True):
     return out
 
 
-def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, square_x: bool = False, want_bias: bool = False):
+def _conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, square_x: bool = False, want_bias: bool = False,
+                  out=None):
     """dW [Cout, Cin, k, k] of y = conv(x, W) + b from NCHW x and dy (channel-major copies are made here, one launch for
     the pair); with `want_bias` returns (dW, db) where db[co] = sum of dy over images and pixels, from the same kernel."""
     x, dy = _dev(x, "x"), _dev(dy, "dy")
@@ -1214,8 +1328,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
         nws = lib.mcq_conv2d_wgrad_nchw_workspace_floats(n, cin, h, w, cout)
         if nws:
             ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-            dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
-            db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+            dw, db = out if out is not None else _wgrad_outputs(x, dy, 3, want_bias)
             with _guard(x.device):
                 check(lib.mcq_conv2d_wgrad_nchw_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream()),
                       "mcq_conv2d_wgrad_nchw_f32")
@@ -1225,8 +1338,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
         nws = lib.mcq_conv2d_wgrad_s2_nchw_workspace_floats(n, cin, h, w, cout)
         if nws:
             ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-            dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
-            db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+            dw, db = out if out is not None else _wgrad_outputs(x, dy, 3, want_bias)
             with _guard(x.device):
                 check(lib.mcq_conv2d_wgrad_s2_nchw_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream()),
                       "mcq_conv2d_wgrad_s2_nchw_f32")
@@ -1236,8 +1348,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
         nws = lib.mcq_conv2d_wgrad1x1_nchw_workspace_floats(n, cin, h, w, cout)
         if nws:
             ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-            dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=x.device)
-            db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+            dw, db = out if out is not None else _wgrad_outputs(x, dy, 1, want_bias)
             with _guard(x.device):
                 check(lib.mcq_conv2d_wgrad1x1_nchw_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout,
                                                        int(square_x), _stream()), "mcq_conv2d_wgrad1x1_nchw_f32")
@@ -1246,8 +1357,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int, squ
     xt = torch.empty((n, h, w, cin), dtype=torch.float32, device=x.device)
     dyt = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
     ws = torch.empty(lib.mcq_conv2d_wgrad_workspace_floats(n, cin, h, w, cout, ksize, stride), dtype=torch.float32, device=x.device)
-    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
-    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    dw, db = out if out is not None else _wgrad_outputs(x, dy, ksize, want_bias)
     with _guard(x.device):
         check(lib.mcq_nchw_to_nhwc_pair_f32(_ptr(x), _ptr(xt), cin, h * w, int(square_x), _ptr(dy), _ptr(dyt), cout, ho * wo, n,
                                             _stream()), "mcq_nchw_to_nhwc_pair_f32")

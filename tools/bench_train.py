@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--crop", type=int, default=256)
     ap.add_argument("--graph", action="store_true", help="capture forward+backward in one hipGraph and replay it (single GPU)")
     ap.add_argument("--graph-streams", action="store_true", help="with --graph: keep the branch streams on during capture (experiment)")
+    ap.add_argument("--split", action="store_true", help="probe (tools/probes/split_capture.py): the step as several single-stream hipGraphs, the weight "
+                    "gradients' batches on a side stream beside the input gradients' chain")
     ap.add_argument("--graphed", action="store_true",
                     help="parallel.GraphedTrainStep: main hipGraph (forward + backward, flat gradient buffer) + one gradient all-reduce "
                          "over the ranks + post hipGraph (SGD update, frequency EMA) -- the data-parallel step without DDP's hooks")
@@ -57,7 +59,7 @@ def main():
             finally:
                 ops.conv2d = conv
         ops.conv2d, ops.conv2d_multi = conv, multi
-    if args.graph and not args.graph_streams:
+    if (args.graph or args.split) and not args.graph_streams:
         # capturing the nested stream forks of the training graph crashes hipGraph capture (ROCm 7.2): one stream there
         os.environ["MCQUIC_AMD_BRANCH_STREAMS"] = "0"
     from mcquic_amd import launch
@@ -100,7 +102,30 @@ def main():
             return gstep(x)
     for _ in range(args.warmup):
         step()
-    if args.graph and not use_dist and not args.graphed:
+    if args.split and not use_dist and not args.graphed:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes"))
+        os.environ.setdefault("MCQUIC_AMD_WGRAD_SIDE", "1")
+        from split_capture import SplitCapture            # (probe: measured slower than one graph, see its header)
+        cap = SplitCapture(dev)
+        with torch.cuda.stream(cap.main):
+            step()
+            step()
+        torch.cuda.synchronize()
+        for p in model.parameters():
+            p.grad = None
+        with cap:
+            xHat, yHat, codes, logits = net(x)
+            static_loss = mse_loss(xHat, x)
+            backward(static_loss)
+            if opt is not None:
+                opt.step()
+        print("split capture:", [w for w, _ in cap.program], file=sys.stderr)
+
+        def step():                                        # noqa: F811
+            cap.replay()
+            return static_loss
+        step()
+    elif args.graph and not use_dist and not args.graphed:
         # whole-step capture: ~5000 kernel launches per step become one graph launch
         torch.cuda.synchronize()
         for p in model.parameters():
@@ -133,7 +158,7 @@ def main():
         print(json.dumps({"metric": "training step (forward + backward), 256x256 crops, qp=2 model", "n_gpus": world,
                           "images_per_gpu": args.batch, "ms_per_step": round(dt / args.steps * 1e3, 2),
                           "images_per_s": round(world * args.batch * args.steps / dt, 2), "loss": float(loss), "grad_norm": gn,
-                          "dtype": "f32", "graph": bool((args.graph and not use_dist) or args.graphed), "ddp": bool(use_dist and not args.graphed),
+                          "dtype": "f32", "graph": bool(((args.graph or args.split) and not use_dist) or args.graphed), "split": bool(args.split), "ddp": bool(use_dist and not args.graphed),
                           "graphed_data_parallel": bool(args.graphed),
                           "optimizer_step": "SGD inside the timed region (weights re-packed every step)" if args.optimizer_step else "not included"}))
     if use_dist:

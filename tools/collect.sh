@@ -12,6 +12,7 @@
 #   bench    only the bench line (+ the torchrun line)
 #   train    training step figures + trace + buckets
 #   tests    the GPU test suite with durations
+#   abtrain VAR A B [runs]   the same on the captured training step (tools/bench_train.py --graph)
 #   ab VAR A B [runs]   alternating `VAR=A` / `VAR=B` headline runs on this box (bench.py --steps 8 --no-secondary): in-step A/B of a switch
 # Outputs: gpurun_out/<round>_<what>/ (merged back by gpurun; what the script copies into profiles/ on the BOX only serves the same call --
 # bench.py reads profiles/rNN_pmc.json -- and is copied from gpurun_out/ into profiles/ again by hand after the call)
@@ -104,6 +105,11 @@ case "$WHAT" in
     VAR=$1; A=$2; B=$3; RUNS=${4:-2}; O=gpurun_out/ab_$VAR; mkdir -p $O
     for r in $(seq $RUNS); do for v in "$A" "$B"; do
       env $VAR=$v python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$VAR=$v', d['value'], d['ms_per_step'], d['roofline']['frac'])" | tee -a $O/ab.txt
+    done; done ;;
+  abtrain)      # the same for the captured training step (configs[4]): tools/bench_train.py --graph, alternating
+    VAR=$1; A=$2; B=$3; RUNS=${4:-2}; O=gpurun_out/abtrain_$VAR; mkdir -p $O
+    for r in $(seq $RUNS); do for v in "$A" "$B"; do
+      env $VAR=$v python tools/bench_train.py --steps 20 --graph 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$VAR=$v', d['ms_per_step'], d['loss'], d['grad_norm'])" | tee -a $O/ab.txt
     done; done ;;
   *) echo "usage: tools/collect.sh final|pmc|bench|train|tests [rNN]  |  ab VAR A B [runs]"; exit 2 ;;
 esac

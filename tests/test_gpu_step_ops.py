@@ -353,9 +353,12 @@ def test_grouped_gdn_operand_refresh_equals_layer_by_layer(dev):
 
 
 @pytest.mark.parametrize("kind", ["compressor", "neon_dense_norm"])
-def test_deferred_reduce_passes_give_the_same_gradients(dev, kind):
+def test_deferred_reduce_passes_give_the_same_gradients(dev, kind, monkeypatch):
     """autograd.backward (weight-gradient reduce passes recorded and run batched at the end of the pass) against a plain
-    loss.backward() (every launch reduces right away): every parameter gradient bit for bit -- same partial tiles, same order."""
+    loss.backward() (every launch reduces right away): every parameter gradient bit for bit -- same partial tiles, same order.
+    Third mode: the opt-in queue of round 6 (MCQUIC_AMD_WGRAD_SIDE=1: the weight-gradient launches themselves issued in batches
+    on a side stream, docs/experiments.md 11.8) -- the same bits again (a gradient the engine cloned because it saw a second
+    reference to a queued output would hold whatever the buffer held before the launch ran)."""
     from mcquic_amd import Compressor, Neon, ops
     from mcquic_amd.autograd import backward, mse_loss
     torch.manual_seed(3407)
@@ -370,7 +373,8 @@ def test_deferred_reduce_passes_give_the_same_gradients(dev, kind):
         us = [(torch.rand((4, 1, s, s, 256), generator=g).to(dev), torch.rand((4, 1, s, s, 256), generator=g).to(dev)) for s in (2, 2, 4, 8)]
     grads = {}
     ema0 = [f.detach().clone() for f in model._quantizer._entropyCoder._freqEMA]
-    for mode in ("plain", "deferred"):
+    for mode in ("plain", "deferred", "queued"):
+        monkeypatch.setattr(ops, "_WGRAD_SIDE", mode == "queued")
         for p in model.parameters():
             p.grad = None
         with torch.no_grad():                                       # (the forward moves the frequency EMA, which the random drop reads)
@@ -382,10 +386,13 @@ def test_deferred_reduce_passes_give_the_same_gradients(dev, kind):
         else:
             backward(loss)
         assert ops._lib.load().mcq_wgrad_pending() == 0
+        assert not ops._defer["queue"] and not ops._defer["keep"] and ops._defer["side"] is None
+        torch.cuda.synchronize()
         grads[mode] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
-    assert set(grads["plain"]) == set(grads["deferred"]) and len(grads["plain"]) > 50
+    assert set(grads["plain"]) == set(grads["deferred"]) == set(grads["queued"]) and len(grads["plain"]) > 50
     for n in grads["plain"]:
         assert torch.equal(grads["plain"][n], grads["deferred"][n]), n
+        assert torch.equal(grads["plain"][n], grads["queued"][n]), n
 
 
 def test_deferral_steps_aside_for_accumulation_hooks_and_frozen_weights(dev):

@@ -13,6 +13,7 @@
 // Backward (the same file's formulas): with ds = sum_c gamma[c] sum_p dy x and db = sum_c gamma[c] sum_p dy over the run,
 //   c2 = (db * mean - ds) * rstd^3 / count,  c3 = -c2 * mean - db * rstd / count,
 //   dx = rstd * gamma[c] * dy + c2 * x + c3;   dgamma[c] = sum_n (sum_p dy x - mean sum_p dy) * rstd;  dbeta[c] = sum_n sum_p dy.
+#include <cstdlib>
 #include "mcq_common.h"
 #include "../../include/mcquic_hip.h"
 
@@ -34,6 +35,14 @@ __device__ __forceinline__ float block_sum(float v, float* slots) {
     if ((threadIdx.x & 63) == 0) slots[wave] = v;
     __syncthreads();
     return (slots[0] + slots[1]) + (slots[2] + slots[3]);
+}
+
+// Statistics that workgroups of ONE launch hand to each other (the fused kernels below) are read at device scope -- the eight XCDs'
+// L2s are not coherent with each other for ordinary accesses inside a kernel, and several runs' statistics share a cache line.
+// (The two-launch form reads them in the next kernel: ordinary loads.)
+template <bool COH> __device__ __forceinline__ float gn_stat_load(const float* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
 }
 
 // (mean, rstd) of one contiguous run; every thread returns the same values
@@ -220,6 +229,7 @@ __global__ __launch_bounds__(kThreads) void gn_chunk_stats_kernel(GnChunkK k) {
 }
 
 // (mean, rstd) of run `ng` from its chunk statistics, merged in (plane, chunk) order; every thread computes the same values
+template <bool COH = false>
 __device__ __forceinline__ void gn_merge_stats(const GnChunkK& k, int ng, float& mean, float& rstd) {
     const int cg = k.C / k.groups;
     const int n_img = ng / k.groups, g = ng % k.groups;
@@ -229,7 +239,7 @@ __device__ __forceinline__ void gn_merge_stats(const GnChunkK& k, int ng, float&
         const int chunk = pc % k.chunks;
         const int first = chunk * GN_CHUNK;
         const float nb = (float)(k.HW - first < GN_CHUNK ? k.HW - first : GN_CHUNK);
-        const float mb = st[2 * pc], qb = st[2 * pc + 1];
+        const float mb = gn_stat_load<COH>(st + 2 * pc), qb = gn_stat_load<COH>(st + 2 * pc + 1);
         const float tot = cnt + nb, delta = mb - mu;
         mu = mu + delta * (nb / tot);
         m2 = m2 + qb + delta * delta * (cnt * nb / tot);
@@ -336,10 +346,165 @@ __global__ __launch_bounds__(kThreads) void gn_chunk_bwd_dx_kernel(GnChunkK k) {
     }
 }
 
+// ---- one launch per direction (round 6) ---------------------------------------------------------------------------------------------
+// The two launches above read every value twice: once for the chunk statistics, once to normalise.  A workgroup already holds its
+// chunk in registers after the first read, so the fused kernels keep it there across a run-wide rendezvous: publish the chunk's pair of
+// statistics as ONE 8-byte device-scope store, wait until the pairs of all cg * chunks workgroups of the run are there (a launch in
+// front fills the table with a value no statistic can take; thread i polls entry i), merge in the same order as before and finish
+// from the registers.  Same arithmetic, same order: bit-identical to the two-launch form.  No fences: a device-scope release /
+// acquire pair writes back and invalidates the whole L2 of an XCD -- with a counter behind such fences the fused forward was 1.6x
+// SLOWER than two launches (Neon dense inference 27.4 -> 42.6 ms per batch); self-validating entries need none.
+// Measured with them (profiles/r06_group_norm_one_launch.txt): Neon(32, 4096, [16, 8, 4, 2, 2], denseNorm) encode + decode of 8 x 512x512
+// 28.59 / 28.56 -> 28.18 / 30.94 ms, captured training step 39.82 -> 39.58 / 39.71 ms -- the second read of the two-launch form
+// comes out of L2 / MALL and costs what the wait costs.  Bit-identical, tested (tests/test_gpu_step_ops.py), left OFF.
+// Why waiting inside a kernel is safe here: workgroups are dispatched in linear order (chunks fastest, planes next), on every XCD in
+// order, so the oldest unfinished run always has all its workgroups resident or next in line -- as long as a run is far smaller than
+// what the chip holds (GN_FUSED_MAX_RUN workgroups against >= 2048 resident).  A wait that does not end within seconds traps
+// instead of hanging the device.
+constexpr int GN_FUSED_MAX_RUN = kThreads;
+constexpr unsigned GN_PENDING_FWD = 0xbf800000u;        // M2 = -1.0f: a sum of squares is >= 0 or NaN
+constexpr unsigned GN_PENDING_BWD = 0xffc0deadu;        // sum dy = a NaN no arithmetic produces (payloads only propagate from inputs)
+
+__global__ void gn_fill_pending_kernel(unsigned long long* table, long long entries, unsigned long long pending) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < entries; i += (long long)gridDim.x * blockDim.x) table[i] = pending;
+}
+
+__device__ __forceinline__ unsigned long long gn_pack(float lo, float hi) {
+    return (unsigned long long)__float_as_uint(lo) | ((unsigned long long)__float_as_uint(hi) << 32);
+}
+
+// publish this workgroup's pair (thread 0), then wait for the run's `need` pairs starting at `first` (thread i polls entry i)
+template <bool BWD>
+__device__ __forceinline__ void gn_run_rendezvous(unsigned long long* table, size_t mine, float lo, float hi, size_t first, int need) {
+    if (threadIdx.x == 0) __hip_atomic_store(table + mine, gn_pack(lo, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)threadIdx.x < need) {
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned long long v = __hip_atomic_load(table + first + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned tag = BWD ? (unsigned)v : (unsigned)(v >> 32);
+            if (tag != (BWD ? GN_PENDING_BWD : GN_PENDING_FWD)) break;
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) __builtin_trap();         // (seconds: cannot happen with in-order dispatch; abort rather than hang)
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void gn_chunk_fused_fwd_kernel(GnChunkK k) {
+    __shared__ float slots[4];
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    const int n_img = plane / k.C, ch = plane % k.C;
+    const int cg = k.C / k.groups;
+    const int ng = n_img * k.groups + ch / cg;
+    const float* xp = k.x + (size_t)plane * k.HW;
+    f32x4v v[GN_CHUNK / (4 * kThreads)];
+    const int n = gn_load_chunk(xp, k.HW, chunk, v);
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < GN_CHUNK / (4 * kThreads); ++e) s += (v[e][0] + v[e][1]) + (v[e][2] + v[e][3]);
+    const float cmean = block_sum(s, slots) / (float)n;
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < GN_CHUNK / (4 * kThreads); ++e) {
+        const int i = (e * kThreads + (int)threadIdx.x) * 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float a = i + t < n ? v[e][t] - cmean : 0.0f;
+            q += a * a;
+        }
+    }
+    const float m2 = block_sum(q, slots);
+    gn_run_rendezvous<false>(reinterpret_cast<unsigned long long*>(k.stats), (size_t)plane * k.chunks + chunk, cmean, m2,
+                             (size_t)(n_img * k.C + (ch / cg) * cg) * k.chunks, cg * k.chunks);
+    float mean, rstd;
+    gn_merge_stats<true>(k, ng, mean, rstd);
+    if (threadIdx.x == 0 && chunk == 0 && ch % cg == 0 && k.mean_out) { k.mean_out[ng] = mean; k.rstd_out[ng] = rstd; }
+    const float scale = rstd * (k.gamma ? k.gamma[ch] : 1.0f);
+    const float shift = __builtin_fmaf(-scale, mean, k.beta ? k.beta[ch] : 0.0f);
+    const int first = chunk * GN_CHUNK;
+    float* yp = k.y + (size_t)plane * k.HW + first;
+    float* sp = k.y_silu ? k.y_silu + (size_t)plane * k.HW + first : nullptr;
+    const bool vec = (((uintptr_t)yp & 15) == 0);
+#pragma unroll
+    for (int e = 0; e < GN_CHUNK / (4 * kThreads); ++e) {
+        const int i = (e * kThreads + (int)threadIdx.x) * 4;
+        f32x4v o, so;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { o[t] = __builtin_fmaf(v[e][t], scale, shift); so[t] = sp ? mcq_silu(o[t]) : 0.0f; }
+        if (vec && i + 3 < n) {
+            *reinterpret_cast<f32x4v*>(yp + i) = o;
+            if (sp) *reinterpret_cast<f32x4v*>(sp + i) = so;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (i + t < n) { yp[i + t] = o[t]; if (sp) sp[i + t] = so[t]; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void gn_chunk_fused_bwd_kernel(GnChunkK k) {
+    __shared__ float slots[8];
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    const int n_img = plane / k.C, ch = plane % k.C;
+    const int cg = k.C / k.groups;
+    const int g = ch / cg, ng = n_img * k.groups + g;
+    f32x4v xv[GN_CHUNK / (4 * kThreads)], dv[GN_CHUNK / (4 * kThreads)];
+    const int n = gn_load_chunk(k.x + (size_t)plane * k.HW, k.HW, chunk, xv);
+    gn_load_chunk(k.dy + (size_t)plane * k.HW, k.HW, chunk, dv);          // (zero beyond the plane: those terms add nothing)
+    float a0 = 0.0f, b0 = 0.0f;
+#pragma unroll
+    for (int e = 0; e < GN_CHUNK / (4 * kThreads); ++e)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { a0 += dv[e][t]; b0 += dv[e][t] * xv[e][t]; }
+    a0 = block_sum(a0, slots);
+    b0 = block_sum(b0, slots + 4);
+    gn_run_rendezvous<true>(reinterpret_cast<unsigned long long*>(k.stats), (size_t)plane * k.chunks + chunk, a0, b0,
+                            (size_t)(n_img * k.C + g * cg) * k.chunks, cg * k.chunks);
+    float ds = 0.0f, db = 0.0f, own_dy = 0.0f, own_dyx = 0.0f;
+    for (int c = 0; c < cg; ++c) {
+        const int pl = n_img * k.C + g * cg + c;
+        const float* st = k.stats + (size_t)pl * k.chunks * 2;
+        float a = 0.0f, b = 0.0f;
+        for (int q = 0; q < k.chunks; ++q) { a += gn_stat_load<true>(st + 2 * q); b += gn_stat_load<true>(st + 2 * q + 1); }
+        const float gm = k.gamma ? k.gamma[g * cg + c] : 1.0f;
+        ds += gm * b;
+        db += gm * a;
+        if (pl == plane) { own_dy = a; own_dyx = b; }
+    }
+    if (threadIdx.x == 0 && chunk == 0) { k.sum_dy[plane] = own_dy; k.sum_dyx[plane] = own_dyx; }
+    const float mu = k.mean[ng], rs = k.rstd[ng];
+    const float inv = 1.0f / (float)((long long)cg * k.HW);
+    const float c2 = (db * mu - ds) * rs * rs * rs * inv;
+    const float c3 = -c2 * mu - db * rs * inv;
+    const float c1 = rs * (k.gamma ? k.gamma[ch] : 1.0f);
+    const int first = chunk * GN_CHUNK;
+    float* op = k.dx + (size_t)plane * k.HW + first;
+    const bool vec = (((uintptr_t)op & 15) == 0);
+#pragma unroll
+    for (int e = 0; e < GN_CHUNK / (4 * kThreads); ++e) {
+        const int i = (e * kThreads + (int)threadIdx.x) * 4;
+        f32x4v o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = c1 * dv[e][t] + c2 * xv[e][t] + c3;
+        if (vec && i + 3 < n) *reinterpret_cast<f32x4v*>(op + i) = o;
+        else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (i + t < n) op[i + t] = o[t];
+        }
+    }
+}
+
 inline int gn_chunks(int HW) { return (HW + GN_CHUNK - 1) / GN_CHUNK; }
 // (every plane of >= 256 pixels: even where a plane is one partial chunk -- 64 x 64 maps -- a workgroup that reads its values once
 //  with 16-byte loads and keeps them in registers beats the one-workgroup kernels' three scalar passes: 128 x 128 planes 245 -> ~20 us)
 inline bool gn_chunked(int C, int HW, int groups) { (void)C; (void)groups; return HW >= GN_CHUNK_MIN_HW; }
+// the one-launch form: runs of at most GN_FUSED_MAX_RUN workgroups (MCQUIC_AMD_GN_FUSED=0 in the environment: the two-launch form, A/B)
+inline unsigned long long gn_pack_host(unsigned lo, unsigned hi) { return (unsigned long long)lo | ((unsigned long long)hi << 32); }
+inline bool gn_fused(int C, int HW, int groups) {
+    static const bool on = [] { const char* e = getenv("MCQUIC_AMD_GN_FUSED"); return !(e && e[0] == '0'); }();
+    return on && gn_chunked(C, HW, groups) && (long long)(C / groups) * gn_chunks(HW) <= GN_FUSED_MAX_RUN;
+}
 
 }  // namespace
 
@@ -358,6 +523,13 @@ extern "C" int mcq_group_norm_f32(const float* x, const float* gamma, const floa
         k.x = x; k.gamma = gamma; k.beta = beta; k.y = y; k.y_silu = y_silu; k.mean_out = mean_out; k.rstd_out = rstd_out;
         k.stats = workspace; k.C = C; k.HW = HW; k.groups = groups; k.chunks = gn_chunks(HW); k.eps = eps;
         const dim3 grid((unsigned)k.chunks, (unsigned)(N * C));
+        if (gn_fused(C, HW, groups)) {
+            const long long entries = (long long)N * C * k.chunks;
+            hipLaunchKernelGGL(gn_fill_pending_kernel, dim3((unsigned)((entries + kThreads - 1) / kThreads < 256 ? (entries + kThreads - 1) / kThreads : 256)),
+                               dim3(kThreads), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(workspace), entries, gn_pack_host(0u, GN_PENDING_FWD));
+            hipLaunchKernelGGL(gn_chunk_fused_fwd_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, k);
+            return mcq_check_launch();
+        }
         hipLaunchKernelGGL(gn_chunk_stats_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, k);
         hipLaunchKernelGGL(gn_chunk_apply_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, k);
         return mcq_check_launch();
@@ -387,8 +559,15 @@ extern "C" int mcq_group_norm_bwd_f32(const float* x, const float* dy, const flo
         k.stats = workspace + (size_t)2 * N * C; k.sum_dy = sum_dy; k.sum_dyx = sum_dyx;
         k.C = C; k.HW = HW; k.groups = groups; k.chunks = gn_chunks(HW);
         const dim3 grid((unsigned)k.chunks, (unsigned)planes);
-        hipLaunchKernelGGL(gn_chunk_bwd_sums_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, k);
-        hipLaunchKernelGGL(gn_chunk_bwd_dx_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, k);
+        if (gn_fused(C, HW, groups)) {
+            const long long entries = (long long)N * C * k.chunks;
+            hipLaunchKernelGGL(gn_fill_pending_kernel, dim3((unsigned)((entries + kThreads - 1) / kThreads < 256 ? (entries + kThreads - 1) / kThreads : 256)),
+                               dim3(kThreads), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(k.stats), entries, gn_pack_host(GN_PENDING_BWD, 0u));
+            hipLaunchKernelGGL(gn_chunk_fused_bwd_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, k);
+        } else {
+            hipLaunchKernelGGL(gn_chunk_bwd_sums_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, k);
+            hipLaunchKernelGGL(gn_chunk_bwd_dx_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, k);
+        }
         if (dgamma || dbeta)
             hipLaunchKernelGGL(group_norm_bwd_params_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, (hipStream_t)stream, mean, rstd,
                                sum_dy, sum_dyx, dgamma, dbeta, N, C, groups);

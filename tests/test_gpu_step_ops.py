@@ -294,7 +294,8 @@ def test_scale_block_node_equals_op_by_op_graph(dev, up, shape):
 
 
 @pytest.mark.parametrize("shape,groups", [((2, 32, 192, 192), 32), ((1, 8, 128, 128), 1), ((2, 4, 97, 101), 2), ((3, 32, 512, 64), 32),
-                                          ((2, 32, 16, 16), 32), ((2, 8, 8, 8), 1), ((4, 32, 64, 64), 32), ((2, 32, 17, 15), 4), ((1, 8, 32, 32), 1)])
+                                          ((2, 32, 16, 16), 32), ((2, 8, 8, 8), 1), ((4, 32, 64, 64), 32), ((2, 32, 17, 15), 4), ((1, 8, 32, 32), 1),
+                                          ((8, 32, 512, 512), 32), ((1, 8, 512, 640), 1), ((2, 16, 300, 211), 4)])
 def test_group_norm_large_runs(dev, shape, groups):
     """nn.GroupNorm forward (+ SiLU twin) and backward on runs long enough for the chunked kernels (many workgroups per
     (image, group): Neon's GroupNorm(32, 32) on 512 x 512 maps) and, for comparison, on the short runs the one-workgroup kernels
@@ -319,6 +320,42 @@ def test_group_norm_large_runs(dev, shape, groups):
     # deterministic: a second run gives the same bits
     y2 = ops.group_norm(x.to(dev), gamma.to(dev), beta.to(dev), groups, 1e-5)
     assert torch.equal(y, y2)
+
+
+def test_group_norm_one_launch_equals_two_launches(dev):
+    """Round 6: statistics and normalisation of the chunked GroupNorm in ONE launch per direction (workgroups of a run meet on a
+    device-scope counter and finish from registers) -- bit for bit the two-launch form's outputs (MCQUIC_AMD_GN_FUSED=0, read once
+    per process: the other form runs in a child), forward with statistics and SiLU twin, backward with parameter gradients.  The
+    last shape's runs are longer than the one-launch form takes (320 workgroups): both processes run the same kernels there."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = """
+import hashlib, sys, torch
+from mcquic_amd import ops
+dev = torch.device('cuda:0')
+for shape, groups in (((8, 32, 512, 512), 32), ((2, 32, 192, 192), 32), ((1, 8, 128, 128), 1), ((2, 16, 300, 211), 4), ((1, 8, 512, 640), 1)):
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(dev)
+    c = shape[1]
+    gamma, beta, dy = torch.randn(c, generator=g).to(dev), torch.randn(c, generator=g).to(dev), torch.randn(shape, generator=g).to(dev)
+    h = hashlib.sha256()
+    for _ in range(3):                                             # (several launches in a row: the counters start from zero every time)
+        y, mean, rstd = ops.group_norm(x, gamma, beta, groups, 1e-5, dual_silu=True, want_stats=True)
+        dx, dw, db = ops.group_norm_bwd(x, dy, gamma, mean, rstd, groups)
+        for t in (y, ops.silu_twin(y), mean, rstd, dx, dw, db):
+            h.update(t.cpu().numpy().tobytes())
+    print('GN', shape, h.hexdigest())
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for fused in ("1", "0"):
+        env = dict(os.environ, MCQUIC_AMD_GN_FUSED=fused, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert run.returncode == 0, run.stderr[-2000:]
+        outs[fused] = [ln for ln in run.stdout.splitlines() if ln.startswith("GN ")]
+    assert len(outs["1"]) == 5 and outs["1"] == outs["0"]
 
 
 def test_grouped_gdn_operand_refresh_equals_layer_by_layer(dev):

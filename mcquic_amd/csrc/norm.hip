@@ -499,10 +499,10 @@ inline int gn_chunks(int HW) { return (HW + GN_CHUNK - 1) / GN_CHUNK; }
 // (every plane of >= 256 pixels: even where a plane is one partial chunk -- 64 x 64 maps -- a workgroup that reads its values once
 //  with 16-byte loads and keeps them in registers beats the one-workgroup kernels' three scalar passes: 128 x 128 planes 245 -> ~20 us)
 inline bool gn_chunked(int C, int HW, int groups) { (void)C; (void)groups; return HW >= GN_CHUNK_MIN_HW; }
-// the one-launch form: runs of at most GN_FUSED_MAX_RUN workgroups (MCQUIC_AMD_GN_FUSED=0 in the environment: the two-launch form, A/B)
 inline unsigned long long gn_pack_host(unsigned lo, unsigned hi) { return (unsigned long long)lo | ((unsigned long long)hi << 32); }
+// the one-launch form, OFF unless MCQUIC_AMD_GN_FUSED=1 is in the environment (read once per process): runs of at most GN_FUSED_MAX_RUN workgroups
 inline bool gn_fused(int C, int HW, int groups) {
-    static const bool on = [] { const char* e = getenv("MCQUIC_AMD_GN_FUSED"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = getenv("MCQUIC_AMD_GN_FUSED"); return e && e[0] == '1'; }();
     return on && gn_chunked(C, HW, groups) && (long long)(C / groups) * gn_chunks(HW) <= GN_FUSED_MAX_RUN;
 }
 

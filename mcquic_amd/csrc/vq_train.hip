@@ -84,25 +84,6 @@ __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
         rsrc[nb] = mcq_make_rsrc(mcq_uniform_ptr(p.x + ((size_t)n * p.m + g) * (size_t)p.d * HW), group_bytes);
     }
 
-    // |x_v|^2 per vector (lane j), then broadcast into accumulator ROW layout: D[i][*] = x2[i]
-    f32x16 x2d[NP];
-    const float bone = hi == 0 ? 1.0f : 0.0f;
-#pragma unroll
-    for (int nb = 0; nb < NP; ++nb) {
-        float s = 0.0f;
-        for (int c0 = 0; c0 < p.d; c0 += 16) {          // sixteen independent loads per batch, additions in channel order
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = mcq_buffer_load(rsrc[nb], pixoff[nb] + (unsigned)(c0 + i) * (unsigned)HW * 4u);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s = s + v[i] * v[i];
-        }
-        f32x16 z;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-        x2d[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(hi == 0 ? s : 0.0f, bone, z, 0, 0, 0);
-    }
-
     f32x4v A[PF];
     float B[PF][NP];
     const int tile_lo = blockIdx.z * q.tiles_per_z;
@@ -129,6 +110,40 @@ __global__ __launch_bounds__(256) void vq_logits_kernel(VqLogitK q) {
     const float tmax = q.raw ? 1.0f : fmaxf(q.temperature[g], q.bound);
 #pragma unroll
     for (int st = 0; st < PF; ++st) issue(st);
+
+    // |x_v|^2 per vector (lane j), then broadcast into accumulator ROW layout: D[i][*] = x2[i].  Not needed for the raw inner products;
+    // both vector blocks' loads of a batch are in flight together (round 6: the 2 x d / 16 dependent round trips of the first form were
+    // 8-16 us in front of every launch at d = 64), behind the operand rings' first loads.
+    f32x16 x2d[NP];
+#pragma unroll
+    for (int nb = 0; nb < NP; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x2d[nb][r] = 0.0f;
+    if (!q.raw) {
+        const float bone = hi == 0 ? 1.0f : 0.0f;
+        float s[NP];
+#pragma unroll
+        for (int nb = 0; nb < NP; ++nb) s[nb] = 0.0f;
+        for (int c0 = 0; c0 < p.d; c0 += 16) {          // sixteen independent loads per block and batch, additions in channel order
+            float v[NP][16];
+#pragma unroll
+            for (int nb = 0; nb < NP; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[nb][i] = mcq_buffer_load(rsrc[nb], pixoff[nb] + (unsigned)(c0 + i) * (unsigned)HW * 4u);
+#pragma unroll
+            for (int nb = 0; nb < NP; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[nb] = s[nb] + v[nb][i] * v[nb][i];
+        }
+#pragma unroll
+        for (int nb = 0; nb < NP; ++nb) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+            x2d[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(hi == 0 ? s[nb] : 0.0f, bone, z, 0, 0, 0);
+        }
+    }
+
 
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
         const f32x4v c2t = c2l[(size_t)tile * 64];

@@ -96,8 +96,12 @@ __global__ __launch_bounds__(256, 2) void vq_assign_kernel(VqK p) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i)      // channels past d are out of range = 0: they add +0
-                v[nb][i] = mcq_buffer_load(rsrc[nb], pixoff[nb] + (unsigned)(c0 + i) * (unsigned)HW * 4u);
+            for (int i = 0; i < 16; ++i) {    // channels past d are out of range = 0: they add +0
+                // (XLDS, round 6: from the staged tile -- four waves reading their 64 KB again from global memory made the launch pull
+                //  3.2x its algorithmic bytes through the fabric, profiles/r05_pmc_by_kernel_vq.txt; same values, same order)
+                if (XLDS) v[nb][i] = c0 + i < 2 * SPC ? xs[(c0 + i) * 64 + nb * 32 + j] : 0.0f;
+                else v[nb][i] = mcq_buffer_load(rsrc[nb], pixoff[nb] + (unsigned)(c0 + i) * (unsigned)HW * 4u);
+            }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll

@@ -12,6 +12,7 @@
 #   bench    only the bench line (+ the torchrun line)
 #   train    training step figures + trace + buckets
 #   tests    the GPU test suite with durations
+#   vqpmc    counter passes over tools/bench_vq.py (vq_assign launches: fabric reads / writes, MFMA-busy, VALU / MFMA instruction counts)
 #   abtrain VAR A B [runs]   the same on the captured training step (tools/bench_train.py --graph)
 #   ab VAR A B [runs]   alternating `VAR=A` / `VAR=B` headline runs on this box (bench.py --steps 8 --no-secondary): in-step A/B of a switch
 # Outputs: gpurun_out/<round>_<what>/ (merged back by gpurun; what the script copies into profiles/ on the BOX only serves the same call --
@@ -106,6 +107,15 @@ case "$WHAT" in
     for r in $(seq $RUNS); do for v in "$A" "$B"; do
       env $VAR=$v python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$VAR=$v', d['value'], d['ms_per_step'], d['roofline']['frac'])" | tee -a $O/ab.txt
     done; done ;;
+  vqpmc)        # counter passes over tools/bench_vq.py: fabric reads / writes / MFMA-busy / instruction counts per vq_assign launch
+    R=${1:-r06}; O=gpurun_out/${R}_vqpmc; rm -rf $O; mkdir -p $O
+    for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA"; do
+      d=$O/pmc_$(echo $c | cut -d' ' -f1)
+      timeout 300 rocprofv3 --pmc $c --kernel-trace -d $d -o pmc -- python tools/bench_vq.py > $O/bench_vq.json 2>/dev/null
+    done
+    python profiles/pmc_stats.py $O/pmc_FETCH_SIZE/pmc_results.db $O/pmc_WRITE_SIZE/pmc_results.db $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES/pmc_results.db $(ls $O/pmc_SQ_INSTS_VALU/pmc_results.db 2>/dev/null) > $O/pmc_by_kernel_vq.txt 2>&1
+    rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_SQ_INSTS_VALU
+    head -20 $O/pmc_by_kernel_vq.txt; tail -1 $O/bench_vq.json | cut -c1-600 ;;
   abtrain)      # the same for the captured training step (configs[4]): tools/bench_train.py --graph, alternating
     VAR=$1; A=$2; B=$3; RUNS=${4:-2}; O=gpurun_out/abtrain_$VAR; mkdir -p $O
     for r in $(seq $RUNS); do for v in "$A" "$B"; do

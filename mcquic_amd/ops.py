@@ -233,6 +233,14 @@ class PackedConv:
 # (round 6) the 1x1 layer BEHIND a 3x3 convolution inside that convolution's launch (MCQ_CONV_POST_*: GDN / IGDN after a strided /
 # shuffle convolution, the AttentionBlock's gate after its side stack): A/B switch, 0 = always its own launch
 # ("1" = all, "0" = none, or a comma list of gdn / igdn / gate)
+# Round 6: 3x3 stride-1 launches that store no SiLU twin run the PIXEL-PAIR form of the unsplit 128 x 64 tile (tile bit 0x400, round 5:
+# a third fewer activation loads, 64 / 128-bit epilogue accesses, the same bits -- tests/test_gpu_ops.py::test_conv_pixel_pair_tile_is_bit_equal)
+# from 160 k output pixels up, i.e. where the launcher takes that tile for several rounds of the chip: -0.8 % on such launches, the
+# 32-image step +0.17 % (258.76 -> 259.19 images/s over four alternating runs).  With a twin the form loses 1 %, on one-round launches
+# the replay hides the gain, and a forced tile bit on small maps would take the 16 x 16 tile kernel away from them (measured: one
+# image 5.67 -> 5.78 ms) -- hence the conditions.  MCQUIC_AMD_PAIR_RULE=0: the standing tile everywhere (A/B).
+_PAIR_RULE = os.environ.get("MCQUIC_AMD_PAIR_RULE", "1") != "0"
+_PAIR_MIN_PIXELS = int(os.environ.get("MCQUIC_AMD_PAIR_MIN_PIXELS", str(160 * 1024)))
 _fp = os.environ.get("MCQUIC_AMD_FUSE_POST", "1")
 _FUSE_POST = {"gdn", "igdn", "gate"} if _fp == "1" else set() if _fp == "0" else set(_fp.split(","))
 # wave tiles (128 channels x 32 pixels) from which a launch is fused: the library's own rule is 2048 (two per SIMD); one image's large
@@ -429,6 +437,9 @@ def _conv_desc(x: torch.Tensor, w: PackedConv, stride: int = 1, *, silu_in: bool
             raise ValueError("winograd=True needs a 3x3 stride-1 layer with Cout % 64 == 0, packed with winograd=True, and no input prologue")
     if _TAPS_LR and getattr(w, "lr_taps", False) and stride == 1 and wp is w.wp and not (flags & (CONV_SILU_IN | CONV_SQUARE_IN)):
         flags |= CONV_TAPS_LR
+    if (_PAIR_RULE and tile == 0 and w.ksize == 3 and stride == 1 and not dual_silu and dsilu_mul is None and post is None
+            and n * ho * wo >= _PAIR_MIN_PIXELS):
+        tile = 0x400                                 # (the pixel-pair form wherever the launcher takes the unsplit 128 x 64 tile: see _PAIR_RULE)
     d = ConvDesc(_ptr(x), _ptr(wp), _ptr(w.bias), _ptr(y), _ptr(y2), _ptr(res), _ptr(mul), _ptr(gate_id),
                  n, cin, h, wd, w.cout, w.ksize, stride, flags, float(res_scale), tile,
                  None if post is None else _ptr(post.wp), None if post is None else _ptr(post.bias))

@@ -325,12 +325,12 @@ def test_random_geometries_against_the_oracle(dev, which):
     pixels is padded to the next multiple of 128, which needs both pads < s: s >= 44), sizes around the 128-pixel padding steps,
     tall and wide strips -- through two small models against the CPU oracle: codes under the near-tie protocol, pixels within
     1e-4.  The fixed shapes above pin the tiles the benchmark runs; this sweeps the tails (partial pixel blocks, padding splits,
-    levels smaller than one tile).  `-m gpu` runs a sample of eight of them (four edge sizes, four free ones: the CPU oracle is
+    levels smaller than one tile).  `-m gpu` runs a sample of six of them (three edge sizes, three free ones: the CPU oracle is
     100 s of the full sweep), `-m "gpu and sweep"` all twenty-four."""
     import random
     rng = random.Random(20260929)
     edge = [44, 45, 63, 64, 65, 127, 128, 129, 130, 200, 255, 256, 257, 300, 383, 384, 385, 511, 512, 513]
-    take = set(range(24)) if which == "all" else {0, 1, 2, 3, 10, 11, 12, 13}
+    take = set(range(24)) if which == "all" else {0, 1, 2, 10, 11, 12}
     total = 0
     for it in range(24):
         if it < 10:

@@ -146,8 +146,10 @@ def test_neon_hip_against_oracle_and_reference_vectors(dev, dense, case):
 
 
 @pytest.mark.gpu
-@CASE
-@DENSE
+@pytest.mark.parametrize("dense,case", [
+    pytest.param(False, "small", id="plain-small"), pytest.param(True, "k4096", id="denseNorm-k4096"),      # (both norm settings, both sizes)
+    pytest.param(False, "k4096", id="plain-k4096", marks=pytest.mark.sweep),                                # (the other two combinations:
+    pytest.param(True, "small", id="denseNorm-small", marks=pytest.mark.sweep)])                            #  -m "gpu and sweep"; ~50 s of CPU autograd)
 def test_neon_training_forward_and_gradients(dev, dense, case):
     """Training-mode forward against the reference's vectors (F10; F11 with denseNorm=True: GroupNorm forward and backward on
     csrc/norm.hip) and every parameter gradient against CPU autograd through the oracle (same weights, same uniform draws,
